@@ -1,0 +1,117 @@
+/*
+ * usvmpc.h — C ABI of the MI355X batched SQP-RTI solver (libusvmpc.so).
+ *
+ * Drop-in boundary: this is what a binding would call instead of the generated acados solver of
+ * the reference.  Reference interfaces replaced (paths relative to /root/reference):
+ *
+ *   Python (acados_template.AcadosOcpSolver, used by the closed-loop scripts):
+ *     AcadosOcpSolver(ocp, json_file=...)     catkin_ws/src/nmpc_ca/scripts/usv_guidance_ca1/acados_settings.py:207
+ *                                             -> usvmpc_create
+ *     solver.set(stage, "lbx"/"ubx", x0)      .../usv_guidance_ca1/main.py:111-112,174-175 -> usvmpc_set("x0")
+ *     solver.set(stage, "yref", v)            .../usv_guidance_ca1/main.py:125,129         -> usvmpc_set("yref")
+ *     solver.set(stage, "p", v)               .../usv_guidance_ca1/main.py:126,130         -> usvmpc_set("p")
+ *     solver.constraints_set(stage, "lh", v)  .../usv_guidance_ca1/main.py:127             -> usvmpc_set("lh")
+ *     solver.solve()                          .../usv_guidance_ca1/main.py:135             -> usvmpc_solve
+ *     solver.get(stage, "x"|"u")              .../usv_guidance_ca1/main.py:147-148,169     -> usvmpc_get
+ *   C (generated acados_solver_<model>.h + libacados, used by the ROS nodes):
+ *     acados_create / acados_free             catkin_ws/src/nmpc_ca/src/nmpc_guidance_ca1.cpp:165,220 -> usvmpc_create / usvmpc_destroy
+ *     ocp_nlp_constraints_model_set(lbx/ubx/lh) .../nmpc_guidance_ca1.cpp:515-516,571     -> usvmpc_set
+ *     ocp_nlp_cost_model_set(yref)            .../nmpc_guidance_ca1.cpp:569,573            -> usvmpc_set
+ *     acados_update_params(stage, p, np)      .../nmpc_guidance_ca1.cpp:570,574            -> usvmpc_set("p")
+ *     acados_solve()                          .../nmpc_guidance_ca1.cpp:577                -> usvmpc_solve
+ *     ocp_nlp_out_get(stage, "x"|"u")         .../nmpc_guidance_ca1.cpp:583,586            -> usvmpc_get
+ *
+ * One handle = one OCP definition x a batch of B independent instances on one HIP device.
+ * All arrays are FP64, instance-major: element (b, stage, i) of a per-stage field of length n is
+ * at [(b * n_stages + stage) * n + i].  The caller owns every host array; the library copies on
+ * set and fills caller memory on get.  Return value 0 = ok; solver outcomes reuse acados'
+ * status values (0 ok, 4 QP failure); negative values are API errors (usvmpc_last_error).
+ * A handle is single-caller; distinct handles are independent.  Nothing here falls back to the
+ * CPU: without a HIP device usvmpc_create fails.
+ */
+#ifndef USVMPC_H
+#define USVMPC_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define USVMPC_NX_MAX 14
+#define USVMPC_NU_MAX 2
+#define USVMPC_NY_MAX 16
+#define USVMPC_K_MAX 32
+
+enum { USVMPC_MODEL_USV = 0,             /* `usv_model`              nx 5  nu 2           */
+       USVMPC_MODEL_GUIDANCE_CA1 = 1,    /* `usv_model_guidance_ca1` nx 8  nu 1, soft h   */
+       USVMPC_MODEL_PF_CA = 2 };         /* `usv_model_pf_ca`        nx 14 nu 2, hard h   */
+
+enum { USVMPC_E_ARG = -1, USVMPC_E_FIELD = -2, USVMPC_E_STAGE = -3, USVMPC_E_SIZE = -4,
+       USVMPC_E_HIP = -5, USVMPC_E_NODEVICE = -6 };
+
+/* The OCP definition (what AcadosOcp carries).  Dense row-major matrices with the model's
+ * actual dimensions: W ny x ny, W_e nx x nx, Vx ny x nx, Vu ny x nu, Vx_e nx x nx. */
+typedef struct usvmpc_desc {
+    int model;
+    int N;
+    double Tf;
+    int K;                 /* circular obstacles: nh = K, np = 2K */
+    int batch;
+    int device;            /* HIP device ordinal */
+    double W[USVMPC_NY_MAX * USVMPC_NY_MAX];
+    double W_e[USVMPC_NX_MAX * USVMPC_NX_MAX];
+    double Vx[USVMPC_NY_MAX * USVMPC_NX_MAX];
+    double Vu[USVMPC_NY_MAX * USVMPC_NU_MAX];
+    double Vx_e[USVMPC_NX_MAX * USVMPC_NX_MAX];
+    int nbu; int idxbu[USVMPC_NU_MAX]; double lbu[USVMPC_NU_MAX], ubu[USVMPC_NU_MAX];
+    int nbx; int idxbx[USVMPC_NX_MAX]; double lbx[USVMPC_NX_MAX], ubx[USVMPC_NX_MAX];
+    double uh[USVMPC_K_MAX];
+    int soft;              /* 1: all h rows soft (idxsh = 0..K-1) */
+    double lsh[USVMPC_K_MAX], ush[USVMPC_K_MAX];
+    double zl[USVMPC_K_MAX], zu[USVMPC_K_MAX], Zl[USVMPC_K_MAX], Zu[USVMPC_K_MAX];
+    int qp_iter_max;
+    double mu0, thr0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min;
+} usvmpc_desc;
+
+typedef struct usvmpc_handle usvmpc_handle;
+
+/* nx, nu of a model id; returns 0 or USVMPC_E_ARG */
+int usvmpc_model_dims(int model, int *nx, int *nu);
+/* solver option defaults (iter_max 50, mu0 10, thr0 0.1, tolerances 1e-6/1e-8, alpha_min 1e-12) */
+void usvmpc_default_options(usvmpc_desc *d);
+
+int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out);
+int usvmpc_destroy(usvmpc_handle *h);
+
+/* fields: "x0" (n = nx), "yref" (stage 0..N-1: n = ny; stage N: n = nx), "p" (stage 0..N,
+ * n = 2K), "lh" (stage 0..N-1, n = K), "x" (stage 0..N, n = nx), "u" (stage 0..N-1, n = nu).
+ * v holds [batch][n] for one stage, or, with stage = -1, [batch][n_stages][n] for all stages
+ * ("yref" with stage -1 covers stages 0..N-1 only). */
+int usvmpc_set(usvmpc_handle *h, const char *field, int stage, const double *v, size_t n);
+/* fields: "x", "u", "pi" (stage 1..N), "sl", "su" (stage 0..N-1, n = K), "res" (stage ignored,
+ * n = 4: QP residuals stat/eq/ineq/comp); same stage = -1 convention. */
+int usvmpc_get(usvmpc_handle *h, const char *field, int stage, double *out, size_t n);
+/* integer per-instance results: "status" (0 | 4), "qp_status" (0 ok,1 max iter,2 min step,
+ * 3 nan), "qp_iter" */
+int usvmpc_get_int(usvmpc_handle *h, const char *field, int *out);
+
+/* One SQP-RTI iteration for every instance; returns the worst status. status may be NULL. */
+int usvmpc_solve(usvmpc_handle *h, int *status);
+/* Enqueue one RTI iteration on the handle's stream without synchronising or reading back */
+int usvmpc_solve_async(usvmpc_handle *h);
+int usvmpc_sync(usvmpc_handle *h);
+
+/* device pointer of a field ("x","u","x0","yref","yref_e","p","lh","pi","sl","su","status",
+ * "qp_iter","res") for zero-copy use from torch / RCCL */
+int usvmpc_get_device_ptr(usvmpc_handle *h, const char *field, void **dptr);
+/* HIP-event durations (ms) of the two kernels of the most recent completed solve */
+int usvmpc_last_kernel_ms(usvmpc_handle *h, float *linearize_ms, float *qp_ms);
+/* bytes of device memory held by the handle */
+size_t usvmpc_device_bytes(usvmpc_handle *h);
+const char *usvmpc_last_error(usvmpc_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

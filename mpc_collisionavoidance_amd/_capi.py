@@ -1,0 +1,174 @@
+"""ctypes binding of libusvmpc.so (include/usvmpc.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no device is present the
+import / create call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+NXM, NUM, NYM, KM = 14, 2, 16, 32
+MODEL_IDS = {"usv_model": 0, "usv_model_guidance_ca1": 1, "usv_model_pf_ca": 2}
+MODEL_DIMS = {0: (5, 2), 1: (8, 1), 2: (14, 2)}
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class Desc(C.Structure):
+    """usvmpc_desc"""
+    _fields_ = [("model", C.c_int), ("N", C.c_int), ("Tf", C.c_double), ("K", C.c_int),
+                ("batch", C.c_int), ("device", C.c_int),
+                ("W", C.c_double * (NYM * NYM)), ("W_e", C.c_double * (NXM * NXM)),
+                ("Vx", C.c_double * (NYM * NXM)), ("Vu", C.c_double * (NYM * NUM)),
+                ("Vx_e", C.c_double * (NXM * NXM)),
+                ("nbu", C.c_int), ("idxbu", C.c_int * NUM), ("lbu", C.c_double * NUM), ("ubu", C.c_double * NUM),
+                ("nbx", C.c_int), ("idxbx", C.c_int * NXM), ("lbx", C.c_double * NXM), ("ubx", C.c_double * NXM),
+                ("uh", C.c_double * KM), ("soft", C.c_int),
+                ("lsh", C.c_double * KM), ("ush", C.c_double * KM),
+                ("zl", C.c_double * KM), ("zu", C.c_double * KM), ("Zl", C.c_double * KM), ("Zu", C.c_double * KM),
+                ("qp_iter_max", C.c_int), ("mu0", C.c_double), ("thr0", C.c_double),
+                ("tol_stat", C.c_double), ("tol_eq", C.c_double), ("tol_ineq", C.c_double),
+                ("tol_comp", C.c_double), ("alpha_min", C.c_double)]
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libusvmpc.so")
+
+
+_lib = None
+
+EXPORTS = ["usvmpc_model_dims", "usvmpc_default_options", "usvmpc_create", "usvmpc_destroy",
+           "usvmpc_set", "usvmpc_get", "usvmpc_get_int", "usvmpc_solve", "usvmpc_solve_async",
+           "usvmpc_sync", "usvmpc_get_device_ptr", "usvmpc_last_kernel_ms", "usvmpc_device_bytes",
+           "usvmpc_last_error"]
+
+
+def lib():
+    """Load libusvmpc.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "HIP library %s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % path)
+        L = C.CDLL(path)
+        L.usvmpc_model_dims.argtypes = [C.c_int, _ip, _ip]
+        L.usvmpc_default_options.argtypes = [C.POINTER(Desc)]
+        L.usvmpc_default_options.restype = None
+        L.usvmpc_create.argtypes = [C.POINTER(Desc), C.POINTER(C.c_void_p)]
+        L.usvmpc_destroy.argtypes = [C.c_void_p]
+        L.usvmpc_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _dp, C.c_size_t]
+        L.usvmpc_get.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _dp, C.c_size_t]
+        L.usvmpc_get_int.argtypes = [C.c_void_p, C.c_char_p, _ip]
+        L.usvmpc_solve.argtypes = [C.c_void_p, _ip]
+        L.usvmpc_solve_async.argtypes = [C.c_void_p]
+        L.usvmpc_sync.argtypes = [C.c_void_p]
+        L.usvmpc_get_device_ptr.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.usvmpc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.usvmpc_device_bytes.argtypes = [C.c_void_p]
+        L.usvmpc_device_bytes.restype = C.c_size_t
+        L.usvmpc_last_error.argtypes = [C.c_void_p]
+        L.usvmpc_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _fill(dst, src, n):
+    a = np.ascontiguousarray(src, dtype=np.float64).reshape(-1)
+    if a.size != n:
+        raise Exception("mismatching dimension: expected %d values, got %d" % (n, a.size))
+    for i in range(n):
+        dst[i] = a[i]
+
+
+def default_options(d):
+    """Solver option defaults (mirrors usvmpc_default_options so that it works without the .so)."""
+    d.qp_iter_max = 50
+    d.mu0, d.thr0 = 10.0, 0.1
+    d.tol_stat, d.tol_eq, d.tol_ineq, d.tol_comp = 1e-6, 1e-8, 1e-8, 1e-8
+    d.alpha_min = 1e-12
+    return d
+
+
+def desc_from_ocp(ocp, batch=1, device=0):
+    """Translate an AcadosOcp look-alike into the C description; validates like acados'
+    make_consistent (dimension mismatches raise Exception)."""
+    name = ocp.model.name
+    if name not in MODEL_IDS:
+        raise Exception("model '%s' is not in the registry %s" % (name, sorted(MODEL_IDS)))
+    mid = MODEL_IDS[name]
+    nx, nu = MODEL_DIMS[mid]
+    opts, cost, con = ocp.solver_options, ocp.cost, ocp.constraints
+    if ocp.model.x.size()[0] != nx or ocp.model.u.size()[0] != nu:
+        raise Exception("model dimensions do not match registry entry '%s'" % name)
+    for fld, want in (("cost_type", "LINEAR_LS"), ("cost_type_e", "LINEAR_LS")):
+        if getattr(cost, fld) != want:
+            raise Exception("only %s = %s is supported" % (fld, want))
+    if opts.nlp_solver_type not in ("SQP_RTI",):
+        raise Exception("nlp_solver_type must be SQP_RTI")
+    if opts.integrator_type != "ERK" or opts.hessian_approx != "GAUSS_NEWTON":
+        raise Exception("integrator_type must be ERK and hessian_approx GAUSS_NEWTON")
+    if opts.qp_solver not in ("PARTIAL_CONDENSING_HPIPM", "FULL_CONDENSING_HPIPM"):
+        raise Exception("qp_solver must be an HPIPM variant")
+    if opts.tf is None or ocp.dims.N is None:
+        raise Exception("solver_options.tf and dims.N must be set")
+    ny, ny_e = nx + nu, nx
+    d = Desc()
+    default_options(d)
+    d.model, d.N, d.Tf, d.batch, d.device = mid, int(ocp.dims.N), float(opts.tf), int(batch), int(device)
+    npar = ocp.model.p.size()[0]
+    K = 0 if ocp.model.con_h_expr is None else ocp.model.con_h_expr.size()[0]
+    if K and npar != 2 * K:
+        raise Exception("parameter vector must hold (ox, oy) per obstacle row: np = %d, nh = %d" % (npar, K))
+    d.K = K
+    _fill(d.W, np.asarray(cost.W).reshape(ny, ny), ny * ny)
+    _fill(d.W_e, np.asarray(cost.W_e).reshape(ny_e, ny_e), ny_e * ny_e)
+    _fill(d.Vx, np.asarray(cost.Vx).reshape(ny, nx), ny * nx)
+    _fill(d.Vu, np.asarray(cost.Vu).reshape(ny, nu), ny * nu)
+    _fill(d.Vx_e, np.asarray(cost.Vx_e).reshape(ny_e, nx), ny_e * nx)
+    idxbu = np.asarray(con.idxbu, dtype=int).reshape(-1)
+    d.nbu = idxbu.size
+    if np.asarray(con.lbu).size != d.nbu or np.asarray(con.ubu).size != d.nbu:
+        raise Exception("lbu/ubu/idxbu dimension mismatch")
+    for i in range(d.nbu):
+        d.idxbu[i], d.lbu[i], d.ubu[i] = int(idxbu[i]), float(con.lbu[i]), float(con.ubu[i])
+    idxbx = np.asarray(con.idxbx, dtype=int).reshape(-1)
+    d.nbx = idxbx.size
+    if np.asarray(con.lbx).size != d.nbx or np.asarray(con.ubx).size != d.nbx:
+        raise Exception("lbx/ubx/idxbx dimension mismatch")
+    for i in range(d.nbx):
+        d.idxbx[i], d.lbx[i], d.ubx[i] = int(idxbx[i]), float(con.lbx[i]), float(con.ubx[i])
+    if K:
+        if np.asarray(con.lh).size != K or np.asarray(con.uh).size != K:
+            raise Exception("lh/uh must have nh = %d entries" % K)
+        for i in range(K):
+            d.uh[i] = float(con.uh[i])
+    idxsh = np.asarray(con.idxsh, dtype=int).reshape(-1)
+    if idxsh.size:
+        if sorted(idxsh.tolist()) != list(range(K)):
+            raise Exception("soft constraints are supported for all h rows at once (idxsh = 0..nh-1)")
+        for nm in ("lsh", "ush"):
+            if np.asarray(getattr(con, nm)).size != K:
+                raise Exception("%s must have nsh = %d entries" % (nm, K))
+        for nm in ("zl", "zu", "Zl", "Zu"):
+            if np.asarray(getattr(cost, nm)).size != K:
+                raise Exception("cost.%s must have ns = %d entries" % (nm, K))
+        d.soft = 1
+        for i in range(K):
+            d.lsh[i], d.ush[i] = float(con.lsh[i]), float(con.ush[i])
+            d.zl[i], d.zu[i] = float(cost.zl[i]), float(cost.zu[i])
+            d.Zl[i], d.Zu[i] = float(cost.Zl[i]), float(cost.Zu[i])
+    if mid == 1 and K and not d.soft:
+        raise Exception("usv_model_guidance_ca1 is built with soft obstacle rows")
+    if mid == 2 and d.soft:
+        raise Exception("usv_model_pf_ca is built with hard obstacle rows")
+    if opts.qp_solver_iter_max is not None:
+        d.qp_iter_max = int(opts.qp_solver_iter_max)
+    for src, dst in (("qp_solver_tol_stat", "tol_stat"), ("qp_solver_tol_eq", "tol_eq"),
+                     ("qp_solver_tol_ineq", "tol_ineq"), ("qp_solver_tol_comp", "tol_comp")):
+        if getattr(opts, src) is not None:
+            setattr(d, dst, float(getattr(opts, src)))
+    return d

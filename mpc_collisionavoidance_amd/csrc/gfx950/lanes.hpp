@@ -1,0 +1,94 @@
+// lanes.hpp (gfx950) — cross-lane primitives for the "16 lanes per OCP instance" layout.
+//
+// One OCP instance is owned by one DPP row (16 consecutive lanes of a wave64), so a wave carries
+// four instances.  Lane r of a group owns row r of every small matrix (variable ordering [u;x])
+// and entry r of every vector; other lanes' entries are fetched with DPP `row_newbcast`
+// (broadcast lane K of each row to the whole row), reductions use DPP `row_ror` butterflies.
+// No LDS, no shuffles through memory, no MFMA.
+//
+// Control flow around these primitives must be wave-uniform: a DPP read from an EXEC-disabled
+// lane is undefined, so kernels freeze finished instances with selects instead of branching.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define USV_DEV __device__ __forceinline__
+
+namespace lanes {
+
+constexpr int GROUP = 16;
+
+USV_DEV int lane() { return (int)(threadIdx.x & 15u); }
+// global index of this 16-lane group (one group = one OCP instance or one (instance,stage) pair)
+USV_DEV long group_linear() { return (long)blockIdx.x * (long)(blockDim.x >> 4) + (long)(threadIdx.x >> 4); }
+
+template <int CTRL>
+USV_DEV double dpp_mov(double v)
+{
+    const long l = __builtin_bit_cast(long, v);
+    int lo = (int)l, hi = (int)(l >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long)(unsigned)lo) | ((long)hi << 32));
+}
+
+// value held by lane K of this group, delivered to all 16 lanes (DPP row_newbcast:K)
+template <int K>
+USV_DEV double bcast(double v)
+{
+    static_assert(K >= 0 && K < 16, "lane index");
+    return dpp_mov<0x150 + K>(v);
+}
+
+// c += bcast<K>(b_remote) * a_own
+template <int K>
+USV_DEV void fma_bc(double &c, double b_remote, double a_own)
+{
+#if USV_FUSED_DPP_FMA
+    // v_fmac_f64_dpp with row_newbcast is the one DP-ALU DPP form gfx950 has; hipcc cannot select
+    // it from builtins, and it does not pad the VALU-write -> DPP-read hazard inside asm, hence
+    // the leading s_nop 1.
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(c) : "v"(b_remote), "v"(a_own), "n"(K));
+#else
+    c = __builtin_fma(bcast<K>(b_remote), a_own, c);
+#endif
+}
+
+// rotate right by N lanes within the group (DPP row_ror:N)
+template <int N>
+USV_DEV double ror(double v)
+{
+    static_assert(N >= 1 && N < 16, "rotation");
+    return dpp_mov<0x120 + N>(v);
+}
+
+// all-reduce over the 16 lanes of the group; every lane receives bitwise the same result
+USV_DEV double gsum(double v)
+{
+    v += ror<8>(v);
+    v += ror<4>(v);
+    v += ror<2>(v);
+    v += ror<1>(v);
+    return v;
+}
+USV_DEV double gmax(double v)
+{
+    v = fmax(v, ror<8>(v));
+    v = fmax(v, ror<4>(v));
+    v = fmax(v, ror<2>(v));
+    v = fmax(v, ror<1>(v));
+    return v;
+}
+USV_DEV double gmin(double v)
+{
+    v = fmin(v, ror<8>(v));
+    v = fmin(v, ror<4>(v));
+    v = fmin(v, ror<2>(v));
+    v = fmin(v, ror<1>(v));
+    return v;
+}
+
+// true if the predicate holds in any lane of the wave (four instances)
+USV_DEV bool wave_any(bool p) { return __any((int)p) != 0; }
+
+} // namespace lanes

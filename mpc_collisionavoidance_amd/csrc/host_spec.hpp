@@ -1,0 +1,111 @@
+// host_spec.hpp — host-side translation of the caller's OCP description (usvmpc_desc, i.e. what
+// an AcadosOcp carries) into the constant tables the kernels read (DevSpec).
+#pragma once
+#include "../../include/usvmpc.h"
+#include "params.hpp"
+#include <cstring>
+#include <string>
+
+namespace usv {
+
+inline int model_dims(int model, int &nx, int &nu)
+{
+    switch (model) {
+    case USVMPC_MODEL_USV: nx = 5; nu = 2; return 0;
+    case USVMPC_MODEL_GUIDANCE_CA1: nx = 8; nu = 1; return 0;
+    case USVMPC_MODEL_PF_CA: nx = 14; nu = 2; return 0;
+    }
+    return -1;
+}
+
+// Returns "" on success, else a description of what is wrong with the description.
+inline std::string build_spec(const usvmpc_desc &d, DevSpec &S)
+{
+    int nx, nu;
+    if (model_dims(d.model, nx, nu)) return "unknown model id";
+    if (d.N < 2) return "N must be >= 2";
+    if (!(d.Tf > 0.0)) return "Tf must be positive";
+    if (d.batch < 1) return "batch must be >= 1";
+    if (d.K < 0 || d.K > KMAX) return "K out of range (0..32)";
+    if (d.model == USVMPC_MODEL_USV && d.K != 0) return "model usv_model has no obstacle rows (K must be 0)";
+    if (d.nbu < 0 || d.nbu > nu || d.nbx < 0 || d.nbx > nx) return "nbu/nbx out of range";
+    const int nz = nx + nu, ny = nx + nu, ny_e = nx;
+    std::memset(&S, 0, sizeof(S));
+    S.dt = d.Tf / d.N;
+    S.N = d.N; S.K = d.K; S.B = d.batch; S.Bp = (d.batch + 3) / 4 * 4;
+    S.ny = ny; S.ny_e = ny_e;
+    // V = [Vu Vx] (ny x nz); Hc = dt V'WV; Mc = dt V'W
+    double V[LANES * LANES] = {0}, WV[LANES * LANES] = {0};
+    for (int i = 0; i < ny; i++) {
+        for (int j = 0; j < nu; j++) V[i * LANES + j] = d.Vu[i * nu + j];
+        for (int j = 0; j < nx; j++) V[i * LANES + nu + j] = d.Vx[i * nx + j];
+    }
+    for (int i = 0; i < ny; i++)
+        for (int j = 0; j < nz; j++) {
+            double a = 0;
+            for (int k = 0; k < ny; k++) a += d.W[i * ny + k] * V[k * LANES + j];
+            WV[i * LANES + j] = a;
+        }
+    for (int i = 0; i < nz; i++) {
+        for (int j = 0; j < nz; j++) {
+            double a = 0;
+            for (int k = 0; k < ny; k++) a += V[k * LANES + i] * WV[k * LANES + j];
+            S.Hc[i * LANES + j] = S.dt * a;
+        }
+        for (int y = 0; y < ny; y++) {
+            double a = 0;
+            for (int k = 0; k < ny; k++) a += V[k * LANES + i] * d.W[k * ny + y];
+            S.Mc[i * LANES + y] = S.dt * a;
+        }
+    }
+    // terminal: He = Vx_e' W_e Vx_e, Me = Vx_e' W_e, placed at the x rows/cols
+    for (int i = 0; i < nx; i++) {
+        for (int j = 0; j < nx; j++) {
+            double a = 0;
+            for (int k = 0; k < ny_e; k++)
+                for (int l = 0; l < ny_e; l++) a += d.Vx_e[k * nx + i] * d.W_e[k * ny_e + l] * d.Vx_e[l * nx + j];
+            S.He[(nu + i) * LANES + nu + j] = a;
+        }
+        for (int y = 0; y < ny_e; y++) {
+            double a = 0;
+            for (int k = 0; k < ny_e; k++) a += d.Vx_e[k * nx + i] * d.W_e[k * ny_e + y];
+            S.Me[(nu + i) * LANES + y] = a;
+        }
+    }
+    for (int i = 0; i < d.nbu; i++) {
+        const int j = d.idxbu[i];
+        if (j < 0 || j >= nu) return "idxbu out of range";
+        S.has_b[j] = 1; S.lb[j] = d.lbu[i]; S.ub[j] = d.ubu[i];
+    }
+    for (int i = 0; i < d.nbx; i++) {
+        const int j = d.idxbx[i];
+        if (j < 0 || j >= nx) return "idxbx out of range";
+        S.has_b[nu + j] = 1; S.lb[nu + j] = d.lbx[i]; S.ub[nu + j] = d.ubx[i];
+    }
+    for (int i = 0; i < d.K; i++) {
+        S.uh[i] = d.uh[i];
+        S.lsl[i] = d.lsh[i]; S.lsu[i] = d.ush[i];
+        S.zl[i] = S.dt * d.zl[i]; S.zu[i] = S.dt * d.zu[i];
+        S.Zl[i] = S.dt * d.Zl[i]; S.Zu[i] = S.dt * d.Zu[i];
+    }
+    S.nc = d.N * d.nbu * 2 + (d.N - 1) * (d.nbx * 2 + d.K * (d.soft ? 4 : 2));
+    S.iter_max = d.qp_iter_max;
+    S.mu0 = d.mu0; S.thr0 = d.thr0;
+    S.tol_stat = d.tol_stat; S.tol_eq = d.tol_eq; S.tol_ineq = d.tol_ineq; S.tol_comp = d.tol_comp;
+    S.alpha_min = d.alpha_min;
+    if (S.iter_max < 1) return "qp_iter_max must be >= 1";
+    return "";
+}
+
+inline void default_options(usvmpc_desc &d)
+{
+    d.qp_iter_max = 50;
+    d.mu0 = 10.0; d.thr0 = 0.1;
+    d.tol_stat = 1e-6; d.tol_eq = 1e-8; d.tol_ineq = 1e-8; d.tol_comp = 1e-8;
+    d.alpha_min = 1e-12;
+}
+
+// planes of the QP workspace per stage for a (model, KCH, soft) combination (see qp_ipm.hpp)
+inline int ws_planes(int nx, int nu, int kch, bool soft) { return 14 + kch * (soft ? 10 : 4) + nu + nx; }
+
+} // namespace usv

@@ -1,0 +1,126 @@
+// linearize.hpp — preparation phase of one SQP-RTI iteration, one 16-lane group per
+// (instance, stage) pair.  Replaces acados' sim_erk (+ generated *_expl_vde_forw),
+// ocp_nlp_cost_ls and ocp_nlp_constraints_bgh evaluation for the reference's OCPs
+// (/root/reference/catkin_ws/src/nmpc_ca/scripts/usv_guidance_ca1/acados_settings.py:83-194).
+//
+// Lane r (variable r of [u;x]) integrates ITS OWN column of the forward sensitivities
+// S = [dx+/du | dx+/dx] through the 4 RK stages (the VDE is linear in S column by column), while
+// every lane carries the nominal RK stage points.  The lane therefore ends up holding row r of
+// [B A]' — exactly the operand layout of the Riccati recursion (qp_ipm.hpp) — with no transpose.
+#pragma once
+#include "lanes.hpp"
+#include "params.hpp"
+#include "sfor.hpp"
+
+namespace usv {
+
+template <class M, int KCH>
+struct Linearize {
+    static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
+
+    // gid = k * Bp + g  (groups of a wave share the stage k)
+    USV_DEV static void run(const DevPtrs &P, long gid)
+    {
+        const DevSpec &S = *P.spec;
+        const int lane = lanes::lane();
+        const int N = S.N, K = S.K;
+        const long Bp = S.Bp;
+        const int k = (int)(gid / Bp);
+        const long g = gid - (long)k * Bp;
+        const long b = g < S.B ? g : (long)S.B - 1; // padded groups replay the last instance
+        const long stride = Bp * LANES;
+        const long gl = g * LANES + lane;
+        const bool xlane = lane >= NU && lane < NZ;
+
+        double x[NX], U[NU > 0 ? NU : 1];
+        const double *xk = P.x + ((long)b * (N + 1) + k) * NX;
+        sfor<0, NX>([&](auto i) { x[i] = xk[i]; });
+        if (k < N) {
+            const double *uk = P.u + ((long)b * N + k) * NU;
+            sfor<0, NU>([&](auto i) { U[i] = uk[i]; });
+        } else {
+            sfor<0, NU>([&](auto i) { U[i] = 0.0; });
+        }
+
+        // ---- cost gradient: g = Hc z - Mc yref (stage) | He z - Me yref_e (terminal) ----
+        {
+            const double *Hrow = (k < N ? S.Hc : S.He) + lane * LANES;
+            const double *Mrow = (k < N ? S.Mc : S.Me) + lane * LANES;
+            const double *yr = (k < N) ? P.yref + ((long)b * N + k) * S.ny : P.yref_e + (long)b * S.ny_e;
+            const int ny = (k < N) ? S.ny : S.ny_e;
+            double acc = 0.0;
+            sfor<0, NU>([&](auto i) { acc = fma(Hrow[i], U[i], acc); });
+            sfor<0, NX>([&](auto i) { acc = fma(Hrow[NU + i], x[i], acc); });
+            for (int y = 0; y < ny; y++) acc = fma(-Mrow[y], yr[y], acc);
+            P.gq[(long)k * stride + gl] = acc;
+        }
+        if (k == N) return; // wave-uniform
+
+        // ---- ERK4 + forward VDE for this lane's sensitivity column ----
+        const double dt = S.dt;
+        double s0[NX], f[NX], js[NX], xs[NX], ss[NX], xa[NX], sa[NX];
+        sfor<0, NX>([&](auto i) { s0[i] = (lane == NU + i) ? 1.0 : 0.0; });
+        M::fjvp(x, U, s0, f, js);
+        M::ju_add(lane, js);
+        sfor<0, NX>([&](auto i) {
+            xa[i] = f[i];
+            sa[i] = js[i];
+            xs[i] = fma(0.5 * dt, f[i], x[i]);
+            ss[i] = fma(0.5 * dt, js[i], s0[i]);
+        });
+        M::fjvp(xs, U, ss, f, js);
+        M::ju_add(lane, js);
+        sfor<0, NX>([&](auto i) {
+            xa[i] = fma(2.0, f[i], xa[i]);
+            sa[i] = fma(2.0, js[i], sa[i]);
+            xs[i] = fma(0.5 * dt, f[i], x[i]);
+            ss[i] = fma(0.5 * dt, js[i], s0[i]);
+        });
+        M::fjvp(xs, U, ss, f, js);
+        M::ju_add(lane, js);
+        sfor<0, NX>([&](auto i) {
+            xa[i] = fma(2.0, f[i], xa[i]);
+            sa[i] = fma(2.0, js[i], sa[i]);
+            xs[i] = fma(dt, f[i], x[i]);
+            ss[i] = fma(dt, js[i], s0[i]);
+        });
+        M::fjvp(xs, U, ss, f, js);
+        M::ju_add(lane, js);
+        const double *xn = P.x + ((long)b * (N + 1) + k + 1) * NX;
+        double bres = 0.0;
+        sfor<0, NX>([&](auto i) {
+            const double xnext = fma(dt / 6.0, xa[i] + f[i], x[i]);
+            sa[i] = fma(dt / 6.0, sa[i] + js[i], s0[i]);
+            bres = (lane == NU + i) ? xnext - xn[i] : bres;
+        });
+        // row r of [B A]' (coalesced) and, scattered, column r of the rows of [B A] that the
+        // forward sweep reads (lane nu+j gets d x+_j / d z_r)
+        sfor<0, NX>([&](auto i) {
+            P.BAt[((long)k * NX + i) * stride + gl] = (lane < NZ) ? sa[i] : 0.0;
+            if (lane < NZ) P.ABr[((long)k * NZ + lane) * stride + g * LANES + NU + i] = sa[i];
+        });
+        P.rb0[(long)k * stride + gl] = xlane ? bres : 0.0;
+
+        // ---- obstacle rows: h_i = |pos - o_i|, gradient, bounds relative to h ----
+        if constexpr (KCH > 0) {
+            const double px = x[M::IPX], py = x[M::IPY];
+            const double *pk = P.p + ((long)b * (N + 1) + k) * 2 * K;
+            const double *lhk = P.lh + ((long)b * N + k) * K;
+            sfor<0, KCH>([&](auto c) {
+                const int i = c * LANES + lane;
+                const bool act = i < K;
+                const int ii = act ? i : 0;
+                const double dx = px - pk[2 * ii], dy = py - pk[2 * ii + 1];
+                const double d = sqrt(dx * dx + dy * dy);
+                const double id = 1.0 / d;
+                double *cp = P.con + (((long)k * KCH + c) * 4) * stride + gl;
+                cp[0 * stride] = act ? dx * id : 0.0;
+                cp[1 * stride] = act ? dy * id : 0.0;
+                cp[2 * stride] = act ? lhk[ii] - d : -1.0;
+                cp[3 * stride] = act ? S.uh[ii] - d : 1.0;
+            });
+        }
+    }
+};
+
+} // namespace usv

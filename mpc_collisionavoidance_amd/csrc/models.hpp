@@ -1,0 +1,169 @@
+// models.hpp — the three in-scope USV models as device functions.
+//
+// Each model provides f(x,u) together with the directional derivative Jx(x)·s for ONE
+// sensitivity column s (the lane's own column of [dx+/du | dx+/dx]); the control Jacobian of
+// all three models is constant and is added by ju_add().  Formulas follow the reference's
+// CasADi definitions (paths relative to /root/reference/catkin_ws/src/nmpc_ca/scripts/):
+//   M0 usv_model              usv_acados/usv_model.py:61-122
+//   M1 usv_model_guidance_ca1 usv_guidance_ca1/usv_model.py:61-140
+//   M2 usv_model_pf_ca        usv_pf_ca/usv_model.py:61-168
+// CasADi differentiates fabs() to sign(), if_else() branches to their own derivatives and
+// sqrt(u²+v²) to a 0/0 at the origin; the same conventions are used here.
+#pragma once
+#include "lanes.hpp"
+#include <cmath>
+
+namespace usv {
+
+USV_DEV double sgn(double a) { return (a > 0.0 ? 1.0 : 0.0) - (a < 0.0 ? 1.0 : 0.0); }
+
+// 3-DOF surface-vessel block shared by M0 and M2 (usv_acados/usv_model.py:61-77,110-122).
+// In: u,v,r,Tp,Ts and the matching entries of the column s; out: (udot,vdot,rdot) and J·s.
+struct Dof3 {
+    static constexpr double m = 30.0, Iz = 4.1, Bw = 0.41;
+    static constexpr double Xud = -2.25, Yvd = -23.13, Yrd = -1.31, Nvd = -16.41, Nrd = -2.79;
+    static constexpr double Yvv = -99.99, Yvr = -5.49, Nrv = -8.8, Nrr = -3.49;
+
+    USV_DEV static void eval(double c, double u, double v, double r, double Tp, double Ts,
+                             double su, double sv, double sr, double sTp, double sTs,
+                             double *f, double *js)
+    {
+        const double CY = 0.5 * (-40.0 * 1000.0) *
+                          (1.1 + 0.0045 * (1.01 / 0.09) - 0.1 * (0.27 / 0.09) + 0.016 * ((0.27 / 0.09) * (0.27 / 0.09)));
+        const bool fast = u > 1.25;
+        const double Xu = fast ? 64.55 : -25.0;
+        const double Xuu = fast ? -70.92 : 0.0;
+        const double au = fabs(u), av = fabs(v), ar = fabs(r);
+        const double sp = sqrt(u * u + v * v);
+        const double Nr = -0.52 * sp;
+        const double idu = 1.0 / (m - Xud), idv = 1.0 / (m - Yvd), idr = 1.0 / (Iz - Nrd);
+        const double Tu = Tp + c * Ts;
+        const double Tr = (Tp - c * Ts) * (Bw / 2.0);
+        const double a = Yrd + Nvd;
+        f[0] = (Tu - (-m + 2.0 * Yvd) * v - a * r * r - (-Xu * u - Xuu * au * u)) * idu;
+        f[1] = (-(m - Xud) * u * r - (-CY * av - Yvv * av - Yvr * ar) * v) * idv;
+        f[2] = (Tr - (-2.0 * Yvd * u * v - a * r * u + Xud * u * r) - (-Nr * r - Nrv * av * r - Nrr * ar * r)) * idr;
+        // rows of the 3x5 Jacobian applied to (su,sv,sr,sTp,sTs)
+        js[0] = ((Xu + 2.0 * Xuu * au) * su + (m - 2.0 * Yvd) * sv - 2.0 * a * r * sr + sTp + c * sTs) * idu;
+        js[1] = (-(m - Xud) * r * su + (2.0 * (CY + Yvv) * av + Yvr * ar) * sv +
+                 (-(m - Xud) * u + Yvr * sgn(r) * v) * sr) * idv;
+        {
+            const double isp = 1.0 / sp; // inf at u=v=0 -> NaN, as the CasADi expression
+            const double dNu = -0.52 * u * isp, dNv = -0.52 * v * isp;
+            js[2] = ((2.0 * Yvd * v + a * r - Xud * r + dNu * r) * su +
+                     (2.0 * Yvd * u + dNv * r + Nrv * sgn(v) * r) * sv +
+                     (a * u - Xud * u + Nr + Nrv * av + 2.0 * Nrr * ar) * sr +
+                     (Bw / 2.0) * sTp - c * (Bw / 2.0) * sTs) * idr;
+        }
+    }
+};
+
+struct ModelM0 {
+    static constexpr int ID = 0, NX = 5, NU = 2, IPX = 0, IPY = 0; // no obstacles (K = 0)
+    USV_DEV static void fjvp(const double *x, const double *U, const double *s, double *f, double *js)
+    {
+        Dof3::eval(0.78, x[0], x[1], x[2], x[3], x[4], s[0], s[1], s[2], s[3], s[4], f, js);
+        f[3] = U[0];
+        f[4] = U[1];
+        js[3] = 0.0;
+        js[4] = 0.0;
+    }
+    USV_DEV static void ju_add(int lane, double *js)
+    {
+        js[3] += (lane == 0) ? 1.0 : 0.0;
+        js[4] += (lane == 1) ? 1.0 : 0.0;
+    }
+};
+
+struct ModelM1 {
+    static constexpr int ID = 1, NX = 8, NU = 1, IPX = 5, IPY = 6;
+    // x = (u, v, ye, chie, psied, xned, yned, psi), T1 = 1
+    USV_DEV static void fjvp(const double *x, const double *U, const double *s, double *f, double *js)
+    {
+        const double u = x[0], v = x[1], chie = x[3], psied = x[4], psi = x[7];
+        const double ue = u + 0.001;
+        const double iden = 1.0 / (ue * ue + v * v);
+        const double beta = atan2(v, ue);
+        const double psie = chie - beta;
+        double sp, cp, sq, cq;
+        sincos(psie, &sp, &cp);
+        sincos(psi, &sq, &cq);
+        // directional derivative of psie along s
+        const double dpsie = s[3] - (-v * iden * s[0] + ue * iden * s[1]);
+        f[0] = 0.0;
+        f[1] = 0.0;
+        f[2] = u * sp + v * cp;
+        f[3] = psied - psie;
+        f[4] = U[0];
+        f[5] = u * cq - v * sq;
+        f[6] = u * sq + v * cq;
+        f[7] = psied - psie;
+        js[0] = 0.0;
+        js[1] = 0.0;
+        js[2] = sp * s[0] + cp * s[1] + (u * cp - v * sp) * dpsie;
+        js[3] = s[4] - dpsie;
+        js[4] = 0.0;
+        js[5] = cq * s[0] - sq * s[1] + (-u * sq - v * cq) * s[7];
+        js[6] = sq * s[0] + cq * s[1] + (u * cq - v * sq) * s[7];
+        js[7] = s[4] - dpsie;
+    }
+    USV_DEV static void ju_add(int lane, double *js) { js[4] += (lane == 0) ? 1.0 : 0.0; }
+};
+
+struct ModelM2 {
+    static constexpr int ID = 2, NX = 14, NU = 2, IPX = 10, IPY = 11;
+    // x = (psi, sinpsi, cospsi, u, v, r, ye, x1, y1, ak, nedx, nedy, Tport, Tstbd), c = 1
+    USV_DEV static void fjvp(const double *x, const double *U, const double *s, double *f, double *js)
+    {
+        const double psi = x[0], u = x[3], v = x[4], r = x[5], ak = x[9];
+        const double ue = u + .001;
+        const double iden = 1.0 / (ue * ue + v * v);
+        const double beta = atan2(v, ue);
+        double sc, cc, sp, cp, sa, ca;
+        sincos(psi + beta, &sc, &cc);
+        sincos(psi, &sp, &cp);
+        sincos(ak, &sa, &ca);
+        const double dchi = s[0] + (-v * iden) * s[3] + (ue * iden) * s[4];
+        double f3[3], j3[3];
+        Dof3::eval(1.0, u, v, r, x[12], x[13], s[3], s[4], s[5], s[12], s[13], f3, j3);
+        const double vx = u * cp - v * sp; // NED velocity components
+        const double vy = u * sp + v * cp;
+        f[0] = r;
+        f[1] = cc * r;
+        f[2] = -sc * r;
+        f[3] = f3[0];
+        f[4] = f3[1];
+        f[5] = f3[2];
+        f[6] = -vx * sa + vy * ca;
+        f[7] = 0.0;
+        f[8] = 0.0;
+        f[9] = 0.0;
+        f[10] = vx;
+        f[11] = vy;
+        f[12] = U[0];
+        f[13] = U[1] / 1.0;
+        const double dvx = cp * s[3] - sp * s[4] - vy * s[0];
+        const double dvy = sp * s[3] + cp * s[4] + vx * s[0];
+        js[0] = s[5];
+        js[1] = -sc * r * dchi + cc * s[5];
+        js[2] = -cc * r * dchi - sc * s[5];
+        js[3] = j3[0];
+        js[4] = j3[1];
+        js[5] = j3[2];
+        js[6] = -dvx * sa + dvy * ca + (-vx * ca - vy * sa) * s[9];
+        js[7] = 0.0;
+        js[8] = 0.0;
+        js[9] = 0.0;
+        js[10] = dvx;
+        js[11] = dvy;
+        js[12] = 0.0;
+        js[13] = 0.0;
+    }
+    USV_DEV static void ju_add(int lane, double *js)
+    {
+        js[12] += (lane == 0) ? 1.0 : 0.0;
+        js[13] += (lane == 1) ? 1.0 / 1.0 : 0.0;
+    }
+};
+
+} // namespace usv

@@ -1,0 +1,57 @@
+// params.hpp — plain-data structs shared by the host C-ABI layer and the device kernels.
+#pragma once
+
+namespace usv {
+
+constexpr int LANES = 16;   // lanes per OCP instance (one DPP row)
+constexpr int KMAX = 32;    // obstacle rows per stage (2 chunks of 16 lanes)
+
+// Constants of one OCP definition (identical for every instance of the batch). Lives in device
+// memory; row-indexed tables are read per lane.
+struct DevSpec {
+    double Hc[LANES * LANES];  // dt * [Vu Vx]' W [Vu Vx], [u;x] ordering, 16x16 zero padded
+    double He[LANES * LANES];  // terminal Vx_e' W_e Vx_e placed at the x rows/cols
+    double Mc[LANES * LANES];  // dt * [Vu Vx]' W        (nz x ny)
+    double Me[LANES * LANES];  // Vx_e' W_e at the x rows (nz x ny_e)
+    double lb[LANES], ub[LANES];  // box bounds per variable of [u;x]
+    int has_b[LANES];             // 1: variable carries a box constraint
+    double uh[KMAX];
+    double lsl[KMAX], lsu[KMAX];  // lower bounds of the soft slacks (lsh, ush)
+    double zl[KMAX], zu[KMAX], Zl[KMAX], Zu[KMAX];  // slack penalties, already scaled by dt
+    double dt;
+    int N, K, B, Bp;              // horizon, obstacles, batch, batch padded to a multiple of 4
+    int ny, ny_e;
+    int nc;                       // number of (lambda, t) pairs of the whole QP
+    int iter_max;
+    double mu0, thr0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min;
+};
+
+// Device pointers of one solver handle.
+struct DevPtrs {
+    const DevSpec *spec;
+    // caller-visible arrays, natural layout, instance-major
+    double *x;            // [B][N+1][nx]
+    double *u;            // [B][N][nu]
+    const double *x0;     // [B][nx]
+    const double *yref;   // [B][N][ny]
+    const double *yref_e; // [B][ny_e]
+    const double *p;      // [B][N+1][2K]
+    const double *lh;     // [B][N][K]
+    double *sl, *su;      // [B][N][K]   soft slack values of the last QP
+    double *pi;           // [B][N][nx]  dynamics multipliers pi_1..pi_N of the last QP
+    int *status;          // [B]
+    int *qp_iter;         // [B]
+    int *qp_status;       // [B]   0 ok, 1 max iter, 2 min step, 3 nan
+    double *res;          // [B][4]      final QP residuals (stat, eq, ineq, comp)
+    // linearisation output, lane-major planes: element (k, e) of group g, lane r at
+    // ((k*E + e) * Bp + g) * 16 + r
+    double *BAt;          // [N][nx]   row r of [B A]'   (lane r = variable r of [u;x])
+    double *ABr;          // [N][nz]   row j of [B A]    (lane nu+j = state j)
+    double *rb0;          // [N]       dynamics residual b_k (x lanes)
+    double *gq;           // [N+1]     cost gradient
+    double *con;          // [N][KCH][4] obstacle rows: cx, cy, lg, ug (lane i = obstacle c*16+i)
+    // QP workspace, lane-major planes [N+1][NPL]
+    double *ws;
+};
+
+} // namespace usv

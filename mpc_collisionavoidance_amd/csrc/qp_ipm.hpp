@@ -1,0 +1,654 @@
+// qp_ipm.hpp — feedback phase of one SQP-RTI iteration: the OCP-structured QP solved by a
+// Mehrotra predictor-corrector interior-point method on a Riccati recursion, followed by the
+// full RTI step.  Replaces acados' ocp_qp_hpipm (HPIPM d_ocp_qp_ipm_solve + Riccati KKT
+// factor/solve) and ocp_nlp_update_variables for the reference's OCPs (qp_solver =
+// PARTIAL_CONDENSING_HPIPM with the default block size, i.e. no condensing:
+// /root/reference/catkin_ws/src/nmpc_ca/scripts/usv_guidance_ca1/acados_settings.py:190-194).
+//
+// Mapping: one OCP instance = one 16-lane DPP row (lanes.hpp).  Lane r owns variable r of the
+// stage vector z = [u;x], row r of every stage matrix ([B A]', P, G), the box constraint on
+// variable r, and obstacle row c*16+r of chunk c.  All matrix products are "own row × broadcast
+// row" FMAs; the only reductions are the obstacle-row sums and the nu gain dot products.
+//
+// Riccati form: classical (explicit, symmetric P_k; Cholesky of the nu×nu block only).  In the
+// row-per-lane layout every product it needs is a natural one, whereas the square-root form
+// would need transposed products (L'b) and a 16-step sequential potrf per stage.
+//
+// Five sweeps over the horizon per IPM iteration, all state streamed through lane-major planes
+// in HBM (ws): backward A (residuals + factorise + predictor rhs), forward A (affine step),
+// backward B (corrector rhs), forward B (step), update.
+#pragma once
+#include "lanes.hpp"
+#include "params.hpp"
+#include "sfor.hpp"
+
+namespace usv {
+
+// One two-sided inequality row  dl <= v (+ sl),  v (- su) <= du  with its multipliers/slacks,
+// and the closed-form elimination of (lambda, t, sl, su) used by HPIPM-style IPMs.
+template <bool SOFTROW>
+struct RowCalc {
+    double ll, lu, tl, tu, sl, su, lsl, lsu, tsl, tsu;          // state
+    double dl, du, zl, zu, Zl, Zu, bsl, bsu;                    // data
+    bool act;
+    double rdl, rdu, rsl, rsu, rdsl, rdsu;                      // residuals
+    double Gl, Gu, iDl, iDu, rhol, rhou;                        // elimination
+    double ml, mu, msl, msu;                                    // complementarity targets
+    double dll, dlu, dtl, dtu, dsl, dsu, dlsl, dlsu, dtsl, dtsu; // step
+
+    USV_DEV void neutral()
+    {
+        ll = lu = 0.0; tl = tu = 1.0; sl = su = 0.0; lsl = lsu = 0.0; tsl = tsu = 1.0;
+        dl = -1.0; du = 1.0; zl = zu = 0.0; Zl = Zu = 1.0; bsl = bsu = -1.0;
+    }
+    USV_DEV void resid(double v)
+    {
+        rdl = v + sl - dl - tl;
+        rdu = du - v + su - tu;
+        if constexpr (SOFTROW) {
+            rsl = Zl * sl + zl - ll - lsl;
+            rsu = Zu * su + zu - lu - lsu;
+            rdsl = sl - bsl - tsl;
+            rdsu = su - bsu - tsu;
+        }
+    }
+    USV_DEV void targets_pred()
+    {
+        ml = ll * tl; mu = lu * tu;
+        if constexpr (SOFTROW) { msl = lsl * tsl; msu = lsu * tsu; }
+    }
+    USV_DEV void targets_corr(double sigmu) // uses the affine step currently held in d*
+    {
+        ml = ll * tl + dll * dtl - sigmu; mu = lu * tu + dlu * dtu - sigmu;
+        if constexpr (SOFTROW) { msl = lsl * tsl + dlsl * dtsl - sigmu; msu = lsu * tsu + dlsu * dtsu - sigmu; }
+    }
+    // Gh: coefficient of c c' added to the stage Hessian; gam: coefficient of c added to the gradient
+    USV_DEV void reduce(double &Gh, double &gam)
+    {
+        const double itl = 1.0 / tl, itu = 1.0 / tu;
+        Gl = ll * itl; Gu = lu * itu;
+        double Ghl, Ghu, gl, gu;
+        if constexpr (SOFTROW) {
+            const double itsl = 1.0 / tsl, itsu = 1.0 / tsu;
+            const double Gsl = lsl * itsl, Gsu = lsu * itsu;
+            iDl = 1.0 / (Zl + Gl + Gsl);
+            iDu = 1.0 / (Zu + Gu + Gsu);
+            rhol = -rsl - ml * itl - Gl * rdl - msl * itsl - Gsl * rdsl;
+            rhou = -rsu - mu * itu - Gu * rdu - msu * itsu - Gsu * rdsu;
+            Ghl = Gl * (1.0 - Gl * iDl);
+            Ghu = Gu * (1.0 - Gu * iDu);
+            gl = ml * itl + Gl * rdl + Gl * rhol * iDl;
+            gu = mu * itu + Gu * rdu + Gu * rhou * iDu;
+        } else {
+            Ghl = Gl; Ghu = Gu;
+            gl = ml * itl + Gl * rdl;
+            gu = mu * itu + Gu * rdu;
+        }
+        Gh = act ? Ghl + Ghu : 0.0;
+        gam = act ? gl - gu : 0.0;
+    }
+    USV_DEV void expand(double w) // w = c' dz
+    {
+        if constexpr (SOFTROW) {
+            dsl = (rhol - Gl * w) * iDl;
+            dsu = (rhou + Gu * w) * iDu;
+            dtsl = dsl + rdsl;
+            dtsu = dsu + rdsu;
+            dlsl = -(msl + lsl * dtsl) / tsl;
+            dlsu = -(msu + lsu * dtsu) / tsu;
+        } else {
+            dsl = 0.0; dsu = 0.0;
+        }
+        dtl = w + dsl + rdl;
+        dtu = -w + dsu + rdu;
+        dll = -(ml + ll * dtl) / tl;
+        dlu = -(mu + lu * dtu) / tu;
+    }
+    USV_DEV static double ratio(double v, double dv, double a)
+    {
+        const double q = -v / dv;
+        return (dv < 0.0 && q < a) ? q : a;
+    }
+    USV_DEV double alpha(double a) const
+    {
+        if (!act) return a;
+        a = ratio(ll, dll, a); a = ratio(lu, dlu, a); a = ratio(tl, dtl, a); a = ratio(tu, dtu, a);
+        if constexpr (SOFTROW) {
+            a = ratio(lsl, dlsl, a); a = ratio(lsu, dlsu, a); a = ratio(tsl, dtsl, a); a = ratio(tsu, dtsu, a);
+        }
+        return a;
+    }
+    USV_DEV void apply(double a)
+    {
+        ll += a * dll; lu += a * dlu; tl += a * dtl; tu += a * dtu;
+        if constexpr (SOFTROW) {
+            sl += a * dsl; su += a * dsu;
+            lsl += a * dlsl; lsu += a * dlsu; tsl += a * dtsl; tsu += a * dtsu;
+        }
+    }
+};
+
+template <class M, int KCH, bool SOFT>
+struct QpIpm {
+    static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
+    static constexpr int PXL = NU + M::IPX, PYL = NU + M::IPY;
+    // plane map of the per-stage workspace
+    enum : int { P_Z = 0, P_PI, P_RB, P_RG, P_DZA, P_DZ, P_DPI, P_PV, P_PB, P_LUV,
+                 P_BLL, P_BLU, P_BTL, P_BTU, P_OBS };
+    static constexpr int OBSN = SOFT ? 10 : 4;
+    static constexpr int P_LZU = P_OBS + KCH * OBSN;
+    static constexpr int P_PM = P_LZU + NU;
+    static constexpr int NPL = P_PM + NX;
+
+    using BoxRow = RowCalc<false>;
+    using ObsRow = RowCalc<SOFT>;
+
+    const DevPtrs &P;
+    const DevSpec &S;
+    int lane, N;
+    long g, b, gl, stride;
+    bool xlane, ulane, valid, isPX, isPY;
+
+    USV_DEV QpIpm(const DevPtrs &P_, long g_) : P(P_), S(*P_.spec)
+    {
+        lane = lanes::lane();
+        N = S.N;
+        g = g_;
+        b = g < S.B ? g : (long)S.B - 1;
+        gl = g * LANES + lane;
+        stride = (long)S.Bp * LANES;
+        ulane = lane < NU;
+        xlane = lane >= NU && lane < NZ;
+        valid = lane < NZ;
+        isPX = KCH > 0 && lane == PXL;
+        isPY = KCH > 0 && lane == PYL;
+    }
+
+    USV_DEV double &W(int k, int plane) const { return P.ws[((long)k * NPL + plane) * stride + gl]; }
+
+    // iterate value of this lane's variable at stage k
+    USV_DEV double zbar(int k) const
+    {
+        if (ulane) return (k < N) ? P.u[((long)b * N + k) * NU + lane] : 0.0;
+        if (xlane) return P.x[((long)b * (N + 1) + k) * NX + (lane - NU)];
+        return 0.0;
+    }
+
+    USV_DEV void box_data(int k, BoxRow &r) const
+    {
+        const double zb = zbar(k);
+        const int l = valid ? lane : 0;
+        const bool stage_ok = ulane ? (k < N) : (k >= 1 && k < N);
+        r.act = valid && S.has_b[l] != 0 && stage_ok;
+        r.dl = r.act ? S.lb[l] - zb : -1.0;
+        r.du = r.act ? S.ub[l] - zb : 1.0;
+    }
+    USV_DEV void box_load(int k, BoxRow &r) const
+    {
+        r.neutral();
+        box_data(k, r);
+        if (r.act) { r.ll = W(k, P_BLL); r.lu = W(k, P_BLU); r.tl = W(k, P_BTL); r.tu = W(k, P_BTU); }
+    }
+    USV_DEV void box_store(int k, const BoxRow &r) const
+    {
+        W(k, P_BLL) = r.ll; W(k, P_BLU) = r.lu; W(k, P_BTL) = r.tl; W(k, P_BTU) = r.tu;
+    }
+    // obstacle chunk c at stage k: constants (cx, cy) + row
+    USV_DEV void obs_data(int k, int c, ObsRow &r, double &cx, double &cy) const
+    {
+        const int i = c * LANES + lane;
+        const bool stage_ok = (k >= 1 && k < N);
+        r.act = stage_ok && i < S.K;
+        const int kk = stage_ok ? k : 0;
+        const double *cp = P.con + (((long)kk * KCH + c) * 4) * stride + gl;
+        cx = r.act ? cp[0] : 0.0;
+        cy = r.act ? cp[stride] : 0.0;
+        r.dl = r.act ? cp[2 * stride] : -1.0;
+        r.du = r.act ? cp[3 * stride] : 1.0;
+        if constexpr (SOFT) {
+            const int ii = r.act ? i : 0;
+            r.zl = S.zl[ii]; r.zu = S.zu[ii];
+            r.Zl = r.act ? S.Zl[ii] : 1.0; r.Zu = r.act ? S.Zu[ii] : 1.0;
+            r.bsl = S.lsl[ii]; r.bsu = S.lsu[ii];
+        }
+    }
+    USV_DEV void obs_load(int k, int c, ObsRow &r, double &cx, double &cy) const
+    {
+        r.neutral();
+        obs_data(k, c, r, cx, cy);
+        if (r.act) {
+            const int p0 = P_OBS + c * OBSN;
+            r.ll = W(k, p0); r.lu = W(k, p0 + 1); r.tl = W(k, p0 + 2); r.tu = W(k, p0 + 3);
+            if constexpr (SOFT) {
+                r.sl = W(k, p0 + 4); r.su = W(k, p0 + 5); r.lsl = W(k, p0 + 6); r.lsu = W(k, p0 + 7);
+                r.tsl = W(k, p0 + 8); r.tsu = W(k, p0 + 9);
+            }
+        }
+    }
+    USV_DEV void obs_store(int k, int c, const ObsRow &r) const
+    {
+        const int p0 = P_OBS + c * OBSN;
+        W(k, p0) = r.ll; W(k, p0 + 1) = r.lu; W(k, p0 + 2) = r.tl; W(k, p0 + 3) = r.tu;
+        if constexpr (SOFT) {
+            W(k, p0 + 4) = r.sl; W(k, p0 + 5) = r.su; W(k, p0 + 6) = r.lsl; W(k, p0 + 7) = r.lsu;
+            W(k, p0 + 8) = r.tsl; W(k, p0 + 9) = r.tsu;
+        }
+    }
+    USV_DEV static double obs_dot(double cx, double cy, double vec)
+    {
+        return cx * lanes::bcast<PXL>(vec) + cy * lanes::bcast<PYL>(vec);
+    }
+
+    // ------------------------------------------------------------------ cold start
+    USV_DEV void init()
+    {
+        for (int k = 0; k <= N; k++) {
+            W(k, P_Z) = 0.0;
+            W(k, P_PI) = 0.0;
+            W(k, P_RB) = (k < N) ? P.rb0[(long)k * stride + gl] : 0.0;
+            BoxRow r;
+            r.neutral();
+            box_data(k, r);
+            r.tl = fmax(0.0 - r.dl, S.thr0); r.tu = fmax(r.du - 0.0, S.thr0);
+            r.ll = S.mu0 / r.tl; r.lu = S.mu0 / r.tu;
+            box_store(k, r);
+            if constexpr (KCH > 0) {
+                sfor<0, KCH>([&](auto c) {
+                    ObsRow o;
+                    double cx, cy;
+                    o.neutral();
+                    obs_data(k, c, o, cx, cy);
+                    o.tl = fmax(0.0 - o.dl, S.thr0); o.tu = fmax(o.du - 0.0, S.thr0);
+                    o.ll = S.mu0 / o.tl; o.lu = S.mu0 / o.tu;
+                    if constexpr (SOFT) {
+                        o.tsl = fmax(0.0 - o.bsl, S.thr0); o.tsu = fmax(0.0 - o.bsu, S.thr0);
+                        o.lsl = S.mu0 / o.tsl; o.lsu = S.mu0 / o.tsu;
+                    }
+                    obs_store(k, c, o);
+                });
+            }
+        }
+    }
+
+    // x0 equality residual  e = (x0 - xbar_0) - z_0  (x lanes)
+    USV_DEV double x0_resid() const
+    {
+        if (!xlane) return 0.0;
+        return (P.x0[(long)b * NX + (lane - NU)] - P.x[((long)b * (N + 1)) * NX + (lane - NU)]) - W(0, P_Z);
+    }
+
+    struct Norms { double rg, rb, rd, rm, musum, nan; };
+
+    // row chain up to the elimination; corr: predictor step (from dza) then corrector targets
+    template <class R>
+    USV_DEV static void chain(R &r, double v, bool corr, double w_aff, double sigmu, double &Gh, double &gam)
+    {
+        r.resid(v);
+        r.targets_pred();
+        r.reduce(Gh, gam);
+        if (corr) {
+            r.expand(w_aff);
+            r.targets_corr(sigmu);
+            r.reduce(Gh, gam);
+        }
+    }
+
+    // ------------------------------------------------------------------ backward sweeps
+    // FACT = true : residuals, norms, Hessian reduction, Riccati factorisation, predictor rhs
+    // FACT = false: corrector rhs only, reusing the stored factors
+    template <bool FACT>
+    USV_DEV void backward(Norms &nm, double sigmu)
+    {
+        double Pn[NX], pn = 0.0, pin = 0.0;
+        sfor<0, NX>([&](auto c) { Pn[c] = 0.0; });
+        if (FACT) { nm.rg = nm.rb = nm.rd = nm.rm = nm.musum = nm.nan = 0.0; }
+        for (int k = N; k >= 0; k--) {
+            const double z = W(k, P_Z);
+            const double *Hrow = (k < N ? S.Hc : S.He) + lane * LANES;
+            // ---- rows
+            BoxRow br;
+            box_load(k, br);
+            double Ghb, gamb;
+            const double dza = FACT ? 0.0 : W(k, P_DZA);
+            chain(br, z, !FACT, dza, sigmu, Ghb, gamb);
+            double Sxx = 0.0, Sxy = 0.0, Syy = 0.0, gx = 0.0, gy = 0.0, lx = 0.0, ly = 0.0;
+            if constexpr (KCH > 0) {
+                sfor<0, KCH>([&](auto c) {
+                    ObsRow o;
+                    double cx, cy, Gh, gam;
+                    obs_load(k, c, o, cx, cy);
+                    const double v = obs_dot(cx, cy, z);
+                    const double wa = FACT ? 0.0 : obs_dot(cx, cy, dza);
+                    chain(o, v, !FACT, wa, sigmu, Gh, gam);
+                    gx += gam * cx; gy += gam * cy;
+                    if (FACT) {
+                        Sxx += Gh * cx * cx; Sxy += Gh * cx * cy; Syy += Gh * cy * cy;
+                        const double dl_ = o.act ? o.ll - o.lu : 0.0;
+                        lx += dl_ * cx; ly += dl_ * cy;
+                        if (o.act) {
+                            nm.rd = fmax(nm.rd, fmax(fabs(o.rdl), fabs(o.rdu)));
+                            nm.rm = fmax(nm.rm, fmax(o.ll * o.tl, o.lu * o.tu));
+                            nm.musum += o.ll * o.tl + o.lu * o.tu;
+                            nm.nan = fma(0.0, o.rdl + o.rdu, nm.nan);
+                            if constexpr (SOFT) {
+                                nm.rg = fmax(nm.rg, fmax(fabs(o.rsl), fabs(o.rsu)));
+                                nm.rd = fmax(nm.rd, fmax(fabs(o.rdsl), fabs(o.rdsu)));
+                                nm.rm = fmax(nm.rm, fmax(o.lsl * o.tsl, o.lsu * o.tsu));
+                                nm.musum += o.lsl * o.tsl + o.lsu * o.tsu;
+                                nm.nan = fma(0.0, o.rsl + o.rsu + o.rdsl + o.rdsu, nm.nan);
+                            }
+                        }
+                    }
+                });
+                gx = lanes::gsum(gx); gy = lanes::gsum(gy);
+                if (FACT) {
+                    Sxx = lanes::gsum(Sxx); Sxy = lanes::gsum(Sxy); Syy = lanes::gsum(Syy);
+                    lx = lanes::gsum(lx); ly = lanes::gsum(ly);
+                }
+            }
+            double bat[NX];
+            if (k < N) sfor<0, NX>([&](auto j) { bat[j] = P.BAt[((long)k * NX + j) * stride + gl]; });
+            else sfor<0, NX>([&](auto j) { bat[j] = 0.0; });
+            const double pik = W(k, P_PI);
+            double rg;
+            if (FACT) {
+                // stationarity residual r_g = H z + g + [B A]' pi_{k+1} - [0; pi_k] - sum c (ll - lu)
+                rg = P.gq[(long)k * stride + gl];
+                sfor<0, NZ>([&](auto c) { lanes::fma_bc<c>(rg, z, Hrow[c]); });
+                sfor<0, NX>([&](auto j) { lanes::fma_bc<NU + j>(rg, pin, bat[j]); });
+                rg -= (xlane && k >= 1) ? pik : 0.0;
+                rg -= br.act ? br.ll - br.lu : 0.0;
+                rg -= isPX ? lx : (isPY ? ly : 0.0);
+                W(k, P_RG) = rg;
+                const bool counts = valid && !(k == 0 && xlane) && !(k == N && ulane);
+                nm.rg = fmax(nm.rg, counts ? fabs(rg) : 0.0);
+                nm.nan = fma(0.0, rg, nm.nan);
+                if (br.act) {
+                    nm.rd = fmax(nm.rd, fmax(fabs(br.rdl), fabs(br.rdu)));
+                    nm.rm = fmax(nm.rm, fmax(br.ll * br.tl, br.lu * br.tu));
+                    nm.musum += br.ll * br.tl + br.lu * br.tu;
+                    nm.nan = fma(0.0, br.rdl + br.rdu, nm.nan);
+                }
+            } else {
+                rg = W(k, P_RG);
+            }
+            const double gt = rg + gamb + (isPX ? gx : (isPY ? gy : 0.0));
+            const double rb = (k < N) ? W(k, P_RB) : 0.0;
+            if (FACT) nm.rb = fmax(nm.rb, fabs(rb));
+
+            double pv;
+            if (k == N) {
+                if (FACT) {
+                    sfor<0, NX>([&](auto c) {
+                        Pn[c] = xlane ? Hrow[NU + c] : 0.0;
+                        W(k, P_PM + c) = Pn[c];
+                    });
+                }
+                pv = xlane ? gt : 0.0;
+                W(k, P_PV) = pv;
+            } else {
+                double Lzu[NU], Pb;
+                if (FACT) {
+                    // T = [B A]' P_{k+1}   (row r: sum_j bat_j * P_{k+1}[j][:])
+                    double T[NX];
+                    sfor<0, NX>([&](auto c) {
+                        double a = 0.0;
+                        sfor<0, NX>([&](auto j) { lanes::fma_bc<NU + j>(a, Pn[c], bat[j]); });
+                        T[c] = a;
+                    });
+                    // G = H~ + T [B A]     (row r, column c': sum_j T_j * BAt[c'][j])
+                    double Gr[NZ];
+                    sfor<0, NZ>([&](auto c) {
+                        double a = Hrow[c] + ((lane == c) ? Ghb : 0.0);
+                        if constexpr (KCH > 0) {
+                            if constexpr (c == PXL) a += isPX ? Sxx : (isPY ? Sxy : 0.0);
+                            if constexpr (c == PYL) a += isPX ? Sxy : (isPY ? Syy : 0.0);
+                        }
+                        sfor<0, NX>([&](auto j) { lanes::fma_bc<c>(a, bat[j], T[j]); });
+                        Gr[c] = a;
+                    });
+                    // Cholesky of the leading nu columns, all rows at once
+                    sfor<0, NU>([&](auto l) {
+                        const double piv = lanes::bcast<l>(Gr[l]);
+                        const double il = 1.0 / sqrt(piv);
+                        Lzu[l] = Gr[l] * il;
+                        sfor<l + 1, NU>([&](auto m) { lanes::fma_bc<m>(Gr[m], Lzu[l], -Lzu[l]); });
+                    });
+                    // P_k = G_xx - Lxu Lxu'
+                    double Pk[NX];
+                    sfor<0, NX>([&](auto c) {
+                        double a = Gr[NU + c];
+                        sfor<0, NU>([&](auto l) { lanes::fma_bc<NU + c>(a, Lzu[l], -Lzu[l]); });
+                        Pk[c] = xlane ? a : 0.0;
+                    });
+                    // P_{k+1} b_k
+                    Pb = 0.0;
+                    sfor<0, NX>([&](auto c) { lanes::fma_bc<NU + c>(Pb, rb, Pn[c]); });
+                    W(k, P_PB) = Pb;
+                    sfor<0, NU>([&](auto l) { W(k, P_LZU + l) = Lzu[l]; });
+                    sfor<0, NX>([&](auto c) {
+                        W(k, P_PM + c) = Pk[c];
+                        Pn[c] = Pk[c];
+                    });
+                } else {
+                    Pb = W(k, P_PB);
+                    sfor<0, NU>([&](auto l) { Lzu[l] = W(k, P_LZU + l); });
+                }
+                // vector recursion
+                const double h = Pb + pn;
+                double rq = gt;
+                sfor<0, NX>([&](auto j) { lanes::fma_bc<NU + j>(rq, h, bat[j]); });
+                double lu[NU], luv = 0.0;
+                sfor<0, NU>([&](auto l) {
+                    double a = lanes::bcast<l>(rq);
+                    sfor<0, l>([&](auto m) { a -= lanes::bcast<l>(Lzu[m]) * lu[m]; });
+                    lu[l] = a / lanes::bcast<l>(Lzu[l]);
+                    luv = (lane == l) ? lu[l] : luv;
+                });
+                pv = rq;
+                sfor<0, NU>([&](auto l) { pv -= Lzu[l] * lu[l]; });
+                pv = xlane ? pv : 0.0;
+                W(k, P_PV) = pv;
+                W(k, P_LUV) = luv;
+            }
+            pn = pv;
+            pin = pik;
+        }
+        if (FACT) {
+            nm.rg = lanes::gmax(nm.rg);
+            nm.rb = lanes::gmax(fmax(nm.rb, fabs(x0_resid())));
+            nm.rd = lanes::gmax(nm.rd);
+            nm.rm = lanes::gmax(nm.rm);
+            nm.musum = lanes::gsum(nm.musum);
+            nm.nan = lanes::gsum(nm.nan);
+        }
+    }
+
+    // ------------------------------------------------------------------ forward sweeps
+    // FINAL = false: affine step -> alpha_aff and the sums for mu_aff, stores dza
+    // FINAL = true : corrected step -> alpha, stores dz and dpi
+    template <bool FINAL>
+    USV_DEV void forward(double sigmu, double &alpha, double &S1, double &S2)
+    {
+        double dzx = x0_resid();
+        double a = 1.0, s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k <= N; k++) {
+            double dz;
+            if (k < N) {
+                double Lzu[NU], t[NU], du[NU];
+                sfor<0, NU>([&](auto l) { Lzu[l] = W(k, P_LZU + l); });
+                const double luv = W(k, P_LUV);
+                sfor<0, NU>([&](auto l) {
+                    t[l] = lanes::bcast<l>(luv) + lanes::gsum(xlane ? Lzu[l] * dzx : 0.0);
+                });
+                sfor<0, NU>([&](auto q) { // back substitution with Luu'
+                    constexpr int l = NU - 1 - q;
+                    double acc = t[l];
+                    sfor<l + 1, NU>([&](auto m) { acc -= lanes::bcast<m>(Lzu[l]) * du[m]; });
+                    du[l] = acc / lanes::bcast<l>(Lzu[l]);
+                });
+                dz = xlane ? dzx : 0.0;
+                sfor<0, NU>([&](auto l) { dz = (lane == l) ? -du[l] : dz; });
+            } else {
+                dz = xlane ? dzx : 0.0;
+            }
+            // ---- rows of stage k
+            {
+                const double z = W(k, P_Z);
+                const double dza = FINAL ? W(k, P_DZA) : dz;
+                BoxRow br;
+                box_load(k, br);
+                double Gh, gam;
+                chain(br, z, FINAL, dza, sigmu, Gh, gam);
+                br.expand(dz);
+                a = br.alpha(a);
+                if (!FINAL && br.act) {
+                    s1 += br.ll * br.dtl + br.tl * br.dll + br.lu * br.dtu + br.tu * br.dlu;
+                    s2 += br.dll * br.dtl + br.dlu * br.dtu;
+                }
+                if constexpr (KCH > 0) {
+                    sfor<0, KCH>([&](auto c) {
+                        ObsRow o;
+                        double cx, cy, Gh2, gam2;
+                        obs_load(k, c, o, cx, cy);
+                        const double v = obs_dot(cx, cy, z);
+                        const double w = obs_dot(cx, cy, dz);
+                        const double wa = FINAL ? obs_dot(cx, cy, dza) : w;
+                        chain(o, v, FINAL, wa, sigmu, Gh2, gam2);
+                        o.expand(w);
+                        a = o.alpha(a);
+                        if (!FINAL && o.act) {
+                            s1 += o.ll * o.dtl + o.tl * o.dll + o.lu * o.dtu + o.tu * o.dlu;
+                            s2 += o.dll * o.dtl + o.dlu * o.dtu;
+                            if constexpr (SOFT) {
+                                s1 += o.lsl * o.dtsl + o.tsl * o.dlsl + o.lsu * o.dtsu + o.tsu * o.dlsu;
+                                s2 += o.dlsl * o.dtsl + o.dlsu * o.dtsu;
+                            }
+                        }
+                    });
+                }
+            }
+            W(k, FINAL ? P_DZ : P_DZA) = dz;
+            if (k < N) {
+                double dxn = W(k, P_RB);
+                sfor<0, NZ>([&](auto c) {
+                    const double abr = P.ABr[((long)k * NZ + c) * stride + gl];
+                    lanes::fma_bc<c>(dxn, dz, abr);
+                });
+                dxn = xlane ? dxn : 0.0;
+                if (FINAL) {
+                    double dpi = W(k + 1, P_PV);
+                    sfor<0, NX>([&](auto c) {
+                        const double pm = W(k + 1, P_PM + c);
+                        lanes::fma_bc<NU + c>(dpi, dxn, pm);
+                    });
+                    W(k + 1, P_DPI) = xlane ? dpi : 0.0;
+                }
+                dzx = dxn;
+            }
+        }
+        alpha = lanes::gmin(a);
+        if (!FINAL) { S1 = lanes::gsum(s1); S2 = lanes::gsum(s2); }
+    }
+
+    // ------------------------------------------------------------------ update
+    USV_DEV void update(double a, double sigmu, bool frozen)
+    {
+        for (int k = 0; k <= N; k++) {
+            const double z = W(k, P_Z), dz = W(k, P_DZ), dza = W(k, P_DZA);
+            BoxRow br;
+            box_load(k, br);
+            double Gh, gam;
+            chain(br, z, true, dza, sigmu, Gh, gam);
+            br.expand(dz);
+            if (!frozen && br.act) { br.apply(a); box_store(k, br); }
+            if constexpr (KCH > 0) {
+                sfor<0, KCH>([&](auto c) {
+                    ObsRow o;
+                    double cx, cy, Gh2, gam2;
+                    obs_load(k, c, o, cx, cy);
+                    const double v = obs_dot(cx, cy, z);
+                    const double w = obs_dot(cx, cy, dz);
+                    const double wa = obs_dot(cx, cy, dza);
+                    chain(o, v, true, wa, sigmu, Gh2, gam2);
+                    o.expand(w);
+                    if (!frozen && o.act) { o.apply(a); obs_store(k, c, o); }
+                });
+            }
+            if (!frozen) {
+                W(k, P_Z) = z + a * dz;
+                if (k >= 1) W(k, P_PI) = W(k, P_PI) + a * W(k, P_DPI);
+                if (k < N) W(k, P_RB) = (1.0 - a) * W(k, P_RB);
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ driver
+    USV_DEV void solve()
+    {
+        init();
+        bool done = false;
+        int status = 1, iters = 0;
+        Norms nm;
+        double res0 = 0, res1 = 0, res2 = 0, res3 = 0;
+        const double nc = (double)S.nc;
+        for (int it = 0;; it++) {
+            backward<true>(nm, 0.0);
+            if (!done) {
+                res0 = nm.rg; res1 = nm.rb; res2 = nm.rd; res3 = nm.rm;
+                iters = it;
+                if (nm.nan != nm.nan) { status = 3; done = true; }
+                else if (nm.rg <= S.tol_stat && nm.rb <= S.tol_eq && nm.rd <= S.tol_ineq && nm.rm <= S.tol_comp) {
+                    status = 0; done = true;
+                } else if (it >= S.iter_max) { status = 1; done = true; }
+            }
+            if (!lanes::wave_any(!done)) break;
+            const double mu = nc > 0.0 ? nm.musum / nc : 0.0;
+            double a_aff, S1, S2, a, d1, d2;
+            forward<false>(0.0, a_aff, S1, S2);
+            double sigmu = 0.0;
+            if (nc > 0.0) {
+                const double mu_aff = (nm.musum + a_aff * S1 + a_aff * a_aff * S2) / nc;
+                const double sg = mu_aff / mu;
+                sigmu = sg * sg * sg * mu;
+            }
+            backward<false>(nm, sigmu);
+            forward<true>(sigmu, a, d1, d2);
+            if (!done && a < S.alpha_min) { status = 2; done = true; iters = it; }
+            a = a * ((1.0 - a) * 0.99 + a * 0.9999999);
+            update(a, sigmu, done);
+        }
+        // ---- RTI step + outputs
+        const bool ok = (status == 0 || status == 1);
+        const bool real = g < S.B;
+        for (int k = 0; k <= N; k++) {
+            const double z = W(k, P_Z);
+            if (real) {
+                if (ok && xlane) P.x[((long)b * (N + 1) + k) * NX + (lane - NU)] += z;
+                if (ok && ulane && k < N) P.u[((long)b * N + k) * NU + lane] += z;
+                if (k >= 1 && xlane && P.pi) P.pi[((long)b * N + (k - 1)) * NX + (lane - NU)] = W(k, P_PI);
+            }
+            if constexpr (KCH > 0 && SOFT) {
+                if (k < N) {
+                    sfor<0, KCH>([&](auto c) {
+                        const int i = c * LANES + lane;
+                        if (real && i < S.K && P.sl) {
+                            const bool act = k >= 1;
+                            const int p0 = P_OBS + c * OBSN;
+                            P.sl[((long)b * N + k) * S.K + i] = act ? W(k, p0 + 4) : 0.0;
+                            P.su[((long)b * N + k) * S.K + i] = act ? W(k, p0 + 5) : 0.0;
+                        }
+                    });
+                }
+            }
+        }
+        if (real && lane == 0) {
+            P.status[b] = ok ? 0 : 4;
+            P.qp_iter[b] = iters;
+            P.res[b * 4 + 0] = res0; P.res[b * 4 + 1] = res1; P.res[b * 4 + 2] = res2; P.res[b * 4 + 3] = res3;
+            P.qp_status[b] = status;
+        }
+    }
+};
+
+} // namespace usv

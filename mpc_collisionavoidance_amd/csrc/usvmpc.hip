@@ -1,0 +1,382 @@
+// usvmpc.hip — gfx950 kernels + the C ABI of include/usvmpc.h.
+//
+// Two kernels per SQP-RTI iteration:
+//   usv_linearize<M,KCH>      one 16-lane group per (instance, stage): ERK4 + forward VDE, GN
+//                             gradient, obstacle rows                       (linearize.hpp)
+//   usv_qp_rti<M,KCH,SOFT>    one 16-lane group per instance: Riccati-IPM QP + RTI step
+//                             (qp_ipm.hpp)
+// Both are FP64 VALU + DPP kernels: no LDS, no MFMA (blocks are at most 16x16).
+#include "gfx950/lanes.hpp"
+
+#include "host_spec.hpp"
+#include "linearize.hpp"
+#include "models.hpp"
+#include "qp_ipm.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+using namespace usv;
+
+// ---------------------------------------------------------------------------------- kernels
+template <class M, int KCH>
+__global__ void __launch_bounds__(256, 2) usv_linearize(DevPtrs P, long ngroups)
+{
+    const long gid = lanes::group_linear();
+    if (gid >= ngroups) return; // ngroups is a multiple of 4: whole waves leave together
+    Linearize<M, KCH>::run(P, gid);
+}
+
+template <class M, int KCH, bool SOFT>
+__global__ void __launch_bounds__(64, 2) usv_qp_rti(DevPtrs P, long ngroups)
+{
+    const long gid = lanes::group_linear();
+    if (gid >= ngroups) return;
+    QpIpm<M, KCH, SOFT> q(P, gid);
+    q.solve();
+}
+
+// ---------------------------------------------------------------------------------- handle
+struct usvmpc_handle {
+    usvmpc_desc desc;
+    DevSpec spec;
+    DevPtrs ptrs;
+    int nx, nu, nz, ny, ny_e, N, K, B, Bp, kch;
+    bool soft;
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev[3];
+    bool ev_valid;
+    DevSpec *d_spec;
+    size_t bytes;
+    std::string err;
+    void *allocs[32];
+    int nallocs;
+};
+
+namespace {
+
+thread_local std::string g_create_err;
+
+#define HIP_TRY(h, call)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+            return USVMPC_E_HIP;                                                                  \
+        }                                                                                         \
+    } while (0)
+
+template <class T>
+int dev_alloc(usvmpc_handle *h, T **p, size_t count, bool zero)
+{
+    const size_t nbytes = (count ? count : 1) * sizeof(T);
+    HIP_TRY(h, hipMalloc((void **)p, nbytes));
+    h->allocs[h->nallocs++] = (void *)*p;
+    h->bytes += nbytes;
+    if (zero) HIP_TRY(h, hipMemset((void *)*p, 0, nbytes));
+    return 0;
+}
+
+struct Field {
+    double *base;   // device pointer
+    int n;          // per-stage length
+    int stages;     // number of stages in the array
+    int stage_off;  // caller stage that maps to slot 0
+};
+
+// caller-visible field table; `set` = writable by the caller
+int lookup(usvmpc_handle *h, const char *f, int stage, bool set, Field &o)
+{
+    const std::string s(f ? f : "");
+    DevPtrs &P = h->ptrs;
+    const int N = h->N;
+    if (s == "x") o = {P.x, h->nx, N + 1, 0};
+    else if (s == "u") o = {P.u, h->nu, N, 0};
+    else if (s == "x0") o = {const_cast<double *>(P.x0), h->nx, 1, 0};
+    else if (s == "yref") {
+        if (stage == N) o = {const_cast<double *>(P.yref_e), h->ny_e, 1, N};
+        else o = {const_cast<double *>(P.yref), h->ny, N, 0};
+    } else if (s == "yref_e") o = {const_cast<double *>(P.yref_e), h->ny_e, 1, 0};
+    else if (s == "p") o = {const_cast<double *>(P.p), 2 * h->K, N + 1, 0};
+    else if (s == "lh") o = {const_cast<double *>(P.lh), h->K, N, 0};
+    else if (!set && s == "pi") o = {P.pi, h->nx, N, 1};
+    else if (!set && s == "sl") o = {P.sl, h->K, N, 0};
+    else if (!set && s == "su") o = {P.su, h->K, N, 0};
+    else if (!set && s == "res") o = {P.res, 4, 1, 0};
+    else {
+        h->err = "unknown field '" + s + "'";
+        return USVMPC_E_FIELD;
+    }
+    return 0;
+}
+
+int copy_field(usvmpc_handle *h, const char *field, int stage, double *host, size_t n, bool set)
+{
+    if (!h) return USVMPC_E_ARG;
+    if (!host) { h->err = "null buffer"; return USVMPC_E_ARG; }
+    Field f;
+    if (std::string(field ? field : "") == "res" || std::string(field ? field : "") == "x0" ||
+        std::string(field ? field : "") == "yref_e")
+        stage = stage < 0 ? -1 : 0;
+    int rc = lookup(h, field, stage, set, f);
+    if (rc) return rc;
+    if ((int)n != f.n) {
+        h->err = std::string("mismatching dimension for field '") + field + "': expected " + std::to_string(f.n) +
+                 ", got " + std::to_string(n);
+        return USVMPC_E_SIZE;
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (f.n == 0) return 0;
+    const size_t B = (size_t)h->B;
+    if (stage < 0 || f.stages == 1) {
+        if (stage >= 0 && f.stages == 1 && stage - f.stage_off != 0) {
+            h->err = "stage out of range"; return USVMPC_E_STAGE;
+        }
+        const size_t nbytes = B * f.stages * f.n * sizeof(double);
+        if (set) HIP_TRY(h, hipMemcpyAsync(f.base, host, nbytes, hipMemcpyHostToDevice, h->stream));
+        else HIP_TRY(h, hipMemcpyAsync(host, f.base, nbytes, hipMemcpyDeviceToHost, h->stream));
+    } else {
+        const int slot = stage - f.stage_off;
+        if (slot < 0 || slot >= f.stages) {
+            h->err = std::string("stage ") + std::to_string(stage) + " out of range for field '" + field + "'";
+            return USVMPC_E_STAGE;
+        }
+        const size_t row = (size_t)f.n * sizeof(double), pitch = (size_t)f.stages * row;
+        double *d = f.base + (size_t)slot * f.n;
+        if (set) HIP_TRY(h, hipMemcpy2DAsync(d, pitch, host, row, row, B, hipMemcpyHostToDevice, h->stream));
+        else HIP_TRY(h, hipMemcpy2DAsync(host, row, d, pitch, row, B, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+template <class M, int KCH, bool SOFT>
+int launch_pair(usvmpc_handle *h)
+{
+    const long lin_groups = (long)(h->N + 1) * h->Bp;
+    const long qp_groups = h->Bp;
+    const int lin_block = 256, qp_block = 64;
+    const long lin_grid = (lin_groups * LANES + lin_block - 1) / lin_block;
+    const long qp_grid = (qp_groups * LANES + qp_block - 1) / qp_block;
+    HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+    hipLaunchKernelGGL((usv_linearize<M, KCH>), dim3((unsigned)lin_grid), dim3(lin_block), 0, h->stream, h->ptrs, lin_groups);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
+    hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT>), dim3((unsigned)qp_grid), dim3(qp_block), 0, h->stream, h->ptrs, qp_groups);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
+    h->ev_valid = true;
+    return 0;
+}
+
+int launch(usvmpc_handle *h)
+{
+    switch (h->desc.model) {
+    case USVMPC_MODEL_USV: return launch_pair<ModelM0, 0, false>(h);
+    case USVMPC_MODEL_GUIDANCE_CA1:
+        return h->kch <= 1 ? launch_pair<ModelM1, 1, true>(h) : launch_pair<ModelM1, 2, true>(h);
+    case USVMPC_MODEL_PF_CA:
+        return h->kch <= 1 ? launch_pair<ModelM2, 1, false>(h) : launch_pair<ModelM2, 2, false>(h);
+    }
+    h->err = "unknown model";
+    return USVMPC_E_ARG;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------- C ABI
+extern "C" {
+
+int usvmpc_model_dims(int model, int *nx, int *nu)
+{
+    int a, b;
+    if (model_dims(model, a, b)) return USVMPC_E_ARG;
+    if (nx) *nx = a;
+    if (nu) *nu = b;
+    return 0;
+}
+
+void usvmpc_default_options(usvmpc_desc *d)
+{
+    if (d) default_options(*d);
+}
+
+int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
+{
+    if (!d || !out) return USVMPC_E_ARG;
+    *out = nullptr;
+    DevSpec S;
+    const std::string err = build_spec(*d, S);
+    if (!err.empty()) {
+        g_create_err = err;
+        std::fprintf(stderr, "usvmpc_create: %s\n", err.c_str());
+        return USVMPC_E_ARG;
+    }
+    if ((d->model == USVMPC_MODEL_GUIDANCE_CA1) != (d->soft != 0) && d->K > 0) {
+        std::fprintf(stderr, "usvmpc_create: obstacle rows are soft for model 1 and hard for model 2\n");
+        return USVMPC_E_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || d->device < 0 || d->device >= ndev) {
+        std::fprintf(stderr, "usvmpc_create: no usable HIP device (count %d, requested %d); there is no CPU fallback\n",
+                     ndev, d->device);
+        return USVMPC_E_NODEVICE;
+    }
+    usvmpc_handle *h = new usvmpc_handle();
+    h->desc = *d;
+    h->spec = S;
+    model_dims(d->model, h->nx, h->nu);
+    h->nz = h->nx + h->nu; h->ny = S.ny; h->ny_e = S.ny_e;
+    h->N = S.N; h->K = S.K; h->B = S.B; h->Bp = S.Bp;
+    h->kch = d->model == USVMPC_MODEL_USV ? 0 : ((S.K + LANES - 1) / LANES > 1 ? 2 : 1);
+    h->soft = d->soft != 0 || d->model == USVMPC_MODEL_GUIDANCE_CA1;
+    h->device = d->device;
+    h->nallocs = 0; h->bytes = 0; h->ev_valid = false;
+    std::memset(&h->ptrs, 0, sizeof(h->ptrs));
+    auto fail = [&](int rc) {
+        std::fprintf(stderr, "usvmpc_create: %s\n", h->err.c_str());
+        for (int i = 0; i < h->nallocs; i++) (void)hipFree(h->allocs[i]);
+        delete h;
+        return rc;
+    };
+#define TRY_C(x) do { int rc_ = (x); if (rc_) return fail(rc_); } while (0)
+#define HIP_C(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); return fail(USVMPC_E_HIP); } } while (0)
+    HIP_C(hipSetDevice(h->device));
+    HIP_C(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 3; i++) HIP_C(hipEventCreate(&h->ev[i]));
+    const size_t B = h->B, N = h->N, K = h->K;
+    const size_t stride = (size_t)h->Bp * LANES;
+    const size_t kch = h->kch ? h->kch : 1;
+    DevPtrs &P = h->ptrs;
+    TRY_C(dev_alloc(h, &h->d_spec, 1, false));
+    HIP_C(hipMemcpy(h->d_spec, &h->spec, sizeof(DevSpec), hipMemcpyHostToDevice));
+    P.spec = h->d_spec;
+    double *t;
+    TRY_C(dev_alloc(h, &P.x, B * (N + 1) * h->nx, true));
+    TRY_C(dev_alloc(h, &P.u, B * N * h->nu, true));
+    TRY_C(dev_alloc(h, &t, B * h->nx, true)); P.x0 = t;
+    TRY_C(dev_alloc(h, &t, B * N * h->ny, true)); P.yref = t;
+    TRY_C(dev_alloc(h, &t, B * h->ny_e, true)); P.yref_e = t;
+    TRY_C(dev_alloc(h, &t, B * (N + 1) * 2 * K, true)); P.p = t;
+    TRY_C(dev_alloc(h, &t, B * N * K, true)); P.lh = t;
+    TRY_C(dev_alloc(h, &P.sl, B * N * K, true));
+    TRY_C(dev_alloc(h, &P.su, B * N * K, true));
+    TRY_C(dev_alloc(h, &P.pi, B * N * h->nx, true));
+    TRY_C(dev_alloc(h, &P.status, B, true));
+    TRY_C(dev_alloc(h, &P.qp_iter, B, true));
+    TRY_C(dev_alloc(h, &P.qp_status, B, true));
+    TRY_C(dev_alloc(h, &P.res, B * 4, true));
+    TRY_C(dev_alloc(h, &P.BAt, N * h->nx * stride, true));
+    TRY_C(dev_alloc(h, &P.ABr, N * h->nz * stride, true)); // u lanes / idle lanes stay zero
+    TRY_C(dev_alloc(h, &P.rb0, N * stride, true));
+    TRY_C(dev_alloc(h, &P.gq, (N + 1) * stride, true));
+    TRY_C(dev_alloc(h, &P.con, N * kch * 4 * stride, true));
+    TRY_C(dev_alloc(h, &P.ws, (N + 1) * (size_t)ws_planes(h->nx, h->nu, h->kch, h->soft) * stride, true));
+    HIP_C(hipDeviceSynchronize());
+#undef TRY_C
+#undef HIP_C
+    *out = h;
+    return 0;
+}
+
+int usvmpc_destroy(usvmpc_handle *h)
+{
+    if (!h) return USVMPC_E_ARG;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < h->nallocs; i++) (void)hipFree(h->allocs[i]);
+    for (int i = 0; i < 3; i++) (void)hipEventDestroy(h->ev[i]);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int usvmpc_set(usvmpc_handle *h, const char *field, int stage, const double *v, size_t n)
+{
+    return copy_field(h, field, stage, const_cast<double *>(v), n, true);
+}
+
+int usvmpc_get(usvmpc_handle *h, const char *field, int stage, double *out, size_t n)
+{
+    return copy_field(h, field, stage, out, n, false);
+}
+
+int usvmpc_get_int(usvmpc_handle *h, const char *field, int *out)
+{
+    if (!h || !out) return USVMPC_E_ARG;
+    const std::string s(field ? field : "");
+    const int *src = s == "status" ? h->ptrs.status : s == "qp_iter" ? h->ptrs.qp_iter : s == "qp_status" ? h->ptrs.qp_status : nullptr;
+    if (!src) { h->err = "unknown integer field '" + s + "'"; return USVMPC_E_FIELD; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(out, src, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int usvmpc_solve_async(usvmpc_handle *h)
+{
+    if (!h) return USVMPC_E_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return launch(h);
+}
+
+int usvmpc_sync(usvmpc_handle *h)
+{
+    if (!h) return USVMPC_E_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int usvmpc_solve(usvmpc_handle *h, int *status)
+{
+    int rc = usvmpc_solve_async(h);
+    if (rc) return rc;
+    rc = usvmpc_sync(h);
+    if (rc) return rc;
+    int worst = 0;
+    if (status) {
+        rc = usvmpc_get_int(h, "status", status);
+        if (rc) return rc;
+        for (int b = 0; b < h->B; b++) worst = status[b] > worst ? status[b] : worst;
+    }
+    return worst;
+}
+
+int usvmpc_get_device_ptr(usvmpc_handle *h, const char *field, void **dptr)
+{
+    if (!h || !dptr) return USVMPC_E_ARG;
+    const std::string s(field ? field : "");
+    const DevPtrs &P = h->ptrs;
+    const void *p = s == "x" ? (const void *)P.x : s == "u" ? (const void *)P.u : s == "x0" ? (const void *)P.x0
+                  : s == "yref" ? (const void *)P.yref : s == "yref_e" ? (const void *)P.yref_e
+                  : s == "p" ? (const void *)P.p : s == "lh" ? (const void *)P.lh : s == "pi" ? (const void *)P.pi
+                  : s == "sl" ? (const void *)P.sl : s == "su" ? (const void *)P.su
+                  : s == "status" ? (const void *)P.status : s == "qp_iter" ? (const void *)P.qp_iter
+                  : s == "qp_status" ? (const void *)P.qp_status : s == "res" ? (const void *)P.res : nullptr;
+    if (!p) { h->err = "unknown field '" + s + "'"; return USVMPC_E_FIELD; }
+    *dptr = const_cast<void *>(p);
+    return 0;
+}
+
+int usvmpc_last_kernel_ms(usvmpc_handle *h, float *linearize_ms, float *qp_ms)
+{
+    if (!h) return USVMPC_E_ARG;
+    if (!h->ev_valid) { h->err = "no solve has been run"; return USVMPC_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventSynchronize(h->ev[2]));
+    float a = 0, b = 0;
+    HIP_TRY(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+    HIP_TRY(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+    if (linearize_ms) *linearize_ms = a;
+    if (qp_ms) *qp_ms = b;
+    return 0;
+}
+
+size_t usvmpc_device_bytes(usvmpc_handle *h) { return h ? h->bytes : 0; }
+
+const char *usvmpc_last_error(usvmpc_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+} // extern "C"

@@ -1,0 +1,179 @@
+// emu_driver.cpp (TEST-ONLY) — runs the unmodified kernel bodies of
+// mpc_collisionavoidance_amd/csrc/{linearize,qp_ipm}.hpp on the CPU through the fiber-based lane
+// emulator (tests/emu/lanes.hpp).  Lets the CPU test suite check the cross-lane algorithm of the
+// HIP kernels against the oracle without a GPU.  Not part of the product library.
+#include "lanes.hpp"
+
+#include "host_spec.hpp"
+#include "linearize.hpp"
+#include "models.hpp"
+#include "qp_ipm.hpp"
+
+#include <cstring>
+#include <vector>
+
+namespace lanes {
+
+Emu g_emu;
+
+// minimal x86-64 SysV context switch: callee-saved registers + stack pointer
+asm(R"(
+.text
+.globl usv_emu_switch
+.type usv_emu_switch,@function
+usv_emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size usv_emu_switch,.-usv_emu_switch
+)");
+
+static void (*g_body)(void *) = nullptr;
+static void *g_arg = nullptr;
+
+static void fiber_entry()
+{
+    Emu &e = g_emu;
+    g_body(g_arg);
+    e.finished[e.cur] = true;
+    for (;;) usv_emu_switch(&e.sp[e.cur], e.main_sp);
+}
+
+void run_group(long group, void (*body)(void *), void *arg)
+{
+    Emu &e = g_emu;
+    constexpr size_t STACK = 1 << 20;
+    static std::vector<char> stacks(GROUP * STACK);
+    g_body = body;
+    g_arg = arg;
+    e.group = group;
+    for (int l = 0; l < GROUP; l++) {
+        char *top = stacks.data() + (size_t)(l + 1) * STACK;
+        uintptr_t sp = ((uintptr_t)top) & ~(uintptr_t)15;
+        void **s = (void **)sp;
+        // layout popped by usv_emu_switch: r15 r14 r13 r12 rbx rbp, then ret -> fiber_entry with
+        // rsp = 8 mod 16 as after a call
+        *--s = nullptr;              // alignment slot (acts as the fake return address)
+        *--s = (void *)&fiber_entry; // ret target
+        for (int i = 0; i < 6; i++) *--s = nullptr;
+        e.sp[l] = (void *)s;
+        e.par[l] = 0;
+        e.nops[l] = 0;
+        e.finished[l] = false;
+    }
+    for (;;) {
+        int nfin = 0;
+        for (int l = 0; l < GROUP; l++) {
+            if (e.finished[l]) { nfin++; continue; }
+            e.cur = l;
+            usv_emu_switch(&e.main_sp, e.sp[l]);
+            if (e.finished[l]) nfin++;
+        }
+        if (nfin == GROUP) break;
+        for (int l = 0; l < GROUP; l++) {
+            if (e.finished[l] != e.finished[0] || e.nops[l] != e.nops[0]) {
+                std::fprintf(stderr, "lane emulator: divergent cross-lane op (lane %d: %ld ops, fin %d; lane 0: %ld ops, fin %d)\n",
+                             l, e.nops[l], (int)e.finished[l], e.nops[0], (int)e.finished[0]);
+                std::abort();
+            }
+        }
+    }
+}
+
+} // namespace lanes
+
+namespace {
+
+using namespace usv;
+
+struct Job { const DevPtrs *P; long gid; };
+
+template <class M, int KCH, bool SOFT>
+void lin_body(void *a)
+{
+    Job *j = (Job *)a;
+    Linearize<M, KCH>::run(*j->P, j->gid);
+}
+template <class M, int KCH, bool SOFT>
+void qp_body(void *a)
+{
+    Job *j = (Job *)a;
+    QpIpm<M, KCH, SOFT> q(*j->P, j->gid);
+    q.solve();
+}
+
+template <class M, int KCH, bool SOFT>
+void run_all(const DevPtrs &P, const DevSpec &S, int phase)
+{
+    if (phase & 1)
+        for (long gid = 0; gid < (long)(S.N + 1) * S.Bp; gid++) {
+            Job j{&P, gid};
+            lanes::run_group(gid, &lin_body<M, KCH, SOFT>, &j);
+        }
+    if (phase & 2)
+        for (long g = 0; g < S.Bp; g++) {
+            Job j{&P, g};
+            lanes::run_group(g, &qp_body<M, KCH, SOFT>, &j);
+        }
+}
+
+} // namespace
+
+// One RTI iteration of every instance on the emulator. Arrays as in include/usvmpc.h (host).
+// dbg (optional, may be NULL) receives the linearisation planes for inspection:
+// BAt [N][nx][Bp*16], rb0 [N][Bp*16], gq [N+1][Bp*16].
+extern "C" int usv_emu_solve(const usvmpc_desc *d, double *x, double *u, const double *x0,
+                             const double *yref, const double *yref_e, const double *p,
+                             const double *lh, double *sl, double *su, double *pi, int *status,
+                             int *qp_status, int *qp_iter, double *res, double *dbg_BAt,
+                             double *dbg_rb0, double *dbg_gq)
+{
+    DevSpec S;
+    const std::string err = build_spec(*d, S);
+    if (!err.empty()) {
+        std::fprintf(stderr, "usv_emu_solve: %s\n", err.c_str());
+        return -1;
+    }
+    int nx, nu;
+    model_dims(d->model, nx, nu);
+    const int nz = nx + nu, N = S.N;
+    const int kch = (S.K + LANES - 1) / LANES;
+    const bool soft = d->soft != 0;
+    const long stride = (long)S.Bp * LANES;
+    std::vector<double> BAt((size_t)N * nx * stride), ABr((size_t)N * nz * stride), rb0((size_t)N * stride),
+        gq((size_t)(N + 1) * stride), con((size_t)N * (kch ? kch : 1) * 4 * stride),
+        ws((size_t)(N + 1) * ws_planes(nx, nu, kch, soft) * stride);
+    DevPtrs P;
+    std::memset(&P, 0, sizeof(P));
+    P.spec = &S;
+    P.x = x; P.u = u; P.x0 = x0; P.yref = yref; P.yref_e = yref_e; P.p = p; P.lh = lh;
+    P.sl = sl; P.su = su; P.pi = pi; P.status = status; P.qp_iter = qp_iter; P.qp_status = qp_status; P.res = res;
+    P.BAt = BAt.data(); P.ABr = ABr.data(); P.rb0 = rb0.data(); P.gq = gq.data(); P.con = con.data(); P.ws = ws.data();
+    const int phase = 3;
+    if (d->model == USVMPC_MODEL_USV) run_all<ModelM0, 0, false>(P, S, phase);
+    else if (d->model == USVMPC_MODEL_GUIDANCE_CA1) {
+        if (!soft) return -2;
+        if (kch <= 1) run_all<ModelM1, 1, true>(P, S, phase);
+        else run_all<ModelM1, 2, true>(P, S, phase);
+    } else {
+        if (soft) return -2;
+        if (kch <= 1) run_all<ModelM2, 1, false>(P, S, phase);
+        else run_all<ModelM2, 2, false>(P, S, phase);
+    }
+    if (dbg_BAt) std::memcpy(dbg_BAt, BAt.data(), BAt.size() * sizeof(double));
+    if (dbg_rb0) std::memcpy(dbg_rb0, rb0.data(), rb0.size() * sizeof(double));
+    if (dbg_gq) std::memcpy(dbg_gq, gq.data(), gq.size() * sizeof(double));
+    return 0;
+}

@@ -1,0 +1,97 @@
+// lanes.hpp (CPU emulation, TEST-ONLY) — same interface as
+// mpc_collisionavoidance_amd/csrc/gfx950/lanes.hpp, implemented with 16 cooperative fibers so
+// that the *unmodified* kernel bodies (linearize.hpp, qp_ipm.hpp) can be executed and debugged
+// on the CPU.  Selected by include path (-Itests/emu before csrc/gfx950); never part of the
+// shipped library.  Every cross-lane primitive is a rendezvous of all 16 lanes: a lane that
+// skips one (divergent control flow around a DPP op — undefined on the GPU) is detected.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#define USV_DEV inline __attribute__((always_inline))
+
+namespace lanes {
+
+constexpr int GROUP = 16;
+
+struct Emu {
+    int cur = 0;           // lane currently running
+    long group = 0;        // group index handed to the body
+    double slot[2][GROUP]; // exchange buffers, double-buffered by parity
+    int par[GROUP];        // per-lane parity
+    long nops[GROUP];      // per-lane exchange counter (divergence check)
+    bool finished[GROUP];
+    void *sp[GROUP];       // saved stack pointers of the fibers
+    void *main_sp = nullptr;
+};
+extern Emu g_emu;
+extern "C" void usv_emu_switch(void **save_sp, void *load_sp);
+
+inline int lane() { return g_emu.cur; }
+inline long group_linear() { return g_emu.group; }
+
+// publish v, wait until all 16 lanes have published, return the value published by lane src
+inline double exchange(double v, int src)
+{
+    Emu &e = g_emu;
+    const int me = e.cur;
+    const int p = e.par[me];
+    e.slot[p][me] = v;
+    e.nops[me]++;
+    usv_emu_switch(&e.sp[me], e.main_sp); // yield to the scheduler
+    e.par[me] = p ^ 1;
+    return e.slot[p][src & 15];
+}
+
+template <int K>
+inline double bcast(double v) { return exchange(v, K); }
+
+template <int K>
+inline void fma_bc(double &c, double b_remote, double a_own) { c = std::fma(bcast<K>(b_remote), a_own, c); }
+
+template <int N>
+inline double ror(double v) { return exchange(v, (g_emu.cur - N) & 15); }
+
+inline double gsum(double v)
+{
+    v += ror<8>(v);
+    v += ror<4>(v);
+    v += ror<2>(v);
+    v += ror<1>(v);
+    return v;
+}
+inline double gmax(double v)
+{
+    v = std::fmax(v, ror<8>(v));
+    v = std::fmax(v, ror<4>(v));
+    v = std::fmax(v, ror<2>(v));
+    v = std::fmax(v, ror<1>(v));
+    return v;
+}
+inline double gmin(double v)
+{
+    v = std::fmin(v, ror<8>(v));
+    v = std::fmin(v, ror<4>(v));
+    v = std::fmin(v, ror<2>(v));
+    v = std::fmin(v, ror<1>(v));
+    return v;
+}
+
+// the emulator runs one group at a time, so "any lane of the wave" is "any lane of the group";
+// finished instances are frozen by the kernels, so results do not depend on the grouping
+inline bool wave_any(bool p) { return gmax(p ? 1.0 : 0.0) > 0.5; }
+
+// run body(lane) on 16 fibers in lock step
+void run_group(long group, void (*body)(void *), void *arg);
+
+} // namespace lanes
+
+// device math names used by the kernel bodies
+using std::atan2;
+using std::fabs;
+using std::fma;
+using std::fmax;
+using std::fmin;
+using std::sqrt;

@@ -1,0 +1,29 @@
+"""Shared helpers for the parity tests: run the same workload through the CPU oracle and compare."""
+import numpy as np
+
+from mpc_collisionavoidance_amd import _capi, scenario, usv_models
+
+MODEL_ID = _capi.MODEL_IDS
+
+
+def oracle_spec(ob, name, N, dt, K, **opts):
+    return ob.spec(MODEL_ID[name], N, N * dt, K if name != "usv_model" else 0, **opts)
+
+
+def oracle_rti(ob, spec, wl, x, u, x0=None):
+    """One batched RTI iteration of the oracle on copies of (x, u)."""
+    x, u = x.copy(), u.copy()
+    st, it = ob.rti_batch(spec, x, u, wl["x0"] if x0 is None else x0, wl["yref"], wl["yref_e"], wl["p"], wl["lh"])
+    return x, u, st, it
+
+
+def rel_err(a, b):
+    """max |a-b| / max(1, max|b|): the relative trajectory error used by every parity test."""
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+def make(name, N, K, B, dt=None, seed=1234, **kw):
+    dt = scenario.DT[name] if dt is None else dt
+    ocp = usv_models.make_ocp(name, N * dt, N, None if name == "usv_model" else K)
+    wl = scenario.make_batch(name, N, K if name != "usv_model" else 0, B, dt=dt, seed=seed, **kw)
+    return ocp, wl

@@ -105,8 +105,16 @@ int usvmpc_sync(usvmpc_handle *h);
 /* device pointer of a field ("x","u","x0","yref","yref_e","p","lh","pi","sl","su","status",
  * "qp_iter","res") for zero-copy use from torch / RCCL */
 int usvmpc_get_device_ptr(usvmpc_handle *h, const char *field, void **dptr);
-/* HIP-event durations (ms) of the two kernels of the most recent completed solve */
+/* HIP-event durations (ms) of the two kernels of the most recent solve / of the last n solves
+ * (oldest first, n <= 64), measured on the stream the kernels were launched on */
 int usvmpc_last_kernel_ms(usvmpc_handle *h, float *linearize_ms, float *qp_ms);
+int usvmpc_kernel_ms(usvmpc_handle *h, int n, float *linearize_ms, float *qp_ms);
+/* Closed-loop hand-over on the device: x0 <- x_1 (+ sigma * N(0,1)), enqueued on the stream.
+ * Replaces x0 = solver.get(1,"x"); solver.set(0,"lbx",x0); solver.set(0,"ubx",x0)
+ * (catkin_ws/src/nmpc_ca/scripts/usv_guidance_ca1/main.py:169-175). */
+int usvmpc_advance(usvmpc_handle *h, double sigma, unsigned long long seed);
+/* Adopt a caller-owned HIP stream (e.g. torch's current stream) for all subsequent work */
+int usvmpc_set_stream(usvmpc_handle *h, void *stream);
 /* bytes of device memory held by the handle */
 size_t usvmpc_device_bytes(usvmpc_handle *h);
 const char *usvmpc_last_error(usvmpc_handle *h);

@@ -236,6 +236,20 @@ class BatchOcpSolver:
         self._check(self._lib.usvmpc_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def kernel_ms(self, n):
+        """(linearize_ms[n], qp_ms[n]) of the last n solves, from HIP events on the solver's stream."""
+        a = (C.c_float * n)()
+        b = (C.c_float * n)()
+        self._check(self._lib.usvmpc_kernel_ms(self._h, n, a, b))
+        return np.array(a[:]), np.array(b[:])
+
+    def advance(self, sigma=0.0, seed=0):
+        """Closed-loop hand-over on the device: x0 <- x_1 (+ sigma N(0,1)); asynchronous."""
+        self._check(self._lib.usvmpc_advance(self._h, float(sigma), int(seed)))
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.usvmpc_set_stream(self._h, C.c_void_p(stream_ptr)))
+
     def device_bytes(self):
         return int(self._lib.usvmpc_device_bytes(self._h))
 

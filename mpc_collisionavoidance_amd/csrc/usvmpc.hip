@@ -37,6 +37,36 @@ __global__ void __launch_bounds__(64, 2) usv_qp_rti(DevPtrs P, long ngroups)
     q.solve();
 }
 
+// Closed-loop hand-over between two ticks, as the reference's callers do it on the host
+// (x0 = get(1,"x"); set(0,"lbx",x0): scripts/usv_guidance_ca1/main.py:169-175): the next initial
+// state is the predicted x_1 plus an optional Gaussian disturbance (the commented "Add noise"
+// hooks of scripts/usv_pf_ca/main.py:181-183).  No trajectory shift, as in the reference.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void usv_advance(DevPtrs P, int nx, double sigma, unsigned long long seed)
+{
+    const DevSpec &S = *P.spec;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)S.B * nx) return;
+    const long b = i / nx;
+    const int j = (int)(i - b * nx);
+    double v = P.x[(b * (S.N + 1) + 1) * nx + j];
+    if (sigma != 0.0) {
+        const unsigned long long h1 = splitmix64(seed ^ (unsigned long long)(2 * i));
+        const unsigned long long h2 = splitmix64(seed ^ (unsigned long long)(2 * i + 1));
+        const double u1 = ((double)(h1 >> 11) + 1.0) * (1.0 / 9007199254740993.0);
+        const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);
+        v += sigma * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    }
+    const_cast<double *>(P.x0)[i] = v;
+}
+
 // ---------------------------------------------------------------------------------- handle
 struct usvmpc_handle {
     usvmpc_desc desc;
@@ -46,8 +76,10 @@ struct usvmpc_handle {
     bool soft;
     int device;
     hipStream_t stream;
-    hipEvent_t ev[3];
-    bool ev_valid;
+    bool own_stream;
+    static constexpr int RING = 64;      // per-solve event triples, newest at (nsolves-1) % RING
+    hipEvent_t ev[RING][3];
+    long nsolves;
     DevSpec *d_spec;
     size_t bytes;
     std::string err;
@@ -160,14 +192,15 @@ int launch_pair(usvmpc_handle *h)
     const int lin_block = 256, qp_block = 64;
     const long lin_grid = (lin_groups * LANES + lin_block - 1) / lin_block;
     const long qp_grid = (qp_groups * LANES + qp_block - 1) / qp_block;
-    HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+    hipEvent_t *ev = h->ev[h->nsolves % usvmpc_handle::RING];
+    HIP_TRY(h, hipEventRecord(ev[0], h->stream));
     hipLaunchKernelGGL((usv_linearize<M, KCH>), dim3((unsigned)lin_grid), dim3(lin_block), 0, h->stream, h->ptrs, lin_groups);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
+    HIP_TRY(h, hipEventRecord(ev[1], h->stream));
     hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT>), dim3((unsigned)qp_grid), dim3(qp_block), 0, h->stream, h->ptrs, qp_groups);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
-    h->ev_valid = true;
+    HIP_TRY(h, hipEventRecord(ev[2], h->stream));
+    h->nsolves++;
     return 0;
 }
 
@@ -233,7 +266,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->kch = d->model == USVMPC_MODEL_USV ? 0 : ((S.K + LANES - 1) / LANES > 1 ? 2 : 1);
     h->soft = d->soft != 0 || d->model == USVMPC_MODEL_GUIDANCE_CA1;
     h->device = d->device;
-    h->nallocs = 0; h->bytes = 0; h->ev_valid = false;
+    h->nallocs = 0; h->bytes = 0; h->nsolves = 0; h->own_stream = true;
     std::memset(&h->ptrs, 0, sizeof(h->ptrs));
     auto fail = [&](int rc) {
         std::fprintf(stderr, "usvmpc_create: %s\n", h->err.c_str());
@@ -245,7 +278,8 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
 #define HIP_C(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); return fail(USVMPC_E_HIP); } } while (0)
     HIP_C(hipSetDevice(h->device));
     HIP_C(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    for (int i = 0; i < 3; i++) HIP_C(hipEventCreate(&h->ev[i]));
+    for (int r = 0; r < usvmpc_handle::RING; r++)
+        for (int i = 0; i < 3; i++) HIP_C(hipEventCreate(&h->ev[r][i]));
     const size_t B = h->B, N = h->N, K = h->K;
     const size_t stride = (size_t)h->Bp * LANES;
     const size_t kch = h->kch ? h->kch : 1;
@@ -287,8 +321,9 @@ int usvmpc_destroy(usvmpc_handle *h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < h->nallocs; i++) (void)hipFree(h->allocs[i]);
-    for (int i = 0; i < 3; i++) (void)hipEventDestroy(h->ev[i]);
-    (void)hipStreamDestroy(h->stream);
+    for (int r = 0; r < usvmpc_handle::RING; r++)
+        for (int i = 0; i < 3; i++) (void)hipEventDestroy(h->ev[r][i]);
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
 }
@@ -361,17 +396,46 @@ int usvmpc_get_device_ptr(usvmpc_handle *h, const char *field, void **dptr)
     return 0;
 }
 
+int usvmpc_kernel_ms(usvmpc_handle *h, int n, float *linearize_ms, float *qp_ms)
+{
+    if (!h || n < 1) return USVMPC_E_ARG;
+    if (h->nsolves < n || n > usvmpc_handle::RING) { h->err = "fewer solves recorded than requested"; return USVMPC_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (int i = 0; i < n; i++) { // oldest of the last n first
+        hipEvent_t *ev = h->ev[(h->nsolves - n + i) % usvmpc_handle::RING];
+        HIP_TRY(h, hipEventSynchronize(ev[2]));
+        float a = 0, b = 0;
+        HIP_TRY(h, hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIP_TRY(h, hipEventElapsedTime(&b, ev[1], ev[2]));
+        if (linearize_ms) linearize_ms[i] = a;
+        if (qp_ms) qp_ms[i] = b;
+    }
+    return 0;
+}
+
 int usvmpc_last_kernel_ms(usvmpc_handle *h, float *linearize_ms, float *qp_ms)
 {
+    return usvmpc_kernel_ms(h, 1, linearize_ms, qp_ms);
+}
+
+int usvmpc_advance(usvmpc_handle *h, double sigma, unsigned long long seed)
+{
     if (!h) return USVMPC_E_ARG;
-    if (!h->ev_valid) { h->err = "no solve has been run"; return USVMPC_E_ARG; }
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipEventSynchronize(h->ev[2]));
-    float a = 0, b = 0;
-    HIP_TRY(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
-    HIP_TRY(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
-    if (linearize_ms) *linearize_ms = a;
-    if (qp_ms) *qp_ms = b;
+    const long n = (long)h->B * h->nx;
+    hipLaunchKernelGGL(usv_advance, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ptrs, h->nx, sigma, seed);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int usvmpc_set_stream(usvmpc_handle *h, void *stream)
+{
+    if (!h) return USVMPC_E_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)stream;
+    h->own_stream = false;
     return 0;
 }
 

@@ -79,10 +79,10 @@ def lib():
     return _lib
 
 
-def _fill(dst, src, n):
+def _fill(dst, src, n, what="array"):
     a = np.ascontiguousarray(src, dtype=np.float64).reshape(-1)
     if a.size != n:
-        raise Exception("mismatching dimension: expected %d values, got %d" % (n, a.size))
+        raise Exception("mismatching dimension for %s: expected %d values, got %d" % (what, n, a.size))
     for i in range(n):
         dst[i] = a[i]
 
@@ -127,11 +127,11 @@ def desc_from_ocp(ocp, batch=1, device=0):
     if K and npar != 2 * K:
         raise Exception("parameter vector must hold (ox, oy) per obstacle row: np = %d, nh = %d" % (npar, K))
     d.K = K
-    _fill(d.W, np.asarray(cost.W).reshape(ny, ny), ny * ny)
-    _fill(d.W_e, np.asarray(cost.W_e).reshape(ny_e, ny_e), ny_e * ny_e)
-    _fill(d.Vx, np.asarray(cost.Vx).reshape(ny, nx), ny * nx)
-    _fill(d.Vu, np.asarray(cost.Vu).reshape(ny, nu), ny * nu)
-    _fill(d.Vx_e, np.asarray(cost.Vx_e).reshape(ny_e, nx), ny_e * nx)
+    _fill(d.W, cost.W, ny * ny, "cost.W (ny x ny)")
+    _fill(d.W_e, cost.W_e, ny_e * ny_e, "cost.W_e (ny_e x ny_e)")
+    _fill(d.Vx, cost.Vx, ny * nx, "cost.Vx (ny x nx)")
+    _fill(d.Vu, cost.Vu, ny * nu, "cost.Vu (ny x nu)")
+    _fill(d.Vx_e, cost.Vx_e, ny_e * nx, "cost.Vx_e (ny_e x nx)")
     idxbu = np.asarray(con.idxbu, dtype=int).reshape(-1)
     d.nbu = idxbu.size
     if np.asarray(con.lbu).size != d.nbu or np.asarray(con.ubu).size != d.nbu:

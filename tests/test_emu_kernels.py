@@ -1,0 +1,116 @@
+"""Runs the UNMODIFIED HIP kernel bodies (csrc/linearize.hpp, csrc/qp_ipm.hpp) on the CPU through the
+16-fiber lane emulator (tests/emu) and checks them against the oracle.  This pins the cross-lane
+algorithm (DPP broadcast/rotate patterns, lane ownership, plane layout) without a GPU; the emulator
+aborts on divergent control flow around a cross-lane op.  Test infrastructure only - the product
+library is never routed through it."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from mpc_collisionavoidance_amd import _capi, scenario
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu")
+CSRC = os.path.join(ROOT, "mpc_collisionavoidance_amd", "csrc")
+
+
+@pytest.fixture(scope="session")
+def emu():
+    out = os.path.join(EMU, "libusv_emu.so")
+    srcs = [os.path.join(EMU, "emu_driver.cpp"), os.path.join(EMU, "lanes.hpp")] + \
+           [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + EMU, "-I" + CSRC, "-o", out,
+                               os.path.join(EMU, "emu_driver.cpp")])
+    lib = C.CDLL(out)
+    dp, ip = _capi._dp, _capi._ip
+    lib.usv_emu_solve.argtypes = [C.POINTER(_capi.Desc)] + [dp] * 10 + [ip] * 3 + [dp] * 4
+    return lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_capi._dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_capi._ip)
+
+
+def emu_rti(emu, desc, wl, x, u, dbg=False):
+    B, N = x.shape[0], desc.N
+    nx, K = x.shape[2], desc.K
+    Bp = (B + 3) // 4 * 4
+    sl, su, pi = np.zeros((B, N, max(K, 1))), np.zeros((B, N, max(K, 1))), np.zeros((B, N, nx))
+    st, qs, qi, res = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros((B, 4))
+    BAt = np.zeros((N, nx, Bp, 16)) if dbg else None
+    rb0 = np.zeros((N, Bp, 16)) if dbg else None
+    gq = np.zeros((N + 1, Bp, 16)) if dbg else None
+    x, u = x.copy(), u.copy()
+    rc = emu.usv_emu_solve(C.byref(desc), _d(x), _d(u), _d(wl["x0"]), _d(wl["yref"]), _d(wl["yref_e"]), _d(wl["p"]),
+                           _d(wl["lh"]), _d(sl), _d(su), _d(pi), _i(st), _i(qs), _i(qi), _d(res),
+                           _d(BAt) if dbg else None, _d(rb0) if dbg else None, _d(gq) if dbg else None)
+    assert rc == 0
+    return dict(x=x, u=u, sl=sl[:, :, :K], su=su[:, :, :K], pi=pi, status=st, qp_status=qs, qp_iter=qi, res=res,
+                BAt=BAt, rb0=rb0, gq=gq)
+
+
+CASES = [("usv_model", 8, 0, 3), ("usv_model_guidance_ca1", 8, 5, 3), ("usv_model_pf_ca", 8, 4, 5),
+         ("usv_model_guidance_ca1", 6, 20, 2), ("usv_model_pf_ca", 6, 18, 2)]
+
+
+@pytest.mark.parametrize("name,N,K,B", CASES)
+def test_kernel_bodies_match_oracle(oracle, emu, name, N, K, B):
+    ocp, wl = util.make(name, N, K, B, seed=31)
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    spec = util.oracle_spec(oracle, name, N, scenario.DT[name], K)
+    xo, uo = wl["x_init"].copy(), wl["u_init"].copy()
+    xe, ue = xo.copy(), uo.copy()
+    for it in range(2):
+        r = emu_rti(emu, desc, wl, xe, ue)
+        xe, ue = r["x"], r["u"]
+        xo, uo, sto, ito = util.oracle_rti(oracle, spec, wl, xo, uo)
+        assert np.array_equal(r["status"], sto)
+        assert np.abs(r["qp_iter"] - ito).max() <= 1
+        # classical (kernel) vs square-root (oracle) Riccati: 1e-8 relative is ample for FP64
+        assert util.rel_err(xe, xo) < 1e-8 and util.rel_err(ue, uo) < 1e-8, (util.rel_err(xe, xo), util.rel_err(ue, uo))
+        assert (r["qp_status"] == 0).all()
+
+
+@pytest.mark.parametrize("name,N,K", [("usv_model", 5, 0), ("usv_model_guidance_ca1", 5, 3), ("usv_model_pf_ca", 5, 3)])
+def test_linearize_planes_match_oracle(oracle, emu, name, N, K):
+    """Lane r of the (b, k) group must hold row r of [B_k A_k]' in the BAt planes, the x lanes the
+    dynamics residual b_k, and every lane its entry of the cost gradient."""
+    B = 3  # not a multiple of 4: exercises the padded groups
+    ocp, wl = util.make(name, N, K, B, seed=8)
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    spec = util.oracle_spec(oracle, name, N, scenario.DT[name], K)
+    r = emu_rti(emu, desc, wl, wl["x_init"], wl["u_init"], dbg=True)
+    nx, nu = wl["nx"], wl["nu"]
+    for b in range(B):
+        qp, _ = oracle.linearize_and_solve(spec, wl["x_init"][b], wl["u_init"][b], wl["x0"][b], wl["yref"][b],
+                                           wl["yref_e"][b], wl["p"][b], wl["lh"][b], solve=False)
+        for k in range(N):
+            BA = np.hstack([qp["B"][k], qp["A"][k]])          # nx x nz
+            got = r["BAt"][k, :, b, :nu + nx]                    # [j, lane r] = BAt[r][j]
+            assert np.allclose(got, BA, rtol=1e-12, atol=1e-14)
+            assert np.allclose(r["rb0"][k, b, nu:nu + nx], qp["b"][k], rtol=1e-12, atol=1e-14)
+            assert np.allclose(r["gq"][k, b, :nu + nx], qp["g"][k], rtol=1e-12, atol=1e-13)
+        assert np.allclose(r["gq"][N, b, nu:nu + nx], qp["g"][N][nu:], rtol=1e-12, atol=1e-13)
+        assert np.all(r["BAt"][:, :, b, nu + nx:] == 0.0)      # idle lanes stay zero
+
+
+def test_soft_slacks_and_multipliers_exported(oracle, emu):
+    name, N, K, B = "usv_model_guidance_ca1", 10, 4, 2
+    ocp, wl = util.make(name, N, K, B, seed=77)
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    spec = util.oracle_spec(oracle, name, N, 0.05, K)
+    r = emu_rti(emu, desc, wl, wl["x_init"], wl["u_init"])
+    for b in range(B):
+        o = oracle.rti(spec, wl["x_init"][b], wl["u_init"][b], wl["x0"][b], wl["yref"][b], wl["yref_e"][b], wl["p"][b], wl["lh"][b])
+        assert np.allclose(r["sl"][b], o["sl"], atol=1e-7) and np.allclose(r["su"][b], o["su"], atol=1e-7)
+        assert np.allclose(r["pi"][b], o["pi"], rtol=1e-6, atol=1e-7)
+        assert np.allclose(r["sl"][b][0], 0.0)  # stage 0 carries no h rows

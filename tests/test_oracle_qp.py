@@ -1,0 +1,226 @@
+"""Pins the oracle's QP / RTI layer (rows a3-a7 of SURVEY.md section 8) without trusting it:
+ - the QP solution must satisfy the KKT conditions of the DENSE problem assembled here in numpy
+   (for a convex QP that is optimality, whatever algorithm produced the point);
+ - on a tiny instance the primal solution must equal scipy's SLSQP solution of the same dense QP;
+ - square-root and classical Riccati must agree;
+ - the reference's closed-loop scenarios must show the behaviour SURVEY.md 8c.3 lists.
+"""
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+
+from mpc_collisionavoidance_amd import scenario
+from tests import util
+
+
+def _rows(qp, k):
+    """Inequality rows of stage k as (c [nz], dl, du, soft_idx or None)."""
+    N, nu, nz, K = qp["N"], qp["nu"], qp["nz"], qp["K"]
+    rows = []
+    if k < N:
+        for i, j in enumerate(qp["idxbu"]):
+            c = np.zeros(nz); c[j] = 1
+            rows.append(("bu", i, c, qp["lbu"][k, i], qp["ubu"][k, i]))
+    if 1 <= k < N:
+        for i, j in enumerate(qp["idxbx"]):
+            c = np.zeros(nz); c[nu + j] = 1
+            rows.append(("bx", i, c, qp["lbx"][k, i], qp["ubx"][k, i]))
+        for i in range(K):
+            c = np.zeros(nz); c[nu + qp["ipx"]] = qp["Cxy"][k, i, 0]; c[nu + qp["ipy"]] = qp["Cxy"][k, i, 1]
+            rows.append(("g", i, c, qp["lg"][k, i], qp["ug"][k, i]))
+    return rows
+
+
+def kkt_residuals(qp, sol):
+    """Independent evaluation of stationarity / primal / dual / complementarity residuals."""
+    N, nx, nu, nz = qp["N"], qp["nx"], qp["nu"], qp["nz"]
+    z, pi = sol["dz"], sol["pi"]
+    stat = prim = comp = dual = 0.0
+    prim = max(prim, np.abs(z[0, nu:] - qp["dx0"]).max())
+    for k in range(N + 1):
+        g = qp["H"][k] @ z[k] + qp["g"][k]
+        if k < N:
+            BA = np.hstack([qp["B"][k], qp["A"][k]])
+            g += BA.T @ pi[k + 1]
+            prim = max(prim, np.abs(BA @ z[k] + qp["b"][k] - z[k + 1, nu:]).max())
+        if k >= 1:
+            g[nu:] -= pi[k]
+        for kind, i, c, dl, du in _rows(qp, k):
+            lam = {"bu": sol["lam_bu"], "bx": sol["lam_bx"], "g": sol["lam_g"]}[kind][k]
+            ll, lu = lam[0, i], lam[1, i]
+            v = c @ z[k]
+            sl = su = 0.0
+            if kind == "g" and qp["soft"]:
+                sl, su = sol["sl"][k, i], sol["su"][k, i]
+                lsl, lsu = sol["lam_s"][k, 0, i], sol["lam_s"][k, 1, i]
+                stat = max(stat, abs(qp["Zl"][i] * sl + qp["zl"][i] - ll - lsl), abs(qp["Zu"][i] * su + qp["zu"][i] - lu - lsu))
+                prim = max(prim, max(0.0, qp["lsl"][i] - sl), max(0.0, qp["lsu"][i] - su))
+                comp = max(comp, lsl * (sl - qp["lsl"][i]), lsu * (su - qp["lsu"][i]))
+                dual = max(dual, -min(lsl, lsu, 0.0))
+            g -= c * (ll - lu)
+            prim = max(prim, max(0.0, dl - (v + sl)), max(0.0, (v - su) - du))
+            comp = max(comp, abs(ll * (v + sl - dl)), abs(lu * (du - v + su)))
+            dual = max(dual, -min(ll, lu, 0.0))
+        lo = nu if k == N else 0
+        sel = np.arange(lo, nz)
+        if k == 0:
+            sel = np.arange(0, nu)  # x_0 is fixed, its stationarity row carries the free multiplier
+        stat = max(stat, np.abs(g[sel]).max())
+    return stat, prim, dual, comp
+
+
+@pytest.mark.parametrize("name,N,K", [("usv_model", 20, 0), ("usv_model_guidance_ca1", 20, 8), ("usv_model_pf_ca", 20, 4),
+                                      ("usv_model_guidance_ca1", 40, 10), ("usv_model_pf_ca", 40, 10)])
+def test_qp_solution_satisfies_dense_kkt(oracle, name, N, K):
+    ocp, wl = util.make(name, N, K, 6, seed=21)
+    dt = scenario.DT[name]
+    spec = util.oracle_spec(oracle, name, N, dt, K)
+    x, u = wl["x_init"].copy(), wl["u_init"].copy()
+    for it in range(2):
+        for b in range(x.shape[0]):
+            qp, sol = oracle.linearize_and_solve(spec, x[b], u[b], wl["x0"][b], wl["yref"][b], wl["yref_e"][b], wl["p"][b], wl["lh"][b])
+            assert sol["status"] == 0, (name, b, sol["status"], sol["res"])
+            stat, prim, dual, comp = kkt_residuals(qp, sol)
+            scale = max(1.0, np.abs(qp["g"]).max())
+            assert stat <= 1e-6 * scale and prim <= 1e-7 and dual == 0.0 and comp <= 1e-6, (name, b, stat, prim, dual, comp)
+        x, u, st, _ = util.oracle_rti(oracle, spec, wl, x, u)
+        assert (st == 0).all()
+
+
+def test_tiny_qp_against_scipy_dense_solve(oracle):
+    name, N, K = "usv_model_guidance_ca1", 3, 2
+    ocp, wl = util.make(name, N, K, 1, seed=5)
+    # put an obstacle right on the predicted path so that a soft row is active
+    wl["p"][0, :, 0] = wl["x0"][0, 5] + 0.05 * np.cos(wl["x0"][0, 7])
+    wl["p"][0, :, 1] = wl["x0"][0, 6] + 0.05 * np.sin(wl["x0"][0, 7])
+    wl["lh"][0, :, 0] = 0.3
+    spec = util.oracle_spec(oracle, name, N, 0.05, K, tol_stat=1e-10, tol_comp=1e-11)
+    qp, sol = oracle.linearize_and_solve(spec, wl["x_init"][0], wl["u_init"][0], wl["x0"][0], wl["yref"][0], wl["yref_e"][0], wl["p"][0], wl["lh"][0])
+    assert sol["status"] == 0
+    nx, nu, nz = qp["nx"], qp["nu"], qp["nz"]
+    nzt = (N + 1) * nz
+    nsl = (N + 1) * K
+    # variables: [z_0..z_N, sl, su]
+
+    def unpack(v):
+        return v[:nzt].reshape(N + 1, nz), v[nzt:nzt + nsl].reshape(N + 1, K), v[nzt + nsl:].reshape(N + 1, K)
+
+    def cost(v):
+        z, sl, su = unpack(v)
+        c = 0.0
+        for k in range(N + 1):
+            c += 0.5 * z[k] @ qp["H"][k] @ z[k] + qp["g"][k] @ z[k]
+            if 1 <= k < N:
+                c += qp["zl"] @ sl[k] + qp["zu"] @ su[k] + 0.5 * sl[k] @ (qp["Zl"] * sl[k]) + 0.5 * su[k] @ (qp["Zu"] * su[k])
+        return c
+
+    cons = [{"type": "eq", "fun": lambda v: unpack(v)[0][0, nu:] - qp["dx0"]},
+            {"type": "eq", "fun": lambda v: unpack(v)[0][N, :nu]}]
+    for k in range(N):
+        cons.append({"type": "eq", "fun": lambda v, k=k: np.hstack([qp["B"][k], qp["A"][k]]) @ unpack(v)[0][k] + qp["b"][k] - unpack(v)[0][k + 1, nu:]})
+    for k in range(N + 1):
+        for kind, i, c, dl, du in _rows(qp, k):
+            if kind == "g":
+                cons.append({"type": "ineq", "fun": lambda v, k=k, i=i, c=c, dl=dl: c @ unpack(v)[0][k] + unpack(v)[1][k, i] - dl})
+                cons.append({"type": "ineq", "fun": lambda v, k=k, i=i, c=c, du=du: du - c @ unpack(v)[0][k] + unpack(v)[2][k, i]})
+                cons.append({"type": "ineq", "fun": lambda v, k=k, i=i: unpack(v)[1][k, i] - qp["lsl"][i]})
+                cons.append({"type": "ineq", "fun": lambda v, k=k, i=i: unpack(v)[2][k, i] - qp["lsu"][i]})
+            else:
+                cons.append({"type": "ineq", "fun": lambda v, k=k, c=c, dl=dl: c @ unpack(v)[0][k] - dl})
+                cons.append({"type": "ineq", "fun": lambda v, k=k, c=c, du=du: du - c @ unpack(v)[0][k]})
+        if not (1 <= k < N):
+            cons.append({"type": "eq", "fun": lambda v, k=k: np.concatenate([unpack(v)[1][k], unpack(v)[2][k]])})
+    v0 = np.zeros(nzt + 2 * nsl)
+    r = minimize(cost, v0, constraints=cons, method="SLSQP", options={"maxiter": 500, "ftol": 1e-14})
+    assert r.success, r.message
+    z, sl, su = unpack(r.x)
+    assert np.allclose(z, sol["dz"], atol=2e-6), np.abs(z - sol["dz"]).max()
+    assert abs(cost(r.x) - cost(np.concatenate([sol["dz"].ravel(), sol["sl"].ravel(), sol["su"].ravel()]))) < 1e-8
+    # the obstacle row must really be in play in this instance
+    assert sol["sl"][1:N].max() > qp["lsl"][0] + 1e-3
+
+
+@pytest.mark.parametrize("name,N,K", [("usv_model", 20, 0), ("usv_model_guidance_ca1", 30, 8), ("usv_model_pf_ca", 30, 6)])
+def test_sqrt_and_classical_riccati_agree(oracle, name, N, K):
+    ocp, wl = util.make(name, N, K, 8, seed=2)
+    dt = scenario.DT[name]
+    s0 = util.oracle_spec(oracle, name, N, dt, K, riccati=oracle.RICCATI_SQRT)
+    s1 = util.oracle_spec(oracle, name, N, dt, K, riccati=oracle.RICCATI_CLASSIC)
+    x0, u0, st0, it0 = util.oracle_rti(oracle, s0, wl, wl["x_init"], wl["u_init"])
+    x1, u1, st1, it1 = util.oracle_rti(oracle, s1, wl, wl["x_init"], wl["u_init"])
+    assert (st0 == 0).all() and (st1 == 0).all()
+    assert util.rel_err(x1, x0) < 1e-7 and util.rel_err(u1, u0) < 1e-7
+    assert np.abs(it0 - it1).max() <= 1
+
+
+def test_closed_loop_guidance_ca1_reference_scenario(oracle):
+    """scripts/usv_guidance_ca1/main.py protocol (N=100, Tf=5, 4 obstacles r=1.5): status 0 every
+    tick, |U| <= 0.5, nominal clearance ~0.2 (lsh = -0.2), never deeper than the L1-soft margin."""
+    N, Tf, K = 100, 5.0, 8
+    spec = oracle.spec(1, N, Tf, K)
+    ak = np.arctan2(30.0, 0.0)
+    x0 = np.array([0.7, 0, 4.0, -ak, -ak, 0, 0, 0])
+    x, u = np.zeros((N + 1, 8)), np.zeros((N, 1))
+    obs = [(4, 4), (4, 7.0), (4, 12), (4, 20)]
+    pobs, robs = np.ones(16) * 100, np.zeros(8)
+    for i, (ox, oy) in enumerate(obs):
+        pobs[2 * i], pobs[2 * i + 1], robs[i] = ox, oy, 1.5
+    p, lh = np.tile(pobs, (N + 1, 1)), np.tile(robs, (N, 1))
+    yref, yref_e = np.zeros((N, 9)), np.zeros(8)
+    clear = []
+    for i in range(400):
+        r = oracle.rti(spec, x, u, x0, yref, yref_e, p, lh)
+        assert r["status"] == 0
+        x, u = r["x"], r["u"]
+        assert np.abs(u).max() <= 0.5 + 1e-7
+        clear.append(min(np.hypot(x[0, 5] - ox, x[0, 6] - oy) - 1.5 for ox, oy in obs))
+        x0 = x[1].copy()
+    assert min(clear) > 0.15, min(clear)          # sl rests at lsh = -0.2  =>  h >= r + 0.2 nominally
+    assert min(clear) < 0.3                       # and the path really passes the obstacles
+    assert x[0, 6] > 8.0                          # travelled along the path past the second obstacle
+
+
+def test_closed_loop_speed_controller_reference_scenario(oracle):
+    """scripts/usv_acados/main.py protocol (N=20, Tf=1, uref 1.3): stays within its bounds."""
+    N = 20
+    spec = oracle.spec(0, N, 1.0, 0)
+    x0 = np.array([0.001, 0, 0, 0, 0])
+    x, u = np.tile(x0, (N + 1, 1)), np.zeros((N, 2))
+    yr = np.zeros(7); yr[0] = 1.3
+    yref, yref_e = np.tile(yr, (N, 1)), yr[:5].copy()
+    p, lh = np.zeros((N + 1, 0)), np.zeros((N, 0))
+    for i in range(200):
+        r = oracle.rti(spec, x, u, x0, yref, yref_e, p, lh)
+        assert r["status"] == 0
+        x, u = r["x"], r["u"]
+        x0 = x[1].copy()
+        assert np.abs(u).max() <= 30 + 1e-6 and -30 - 1e-6 <= x[0, 3] <= 35 + 1e-6 and -30 - 1e-6 <= x[0, 4] <= 35 + 1e-6
+    assert 1.0 < x[0, 0] < 1.5  # surge speed approaches the 1.3 m/s reference
+
+
+def test_closed_loop_pf_ca_reference_scenario(oracle):
+    """scripts/usv_pf_ca/main.py protocol (N=100, Tf=1, 4 obstacles r=0.5+0.2): u -> 0.7, h >= 0.7."""
+    N, K = 100, 4
+    spec = oracle.spec(2, N, 1.0, K)
+    x1, y1, x2, y2 = 4.0, -5.0, 4.0, 25.0
+    ak = np.arctan2(y2 - y1, x2 - x1)
+    x0 = np.array([0, 0, 1, 0.001, 0, 0, -(0 - x1) * np.sin(ak) + (0 - y1) * np.cos(ak), x1, y1, ak, 0, 0, 0, 0])
+    xinit = np.array([0, 0, 1, 0.001, 0, 0, 0, 1, -1, np.arctan2(4.8, 0), 0, 0, 0, 0])
+    x, u = np.tile(xinit, (N + 1, 1)), np.zeros((N, 2))
+    obs = [(3, 2), (4, 8), (3.7, 16), (4.2, 20)]
+    pobs, robs = np.zeros(8), np.zeros(4)
+    for i, (ox, oy) in enumerate(obs):
+        pobs[2 * i], pobs[2 * i + 1], robs[i] = ox, oy, 0.7
+    yr = np.zeros(16); yr[1], yr[2], yr[3] = np.sin(ak), np.cos(ak), 0.7
+    p, lh = np.tile(pobs, (N + 1, 1)), np.tile(robs, (N, 1))
+    yref, yref_e = np.tile(yr, (N, 1)), yr[:14].copy()
+    speed = []
+    for i in range(700):  # long enough to round the first obstacle (the vessel slows to ~0.2 m/s there)
+        r = oracle.rti(spec, x, u, x0, yref, yref_e, p, lh)
+        assert r["status"] == 0
+        x, u = r["x"], r["u"]
+        x0 = x[1].copy()
+        speed.append(x[0, 3])
+        assert min(np.hypot(x[0, 10] - ox, x[0, 11] - oy) for ox, oy in obs) >= 0.7 - 1e-3
+    assert abs(speed[399] - 0.7) < 0.1 and abs(speed[-1] - 0.7) < 0.1   # cruise before / after the obstacle
+    assert min(speed[400:650]) < 0.5                                    # and a real avoidance manoeuvre between

@@ -26,8 +26,11 @@ USV_DEV double dpp_mov(double v)
 {
     const long l = __builtin_bit_cast(long, v);
     int lo = (int)l, hi = (int)(l >> 32);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    // bound_ctrl:1 - every lane of the row is written and no source lane is ever masked off (control
+    // flow around these ops is wave-uniform), so there is no `old` value to preserve and the
+    // compiler needs no zero-initialising v_mov in front of each DPP move
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __builtin_bit_cast(double, ((long)(unsigned)lo) | ((long)hi << 32));
 }
 
@@ -90,5 +93,51 @@ USV_DEV double gmin(double v)
 
 // true if the predicate holds in any lane of the wave (four instances)
 USV_DEV bool wave_any(bool p) { return __any((int)p) != 0; }
+
+// 1/x and 1/sqrt(x) from the hardware estimate + two Newton steps (full FP64 accuracy for the
+// normal-range operands of the IPM; ~10 instructions instead of the ~25 of an IEEE division)
+USV_DEV double frcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+USV_DEV double frsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    y = __builtin_fma(0.5 * y, __builtin_fma(-x * y, y, 1.0), y);
+    y = __builtin_fma(0.5 * y, __builtin_fma(-x * y, y, 1.0), y);
+    return y;
+}
+
+// A window of lane-major planes [nplanes][stride] in HBM, addressed through a buffer resource:
+// the descriptor and the plane offset live in SGPRs, the lane offset in ONE VGPR for the whole
+// kernel, so a plane access costs no VALU address arithmetic (buffer_load_dwordx2 ... offen).
+struct Planes {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned voff;        // (group * 16 + lane) * 8
+    unsigned plane_bytes; // stride * 8
+
+    USV_DEV Planes(const double *base, long stride, int nplanes, unsigned gl)
+    {
+        plane_bytes = (unsigned)(stride * 8);
+        voff = gl * 8u;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0,
+                                                 (int)((unsigned)nplanes * plane_bytes), 0x00020000);
+    }
+    USV_DEV double ld(int plane) const
+    {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)((unsigned)plane * plane_bytes), 0);
+        return __builtin_bit_cast(double, v);
+    }
+    USV_DEV void st(int plane, double x) const
+    {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), rsrc, (int)voff,
+                                              (int)((unsigned)plane * plane_bytes), 0);
+    }
+};
 
 } // namespace lanes

@@ -7,16 +7,23 @@
 //
 // Mapping: one OCP instance = one 16-lane DPP row (lanes.hpp).  Lane r owns variable r of the
 // stage vector z = [u;x], row r of every stage matrix ([B A]', P, G), the box constraint on
-// variable r, and obstacle row c*16+r of chunk c.  All matrix products are "own row × broadcast
+// variable r, and obstacle row c*16+r of chunk c.  All matrix products are "own row x broadcast
 // row" FMAs; the only reductions are the obstacle-row sums and the nu gain dot products.
 //
-// Riccati form: classical (explicit, symmetric P_k; Cholesky of the nu×nu block only).  In the
+// Riccati form: classical (explicit, symmetric P_k; Cholesky of the nu x nu block only).  In the
 // row-per-lane layout every product it needs is a natural one, whereas the square-root form
-// would need transposed products (L'b) and a 16-step sequential potrf per stage.
+// would need transposed products (L'b) and a 16-step sequential potrf per stage.  P_k never
+// leaves the registers: it is consumed by the next stage of the same backward sweep.
 //
-// Five sweeps over the horizon per IPM iteration, all state streamed through lane-major planes
-// in HBM (ws): backward A (residuals + factorise + predictor rhs), forward A (affine step),
-// backward B (corrector rhs), forward B (step), update.
+// Dynamics multipliers by the adjoint recursion: the Newton step (dz, dlam, dt) does not depend
+// on the current pi, so instead of carrying pi += alpha*dpi (which needs P_k dx in the forward
+// sweep, i.e. P_k stored and re-read), pi_k := (H z + g - C'(ll-lu))_x + A_k' pi_{k+1} is
+// recomputed inside the backward sweep from the current primal/inequality iterate.  This zeroes
+// the x rows of the stationarity residual by construction; the u rows remain as the residual.
+//
+// Four sweeps over the horizon per IPM iteration, all state streamed through lane-major planes
+// in HBM: backward A (apply the previous step, residuals, factorise, predictor rhs), forward A
+// (affine step), backward B (corrector rhs), forward B (step + step length).
 #pragma once
 #include "lanes.hpp"
 #include "params.hpp"
@@ -32,6 +39,7 @@ struct RowCalc {
     double dl, du, zl, zu, Zl, Zu, bsl, bsu;                    // data
     bool act;
     double rdl, rdu, rsl, rsu, rdsl, rdsu;                      // residuals
+    double itl, itu, itsl, itsu;                                // reciprocals of the slacks
     double Gl, Gu, iDl, iDu, rhol, rhou;                        // elimination
     double ml, mu, msl, msu;                                    // complementarity targets
     double dll, dlu, dtl, dtu, dsl, dsu, dlsl, dlsu, dtsl, dtsu; // step
@@ -45,11 +53,15 @@ struct RowCalc {
     {
         rdl = v + sl - dl - tl;
         rdu = du - v + su - tu;
+        itl = lanes::frcp(tl);
+        itu = lanes::frcp(tu);
         if constexpr (SOFTROW) {
             rsl = Zl * sl + zl - ll - lsl;
             rsu = Zu * su + zu - lu - lsu;
             rdsl = sl - bsl - tsl;
             rdsu = su - bsu - tsu;
+            itsl = lanes::frcp(tsl);
+            itsu = lanes::frcp(tsu);
         }
     }
     USV_DEV void targets_pred()
@@ -65,14 +77,12 @@ struct RowCalc {
     // Gh: coefficient of c c' added to the stage Hessian; gam: coefficient of c added to the gradient
     USV_DEV void reduce(double &Gh, double &gam)
     {
-        const double itl = 1.0 / tl, itu = 1.0 / tu;
         Gl = ll * itl; Gu = lu * itu;
         double Ghl, Ghu, gl, gu;
         if constexpr (SOFTROW) {
-            const double itsl = 1.0 / tsl, itsu = 1.0 / tsu;
             const double Gsl = lsl * itsl, Gsu = lsu * itsu;
-            iDl = 1.0 / (Zl + Gl + Gsl);
-            iDu = 1.0 / (Zu + Gu + Gsu);
+            iDl = lanes::frcp(Zl + Gl + Gsl);
+            iDu = lanes::frcp(Zu + Gu + Gsu);
             rhol = -rsl - ml * itl - Gl * rdl - msl * itsl - Gsl * rdsl;
             rhou = -rsu - mu * itu - Gu * rdu - msu * itsu - Gsu * rdsu;
             Ghl = Gl * (1.0 - Gl * iDl);
@@ -94,29 +104,27 @@ struct RowCalc {
             dsu = (rhou + Gu * w) * iDu;
             dtsl = dsl + rdsl;
             dtsu = dsu + rdsu;
-            dlsl = -(msl + lsl * dtsl) / tsl;
-            dlsu = -(msu + lsu * dtsu) / tsu;
+            dlsl = -(msl + lsl * dtsl) * itsl;
+            dlsu = -(msu + lsu * dtsu) * itsu;
         } else {
             dsl = 0.0; dsu = 0.0;
         }
         dtl = w + dsl + rdl;
         dtu = -w + dsu + rdu;
-        dll = -(ml + ll * dtl) / tl;
-        dlu = -(mu + lu * dtu) / tu;
+        dll = -(ml + ll * dtl) * itl;
+        dlu = -(mu + lu * dtu) * itu;
     }
-    USV_DEV static double ratio(double v, double dv, double a)
+    // largest -dv/v over the pairs of this row (the step length is 1/max(1, that))
+    USV_DEV double blocking(double q) const
     {
-        const double q = -v / dv;
-        return (dv < 0.0 && q < a) ? q : a;
-    }
-    USV_DEV double alpha(double a) const
-    {
-        if (!act) return a;
-        a = ratio(ll, dll, a); a = ratio(lu, dlu, a); a = ratio(tl, dtl, a); a = ratio(tu, dtu, a);
+        if (!act) return q;
+        q = fmax(q, -dtl * itl); q = fmax(q, -dtu * itu);
+        q = fmax(q, -dll * lanes::frcp(ll)); q = fmax(q, -dlu * lanes::frcp(lu));
         if constexpr (SOFTROW) {
-            a = ratio(lsl, dlsl, a); a = ratio(lsu, dlsu, a); a = ratio(tsl, dtsl, a); a = ratio(tsu, dtsu, a);
+            q = fmax(q, -dtsl * itsl); q = fmax(q, -dtsu * itsu);
+            q = fmax(q, -dlsl * lanes::frcp(lsl)); q = fmax(q, -dlsu * lanes::frcp(lsu));
         }
-        return a;
+        return q;
     }
     USV_DEV void apply(double a)
     {
@@ -132,21 +140,22 @@ template <class M, int KCH, bool SOFT>
 struct QpIpm {
     static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
     static constexpr int PXL = NU + M::IPX, PYL = NU + M::IPY;
-    // plane map of the per-stage workspace
-    enum : int { P_Z = 0, P_PI, P_RB, P_RG, P_DZA, P_DZ, P_DPI, P_PV, P_PB, P_LUV,
+    // plane map of the per-stage workspace window
+    enum : int { P_Z = 0, P_ZB, P_RB, P_RG, P_DZA, P_DZ, P_DX0, P_PB, P_LUV, P_PI,
                  P_BLL, P_BLU, P_BTL, P_BTU, P_OBS };
     static constexpr int OBSN = SOFT ? 10 : 4;
     static constexpr int P_LZU = P_OBS + KCH * OBSN;
-    static constexpr int P_PM = P_LZU + NU;
-    static constexpr int NPL = P_PM + NX;
+    static constexpr int NPL = P_LZU + NU;
 
     using BoxRow = RowCalc<false>;
     using ObsRow = RowCalc<SOFT>;
+    using Planes = lanes::Planes;
 
     const DevPtrs &P;
     const DevSpec &S;
     int lane, N;
-    long g, b, gl, stride;
+    long g, b, stride;
+    unsigned gl;
     bool xlane, ulane, valid, isPX, isPY;
 
     USV_DEV QpIpm(const DevPtrs &P_, long g_) : P(P_), S(*P_.spec)
@@ -155,7 +164,7 @@ struct QpIpm {
         N = S.N;
         g = g_;
         b = g < S.B ? g : (long)S.B - 1;
-        gl = g * LANES + lane;
+        gl = (unsigned)(g * LANES + lane);
         stride = (long)S.Bp * LANES;
         ulane = lane < NU;
         xlane = lane >= NU && lane < NZ;
@@ -164,9 +173,13 @@ struct QpIpm {
         isPY = KCH > 0 && lane == PYL;
     }
 
-    USV_DEV double &W(int k, int plane) const { return P.ws[((long)k * NPL + plane) * stride + gl]; }
+    USV_DEV Planes ws(int k) const { return Planes(P.ws + (long)k * NPL * stride, stride, NPL, gl); }
+    USV_DEV Planes conw(int k) const
+    {
+        return Planes(P.con + (long)k * (KCH > 0 ? KCH : 1) * 4 * stride, stride, (KCH > 0 ? KCH : 1) * 4, gl);
+    }
 
-    // iterate value of this lane's variable at stage k
+    // iterate value of this lane's variable at stage k (caller-visible arrays)
     USV_DEV double zbar(int k) const
     {
         if (ulane) return (k < N) ? P.u[((long)b * N + k) * NU + lane] : 0.0;
@@ -174,37 +187,35 @@ struct QpIpm {
         return 0.0;
     }
 
-    USV_DEV void box_data(int k, BoxRow &r) const
+    USV_DEV void box_data(int k, double zb, BoxRow &r) const
     {
-        const double zb = zbar(k);
         const int l = valid ? lane : 0;
         const bool stage_ok = ulane ? (k < N) : (k >= 1 && k < N);
         r.act = valid && S.has_b[l] != 0 && stage_ok;
         r.dl = r.act ? S.lb[l] - zb : -1.0;
         r.du = r.act ? S.ub[l] - zb : 1.0;
     }
-    USV_DEV void box_load(int k, BoxRow &r) const
+    USV_DEV void box_load(const Planes &W, int k, double zb, BoxRow &r) const
     {
         r.neutral();
-        box_data(k, r);
-        if (r.act) { r.ll = W(k, P_BLL); r.lu = W(k, P_BLU); r.tl = W(k, P_BTL); r.tu = W(k, P_BTU); }
+        box_data(k, zb, r);
+        if (r.act) { r.ll = W.ld(P_BLL); r.lu = W.ld(P_BLU); r.tl = W.ld(P_BTL); r.tu = W.ld(P_BTU); }
     }
-    USV_DEV void box_store(int k, const BoxRow &r) const
+    USV_DEV static void box_store(const Planes &W, const BoxRow &r)
     {
-        W(k, P_BLL) = r.ll; W(k, P_BLU) = r.lu; W(k, P_BTL) = r.tl; W(k, P_BTU) = r.tu;
+        W.st(P_BLL, r.ll); W.st(P_BLU, r.lu); W.st(P_BTL, r.tl); W.st(P_BTU, r.tu);
     }
-    // obstacle chunk c at stage k: constants (cx, cy) + row
+    // obstacle chunk c at stage k: constants (cx, cy) + row data
     USV_DEV void obs_data(int k, int c, ObsRow &r, double &cx, double &cy) const
     {
         const int i = c * LANES + lane;
         const bool stage_ok = (k >= 1 && k < N);
         r.act = stage_ok && i < S.K;
-        const int kk = stage_ok ? k : 0;
-        const double *cp = P.con + (((long)kk * KCH + c) * 4) * stride + gl;
-        cx = r.act ? cp[0] : 0.0;
-        cy = r.act ? cp[stride] : 0.0;
-        r.dl = r.act ? cp[2 * stride] : -1.0;
-        r.du = r.act ? cp[3 * stride] : 1.0;
+        cx = 0.0; cy = 0.0; r.dl = -1.0; r.du = 1.0;
+        if (r.act) {
+            const Planes C = conw(k);
+            cx = C.ld(c * 4 + 0); cy = C.ld(c * 4 + 1); r.dl = C.ld(c * 4 + 2); r.du = C.ld(c * 4 + 3);
+        }
         if constexpr (SOFT) {
             const int ii = r.act ? i : 0;
             r.zl = S.zl[ii]; r.zu = S.zu[ii];
@@ -212,26 +223,26 @@ struct QpIpm {
             r.bsl = S.lsl[ii]; r.bsu = S.lsu[ii];
         }
     }
-    USV_DEV void obs_load(int k, int c, ObsRow &r, double &cx, double &cy) const
+    USV_DEV void obs_load(const Planes &W, int k, int c, ObsRow &r, double &cx, double &cy) const
     {
         r.neutral();
         obs_data(k, c, r, cx, cy);
         if (r.act) {
             const int p0 = P_OBS + c * OBSN;
-            r.ll = W(k, p0); r.lu = W(k, p0 + 1); r.tl = W(k, p0 + 2); r.tu = W(k, p0 + 3);
+            r.ll = W.ld(p0); r.lu = W.ld(p0 + 1); r.tl = W.ld(p0 + 2); r.tu = W.ld(p0 + 3);
             if constexpr (SOFT) {
-                r.sl = W(k, p0 + 4); r.su = W(k, p0 + 5); r.lsl = W(k, p0 + 6); r.lsu = W(k, p0 + 7);
-                r.tsl = W(k, p0 + 8); r.tsu = W(k, p0 + 9);
+                r.sl = W.ld(p0 + 4); r.su = W.ld(p0 + 5); r.lsl = W.ld(p0 + 6); r.lsu = W.ld(p0 + 7);
+                r.tsl = W.ld(p0 + 8); r.tsu = W.ld(p0 + 9);
             }
         }
     }
-    USV_DEV void obs_store(int k, int c, const ObsRow &r) const
+    USV_DEV static void obs_store(const Planes &W, int c, const ObsRow &r)
     {
         const int p0 = P_OBS + c * OBSN;
-        W(k, p0) = r.ll; W(k, p0 + 1) = r.lu; W(k, p0 + 2) = r.tl; W(k, p0 + 3) = r.tu;
+        W.st(p0, r.ll); W.st(p0 + 1, r.lu); W.st(p0 + 2, r.tl); W.st(p0 + 3, r.tu);
         if constexpr (SOFT) {
-            W(k, p0 + 4) = r.sl; W(k, p0 + 5) = r.su; W(k, p0 + 6) = r.lsl; W(k, p0 + 7) = r.lsu;
-            W(k, p0 + 8) = r.tsl; W(k, p0 + 9) = r.tsu;
+            W.st(p0 + 4, r.sl); W.st(p0 + 5, r.su); W.st(p0 + 6, r.lsl); W.st(p0 + 7, r.lsu);
+            W.st(p0 + 8, r.tsl); W.st(p0 + 9, r.tsu);
         }
     }
     USV_DEV static double obs_dot(double cx, double cy, double vec)
@@ -242,16 +253,20 @@ struct QpIpm {
     // ------------------------------------------------------------------ cold start
     USV_DEV void init()
     {
+        const Planes RB0(P.rb0, stride, N, gl);
         for (int k = 0; k <= N; k++) {
-            W(k, P_Z) = 0.0;
-            W(k, P_PI) = 0.0;
-            W(k, P_RB) = (k < N) ? P.rb0[(long)k * stride + gl] : 0.0;
+            const Planes W = ws(k);
+            const double zb = zbar(k);
+            W.st(P_Z, 0.0);
+            W.st(P_ZB, zb);
+            W.st(P_RB, (k < N) ? RB0.ld(k) : 0.0);
+            if (k == 0) W.st(P_DX0, xlane ? P.x0[(long)b * NX + (lane - NU)] - zb : 0.0);
             BoxRow r;
             r.neutral();
-            box_data(k, r);
+            box_data(k, zb, r);
             r.tl = fmax(0.0 - r.dl, S.thr0); r.tu = fmax(r.du - 0.0, S.thr0);
             r.ll = S.mu0 / r.tl; r.lu = S.mu0 / r.tu;
-            box_store(k, r);
+            box_store(W, r);
             if constexpr (KCH > 0) {
                 sfor<0, KCH>([&](auto c) {
                     ObsRow o;
@@ -264,22 +279,15 @@ struct QpIpm {
                         o.tsl = fmax(0.0 - o.bsl, S.thr0); o.tsu = fmax(0.0 - o.bsu, S.thr0);
                         o.lsl = S.mu0 / o.tsl; o.lsu = S.mu0 / o.tsu;
                     }
-                    obs_store(k, c, o);
+                    obs_store(W, c, o);
                 });
             }
         }
     }
 
-    // x0 equality residual  e = (x0 - xbar_0) - z_0  (x lanes)
-    USV_DEV double x0_resid() const
-    {
-        if (!xlane) return 0.0;
-        return (P.x0[(long)b * NX + (lane - NU)] - P.x[((long)b * (N + 1)) * NX + (lane - NU)]) - W(0, P_Z);
-    }
-
     struct Norms { double rg, rb, rd, rm, musum, nan; };
 
-    // row chain up to the elimination; corr: predictor step (from dza) then corrector targets
+    // row chain up to the elimination; corr: predictor step (from w_aff) then corrector targets
     template <class R>
     USV_DEV static void chain(R &r, double v, bool corr, double w_aff, double sigmu, double &Gh, double &gam)
     {
@@ -294,30 +302,56 @@ struct QpIpm {
     }
 
     // ------------------------------------------------------------------ backward sweeps
-    // FACT = true : residuals, norms, Hessian reduction, Riccati factorisation, predictor rhs
+    // FACT = true : apply the pending step (pend), residuals + norms, adjoint multipliers, Hessian
+    //               reduction, Riccati factorisation, predictor rhs
     // FACT = false: corrector rhs only, reusing the stored factors
     template <bool FACT>
-    USV_DEV void backward(Norms &nm, double sigmu)
+    USV_DEV void backward(Norms &nm, double sigmu, bool pend, double a_prev, double sigmu_prev)
     {
         double Pn[NX], pn = 0.0, pin = 0.0;
         sfor<0, NX>([&](auto c) { Pn[c] = 0.0; });
         if (FACT) { nm.rg = nm.rb = nm.rd = nm.rm = nm.musum = nm.nan = 0.0; }
+        const Planes GQ(P.gq, stride, N + 1, gl);
         for (int k = N; k >= 0; k--) {
-            const double z = W(k, P_Z);
+            const Planes W = ws(k);
+            double z = W.ld(P_Z);
+            const double zb = W.ld(P_ZB);
             const double *Hrow = (k < N ? S.Hc : S.He) + lane * LANES;
-            // ---- rows
+            const double dza = FACT ? 0.0 : W.ld(P_DZA);
+            double rb = (k < N) ? W.ld(P_RB) : 0.0;
+            // ---- rows (with the pending update of the previous iteration applied first)
             BoxRow br;
-            box_load(k, br);
+            box_load(W, k, zb, br);
             double Ghb, gamb;
-            const double dza = FACT ? 0.0 : W(k, P_DZA);
-            chain(br, z, !FACT, dza, sigmu, Ghb, gamb);
+            double dzp = 0.0, dzap = 0.0;
+            if (FACT) {
+                dzp = W.ld(P_DZ);
+                dzap = W.ld(P_DZA);
+                if (pend && br.act) {
+                    chain(br, z, true, dzap, sigmu_prev, Ghb, gamb);
+                    br.expand(dzp);
+                    br.apply(a_prev);
+                    box_store(W, br);
+                }
+            }
+            const double znew = (FACT && pend) ? z + a_prev * dzp : z;
+            chain(br, znew, !FACT, dza, sigmu, Ghb, gamb);
             double Sxx = 0.0, Sxy = 0.0, Syy = 0.0, gx = 0.0, gy = 0.0, lx = 0.0, ly = 0.0;
             if constexpr (KCH > 0) {
                 sfor<0, KCH>([&](auto c) {
                     ObsRow o;
                     double cx, cy, Gh, gam;
-                    obs_load(k, c, o, cx, cy);
-                    const double v = obs_dot(cx, cy, z);
+                    obs_load(W, k, c, o, cx, cy);
+                    if (FACT) {
+                        const double vo = obs_dot(cx, cy, z), wp = obs_dot(cx, cy, dzp), wap = obs_dot(cx, cy, dzap);
+                        if (pend && o.act) {
+                            chain(o, vo, true, wap, sigmu_prev, Gh, gam);
+                            o.expand(wp);
+                            o.apply(a_prev);
+                            obs_store(W, c, o);
+                        }
+                    }
+                    const double v = obs_dot(cx, cy, znew);
                     const double wa = FACT ? 0.0 : obs_dot(cx, cy, dza);
                     chain(o, v, !FACT, wa, sigmu, Gh, gam);
                     gx += gam * cx; gy += gam * cy;
@@ -346,48 +380,51 @@ struct QpIpm {
                     lx = lanes::gsum(lx); ly = lanes::gsum(ly);
                 }
             }
+            z = znew;
+            if (FACT && pend) {
+                W.st(P_Z, z);
+                if (k < N) { rb = (1.0 - a_prev) * rb; W.st(P_RB, rb); }
+            }
             double bat[NX];
-            if (k < N) sfor<0, NX>([&](auto j) { bat[j] = P.BAt[((long)k * NX + j) * stride + gl]; });
-            else sfor<0, NX>([&](auto j) { bat[j] = 0.0; });
-            const double pik = W(k, P_PI);
-            double rg;
+            if (k < N) {
+                const Planes BT(P.BAt + (long)k * NX * stride, stride, NX, gl);
+                sfor<0, NX>([&](auto j) { bat[j] = BT.ld(j); });
+            } else {
+                sfor<0, NX>([&](auto j) { bat[j] = 0.0; });
+            }
+            double rg, pik = 0.0;
             if (FACT) {
-                // stationarity residual r_g = H z + g + [B A]' pi_{k+1} - [0; pi_k] - sum c (ll - lu)
-                rg = P.gq[(long)k * stride + gl];
-                sfor<0, NZ>([&](auto c) { lanes::fma_bc<c>(rg, z, Hrow[c]); });
-                sfor<0, NX>([&](auto j) { lanes::fma_bc<NU + j>(rg, pin, bat[j]); });
-                rg -= (xlane && k >= 1) ? pik : 0.0;
-                rg -= br.act ? br.ll - br.lu : 0.0;
-                rg -= isPX ? lx : (isPY ? ly : 0.0);
-                W(k, P_RG) = rg;
-                const bool counts = valid && !(k == 0 && xlane) && !(k == N && ulane);
-                nm.rg = fmax(nm.rg, counts ? fabs(rg) : 0.0);
-                nm.nan = fma(0.0, rg, nm.nan);
+                // t = H z + g + [B A]' pi_{k+1} - sum c (ll - lu);  x lanes: pi_k := t (adjoint
+                // recursion, stationarity in x holds by construction);  u lanes: residual r_g
+                double t = GQ.ld(k);
+                sfor<0, NZ>([&](auto c) { lanes::fma_bc<c>(t, z, Hrow[c]); });
+                sfor<0, NX>([&](auto j) { lanes::fma_bc<NU + j>(t, pin, bat[j]); });
+                t -= br.act ? br.ll - br.lu : 0.0;
+                t -= isPX ? lx : (isPY ? ly : 0.0);
+                pik = xlane ? t : 0.0;
+                rg = (ulane && k < N) ? t : 0.0;
+                W.st(P_RG, rg);
+                W.st(P_PI, pik);
+                nm.rg = fmax(nm.rg, fabs(rg));
+                nm.nan = fma(0.0, t, nm.nan);
                 if (br.act) {
                     nm.rd = fmax(nm.rd, fmax(fabs(br.rdl), fabs(br.rdu)));
                     nm.rm = fmax(nm.rm, fmax(br.ll * br.tl, br.lu * br.tu));
                     nm.musum += br.ll * br.tl + br.lu * br.tu;
                     nm.nan = fma(0.0, br.rdl + br.rdu, nm.nan);
                 }
+                nm.rb = fmax(nm.rb, fabs(rb));
             } else {
-                rg = W(k, P_RG);
+                rg = W.ld(P_RG);
             }
             const double gt = rg + gamb + (isPX ? gx : (isPY ? gy : 0.0));
-            const double rb = (k < N) ? W(k, P_RB) : 0.0;
-            if (FACT) nm.rb = fmax(nm.rb, fabs(rb));
 
             double pv;
             if (k == N) {
-                if (FACT) {
-                    sfor<0, NX>([&](auto c) {
-                        Pn[c] = xlane ? Hrow[NU + c] : 0.0;
-                        W(k, P_PM + c) = Pn[c];
-                    });
-                }
+                if (FACT) sfor<0, NX>([&](auto c) { Pn[c] = xlane ? Hrow[NU + c] : 0.0; });
                 pv = xlane ? gt : 0.0;
-                W(k, P_PV) = pv;
             } else {
-                double Lzu[NU], Pb;
+                double Lzu[NU], iLd[NU], Pb;
                 if (FACT) {
                     // T = [B A]' P_{k+1}   (row r: sum_j bat_j * P_{k+1}[j][:])
                     double T[NX];
@@ -396,6 +433,9 @@ struct QpIpm {
                         sfor<0, NX>([&](auto j) { lanes::fma_bc<NU + j>(a, Pn[c], bat[j]); });
                         T[c] = a;
                     });
+                    // P_{k+1} b_k (needs the old P before it is overwritten)
+                    Pb = 0.0;
+                    sfor<0, NX>([&](auto c) { lanes::fma_bc<NU + c>(Pb, rb, Pn[c]); });
                     // G = H~ + T [B A]     (row r, column c': sum_j T_j * BAt[c'][j])
                     double Gr[NZ];
                     sfor<0, NZ>([&](auto c) {
@@ -409,30 +449,25 @@ struct QpIpm {
                     });
                     // Cholesky of the leading nu columns, all rows at once
                     sfor<0, NU>([&](auto l) {
-                        const double piv = lanes::bcast<l>(Gr[l]);
-                        const double il = 1.0 / sqrt(piv);
+                        const double il = lanes::frsqrt(lanes::bcast<l>(Gr[l]));
                         Lzu[l] = Gr[l] * il;
+                        iLd[l] = il;
                         sfor<l + 1, NU>([&](auto m) { lanes::fma_bc<m>(Gr[m], Lzu[l], -Lzu[l]); });
                     });
                     // P_k = G_xx - Lxu Lxu'
-                    double Pk[NX];
                     sfor<0, NX>([&](auto c) {
                         double a = Gr[NU + c];
                         sfor<0, NU>([&](auto l) { lanes::fma_bc<NU + c>(a, Lzu[l], -Lzu[l]); });
-                        Pk[c] = xlane ? a : 0.0;
+                        Pn[c] = xlane ? a : 0.0;
                     });
-                    // P_{k+1} b_k
-                    Pb = 0.0;
-                    sfor<0, NX>([&](auto c) { lanes::fma_bc<NU + c>(Pb, rb, Pn[c]); });
-                    W(k, P_PB) = Pb;
-                    sfor<0, NU>([&](auto l) { W(k, P_LZU + l) = Lzu[l]; });
-                    sfor<0, NX>([&](auto c) {
-                        W(k, P_PM + c) = Pk[c];
-                        Pn[c] = Pk[c];
-                    });
+                    W.st(P_PB, Pb);
+                    sfor<0, NU>([&](auto l) { W.st(P_LZU + l, Lzu[l]); });
                 } else {
-                    Pb = W(k, P_PB);
-                    sfor<0, NU>([&](auto l) { Lzu[l] = W(k, P_LZU + l); });
+                    Pb = W.ld(P_PB);
+                    sfor<0, NU>([&](auto l) {
+                        Lzu[l] = W.ld(P_LZU + l);
+                        iLd[l] = lanes::frcp(lanes::bcast<l>(Lzu[l]));
+                    });
                 }
                 // vector recursion
                 const double h = Pb + pn;
@@ -442,21 +477,22 @@ struct QpIpm {
                 sfor<0, NU>([&](auto l) {
                     double a = lanes::bcast<l>(rq);
                     sfor<0, l>([&](auto m) { a -= lanes::bcast<l>(Lzu[m]) * lu[m]; });
-                    lu[l] = a / lanes::bcast<l>(Lzu[l]);
+                    lu[l] = a * iLd[l];
                     luv = (lane == l) ? lu[l] : luv;
                 });
                 pv = rq;
                 sfor<0, NU>([&](auto l) { pv -= Lzu[l] * lu[l]; });
                 pv = xlane ? pv : 0.0;
-                W(k, P_PV) = pv;
-                W(k, P_LUV) = luv;
+                W.st(P_LUV, luv);
             }
             pn = pv;
             pin = pik;
         }
         if (FACT) {
+            const Planes W0 = ws(0);
+            const double e0 = xlane ? W0.ld(P_DX0) - W0.ld(P_Z) : 0.0;
             nm.rg = lanes::gmax(nm.rg);
-            nm.rb = lanes::gmax(fmax(nm.rb, fabs(x0_resid())));
+            nm.rb = lanes::gmax(fmax(nm.rb, fabs(e0)));
             nm.rd = lanes::gmax(nm.rd);
             nm.rm = lanes::gmax(nm.rm);
             nm.musum = lanes::gsum(nm.musum);
@@ -466,26 +502,31 @@ struct QpIpm {
 
     // ------------------------------------------------------------------ forward sweeps
     // FINAL = false: affine step -> alpha_aff and the sums for mu_aff, stores dza
-    // FINAL = true : corrected step -> alpha, stores dz and dpi
+    // FINAL = true : corrected step -> alpha, stores dz
     template <bool FINAL>
     USV_DEV void forward(double sigmu, double &alpha, double &S1, double &S2)
     {
-        double dzx = x0_resid();
-        double a = 1.0, s1 = 0.0, s2 = 0.0;
+        double dzx;
+        {
+            const Planes W0 = ws(0);
+            dzx = xlane ? W0.ld(P_DX0) - W0.ld(P_Z) : 0.0;
+        }
+        double q = 1.0, s1 = 0.0, s2 = 0.0;
         for (int k = 0; k <= N; k++) {
+            const Planes W = ws(k);
             double dz;
             if (k < N) {
                 double Lzu[NU], t[NU], du[NU];
-                sfor<0, NU>([&](auto l) { Lzu[l] = W(k, P_LZU + l); });
-                const double luv = W(k, P_LUV);
+                sfor<0, NU>([&](auto l) { Lzu[l] = W.ld(P_LZU + l); });
+                const double luv = W.ld(P_LUV);
                 sfor<0, NU>([&](auto l) {
                     t[l] = lanes::bcast<l>(luv) + lanes::gsum(xlane ? Lzu[l] * dzx : 0.0);
                 });
-                sfor<0, NU>([&](auto q) { // back substitution with Luu'
-                    constexpr int l = NU - 1 - q;
+                sfor<0, NU>([&](auto qq) { // back substitution with Luu'
+                    constexpr int l = NU - 1 - qq;
                     double acc = t[l];
                     sfor<l + 1, NU>([&](auto m) { acc -= lanes::bcast<m>(Lzu[l]) * du[m]; });
-                    du[l] = acc / lanes::bcast<l>(Lzu[l]);
+                    du[l] = acc * lanes::frcp(lanes::bcast<l>(Lzu[l]));
                 });
                 dz = xlane ? dzx : 0.0;
                 sfor<0, NU>([&](auto l) { dz = (lane == l) ? -du[l] : dz; });
@@ -494,14 +535,15 @@ struct QpIpm {
             }
             // ---- rows of stage k
             {
-                const double z = W(k, P_Z);
-                const double dza = FINAL ? W(k, P_DZA) : dz;
+                const double z = W.ld(P_Z);
+                const double zb = W.ld(P_ZB);
+                const double dza = FINAL ? W.ld(P_DZA) : dz;
                 BoxRow br;
-                box_load(k, br);
+                box_load(W, k, zb, br);
                 double Gh, gam;
                 chain(br, z, FINAL, dza, sigmu, Gh, gam);
                 br.expand(dz);
-                a = br.alpha(a);
+                q = br.blocking(q);
                 if (!FINAL && br.act) {
                     s1 += br.ll * br.dtl + br.tl * br.dll + br.lu * br.dtu + br.tu * br.dlu;
                     s2 += br.dll * br.dtl + br.dlu * br.dtu;
@@ -510,13 +552,13 @@ struct QpIpm {
                     sfor<0, KCH>([&](auto c) {
                         ObsRow o;
                         double cx, cy, Gh2, gam2;
-                        obs_load(k, c, o, cx, cy);
+                        obs_load(W, k, c, o, cx, cy);
                         const double v = obs_dot(cx, cy, z);
                         const double w = obs_dot(cx, cy, dz);
                         const double wa = FINAL ? obs_dot(cx, cy, dza) : w;
                         chain(o, v, FINAL, wa, sigmu, Gh2, gam2);
                         o.expand(w);
-                        a = o.alpha(a);
+                        q = o.blocking(q);
                         if (!FINAL && o.act) {
                             s1 += o.ll * o.dtl + o.tl * o.dll + o.lu * o.dtu + o.tu * o.dlu;
                             s2 += o.dll * o.dtl + o.dlu * o.dtu;
@@ -528,72 +570,30 @@ struct QpIpm {
                     });
                 }
             }
-            W(k, FINAL ? P_DZ : P_DZA) = dz;
+            W.st(FINAL ? P_DZ : P_DZA, dz);
             if (k < N) {
-                double dxn = W(k, P_RB);
-                sfor<0, NZ>([&](auto c) {
-                    const double abr = P.ABr[((long)k * NZ + c) * stride + gl];
-                    lanes::fma_bc<c>(dxn, dz, abr);
-                });
-                dxn = xlane ? dxn : 0.0;
-                if (FINAL) {
-                    double dpi = W(k + 1, P_PV);
-                    sfor<0, NX>([&](auto c) {
-                        const double pm = W(k + 1, P_PM + c);
-                        lanes::fma_bc<NU + c>(dpi, dxn, pm);
-                    });
-                    W(k + 1, P_DPI) = xlane ? dpi : 0.0;
-                }
-                dzx = dxn;
+                const Planes AB(P.ABr + (long)k * NZ * stride, stride, NZ, gl);
+                double dxn = W.ld(P_RB);
+                sfor<0, NZ>([&](auto c) { lanes::fma_bc<c>(dxn, dz, AB.ld(c)); });
+                dzx = xlane ? dxn : 0.0;
             }
         }
-        alpha = lanes::gmin(a);
+        alpha = 1.0 / lanes::gmax(q); // q >= 1: alpha = min(1, min over blocking pairs of -v/dv)
         if (!FINAL) { S1 = lanes::gsum(s1); S2 = lanes::gsum(s2); }
-    }
-
-    // ------------------------------------------------------------------ update
-    USV_DEV void update(double a, double sigmu, bool frozen)
-    {
-        for (int k = 0; k <= N; k++) {
-            const double z = W(k, P_Z), dz = W(k, P_DZ), dza = W(k, P_DZA);
-            BoxRow br;
-            box_load(k, br);
-            double Gh, gam;
-            chain(br, z, true, dza, sigmu, Gh, gam);
-            br.expand(dz);
-            if (!frozen && br.act) { br.apply(a); box_store(k, br); }
-            if constexpr (KCH > 0) {
-                sfor<0, KCH>([&](auto c) {
-                    ObsRow o;
-                    double cx, cy, Gh2, gam2;
-                    obs_load(k, c, o, cx, cy);
-                    const double v = obs_dot(cx, cy, z);
-                    const double w = obs_dot(cx, cy, dz);
-                    const double wa = obs_dot(cx, cy, dza);
-                    chain(o, v, true, wa, sigmu, Gh2, gam2);
-                    o.expand(w);
-                    if (!frozen && o.act) { o.apply(a); obs_store(k, c, o); }
-                });
-            }
-            if (!frozen) {
-                W(k, P_Z) = z + a * dz;
-                if (k >= 1) W(k, P_PI) = W(k, P_PI) + a * W(k, P_DPI);
-                if (k < N) W(k, P_RB) = (1.0 - a) * W(k, P_RB);
-            }
-        }
     }
 
     // ------------------------------------------------------------------ driver
     USV_DEV void solve()
     {
         init();
-        bool done = false;
+        bool done = false, pend = false;
         int status = 1, iters = 0;
         Norms nm;
         double res0 = 0, res1 = 0, res2 = 0, res3 = 0;
+        double a_prev = 0.0, sig_prev = 0.0;
         const double nc = (double)S.nc;
         for (int it = 0;; it++) {
-            backward<true>(nm, 0.0);
+            backward<true>(nm, 0.0, pend && !done, a_prev, sig_prev);
             if (!done) {
                 res0 = nm.rg; res1 = nm.rb; res2 = nm.rd; res3 = nm.rm;
                 iters = it;
@@ -612,21 +612,23 @@ struct QpIpm {
                 const double sg = mu_aff / mu;
                 sigmu = sg * sg * sg * mu;
             }
-            backward<false>(nm, sigmu);
+            backward<false>(nm, sigmu, false, 0.0, 0.0);
             forward<true>(sigmu, a, d1, d2);
             if (!done && a < S.alpha_min) { status = 2; done = true; iters = it; }
-            a = a * ((1.0 - a) * 0.99 + a * 0.9999999);
-            update(a, sigmu, done);
+            a_prev = a * ((1.0 - a) * 0.99 + a * 0.9999999);
+            sig_prev = sigmu;
+            pend = true;
         }
         // ---- RTI step + outputs
         const bool ok = (status == 0 || status == 1);
         const bool real = g < S.B;
         for (int k = 0; k <= N; k++) {
-            const double z = W(k, P_Z);
+            const Planes W = ws(k);
+            const double z = W.ld(P_Z);
             if (real) {
                 if (ok && xlane) P.x[((long)b * (N + 1) + k) * NX + (lane - NU)] += z;
                 if (ok && ulane && k < N) P.u[((long)b * N + k) * NU + lane] += z;
-                if (k >= 1 && xlane && P.pi) P.pi[((long)b * N + (k - 1)) * NX + (lane - NU)] = W(k, P_PI);
+                if (k >= 1 && xlane && P.pi) P.pi[((long)b * N + (k - 1)) * NX + (lane - NU)] = W.ld(P_PI);
             }
             if constexpr (KCH > 0 && SOFT) {
                 if (k < N) {
@@ -635,8 +637,8 @@ struct QpIpm {
                         if (real && i < S.K && P.sl) {
                             const bool act = k >= 1;
                             const int p0 = P_OBS + c * OBSN;
-                            P.sl[((long)b * N + k) * S.K + i] = act ? W(k, p0 + 4) : 0.0;
-                            P.su[((long)b * N + k) * S.K + i] = act ? W(k, p0 + 5) : 0.0;
+                            P.sl[((long)b * N + k) * S.K + i] = act ? W.ld(p0 + 4) : 0.0;
+                            P.su[((long)b * N + k) * S.K + i] = act ? W.ld(p0 + 5) : 0.0;
                         }
                     });
                 }

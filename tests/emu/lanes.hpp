@@ -83,6 +83,28 @@ inline double gmin(double v)
 // finished instances are frozen by the kernels, so results do not depend on the grouping
 inline bool wave_any(bool p) { return gmax(p ? 1.0 : 0.0) > 0.5; }
 
+inline double frcp(double x) { return 1.0 / x; }
+inline double frsqrt(double x) { return 1.0 / std::sqrt(x); }
+
+// window of lane-major planes (plain pointers here; a buffer resource on the GPU)
+struct Planes {
+    double *base;
+    long stride;
+    int nplanes;
+    unsigned gl;
+    Planes(const double *b, long s, int n, unsigned g) : base(const_cast<double *>(b)), stride(s), nplanes(n), gl(g) {}
+    double ld(int plane) const
+    {
+        if (plane < 0 || plane >= nplanes) { std::fprintf(stderr, "Planes::ld out of window (%d of %d)\n", plane, nplanes); std::abort(); }
+        return base[(long)plane * stride + gl];
+    }
+    void st(int plane, double x) const
+    {
+        if (plane < 0 || plane >= nplanes) { std::fprintf(stderr, "Planes::st out of window (%d of %d)\n", plane, nplanes); std::abort(); }
+        base[(long)plane * stride + gl] = x;
+    }
+};
+
 // run body(lane) on 16 fibers in lock step
 void run_group(long group, void (*body)(void *), void *arg);
 

@@ -34,7 +34,8 @@ class Desc(C.Structure):
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libusvmpc.so")
+    # USVMPC_LIB selects an alternate build of the same library (kernel A/B experiments)
+    return os.environ.get("USVMPC_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libusvmpc.so")
 
 
 _lib = None

@@ -88,6 +88,10 @@ inline std::string build_spec(const usvmpc_desc &d, DevSpec &S)
         S.zl[i] = S.dt * d.zl[i]; S.zu[i] = S.dt * d.zu[i];
         S.Zl[i] = S.dt * d.Zl[i]; S.Zu[i] = S.dt * d.Zu[i];
     }
+    S.hdiag = 1;
+    for (int i = 0; i < LANES; i++)
+        for (int j = 0; j < LANES; j++)
+            if (i != j && (S.Hc[i * LANES + j] != 0.0 || S.He[i * LANES + j] != 0.0)) S.hdiag = 0;
     S.nc = d.N * d.nbu * 2 + (d.N - 1) * (d.nbx * 2 + d.K * (d.soft ? 4 : 2));
     S.iter_max = d.qp_iter_max;
     S.mu0 = d.mu0; S.thr0 = d.thr0;

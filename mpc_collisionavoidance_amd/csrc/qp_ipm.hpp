@@ -136,7 +136,7 @@ struct RowCalc {
     }
 };
 
-template <class M, int KCH, bool SOFT>
+template <class M, int KCH, bool SOFT, bool HDIAG>
 struct QpIpm {
     static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
     static constexpr int PXL = NU + M::IPX, PYL = NU + M::IPY;
@@ -157,6 +157,11 @@ struct QpIpm {
     long g, b, stride;
     unsigned gl;
     bool xlane, ulane, valid, isPX, isPY;
+    // per-lane constants, read once: box bounds of this lane's variable, Hessian diagonal
+    bool hasb;
+    double lbv, ubv, hd_stage, hd_term;
+    double c_zl[KCH > 0 ? KCH : 1], c_zu[KCH > 0 ? KCH : 1], c_Zl[KCH > 0 ? KCH : 1], c_Zu[KCH > 0 ? KCH : 1],
+        c_bsl[KCH > 0 ? KCH : 1], c_bsu[KCH > 0 ? KCH : 1];
 
     USV_DEV QpIpm(const DevPtrs &P_, long g_) : P(P_), S(*P_.spec)
     {
@@ -171,6 +176,20 @@ struct QpIpm {
         valid = lane < NZ;
         isPX = KCH > 0 && lane == PXL;
         isPY = KCH > 0 && lane == PYL;
+        hasb = S.has_b[lane] != 0;
+        lbv = S.lb[lane];
+        ubv = S.ub[lane];
+        hd_stage = S.Hc[lane * LANES + lane];
+        hd_term = S.He[lane * LANES + lane];
+        if constexpr (KCH > 0 && SOFT) {
+            sfor<0, KCH>([&](auto c) {
+                const int i = c * LANES + lane;
+                const int ii = i < S.K ? i : 0;
+                c_zl[c] = S.zl[ii]; c_zu[c] = S.zu[ii];
+                c_Zl[c] = i < S.K ? S.Zl[ii] : 1.0; c_Zu[c] = i < S.K ? S.Zu[ii] : 1.0;
+                c_bsl[c] = S.lsl[ii]; c_bsu[c] = S.lsu[ii];
+            });
+        }
     }
 
     USV_DEV Planes ws(int k) const { return Planes(P.ws + (long)k * NPL * stride, stride, NPL, gl); }
@@ -189,17 +208,20 @@ struct QpIpm {
 
     USV_DEV void box_data(int k, double zb, BoxRow &r) const
     {
-        const int l = valid ? lane : 0;
         const bool stage_ok = ulane ? (k < N) : (k >= 1 && k < N);
-        r.act = valid && S.has_b[l] != 0 && stage_ok;
-        r.dl = r.act ? S.lb[l] - zb : -1.0;
-        r.du = r.act ? S.ub[l] - zb : 1.0;
+        r.act = valid && hasb && stage_ok;
+        r.dl = r.act ? lbv - zb : -1.0;
+        r.du = r.act ? ubv - zb : 1.0;
     }
+    // loads are unconditional (every lane reads its slot, inactive lanes are neutralised by
+    // selects): no data-dependent branch sits between the loads of a stage, so they all issue
+    // back to back and their latencies overlap
     USV_DEV void box_load(const Planes &W, int k, double zb, BoxRow &r) const
     {
         r.neutral();
         box_data(k, zb, r);
-        if (r.act) { r.ll = W.ld(P_BLL); r.lu = W.ld(P_BLU); r.tl = W.ld(P_BTL); r.tu = W.ld(P_BTU); }
+        const double a0 = W.ld(P_BLL), a1 = W.ld(P_BLU), a2 = W.ld(P_BTL), a3 = W.ld(P_BTU);
+        r.ll = r.act ? a0 : 0.0; r.lu = r.act ? a1 : 0.0; r.tl = r.act ? a2 : 1.0; r.tu = r.act ? a3 : 1.0;
     }
     USV_DEV static void box_store(const Planes &W, const BoxRow &r)
     {
@@ -209,30 +231,31 @@ struct QpIpm {
     USV_DEV void obs_data(int k, int c, ObsRow &r, double &cx, double &cy) const
     {
         const int i = c * LANES + lane;
-        const bool stage_ok = (k >= 1 && k < N);
+        const bool stage_ok = (k >= 1 && k < N); // wave-uniform
         r.act = stage_ok && i < S.K;
         cx = 0.0; cy = 0.0; r.dl = -1.0; r.du = 1.0;
-        if (r.act) {
+        if (stage_ok) {
             const Planes C = conw(k);
-            cx = C.ld(c * 4 + 0); cy = C.ld(c * 4 + 1); r.dl = C.ld(c * 4 + 2); r.du = C.ld(c * 4 + 3);
+            const double a0 = C.ld(c * 4 + 0), a1 = C.ld(c * 4 + 1), a2 = C.ld(c * 4 + 2), a3 = C.ld(c * 4 + 3);
+            cx = r.act ? a0 : 0.0; cy = r.act ? a1 : 0.0; r.dl = r.act ? a2 : -1.0; r.du = r.act ? a3 : 1.0;
         }
         if constexpr (SOFT) {
-            const int ii = r.act ? i : 0;
-            r.zl = S.zl[ii]; r.zu = S.zu[ii];
-            r.Zl = r.act ? S.Zl[ii] : 1.0; r.Zu = r.act ? S.Zu[ii] : 1.0;
-            r.bsl = S.lsl[ii]; r.bsu = S.lsu[ii];
+            r.zl = c_zl[c]; r.zu = c_zu[c]; r.Zl = c_Zl[c]; r.Zu = c_Zu[c]; r.bsl = c_bsl[c]; r.bsu = c_bsu[c];
         }
     }
     USV_DEV void obs_load(const Planes &W, int k, int c, ObsRow &r, double &cx, double &cy) const
     {
         r.neutral();
         obs_data(k, c, r, cx, cy);
-        if (r.act) {
+        if (k >= 1 && k < N) { // wave-uniform
             const int p0 = P_OBS + c * OBSN;
-            r.ll = W.ld(p0); r.lu = W.ld(p0 + 1); r.tl = W.ld(p0 + 2); r.tu = W.ld(p0 + 3);
+            const double a0 = W.ld(p0), a1 = W.ld(p0 + 1), a2 = W.ld(p0 + 2), a3 = W.ld(p0 + 3);
+            r.ll = r.act ? a0 : 0.0; r.lu = r.act ? a1 : 0.0; r.tl = r.act ? a2 : 1.0; r.tu = r.act ? a3 : 1.0;
             if constexpr (SOFT) {
-                r.sl = W.ld(p0 + 4); r.su = W.ld(p0 + 5); r.lsl = W.ld(p0 + 6); r.lsu = W.ld(p0 + 7);
-                r.tsl = W.ld(p0 + 8); r.tsu = W.ld(p0 + 9);
+                const double b0 = W.ld(p0 + 4), b1 = W.ld(p0 + 5), b2 = W.ld(p0 + 6), b3 = W.ld(p0 + 7),
+                             b4 = W.ld(p0 + 8), b5 = W.ld(p0 + 9);
+                r.sl = r.act ? b0 : 0.0; r.su = r.act ? b1 : 0.0; r.lsl = r.act ? b2 : 0.0; r.lsu = r.act ? b3 : 0.0;
+                r.tsl = r.act ? b4 : 1.0; r.tsu = r.act ? b5 : 1.0;
             }
         }
     }
@@ -316,7 +339,8 @@ struct QpIpm {
             const Planes W = ws(k);
             double z = W.ld(P_Z);
             const double zb = W.ld(P_ZB);
-            const double *Hrow = (k < N ? S.Hc : S.He) + lane * LANES;
+            const double *Hrow = (k < N ? S.Hc : S.He) + lane * LANES; // only read when !HDIAG
+            const double hd = (k < N) ? hd_stage : hd_term;
             const double dza = FACT ? 0.0 : W.ld(P_DZA);
             double rb = (k < N) ? W.ld(P_RB) : 0.0;
             // ---- rows (with the pending update of the previous iteration applied first)
@@ -397,7 +421,8 @@ struct QpIpm {
                 // t = H z + g + [B A]' pi_{k+1} - sum c (ll - lu);  x lanes: pi_k := t (adjoint
                 // recursion, stationarity in x holds by construction);  u lanes: residual r_g
                 double t = GQ.ld(k);
-                sfor<0, NZ>([&](auto c) { lanes::fma_bc<c>(t, z, Hrow[c]); });
+                if constexpr (HDIAG) t = fma(hd, z, t);
+                else sfor<0, NZ>([&](auto c) { lanes::fma_bc<c>(t, z, Hrow[c]); });
                 sfor<0, NX>([&](auto j) { lanes::fma_bc<NU + j>(t, pin, bat[j]); });
                 t -= br.act ? br.ll - br.lu : 0.0;
                 t -= isPX ? lx : (isPY ? ly : 0.0);
@@ -421,7 +446,10 @@ struct QpIpm {
 
             double pv;
             if (k == N) {
-                if (FACT) sfor<0, NX>([&](auto c) { Pn[c] = xlane ? Hrow[NU + c] : 0.0; });
+                if (FACT) sfor<0, NX>([&](auto c) {
+                    if constexpr (HDIAG) Pn[c] = (lane == NU + c) ? hd : 0.0;
+                    else Pn[c] = xlane ? Hrow[NU + c] : 0.0;
+                });
                 pv = xlane ? gt : 0.0;
             } else {
                 double Lzu[NU], iLd[NU], Pb;
@@ -439,7 +467,9 @@ struct QpIpm {
                     // G = H~ + T [B A]     (row r, column c': sum_j T_j * BAt[c'][j])
                     double Gr[NZ];
                     sfor<0, NZ>([&](auto c) {
-                        double a = Hrow[c] + ((lane == c) ? Ghb : 0.0);
+                        double a;
+                        if constexpr (HDIAG) a = (lane == c) ? hd + Ghb : 0.0;
+                        else a = Hrow[c] + ((lane == c) ? Ghb : 0.0);
                         if constexpr (KCH > 0) {
                             if constexpr (c == PXL) a += isPX ? Sxx : (isPY ? Sxy : 0.0);
                             if constexpr (c == PYL) a += isPX ? Sxy : (isPY ? Syy : 0.0);

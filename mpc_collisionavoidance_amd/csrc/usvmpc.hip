@@ -28,12 +28,12 @@ __global__ void __launch_bounds__(256, 2) usv_linearize(DevPtrs P, long ngroups)
     Linearize<M, KCH>::run(P, gid);
 }
 
-template <class M, int KCH, bool SOFT>
-__global__ void __launch_bounds__(64, 2) usv_qp_rti(DevPtrs P, long ngroups)
+template <class M, int KCH, bool SOFT, bool HDIAG>
+__global__ void __launch_bounds__(64, 3) usv_qp_rti(DevPtrs P, long ngroups)
 {
     const long gid = lanes::group_linear();
     if (gid >= ngroups) return;
-    QpIpm<M, KCH, SOFT> q(P, gid);
+    QpIpm<M, KCH, SOFT, HDIAG> q(P, gid);
     q.solve();
 }
 
@@ -197,7 +197,10 @@ int launch_pair(usvmpc_handle *h)
     hipLaunchKernelGGL((usv_linearize<M, KCH>), dim3((unsigned)lin_grid), dim3(lin_block), 0, h->stream, h->ptrs, lin_groups);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[1], h->stream));
-    hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT>), dim3((unsigned)qp_grid), dim3(qp_block), 0, h->stream, h->ptrs, qp_groups);
+    if (h->spec.hdiag)
+        hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true>), dim3((unsigned)qp_grid), dim3(qp_block), 0, h->stream, h->ptrs, qp_groups);
+    else
+        hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false>), dim3((unsigned)qp_grid), dim3(qp_block), 0, h->stream, h->ptrs, qp_groups);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[2], h->stream));
     h->nsolves++;

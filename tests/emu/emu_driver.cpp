@@ -106,11 +106,11 @@ void lin_body(void *a)
     Job *j = (Job *)a;
     Linearize<M, KCH>::run(*j->P, j->gid);
 }
-template <class M, int KCH, bool SOFT>
+template <class M, int KCH, bool SOFT, bool HDIAG>
 void qp_body(void *a)
 {
     Job *j = (Job *)a;
-    QpIpm<M, KCH, SOFT> q(*j->P, j->gid);
+    QpIpm<M, KCH, SOFT, HDIAG> q(*j->P, j->gid);
     q.solve();
 }
 
@@ -125,7 +125,8 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase)
     if (phase & 2)
         for (long g = 0; g < S.Bp; g++) {
             Job j{&P, g};
-            lanes::run_group(g, &qp_body<M, KCH, SOFT>, &j);
+            if (S.hdiag) lanes::run_group(g, &qp_body<M, KCH, SOFT, true>, &j);
+            else lanes::run_group(g, &qp_body<M, KCH, SOFT, false>, &j);
         }
 }
 

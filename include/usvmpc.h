@@ -115,6 +115,9 @@ int usvmpc_kernel_ms(usvmpc_handle *h, int n, float *linearize_ms, float *qp_ms)
 int usvmpc_advance(usvmpc_handle *h, double sigma, unsigned long long seed);
 /* Adopt a caller-owned HIP stream (e.g. torch's current stream) for all subsequent work */
 int usvmpc_set_stream(usvmpc_handle *h, void *stream);
+/* run-time options: "sort_by_difficulty" (default 1) - group instances of similar IPM iteration
+ * count (from their previous solve) into the same wavefront; scheduling only, results unchanged */
+int usvmpc_set_option(usvmpc_handle *h, const char *name, double value);
 /* bytes of device memory held by the handle */
 size_t usvmpc_device_bytes(usvmpc_handle *h);
 const char *usvmpc_last_error(usvmpc_handle *h);

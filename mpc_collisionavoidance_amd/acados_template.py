@@ -247,6 +247,9 @@ class BatchOcpSolver:
         """Closed-loop hand-over on the device: x0 <- x_1 (+ sigma N(0,1)); asynchronous."""
         self._check(self._lib.usvmpc_advance(self._h, float(sigma), int(seed)))
 
+    def set_option(self, name, value):
+        self._check(self._lib.usvmpc_set_option(self._h, name.encode(), float(value)))
+
     def set_stream(self, stream_ptr):
         self._check(self._lib.usvmpc_set_stream(self._h, C.c_void_p(stream_ptr)))
 

@@ -27,7 +27,8 @@ struct Linearize {
         const long Bp = S.Bp;
         const int k = (int)(gid / Bp);
         const long g = gid - (long)k * Bp;
-        const long b = g < S.B ? g : (long)S.B - 1; // padded groups replay the last instance
+        const long gi = g < S.B ? g : (long)S.B - 1; // padded groups replay the last instance
+        const long b = P.perm ? (long)P.perm[gi] : gi;
         const long stride = Bp * LANES;
         const long gl = g * LANES + lane;
         const bool xlane = lane >= NU && lane < NZ;

@@ -30,6 +30,7 @@ struct DevSpec {
 // Device pointers of one solver handle.
 struct DevPtrs {
     const DevSpec *spec;
+    const int *perm;      // [B] group -> instance (difficulty binning); nullptr = identity
     // caller-visible arrays, natural layout, instance-major
     double *x;            // [B][N+1][nx]
     double *u;            // [B][N][nu]

@@ -168,7 +168,10 @@ struct QpIpm {
         lane = lanes::lane();
         N = S.N;
         g = g_;
-        b = g < S.B ? g : (long)S.B - 1;
+        {
+            const long gi = g < S.B ? g : (long)S.B - 1;
+            b = P.perm ? (long)P.perm[gi] : gi;
+        }
         gl = (unsigned)(g * LANES + lane);
         stride = (long)S.Bp * LANES;
         ulane = lane < NU;
@@ -324,6 +327,78 @@ struct QpIpm {
         }
     }
 
+    // ------------------------------------------------------------------ staged plane reads
+    // Raw plane values of one stage.  The sweeps read them one stage AHEAD of their use (software
+    // prefetch): with 2-3 waves per SIMD there is no other wave to hide an HBM round trip, so each
+    // stage's loads are put in flight while the previous stage is still being computed.
+    struct StageIn {
+        double z, zb, rb, dz, dza, gq, rg, pb, luv;
+        double lzu[NU];
+        double box[4];
+        double obs[KCH > 0 ? KCH : 1][OBSN];
+        double con[KCH > 0 ? KCH : 1][4];
+    };
+    enum : int { SW_BACK_A = 0, SW_FWD_A = 1, SW_BACK_B = 2, SW_FWD_B = 3 };
+
+    template <int SW>
+    USV_DEV void load_in(int k, StageIn &in) const
+    {
+        const Planes W = ws(k);
+        in.z = W.ld(P_Z);
+        in.zb = W.ld(P_ZB);
+        if constexpr (SW != SW_BACK_B) in.rb = (k < N) ? W.ld(P_RB) : 0.0;
+        if constexpr (SW == SW_BACK_A) {
+            in.dz = W.ld(P_DZ);
+            in.dza = W.ld(P_DZA);
+            in.gq = Planes(P.gq, stride, N + 1, gl).ld(k);
+        }
+        if constexpr (SW == SW_BACK_B || SW == SW_FWD_B) in.dza = W.ld(P_DZA);
+        if constexpr (SW == SW_BACK_B) {
+            in.rg = W.ld(P_RG);
+            in.pb = (k < N) ? W.ld(P_PB) : 0.0;
+        }
+        if constexpr (SW != SW_BACK_A) {
+            if (k < N) sfor<0, NU>([&](auto l) { in.lzu[l] = W.ld(P_LZU + l); });
+            else sfor<0, NU>([&](auto l) { in.lzu[l] = 1.0; });
+        }
+        if constexpr (SW == SW_FWD_A || SW == SW_FWD_B) in.luv = (k < N) ? W.ld(P_LUV) : 0.0;
+        in.box[0] = W.ld(P_BLL); in.box[1] = W.ld(P_BLU); in.box[2] = W.ld(P_BTL); in.box[3] = W.ld(P_BTU);
+        if constexpr (KCH > 0) {
+            if (k >= 1 && k < N) { // wave-uniform
+                const Planes C = conw(k);
+                sfor<0, KCH>([&](auto c) {
+                    sfor<0, OBSN>([&](auto e) { in.obs[c][e] = W.ld(P_OBS + c * OBSN + e); });
+                    sfor<0, 4>([&](auto e) { in.con[c][e] = C.ld(c * 4 + e); });
+                });
+            }
+        }
+    }
+    USV_DEV void box_from(const StageIn &in, int k, BoxRow &r) const
+    {
+        r.neutral();
+        box_data(k, in.zb, r);
+        r.ll = r.act ? in.box[0] : 0.0; r.lu = r.act ? in.box[1] : 0.0;
+        r.tl = r.act ? in.box[2] : 1.0; r.tu = r.act ? in.box[3] : 1.0;
+    }
+    template <int C>
+    USV_DEV void obs_from(const StageIn &in, int k, ObsRow &r, double &cx, double &cy) const
+    {
+        const int i = C * LANES + lane;
+        const bool stage_ok = (k >= 1 && k < N);
+        r.neutral();
+        r.act = stage_ok && i < S.K;
+        cx = r.act ? in.con[C][0] : 0.0; cy = r.act ? in.con[C][1] : 0.0;
+        r.dl = r.act ? in.con[C][2] : -1.0; r.du = r.act ? in.con[C][3] : 1.0;
+        r.ll = r.act ? in.obs[C][0] : 0.0; r.lu = r.act ? in.obs[C][1] : 0.0;
+        r.tl = r.act ? in.obs[C][2] : 1.0; r.tu = r.act ? in.obs[C][3] : 1.0;
+        if constexpr (SOFT) {
+            r.sl = r.act ? in.obs[C][4] : 0.0; r.su = r.act ? in.obs[C][5] : 0.0;
+            r.lsl = r.act ? in.obs[C][6] : 0.0; r.lsu = r.act ? in.obs[C][7] : 0.0;
+            r.tsl = r.act ? in.obs[C][8] : 1.0; r.tsu = r.act ? in.obs[C][9] : 1.0;
+            r.zl = c_zl[C]; r.zu = c_zu[C]; r.Zl = c_Zl[C]; r.Zu = c_Zu[C]; r.bsl = c_bsl[C]; r.bsu = c_bsu[C];
+        }
+    }
+
     // ------------------------------------------------------------------ backward sweeps
     // FACT = true : apply the pending step (pend), residuals + norms, adjoint multipliers, Hessian
     //               reduction, Riccati factorisation, predictor rhs
@@ -331,26 +406,34 @@ struct QpIpm {
     template <bool FACT>
     USV_DEV void backward(Norms &nm, double sigmu, bool pend, double a_prev, double sigmu_prev)
     {
+        constexpr int SW = FACT ? SW_BACK_A : SW_BACK_B;
         double Pn[NX], pn = 0.0, pin = 0.0;
         sfor<0, NX>([&](auto c) { Pn[c] = 0.0; });
         if (FACT) { nm.rg = nm.rb = nm.rd = nm.rm = nm.musum = nm.nan = 0.0; }
-        const Planes GQ(P.gq, stride, N + 1, gl);
+        StageIn nxt;
+        load_in<SW>(N, nxt);
         for (int k = N; k >= 0; k--) {
+            const StageIn in = nxt;
             const Planes W = ws(k);
-            double z = W.ld(P_Z);
-            const double zb = W.ld(P_ZB);
+            // this stage's [B A]' rows: in flight while the rows below are processed
+            double bat[NX];
+            if (k < N) {
+                const Planes BT(P.BAt + (long)k * NX * stride, stride, NX, gl);
+                sfor<0, NX>([&](auto j) { bat[j] = BT.ld(j); });
+            } else {
+                sfor<0, NX>([&](auto j) { bat[j] = 0.0; });
+            }
+            double z = in.z;
             const double *Hrow = (k < N ? S.Hc : S.He) + lane * LANES; // only read when !HDIAG
             const double hd = (k < N) ? hd_stage : hd_term;
-            const double dza = FACT ? 0.0 : W.ld(P_DZA);
-            double rb = (k < N) ? W.ld(P_RB) : 0.0;
+            const double dza = FACT ? 0.0 : in.dza;
+            double rb = FACT ? in.rb : 0.0;
             // ---- rows (with the pending update of the previous iteration applied first)
             BoxRow br;
-            box_load(W, k, zb, br);
+            box_from(in, k, br);
             double Ghb, gamb;
-            double dzp = 0.0, dzap = 0.0;
+            const double dzp = FACT ? in.dz : 0.0, dzap = FACT ? in.dza : 0.0;
             if (FACT) {
-                dzp = W.ld(P_DZ);
-                dzap = W.ld(P_DZA);
                 if (pend && br.act) {
                     chain(br, z, true, dzap, sigmu_prev, Ghb, gamb);
                     br.expand(dzp);
@@ -365,7 +448,7 @@ struct QpIpm {
                 sfor<0, KCH>([&](auto c) {
                     ObsRow o;
                     double cx, cy, Gh, gam;
-                    obs_load(W, k, c, o, cx, cy);
+                    obs_from<c>(in, k, o, cx, cy);
                     if (FACT) {
                         const double vo = obs_dot(cx, cy, z), wp = obs_dot(cx, cy, dzp), wap = obs_dot(cx, cy, dzap);
                         if (pend && o.act) {
@@ -409,18 +492,14 @@ struct QpIpm {
                 W.st(P_Z, z);
                 if (k < N) { rb = (1.0 - a_prev) * rb; W.st(P_RB, rb); }
             }
-            double bat[NX];
-            if (k < N) {
-                const Planes BT(P.BAt + (long)k * NX * stride, stride, NX, gl);
-                sfor<0, NX>([&](auto j) { bat[j] = BT.ld(j); });
-            } else {
-                sfor<0, NX>([&](auto j) { bat[j] = 0.0; });
-            }
+            // ---- next stage's planes go in flight before the matrix work of this one
+            if (k > 0) load_in<SW>(k - 1, nxt);
+
             double rg, pik = 0.0;
             if (FACT) {
                 // t = H z + g + [B A]' pi_{k+1} - sum c (ll - lu);  x lanes: pi_k := t (adjoint
                 // recursion, stationarity in x holds by construction);  u lanes: residual r_g
-                double t = GQ.ld(k);
+                double t = in.gq;
                 if constexpr (HDIAG) t = fma(hd, z, t);
                 else sfor<0, NZ>([&](auto c) { lanes::fma_bc<c>(t, z, Hrow[c]); });
                 sfor<0, NX>([&](auto j) { lanes::fma_bc<NU + j>(t, pin, bat[j]); });
@@ -440,7 +519,7 @@ struct QpIpm {
                 }
                 nm.rb = fmax(nm.rb, fabs(rb));
             } else {
-                rg = W.ld(P_RG);
+                rg = in.rg;
             }
             const double gt = rg + gamb + (isPX ? gx : (isPY ? gy : 0.0));
 
@@ -493,9 +572,9 @@ struct QpIpm {
                     W.st(P_PB, Pb);
                     sfor<0, NU>([&](auto l) { W.st(P_LZU + l, Lzu[l]); });
                 } else {
-                    Pb = W.ld(P_PB);
+                    Pb = in.pb;
                     sfor<0, NU>([&](auto l) {
-                        Lzu[l] = W.ld(P_LZU + l);
+                        Lzu[l] = in.lzu[l];
                         iLd[l] = lanes::frcp(lanes::bcast<l>(Lzu[l]));
                     });
                 }
@@ -536,27 +615,37 @@ struct QpIpm {
     template <bool FINAL>
     USV_DEV void forward(double sigmu, double &alpha, double &S1, double &S2)
     {
+        constexpr int SW = FINAL ? SW_FWD_B : SW_FWD_A;
         double dzx;
         {
             const Planes W0 = ws(0);
             dzx = xlane ? W0.ld(P_DX0) - W0.ld(P_Z) : 0.0;
         }
         double q = 1.0, s1 = 0.0, s2 = 0.0;
+        StageIn nxt;
+        load_in<SW>(0, nxt);
         for (int k = 0; k <= N; k++) {
+            const StageIn in = nxt;
             const Planes W = ws(k);
+            // this stage's rows of [B A] and the next stage's small planes: both in flight during
+            // the gain / row computations below
+            double abr[NZ];
+            if (k < N) {
+                const Planes AB(P.ABr + (long)k * NZ * stride, stride, NZ, gl);
+                sfor<0, NZ>([&](auto c) { abr[c] = AB.ld(c); });
+                load_in<SW>(k + 1, nxt);
+            }
             double dz;
             if (k < N) {
-                double Lzu[NU], t[NU], du[NU];
-                sfor<0, NU>([&](auto l) { Lzu[l] = W.ld(P_LZU + l); });
-                const double luv = W.ld(P_LUV);
+                double t[NU], du[NU];
                 sfor<0, NU>([&](auto l) {
-                    t[l] = lanes::bcast<l>(luv) + lanes::gsum(xlane ? Lzu[l] * dzx : 0.0);
+                    t[l] = lanes::bcast<l>(in.luv) + lanes::gsum(xlane ? in.lzu[l] * dzx : 0.0);
                 });
                 sfor<0, NU>([&](auto qq) { // back substitution with Luu'
                     constexpr int l = NU - 1 - qq;
                     double acc = t[l];
-                    sfor<l + 1, NU>([&](auto m) { acc -= lanes::bcast<m>(Lzu[l]) * du[m]; });
-                    du[l] = acc * lanes::frcp(lanes::bcast<l>(Lzu[l]));
+                    sfor<l + 1, NU>([&](auto m) { acc -= lanes::bcast<m>(in.lzu[l]) * du[m]; });
+                    du[l] = acc * lanes::frcp(lanes::bcast<l>(in.lzu[l]));
                 });
                 dz = xlane ? dzx : 0.0;
                 sfor<0, NU>([&](auto l) { dz = (lane == l) ? -du[l] : dz; });
@@ -565,11 +654,10 @@ struct QpIpm {
             }
             // ---- rows of stage k
             {
-                const double z = W.ld(P_Z);
-                const double zb = W.ld(P_ZB);
-                const double dza = FINAL ? W.ld(P_DZA) : dz;
+                const double z = in.z;
+                const double dza = FINAL ? in.dza : dz;
                 BoxRow br;
-                box_load(W, k, zb, br);
+                box_from(in, k, br);
                 double Gh, gam;
                 chain(br, z, FINAL, dza, sigmu, Gh, gam);
                 br.expand(dz);
@@ -582,7 +670,7 @@ struct QpIpm {
                     sfor<0, KCH>([&](auto c) {
                         ObsRow o;
                         double cx, cy, Gh2, gam2;
-                        obs_load(W, k, c, o, cx, cy);
+                        obs_from<c>(in, k, o, cx, cy);
                         const double v = obs_dot(cx, cy, z);
                         const double w = obs_dot(cx, cy, dz);
                         const double wa = FINAL ? obs_dot(cx, cy, dza) : w;
@@ -602,9 +690,8 @@ struct QpIpm {
             }
             W.st(FINAL ? P_DZ : P_DZA, dz);
             if (k < N) {
-                const Planes AB(P.ABr + (long)k * NZ * stride, stride, NZ, gl);
-                double dxn = W.ld(P_RB);
-                sfor<0, NZ>([&](auto c) { lanes::fma_bc<c>(dxn, dz, AB.ld(c)); });
+                double dxn = in.rb;
+                sfor<0, NZ>([&](auto c) { lanes::fma_bc<c>(dxn, dz, abr[c]); });
                 dzx = xlane ? dxn : 0.0;
             }
         }

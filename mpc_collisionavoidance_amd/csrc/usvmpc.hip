@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256, 2) usv_linearize(DevPtrs P, long ngroups)
 }
 
 template <class M, int KCH, bool SOFT, bool HDIAG>
-__global__ void __launch_bounds__(64, 3) usv_qp_rti(DevPtrs P, long ngroups)
+__global__ void __launch_bounds__(64, 2) usv_qp_rti(DevPtrs P, long ngroups)
 {
     const long gid = lanes::group_linear();
     if (gid >= ngroups) return;
@@ -67,6 +67,36 @@ __global__ void usv_advance(DevPtrs P, int nx, double sigma, unsigned long long 
     const_cast<double *>(P.x0)[i] = v;
 }
 
+// Difficulty binning: a wave carries four instances and runs until the slowest one converges, so
+// instances are grouped by the IPM iteration count of their previous solve (a counting sort on the
+// device, hardest first so that long-running waves start early).  Only the group -> instance map
+// changes; the arithmetic of an instance does not depend on its neighbours.
+constexpr int SORT_BINS = 64;
+
+__global__ void usv_sort_hist(const int *qp_iter, int B, int *hist)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) atomicAdd(&hist[min(max(qp_iter[i], 0), SORT_BINS - 1)], 1);
+}
+
+__global__ void usv_sort_scan(int *hist, int *cursor)
+{
+    if (threadIdx.x == 0) {
+        int pos = 0;
+        for (int b = SORT_BINS - 1; b >= 0; b--) { // descending difficulty
+            cursor[b] = pos;
+            pos += hist[b];
+            hist[b] = 0;
+        }
+    }
+}
+
+__global__ void usv_sort_scatter(const int *qp_iter, int B, int *cursor, int *perm)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) perm[atomicAdd(&cursor[min(max(qp_iter[i], 0), SORT_BINS - 1)], 1)] = i;
+}
+
 // ---------------------------------------------------------------------------------- handle
 struct usvmpc_handle {
     usvmpc_desc desc;
@@ -81,6 +111,8 @@ struct usvmpc_handle {
     hipEvent_t ev[RING][3];
     long nsolves;
     DevSpec *d_spec;
+    int *d_perm, *d_hist, *d_cursor;
+    bool sort_enabled;
     size_t bytes;
     std::string err;
     void *allocs[32];
@@ -193,6 +225,14 @@ int launch_pair(usvmpc_handle *h)
     const long lin_grid = (lin_groups * LANES + lin_block - 1) / lin_block;
     const long qp_grid = (qp_groups * LANES + qp_block - 1) / qp_block;
     hipEvent_t *ev = h->ev[h->nsolves % usvmpc_handle::RING];
+    if (h->sort_enabled && h->nsolves > 0) {
+        const int B = h->B;
+        hipLaunchKernelGGL(usv_sort_hist, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_iter, B, h->d_hist);
+        hipLaunchKernelGGL(usv_sort_scan, dim3(1), dim3(64), 0, h->stream, h->d_hist, h->d_cursor);
+        hipLaunchKernelGGL(usv_sort_scatter, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_iter, B, h->d_cursor, h->d_perm);
+        HIP_TRY(h, hipGetLastError());
+        h->ptrs.perm = h->d_perm;
+    }
     HIP_TRY(h, hipEventRecord(ev[0], h->stream));
     hipLaunchKernelGGL((usv_linearize<M, KCH>), dim3((unsigned)lin_grid), dim3(lin_block), 0, h->stream, h->ptrs, lin_groups);
     HIP_TRY(h, hipGetLastError());
@@ -305,6 +345,10 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     TRY_C(dev_alloc(h, &P.qp_iter, B, true));
     TRY_C(dev_alloc(h, &P.qp_status, B, true));
     TRY_C(dev_alloc(h, &P.res, B * 4, true));
+    TRY_C(dev_alloc(h, &h->d_perm, B, true));
+    TRY_C(dev_alloc(h, &h->d_hist, SORT_BINS, true));
+    TRY_C(dev_alloc(h, &h->d_cursor, SORT_BINS, true));
+    h->sort_enabled = true;
     TRY_C(dev_alloc(h, &P.BAt, N * h->nx * stride, true));
     TRY_C(dev_alloc(h, &P.ABr, N * h->nz * stride, true)); // u lanes / idle lanes stay zero
     TRY_C(dev_alloc(h, &P.rb0, N * stride, true));
@@ -429,6 +473,19 @@ int usvmpc_advance(usvmpc_handle *h, double sigma, unsigned long long seed)
     hipLaunchKernelGGL(usv_advance, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ptrs, h->nx, sigma, seed);
     HIP_TRY(h, hipGetLastError());
     return 0;
+}
+
+int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
+{
+    if (!h) return USVMPC_E_ARG;
+    const std::string s(name ? name : "");
+    if (s == "sort_by_difficulty") {
+        h->sort_enabled = value != 0.0;
+        if (!h->sort_enabled) h->ptrs.perm = nullptr;
+        return 0;
+    }
+    h->err = "unknown option '" + s + "'";
+    return USVMPC_E_FIELD;
 }
 
 int usvmpc_set_stream(usvmpc_handle *h, void *stream)

@@ -118,6 +118,10 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
 /* run-time options: "sort_by_difficulty" (default 1) - group instances of similar IPM iteration
  * count (from their previous solve) into the same wavefront; scheduling only, results unchanged */
 int usvmpc_set_option(usvmpc_handle *h, const char *name, double value);
+/* Profiling aid: stream `nplanes` workspace planes with the solver kernels' access instruction
+ * (kernel usv_calib_stream) and report the exact byte counts, to calibrate HBM PMC counters.
+ * Overwrites solver scratch; the next usvmpc_solve re-initialises it. */
+int usvmpc_calibrate_traffic(usvmpc_handle *h, int nplanes, double *bytes_read, double *bytes_written);
 /* bytes of device memory held by the handle */
 size_t usvmpc_device_bytes(usvmpc_handle *h);
 const char *usvmpc_last_error(usvmpc_handle *h);

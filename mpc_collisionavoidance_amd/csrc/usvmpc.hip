@@ -67,6 +67,20 @@ __global__ void usv_advance(DevPtrs P, int nx, double sigma, unsigned long long 
     const_cast<double *>(P.x0)[i] = v;
 }
 
+// Traffic calibration for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters: streams a KNOWN number of
+// workspace planes with exactly the access instruction of the solver kernels (one
+// buffer_load_dwordx2 per lane per plane, 16 lanes of a group contiguous) and writes one plane.
+__global__ void __launch_bounds__(64) usv_calib_stream(DevPtrs P, long ngroups, int nread, long stride)
+{
+    const long g = lanes::group_linear();
+    if (g >= ngroups) return;
+    const unsigned gl = (unsigned)(g * LANES + lanes::lane());
+    const lanes::Planes W(P.ws, stride, nread + 1, gl);
+    double acc = 0.0;
+    for (int i = 0; i < nread; i++) acc += W.ld(i);
+    W.st(nread, acc);
+}
+
 // Difficulty binning: a wave carries four instances and runs until the slowest one converges, so
 // instances are grouped by the IPM iteration count of their previous solve (a counting sort on the
 // device, hardest first so that long-running waves start early).  Only the group -> instance map
@@ -486,6 +500,22 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
     }
     h->err = "unknown option '" + s + "'";
     return USVMPC_E_FIELD;
+}
+
+int usvmpc_calibrate_traffic(usvmpc_handle *h, int nplanes, double *bytes_read, double *bytes_written)
+{
+    if (!h || nplanes < 1) return USVMPC_E_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const long stride = (long)h->Bp * LANES;
+    const long avail = (long)(h->N + 1) * ws_planes(h->nx, h->nu, h->kch, h->soft);
+    if (nplanes + 1 > avail) { h->err = "nplanes exceeds the workspace"; return USVMPC_E_ARG; }
+    const long groups = h->Bp;
+    hipLaunchKernelGGL(usv_calib_stream, dim3((unsigned)((groups * LANES + 63) / 64)), dim3(64), 0, h->stream, h->ptrs, groups, nplanes, stride);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (bytes_read) *bytes_read = (double)nplanes * stride * 8.0;
+    if (bytes_written) *bytes_written = (double)stride * 8.0;
+    return 0;
 }
 
 int usvmpc_set_stream(usvmpc_handle *h, void *stream)

@@ -95,7 +95,15 @@ def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None):
             oy = nedy[:, None] + s_al * cy_ + off * cx_
         if na < K:
             ox[:, na:], oy[:, na:], lhv[:, na:] = 1000.0, 1000.0, 0.0
-        vel = rng.uniform(-0.3, 0.3, (B, K, 2)) if moving else np.zeros((B, K, 2))
+        if not moving:
+            vel = np.zeros((B, K, 2))
+        elif name == "usv_model_guidance_ca1":
+            vel = rng.uniform(-0.3, 0.3, (B, K, 2))
+        else:
+            # hard rows: obstacles slide parallel to the course, which keeps their lateral clearance
+            # (a drift towards the path would make the hard-constrained QPs infeasible)
+            vpar = rng.uniform(-0.3, 0.3, (B, K))
+            vel = np.stack([vpar * np.cos(course)[:, None], vpar * np.sin(course)[:, None]], axis=2)
         t = (np.arange(N + 1) * dt)[None, :, None]
         p[:, :, 0::2] = ox[:, None, :] + t * vel[:, None, :, 0]
         p[:, :, 1::2] = oy[:, None, :] + t * vel[:, None, :, 1]

@@ -96,9 +96,12 @@ struct Linearize {
         });
         // row r of [B A]' (coalesced) and, scattered, column r of the rows of [B A] that the
         // forward sweep reads (lane nu+j gets d x+_j / d z_r)
+        // planes that are structurally unit vectors (M::OUT_UNIT / M::IN_UNIT) are not materialised
+        const bool in_unit = ((M::IN_UNIT >> lane) & 1u) != 0u;
         sfor<0, NX>([&](auto i) {
-            P.BAt[((long)k * NX + i) * stride + gl] = (lane < NZ) ? sa[i] : 0.0;
-            if (lane < NZ) P.ABr[((long)k * NZ + lane) * stride + g * LANES + NU + i] = sa[i];
+            if constexpr (((M::OUT_UNIT >> i) & 1u) == 0u)
+                P.BAt[((long)k * NX + i) * stride + gl] = (lane < NZ) ? sa[i] : 0.0;
+            if (lane < NZ && !in_unit) P.ABr[((long)k * NZ + lane) * stride + g * LANES + NU + i] = sa[i];
         });
         P.rb0[(long)k * stride + gl] = xlane ? bres : 0.0;
 

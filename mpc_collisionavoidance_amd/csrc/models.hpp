@@ -60,6 +60,8 @@ struct Dof3 {
 
 struct ModelM0 {
     static constexpr int ID = 0, NX = 5, NU = 2, IPX = 0, IPY = 0; // no obstacles (K = 0)
+    // structural identities of the discrete map (see ModelM2): none for this model
+    static constexpr unsigned OUT_UNIT = 0u, IN_UNIT = 0u;
     USV_DEV static void fjvp(const double *x, const double *U, const double *s, double *f, double *js)
     {
         Dof3::eval(0.78, x[0], x[1], x[2], x[3], x[4], s[0], s[1], s[2], s[3], s[4], f, js);
@@ -77,6 +79,9 @@ struct ModelM0 {
 
 struct ModelM1 {
     static constexpr int ID = 1, NX = 8, NU = 1, IPX = 5, IPY = 6;
+    // outputs u, v have f = 0; inputs ye, xned, yned appear in no right-hand side
+    static constexpr unsigned OUT_UNIT = (1u << 0) | (1u << 1);
+    static constexpr unsigned IN_UNIT = (1u << (NU + 2)) | (1u << (NU + 5)) | (1u << (NU + 6));
     // x = (u, v, ye, chie, psied, xned, yned, psi), T1 = 1
     USV_DEV static void fjvp(const double *x, const double *U, const double *s, double *f, double *js)
     {
@@ -112,6 +117,16 @@ struct ModelM1 {
 
 struct ModelM2 {
     static constexpr int ID = 2, NX = 14, NU = 2, IPX = 10, IPY = 11;
+    // Structural identities of x+ = Phi(x,u), exact for any explicit RK scheme:
+    //  OUT_UNIT bit j : f_j == 0, so x+_j = x_j and row j of [A B] is the unit vector e_j
+    //                   (x1, y1, ak) -> plane j of [B A]' is never stored or loaded;
+    //  IN_UNIT bit c  : variable c of [u;x] appears in no right-hand side, so column c of [B A] is
+    //                   the unit vector (sinpsi, cospsi, ye, x1, y1, nedx, nedy) -> plane c of the
+    //                   [B A] rows is never stored or loaded.
+    // Pinned against the oracle's dense sensitivities in tests/test_oracle_models.py.
+    static constexpr unsigned OUT_UNIT = (1u << 7) | (1u << 8) | (1u << 9);
+    static constexpr unsigned IN_UNIT = (1u << (NU + 1)) | (1u << (NU + 2)) | (1u << (NU + 6)) | (1u << (NU + 7)) |
+                                        (1u << (NU + 8)) | (1u << (NU + 10)) | (1u << (NU + 11));
     // x = (psi, sinpsi, cospsi, u, v, r, ye, x1, y1, ak, nedx, nedy, Tport, Tstbd), c = 1
     USV_DEV static void fjvp(const double *x, const double *U, const double *s, double *f, double *js)
     {

@@ -419,7 +419,10 @@ struct QpIpm {
             double bat[NX];
             if (k < N) {
                 const Planes BT(P.BAt + (long)k * NX * stride, stride, NX, gl);
-                sfor<0, NX>([&](auto j) { bat[j] = BT.ld(j); });
+                sfor<0, NX>([&](auto j) {
+                    if constexpr (((M::OUT_UNIT >> j) & 1u) != 0u) bat[j] = (lane == NU + j) ? 1.0 : 0.0;
+                    else bat[j] = BT.ld(j);
+                });
             } else {
                 sfor<0, NX>([&](auto j) { bat[j] = 0.0; });
             }
@@ -632,7 +635,10 @@ struct QpIpm {
             double abr[NZ];
             if (k < N) {
                 const Planes AB(P.ABr + (long)k * NZ * stride, stride, NZ, gl);
-                sfor<0, NZ>([&](auto c) { abr[c] = AB.ld(c); });
+                sfor<0, NZ>([&](auto c) {
+                    if constexpr (((M::IN_UNIT >> c) & 1u) != 0u) abr[c] = (lane == c) ? 1.0 : 0.0;
+                    else abr[c] = AB.ld(c);
+                });
                 load_in<SW>(k + 1, nxt);
             }
             double dz;

@@ -96,7 +96,13 @@ def test_linearize_planes_match_oracle(oracle, emu, name, N, K):
         for k in range(N):
             BA = np.hstack([qp["B"][k], qp["A"][k]])          # nx x nz
             got = r["BAt"][k, :, b, :nu + nx]                    # [j, lane r] = BAt[r][j]
-            assert np.allclose(got, BA, rtol=1e-12, atol=1e-14)
+            # planes that are structurally unit vectors (csrc/models.hpp OUT_UNIT) are never written
+            unit = {"usv_model": [], "usv_model_guidance_ca1": [0, 1], "usv_model_pf_ca": [7, 8, 9]}[name]
+            live = [j for j in range(nx) if j not in unit]
+            assert np.allclose(got[live], BA[live], rtol=1e-12, atol=1e-14)
+            for j in unit:
+                e = np.zeros(nu + nx); e[nu + j] = 1.0
+                assert np.array_equal(BA[j], e) and not got[j].any()
             assert np.allclose(r["rb0"][k, b, nu:nu + nx], qp["b"][k], rtol=1e-12, atol=1e-14)
             assert np.allclose(r["gq"][k, b, :nu + nx], qp["g"][k], rtol=1e-12, atol=1e-13)
         assert np.allclose(r["gq"][N, b, nu:nu + nx], qp["g"][N][nu:], rtol=1e-12, atol=1e-13)

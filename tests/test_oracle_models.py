@@ -150,3 +150,28 @@ def test_rk4_step_against_adaptive_integrator(oracle, model, dt):
     sol = solve_ivp(lambda t, y: oracle.model_f(model, y, U), (0, dt), x, rtol=1e-12, atol=1e-14)
     # one RK4 step: O(dt^5) local error; the 3-DOF block at dt = 0.05 is mildly stiff (sway damping)
     assert np.allclose(xn, sol.y[:, -1], rtol=0, atol=5e-5 if model == 0 else 5e-6)
+
+
+# structural identities the HIP kernels rely on (csrc/models.hpp OUT_UNIT / IN_UNIT): checked on the
+# oracle's dense RK4 sensitivities, which know nothing about them
+STRUCT = {1: dict(out_unit=[0, 1], in_unit_x=[2, 5, 6]),
+          2: dict(out_unit=[7, 8, 9], in_unit_x=[1, 2, 6, 7, 8, 10, 11])}
+
+
+@pytest.mark.parametrize("model,dt", [(1, 0.05), (2, 0.01)])
+def test_structural_unit_rows_and_columns(oracle, model, dt):
+    rng = np.random.default_rng(42 + model)
+    nx, nu = oracle.dims(model)
+    for _ in range(10):
+        x = rng.normal(size=nx)
+        x[0 if model == 1 else 3] += 0.7
+        if model == 2:
+            x[4] *= 0.05
+        U = rng.normal(size=nu)
+        _, A, B = oracle.rk4_sens(model, dt, x, U)
+        for j in STRUCT[model]["out_unit"]:      # x+_j = x_j exactly
+            e = np.zeros(nx); e[j] = 1.0
+            assert np.array_equal(A[j], e) and np.array_equal(B[j], np.zeros(nu))
+        for c in STRUCT[model]["in_unit_x"]:     # state c feeds nothing but itself
+            e = np.zeros(nx); e[c] = 1.0
+            assert np.array_equal(A[:, c], e)

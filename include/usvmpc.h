@@ -118,6 +118,23 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
 /* run-time options: "sort_by_difficulty" (default 1) - group instances of similar IPM iteration
  * count (from their previous solve) into the same wavefront; scheduling only, results unchanged */
 int usvmpc_set_option(usvmpc_handle *h, const char *name, double value);
+/* ---- Guidance front end (model usv_model_guidance_ca1 only): the arithmetic either side of the solver
+ * call in the reference's ROS node, batched on the device (class NMPC in
+ * catkin_ws/src/nmpc_ca/src/nmpc_guidance_ca1.cpp).  Per-instance state (waypoint index k, past_psied) lives in
+ * the handle.  Arrays are host pointers, instance-major.
+ *   reset   = main(), new waypoint list                        :616-632  (waypoints [B][2*npts], psi [B])
+ *   prepare = velocityCallback / obstaclesCallback / body2NED / waypoint_manager / control (input part)
+ *                                                               :223-230,252-376,441-574
+ *             vel_uv [B][2], pose [B][3] = (nedx, nedy, psi), obstacles [B][lmax][3] = body (x, y, R),
+ *             n_obstacles [B], lmax <= 64; writes x0 and the (stage-independent) p / lh of the solver and switches
+ *             the solver to static obstacles; asynchronous on the handle's stream
+ *   publish = control (output part)                             :583-600  desired heading / r / speed, ye
+ * The "static_obstacles" option (usvmpc_set_option) makes every stage use stage 0's p and lh. */
+int usvmpc_guidance_reset(usvmpc_handle *h, const double *waypoints, int npts, const double *psi);
+int usvmpc_guidance_prepare(usvmpc_handle *h, const double *vel_uv, const double *pose, const double *obstacles,
+                            const int *n_obstacles, int lmax);
+int usvmpc_guidance_publish(usvmpc_handle *h, double *heading, double *r_des, double *speed, double *ye, int *active);
+int usvmpc_guidance_state(usvmpc_handle *h, int *wp_index, float *past_psied);
 /* Profiling aid: stream `nplanes` workspace planes with the solver kernels' access instruction
  * (kernel usv_calib_stream) and report the exact byte counts, to calibrate HBM PMC counters.
  * Overwrites solver scratch; the next usvmpc_solve re-initialises it. */

@@ -43,7 +43,8 @@ _lib = None
 EXPORTS = ["usvmpc_model_dims", "usvmpc_default_options", "usvmpc_create", "usvmpc_destroy",
            "usvmpc_set", "usvmpc_get", "usvmpc_get_int", "usvmpc_solve", "usvmpc_solve_async",
            "usvmpc_sync", "usvmpc_get_device_ptr", "usvmpc_last_kernel_ms", "usvmpc_kernel_ms",
-           "usvmpc_advance", "usvmpc_set_stream", "usvmpc_set_option", "usvmpc_calibrate_traffic", "usvmpc_device_bytes", "usvmpc_last_error"]
+           "usvmpc_advance", "usvmpc_set_stream", "usvmpc_set_option", "usvmpc_calibrate_traffic", "usvmpc_guidance_reset", "usvmpc_guidance_prepare",
+           "usvmpc_guidance_publish", "usvmpc_guidance_state", "usvmpc_device_bytes", "usvmpc_last_error"]
 
 
 def lib():
@@ -74,6 +75,10 @@ def lib():
         L.usvmpc_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.usvmpc_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         L.usvmpc_calibrate_traffic.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        L.usvmpc_guidance_reset.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
+        L.usvmpc_guidance_prepare.argtypes = [C.c_void_p, _dp, _dp, _dp, _ip, C.c_int]
+        L.usvmpc_guidance_publish.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _ip]
+        L.usvmpc_guidance_state.argtypes = [C.c_void_p, _ip, C.POINTER(C.c_float)]
         L.usvmpc_device_bytes.argtypes = [C.c_void_p]
         L.usvmpc_device_bytes.restype = C.c_size_t
         L.usvmpc_last_error.argtypes = [C.c_void_p]

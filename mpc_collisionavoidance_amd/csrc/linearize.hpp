@@ -108,8 +108,9 @@ struct Linearize {
         // ---- obstacle rows: h_i = |pos - o_i|, gradient, bounds relative to h ----
         if constexpr (KCH > 0) {
             const double px = x[M::IPX], py = x[M::IPY];
-            const double *pk = P.p + ((long)b * (N + 1) + k) * 2 * K;
-            const double *lhk = P.lh + ((long)b * N + k) * K;
+            const int kp = S.p_static ? 0 : k;
+            const double *pk = P.p + ((long)b * (N + 1) + kp) * 2 * K;
+            const double *lhk = P.lh + ((long)b * N + kp) * K;
             sfor<0, KCH>([&](auto c) {
                 const int i = c * LANES + lane;
                 const bool act = i < K;

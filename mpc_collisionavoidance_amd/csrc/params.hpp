@@ -22,6 +22,7 @@ struct DevSpec {
     int N, K, B, Bp;              // horizon, obstacles, batch, batch padded to a multiple of 4
     int ny, ny_e;
     int nc;                       // number of (lambda, t) pairs of the whole QP
+    int p_static;                 // 1: every stage uses the obstacle set / lh of stage 0 (the ROS node's usage)
     int hdiag;                    // 1: Hc and He are diagonal (true for every OCP of the reference)
     int iter_max;
     double mu0, thr0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min;

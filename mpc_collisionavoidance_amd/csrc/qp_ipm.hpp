@@ -725,9 +725,16 @@ struct QpIpm {
                     status = 0; done = true;
                 } else if (it >= S.iter_max) { status = 1; done = true; }
             }
+#ifdef USV_DEBUG_FIXED_ITERS // timing experiments only: fixed iteration count, subset of sweeps
+            done = false;
+            if (it >= USV_DEBUG_FIXED_ITERS) break;
+#endif
             if (!lanes::wave_any(!done)) break;
             const double mu = nc > 0.0 ? nm.musum / nc : 0.0;
-            double a_aff, S1, S2, a, d1, d2;
+            double a_aff = 1.0, S1 = 0.0, S2 = 0.0, a = 1.0, d1, d2;
+#ifdef USV_DEBUG_FIXED_ITERS
+            if (USV_DEBUG_SWEEPS & 1)
+#endif
             forward<false>(0.0, a_aff, S1, S2);
             double sigmu = 0.0;
             if (nc > 0.0) {
@@ -735,7 +742,13 @@ struct QpIpm {
                 const double sg = mu_aff / mu;
                 sigmu = sg * sg * sg * mu;
             }
+#ifdef USV_DEBUG_FIXED_ITERS
+            if (USV_DEBUG_SWEEPS & 2)
+#endif
             backward<false>(nm, sigmu, false, 0.0, 0.0);
+#ifdef USV_DEBUG_FIXED_ITERS
+            if (USV_DEBUG_SWEEPS & 4)
+#endif
             forward<true>(sigmu, a, d1, d2);
             if (!done && a < S.alpha_min) { status = 2; done = true; iters = it; }
             a_prev = a * ((1.0 - a) * 0.99 + a * 0.9999999);

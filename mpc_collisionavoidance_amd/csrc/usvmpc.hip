@@ -8,6 +8,7 @@
 // Both are FP64 VALU + DPP kernels: no LDS, no MFMA (blocks are at most 16x16).
 #include "gfx950/lanes.hpp"
 
+#include "guidance.hpp"
 #include "host_spec.hpp"
 #include "linearize.hpp"
 #include "models.hpp"
@@ -126,10 +127,14 @@ struct usvmpc_handle {
     long nsolves;
     DevSpec *d_spec;
     int *d_perm, *d_hist, *d_cursor;
+    GuidancePtrs gd;          // device buffers of the guidance front end (allocated on first use)
+    bool gd_ready;
+    int gd_npts_cap;
+    double *gd_psi;
     bool sort_enabled;
     size_t bytes;
     std::string err;
-    void *allocs[32];
+    void *allocs[64];
     int nallocs;
 };
 
@@ -363,6 +368,8 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     TRY_C(dev_alloc(h, &h->d_hist, SORT_BINS, true));
     TRY_C(dev_alloc(h, &h->d_cursor, SORT_BINS, true));
     h->sort_enabled = true;
+    h->gd_ready = false; h->gd_npts_cap = 0; h->gd_psi = nullptr;
+    std::memset(&h->gd, 0, sizeof(h->gd));
     TRY_C(dev_alloc(h, &P.BAt, N * h->nx * stride, true));
     TRY_C(dev_alloc(h, &P.ABr, N * h->nz * stride, true)); // u lanes / idle lanes stay zero
     TRY_C(dev_alloc(h, &P.rb0, N * stride, true));
@@ -498,8 +505,119 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         if (!h->sort_enabled) h->ptrs.perm = nullptr;
         return 0;
     }
+    if (s == "static_obstacles") {
+        h->spec.p_static = value != 0.0;
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipMemcpyAsync(h->d_spec, &h->spec, sizeof(DevSpec), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return 0;
+    }
     h->err = "unknown option '" + s + "'";
     return USVMPC_E_FIELD;
+}
+
+// ---- guidance front end (M1 only): see guidance.hpp
+static int guidance_alloc(usvmpc_handle *h, int npts)
+{
+    if (h->desc.model != USVMPC_MODEL_GUIDANCE_CA1) { h->err = "the guidance front end belongs to usv_model_guidance_ca1"; return USVMPC_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t B = h->B;
+    GuidancePtrs &G = h->gd;
+    if (!h->gd_ready) {
+        double *d; int *i; float *f;
+        if (dev_alloc(h, &d, B * 2, true)) return USVMPC_E_HIP; G.vel = d;
+        if (dev_alloc(h, &d, B * 3, true)) return USVMPC_E_HIP; G.pose = d;
+        if (dev_alloc(h, &d, B * GUIDANCE_LMAX * 3, true)) return USVMPC_E_HIP; G.obs = d;
+        if (dev_alloc(h, &i, B, true)) return USVMPC_E_HIP; G.nobs = i;
+        if (dev_alloc(h, &G.k, B, true)) return USVMPC_E_HIP;
+        if (dev_alloc(h, &f, B, true)) return USVMPC_E_HIP; G.past_psied = f;
+        if (dev_alloc(h, &G.ak, B, true)) return USVMPC_E_HIP;
+        if (dev_alloc(h, &G.ye, B, true)) return USVMPC_E_HIP;
+        if (dev_alloc(h, &G.active, B, true)) return USVMPC_E_HIP;
+        if (dev_alloc(h, &G.heading, B, true)) return USVMPC_E_HIP;
+        if (dev_alloc(h, &G.rdes, B, true)) return USVMPC_E_HIP;
+        if (dev_alloc(h, &G.speed, B, true)) return USVMPC_E_HIP;
+        if (dev_alloc(h, &h->gd_psi, B, true)) return USVMPC_E_HIP;
+        G.lmax = GUIDANCE_LMAX;
+        h->gd_ready = true;
+    }
+    if (npts > h->gd_npts_cap) {
+        double *d;
+        if (dev_alloc(h, &d, B * 2 * (size_t)npts, true)) return USVMPC_E_HIP;
+        G.wp = d;
+        h->gd_npts_cap = npts;
+    }
+    return 0;
+}
+
+int usvmpc_guidance_reset(usvmpc_handle *h, const double *waypoints, int npts, const double *psi)
+{
+    if (!h || !waypoints || !psi || npts < 2) return USVMPC_E_ARG;
+    int rc = guidance_alloc(h, npts);
+    if (rc) return rc;
+    GuidancePtrs &G = h->gd;
+    G.npts = npts;
+    const size_t B = h->B;
+    HIP_TRY(h, hipMemcpyAsync(const_cast<double *>(G.wp), waypoints, B * 2 * npts * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->gd_psi, psi, B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(usv_guidance_reset, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, G, h->gd_psi, (int)B);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!h->spec.p_static) return usvmpc_set_option(h, "static_obstacles", 1.0);
+    return 0;
+}
+
+int usvmpc_guidance_prepare(usvmpc_handle *h, const double *vel_uv, const double *pose, const double *obstacles,
+                            const int *n_obstacles, int lmax)
+{
+    if (!h || !vel_uv || !pose || !n_obstacles || lmax < 0 || lmax > GUIDANCE_LMAX) return USVMPC_E_ARG;
+    if (!h->gd_ready || h->gd.npts < 2) { h->err = "usvmpc_guidance_reset must be called first"; return USVMPC_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    GuidancePtrs &G = h->gd;
+    const size_t B = h->B;
+    HIP_TRY(h, hipMemcpyAsync(const_cast<double *>(G.vel), vel_uv, B * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(const_cast<double *>(G.pose), pose, B * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(const_cast<int *>(G.nobs), n_obstacles, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (lmax > 0) {
+        if (!obstacles) return USVMPC_E_ARG;
+        // [B][lmax][3] -> [B][GUIDANCE_LMAX][3]
+        HIP_TRY(h, hipMemcpy2DAsync(const_cast<double *>(G.obs), GUIDANCE_LMAX * 3 * sizeof(double), obstacles,
+                                    (size_t)lmax * 3 * sizeof(double), (size_t)lmax * 3 * sizeof(double), B,
+                                    hipMemcpyHostToDevice, h->stream));
+    }
+    hipLaunchKernelGGL(usv_guidance_pre, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, h->stream, h->ptrs, G);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int usvmpc_guidance_publish(usvmpc_handle *h, double *heading, double *r_des, double *speed, double *ye, int *active)
+{
+    if (!h) return USVMPC_E_ARG;
+    if (!h->gd_ready) { h->err = "usvmpc_guidance_reset must be called first"; return USVMPC_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    GuidancePtrs &G = h->gd;
+    const size_t B = h->B;
+    hipLaunchKernelGGL(usv_guidance_post, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, h->ptrs, G);
+    HIP_TRY(h, hipGetLastError());
+    if (heading) HIP_TRY(h, hipMemcpyAsync(heading, G.heading, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (r_des) HIP_TRY(h, hipMemcpyAsync(r_des, G.rdes, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (speed) HIP_TRY(h, hipMemcpyAsync(speed, G.speed, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (ye) HIP_TRY(h, hipMemcpyAsync(ye, G.ye, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (active) HIP_TRY(h, hipMemcpyAsync(active, G.active, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int usvmpc_guidance_state(usvmpc_handle *h, int *wp_index, float *past_psied)
+{
+    if (!h) return USVMPC_E_ARG;
+    if (!h->gd_ready) { h->err = "usvmpc_guidance_reset must be called first"; return USVMPC_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t B = h->B;
+    if (wp_index) HIP_TRY(h, hipMemcpyAsync(wp_index, h->gd.k, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (past_psied) HIP_TRY(h, hipMemcpyAsync(past_psied, h->gd.past_psied, B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return 0;
 }
 
 int usvmpc_calibrate_traffic(usvmpc_handle *h, int nplanes, double *bytes_read, double *bytes_written)

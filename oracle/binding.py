@@ -58,10 +58,9 @@ class QpSol(C.Structure):
 
 def build(force=False):
     """Compile oracle/libusv_oracle.so with gcc (idempotent)."""
-    src = os.path.join(_HERE, "usv_oracle.c")
-    hdr = os.path.join(_HERE, "usv_oracle.h")
-    if (not force and os.path.exists(_LIB)
-            and os.path.getmtime(_LIB) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+    srcs = [os.path.join(_HERE, f) for f in ("usv_oracle.c", "usv_oracle.h", "usv_guidance_oracle.c",
+                                             "usv_guidance_oracle.h", "Makefile")]
+    if not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= max(os.path.getmtime(f) for f in srcs):
         return _LIB
     subprocess.check_call(["make", "-C", _HERE, "-B", "libusv_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB
@@ -98,6 +97,14 @@ def lib():
         L.usv_qp_solve.argtypes = [C.POINTER(Qp), C.POINTER(Opts), C.POINTER(QpSol)]
         L.usv_rti.argtypes = [C.POINTER(Spec)] + [_dp] * 11
         L.usv_rti_batch.argtypes = [C.POINTER(Spec), C.c_int] + [_dp] * 7 + [_ip, _ip]
+        _fp = C.POINTER(C.c_float)
+        L.usv_guidance_reset_ref.argtypes = [_dp, C.c_double, _ip, _fp]
+        L.usv_guidance_reset_ref.restype = None
+        L.usv_guidance_obstacles_ref.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, _dp, C.c_int, _dp, _dp, _ip]
+        L.usv_guidance_obstacles_ref.restype = None
+        L.usv_guidance_prepare_ref.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int, _dp, C.c_int, _ip, _fp] + [_dp] * 5
+        L.usv_guidance_publish_ref.argtypes = [C.c_double, C.c_double, C.c_double, _fp, _dp, _dp, _dp]
+        L.usv_guidance_publish_ref.restype = None
         _lib = L
     return _lib
 
@@ -223,3 +230,37 @@ def rti_batch(s, x, u, x0, yref, yref_e, p, lh):
     lib().usv_rti_batch(C.byref(s), B, _d(x), _d(u), _d(x0), _d(yref), _d(yref_e), _d(p), _d(lh),
                         status.ctypes.data_as(_ip), it.ctypes.data_as(_ip))
     return status, it
+
+
+# ---- reference ROS-node arithmetic either side of the solve (usv_guidance_oracle.c)
+def guidance_reset(waypoints, psi):
+    w = _arr(waypoints)
+    k, pp = C.c_int(), C.c_float()
+    lib().usv_guidance_reset_ref(_d(w), float(psi), C.byref(k), C.byref(pp))
+    return k.value, pp.value
+
+
+def guidance_obstacles(K, psi, nedx, nedy, obs):
+    obs = _arr(obs).reshape(-1, 3)
+    p, r, ch = np.zeros(2 * K), np.zeros(K), np.zeros(K, dtype=np.int32)
+    lib().usv_guidance_obstacles_ref(K, float(psi), float(nedx), float(nedy), _d(obs), obs.shape[0], _d(p), _d(r),
+                                     ch.ctypes.data_as(_ip))
+    return p, r, ch
+
+
+def guidance_prepare(K, vel_uv, pose, waypoints, obs, k, past_psied):
+    """Returns dict(active, k, past_psied, x0, p_obs, r_obs, ak, ye) for one instance."""
+    vel_uv, pose, w = _arr(vel_uv), _arr(pose), _arr(waypoints)
+    obs = _arr(obs).reshape(-1, 3)
+    kk, pp = C.c_int(int(k)), C.c_float(float(past_psied))
+    x0, p, r, ak, ye = np.zeros(8), np.zeros(2 * K), np.zeros(K), np.zeros(1), np.zeros(1)
+    act = lib().usv_guidance_prepare_ref(K, _d(vel_uv), _d(pose), _d(w), w.size // 2, _d(obs), obs.shape[0],
+                                         C.byref(kk), C.byref(pp), _d(x0), _d(p), _d(r), _d(ak), _d(ye))
+    return dict(active=act, k=kk.value, past_psied=pp.value, x0=x0, p_obs=p, r_obs=r, ak=ak[0], ye=ye[0])
+
+
+def guidance_publish(x1_psied, u0, ak, past_psied):
+    pp = C.c_float(float(past_psied))
+    h, r, s = C.c_double(), C.c_double(), C.c_double()
+    lib().usv_guidance_publish_ref(float(x1_psied), float(u0), float(ak), C.byref(pp), C.byref(h), C.byref(r), C.byref(s))
+    return dict(heading=h.value, r=r.value, speed=s.value, past_psied=pp.value)

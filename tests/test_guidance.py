@@ -1,0 +1,150 @@
+"""The arithmetic either side of the solver call in the reference's obstacle-avoidance ROS node
+(catkin_ws/src/nmpc_ca/src/nmpc_guidance_ca1.cpp :223-376, :441-600, :616-632):
+ - CPU: the restatement oracle/usv_guidance_oracle.c against hand-derived answers (the reference has
+   no tests for it; the node needs ROS + Eigen + the generated solver and cannot be built here);
+ - GPU: the batched device kernels (csrc/guidance.hpp) against that oracle through the C ABI.
+Obstacle fixture: the 22-buoy field of the reference's simulator
+(catkin_ws/src/simulation/scripts/obstacle_sim_node.py:207-270, first 14 entries).
+"""
+import numpy as np
+import pytest
+
+from mpc_collisionavoidance_amd import usv_models
+
+BUOYS = np.array([[3.1, 1.1], [3.3, 2.2], [3.2, -3.3], [6.2, 1.2], [4.1, -4.2], [4.4, -2.5], [5.3, -3.4], [6.2, 2.3],
+                  [9.1, -4.4], [9.6, -3.6], [12.6, 3.4], [10.7, -4.6], [10.3, 6.1], [9.3, 4.1]])
+BUOY_R = 0.105
+
+
+def ned_to_body(pts, nedx, nedy, psi):
+    """obstacle_sim_node.py:101-115 (inverse rotation)."""
+    d = pts - np.array([nedx, nedy])
+    c, s = np.cos(psi), np.sin(psi)
+    return np.stack([c * d[:, 0] + s * d[:, 1], -s * d[:, 0] + c * d[:, 1]], axis=1)
+
+
+def test_fewer_obstacles_than_slots_are_padded(oracle):
+    obs = np.array([[2.0, 0.5, 1.0], [5.0, -1.0, 0.3]])
+    p, r, ch = oracle.guidance_obstacles(8, 0.4, 1.0, 2.0, obs)
+    assert list(ch) == [0, 1] + [-1] * 6
+    # body -> NED by hand (double), the node does it in single precision
+    ex = [1.0 + np.cos(0.4) * 2.0 - np.sin(0.4) * 0.5, 2.0 + np.sin(0.4) * 2.0 + np.cos(0.4) * 0.5]
+    assert np.allclose(p[:2], ex, rtol=0, atol=1e-6) and p[0] != ex[0]      # float32 rounding is reproduced
+    assert p[0] == np.float32(p[0]) and p[1] == np.float32(p[1])
+    assert np.all(p[4:] == 1000.0) and np.all(r[2:] == 0.0)                 # initializeObstacles :365-376
+    assert r[0] == 1.5 and r[1] == float(np.float32(0.3 + 0.5))             # R + boat radius, stored as float
+
+
+def test_more_obstacles_than_slots_keeps_the_nearest(oracle):
+    nedx, nedy, psi = 5.0, -1.0, 0.7
+    body = ned_to_body(BUOYS, nedx, nedy, psi)
+    obs = np.column_stack([body, np.full(len(BUOYS), BUOY_R)])
+    p, r, ch = oracle.guidance_obstacles(8, psi, nedx, nedy, obs)
+    dist = np.hypot(body[:, 0], body[:, 1]) - (BUOY_R + 0.5)                # :262-270
+    want = np.argsort(dist, kind="stable")[:8]
+    assert list(ch) == list(want)
+    assert np.allclose(p.reshape(8, 2), BUOYS[want], atol=2e-6)            # round trip body -> NED
+    assert np.all(r == float(np.float32(BUOY_R + 0.5)))
+    # ties are broken by index
+    tie = np.array([[1.0, 0.0, 0.2]] * 10)
+    _, _, ch = oracle.guidance_obstacles(8, 0.0, 0.0, 0.0, tie)
+    assert list(ch) == list(range(8))
+
+
+def test_waypoint_manager_and_control_inputs(oracle):
+    wps = [4.0, -5.0, 4.0, 25.0, 10.0, 30.0]
+    k, pp = oracle.guidance_reset(wps, 0.3)
+    ak = np.arctan2(30.0, 0.0)
+    assert k == 1 and pp == np.float32(0.3 - ak)
+    # far from the segment end: ye, chie against the formulas of :460-461, :495-511
+    r = oracle.guidance_prepare(8, [0.7, 0.02], [1.0, 2.0, 0.4], wps, np.zeros((0, 3)), k, pp)
+    assert r["active"] == 1 and r["k"] == 1 and r["ak"] == ak
+    assert np.isclose(r["ye"], -(1.0 - 4.0) * np.sin(ak) + (2.0 + 5.0) * np.cos(ak), atol=1e-15)
+    beta = np.arctan2(0.02, 0.7)                                            # no +0.001: the enum test at :496 is always true
+    assert np.allclose(r["x0"], [0.7, 0.02, r["ye"], 0.4 + beta - ak, float(pp), 1.0, 2.0, 0.4], atol=1e-15)
+    # u == 0 -> 0.001 (:225-228)
+    r0 = oracle.guidance_prepare(8, [0.0, 0.0], [1.0, 2.0, 0.4], wps, np.zeros((0, 3)), k, pp)
+    assert r0["x0"][0] == 0.001
+    # within 1 m of the segment end: switch segment, re-reference psied (:464-484)
+    r2 = oracle.guidance_prepare(8, [0.7, 0.0], [4.2, 24.5, 1.5], wps, np.zeros((0, 3)), 1, np.float32(-0.2))
+    ak2 = np.arctan2(5.0, 6.0)
+    assert r2["k"] == 2 and r2["ak"] == ak2
+    assert r2["past_psied"] == np.float32(np.float32(-0.2) - ak2 + ak)
+    assert np.isclose(r2["ye"], -(4.2 - 4.0) * np.sin(ak2) + (24.5 - 25.0) * np.cos(ak2), atol=1e-15)
+    # past the last segment: no control tick
+    r3 = oracle.guidance_prepare(8, [0.7, 0.0], [10.0, 30.0, 0.0], wps, np.zeros((0, 3)), 2, 0.0)
+    assert r3["active"] == 0
+    # chie wrap (:500-502)
+    r4 = oracle.guidance_prepare(8, [-0.7, 0.0], [1.0, 2.0, 3.0], wps, np.zeros((0, 3)), 1, 0.0)
+    chie = 3.0 + np.pi - ak
+    assert np.isclose(r4["x0"][3], chie - 2 * np.pi, atol=1e-15)
+
+
+def test_published_setpoints(oracle):
+    out = oracle.guidance_publish(-1.2, 0.1, np.pi / 2, 0.0)
+    assert out["heading"] == float(np.float32(-1.2 + np.pi / 2)) and out["r"] == 0.1 and out["speed"] == 0.7
+    assert out["past_psied"] == np.float32(-1.2)
+    out = oracle.guidance_publish(2.5, 0.0, np.pi / 2, 0.0)                 # |psid| > pi -> wrapped (:589-591)
+    psid = float(np.float32(2.5 + np.pi / 2))   # float variable, double arithmetic, rounded on assignment
+    assert out["heading"] == float(np.float32((psid / abs(psid)) * (abs(psid) - 2 * np.pi)))
+
+
+@pytest.mark.gpu
+def test_device_front_end_matches_oracle(oracle):
+    from mpc_collisionavoidance_amd import BatchOcpSolver
+    from mpc_collisionavoidance_amd.guidance import GuidanceFrontEnd
+    B, N, K, L = 300, 20, 8, 22
+    rng = np.random.default_rng(11)
+    ocp = usv_models.make_ocp("usv_model_guidance_ca1", N * 0.05, N, K)
+    s = BatchOcpSolver(ocp, B)
+    fe = GuidanceFrontEnd(s)
+    wps = np.array([[4.0, -5.0], [4.0, 25.0], [10.0, 30.0]])
+    pose = np.column_stack([rng.uniform(2, 6, B), rng.uniform(-5, 26, B), rng.uniform(-3.2, 3.2, B)])
+    pose[:20, 0], pose[:20, 1] = 4.0 + rng.uniform(-0.5, 0.5, 20), 25.0 + rng.uniform(-0.5, 0.5, 20)  # at the switch radius
+    vel = np.column_stack([rng.uniform(0.3, 1.2, B), rng.uniform(-0.1, 0.1, B)])
+    vel[5, 0] = 0.0
+    nobs = rng.integers(0, L + 1, B).astype(np.int32)
+    obs = np.zeros((B, L, 3))
+    for b in range(B):
+        pts = rng.uniform(-15, 15, (L, 2))
+        obs[b] = np.column_stack([pts, rng.uniform(0.1, 1.5, L)])
+    obs[7, :12] = [1.0, 0.0, 0.2]                                           # ties
+    nobs[7] = 12
+    fe.reset(wps, pose[:, 2])
+    k0, pp0 = fe.state()
+    for b in range(B):
+        k, pp = oracle.guidance_reset(wps.ravel(), pose[b, 2])
+        assert k0[b] == k and pp0[b] == np.float32(pp)
+    fe.prepare(vel, pose, obs, nobs)
+    s.sync()
+    x0, p, lh = s.get("x0", 0), s.get_all("p"), s.get_all("lh")
+    k1, pp1 = fe.state()
+    ref = [oracle.guidance_prepare(K, vel[b], pose[b], wps.ravel(), obs[b, :nobs[b]], k0[b], pp0[b]) for b in range(B)]
+    for b, r in enumerate(ref):
+        assert k1[b] == r["k"]
+        # single-precision positions: equal up to one float ulp (device cos/sin vs libm), radii exact
+        assert np.allclose(p[b, 0], r["p_obs"], rtol=2e-7, atol=2e-6), b
+        assert np.array_equal(lh[b, 0], r["r_obs"]), b
+        if r["active"]:
+            assert abs(float(pp1[b]) - r["past_psied"]) <= 2.4e-7
+            assert np.allclose(x0[b], r["x0"], rtol=0, atol=3e-7), (b, x0[b], r["x0"])
+            assert np.allclose(np.delete(x0[b], 4), np.delete(r["x0"], 4), rtol=0, atol=1e-12)
+    # one closed-loop tick: solve with static obstacles, then the published set-points
+    s.solve()
+    out = fe.publish()
+    x1, u0 = s.get("x", 1), s.get("u", 0)
+    for b, r in enumerate(ref):
+        assert out["active"][b] == r["active"]
+        if r["active"]:
+            o = oracle.guidance_publish(x1[b, 4], u0[b, 0], r["ak"], r["past_psied"])
+            assert abs(out["heading"][b] - o["heading"]) <= 5e-7 and out["r"][b] == o["r"] and out["speed"][b] == 0.7
+            assert np.isclose(out["ye"][b], r["ye"], atol=1e-12)
+    # static-obstacle mode == replicating stage 0 on every stage
+    s2 = BatchOcpSolver(ocp, B)
+    for f in ("x0",):
+        s2.set(f, 0, x0)
+    s2.set_all("p", np.tile(p[:, :1], (1, N + 1, 1)))
+    s2.set_all("lh", np.tile(lh[:, :1], (1, N, 1)))
+    s2.solve()
+    assert np.array_equal(s2.get_all("x"), s.get_all("x")) and np.array_equal(s2.get_all("u"), s.get_all("u"))
+    s.close(); s2.close()

@@ -5,6 +5,7 @@ import / create call raises.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -39,6 +40,10 @@ def lib_path():
 
 
 _lib = None
+# torch bundles its own HIP runtime under the same SONAME.  If torch is imported BEFORE this library is
+# loaded both share torch's copy and zero-copy tensors / RCCL on solver buffers work; the other order
+# leaves torch unable to initialise its device.  Recorded here so the torch helpers can say so.
+loaded_before_torch = False
 
 EXPORTS = ["usvmpc_model_dims", "usvmpc_default_options", "usvmpc_create", "usvmpc_destroy",
            "usvmpc_set", "usvmpc_get", "usvmpc_get_int", "usvmpc_solve", "usvmpc_solve_async",
@@ -56,6 +61,8 @@ def lib():
             raise RuntimeError(
                 "HIP library %s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback)" % path)
+        global loaded_before_torch
+        loaded_before_torch = "torch" not in sys.modules
         L = C.CDLL(path)
         L.usvmpc_model_dims.argtypes = [C.c_int, _ip, _ip]
         L.usvmpc_default_options.argtypes = [C.POINTER(Desc)]

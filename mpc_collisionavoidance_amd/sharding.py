@@ -41,6 +41,10 @@ def gather_first_controls(u0_local, total, group=None):
 
 def device_tensor(ptr, shape, device_index=0):
     """Zero-copy torch view of a solver device buffer (usvmpc_get_device_ptr) of float64 `shape`."""
+    from . import _capi
+    if _capi.loaded_before_torch:
+        raise RuntimeError("import torch before creating the first solver: torch and libusvmpc.so must share one "
+                           "HIP runtime for zero-copy views / RCCL on solver buffers")
     import torch
 
     class _Wrap:

@@ -224,3 +224,47 @@ def test_closed_loop_pf_ca_reference_scenario(oracle):
         assert min(np.hypot(x[0, 10] - ox, x[0, 11] - oy) for ox, oy in obs) >= 0.7 - 1e-3
     assert abs(speed[399] - 0.7) < 0.1 and abs(speed[-1] - 0.7) < 0.1   # cruise before / after the obstacle
     assert min(speed[400:650]) < 0.5                                    # and a real avoidance manoeuvre between
+
+
+def test_rti_iterations_converge_to_the_nonlinear_ocp_optimum(oracle):
+    """Composition check of linearisation + QP + step: with fixed inputs, repeated SQP-RTI iterations must
+    converge to a point that is (a) dynamically feasible for the NONLINEAR RK4 dynamics and (b) at least as
+    good as what scipy's SLSQP finds for the same nonlinear OCP (small instance, obstacle far away)."""
+    name, N, K, dt = "usv_model_guidance_ca1", 5, 1, 0.05
+    ocp, wl = util.make(name, N, K, 1, seed=3)
+    wl["p"][:] = 50.0  # inactive obstacle: the soft rows then contribute the constant dt*zl*lsh per stage
+    spec = util.oracle_spec(oracle, name, N, dt, K, tol_stat=1e-10, tol_comp=1e-11)
+    x, u = wl["x_init"].copy(), wl["u_init"].copy()
+    for it in range(25):
+        x, u, st, _ = util.oracle_rti(oracle, spec, wl, x, u)
+        assert st[0] == 0
+    x, u = x[0], u[0]
+    x0 = wl["x0"][0]
+    # (a) nonlinear feasibility
+    assert np.abs(x[0] - x0).max() < 1e-12
+    for k in range(N):
+        xn, _, _ = oracle.rk4_sens(1, dt, x[k], u[k])
+        assert np.abs(xn - x[k + 1]).max() < 1e-9
+    assert np.abs(u).max() <= 0.5 + 1e-9
+
+    # (b) the same OCP by single shooting in scipy
+    W = np.asarray(ocp.cost.W); We = np.asarray(ocp.cost.W_e)
+
+    def rollout(uu):
+        xs = [x0]
+        for k in range(N):
+            xs.append(oracle.rk4_sens(1, dt, xs[-1], [uu[k]])[0])
+        return np.array(xs)
+
+    def cost(uu):
+        xs = rollout(uu)
+        c = 0.0
+        for k in range(N):
+            y = np.concatenate([xs[k], [uu[k]]])
+            c += 0.5 * dt * y @ W @ y
+        return c + 0.5 * xs[N] @ We @ xs[N]
+
+    r = minimize(cost, np.zeros(N), bounds=[(-0.5, 0.5)] * N, method="SLSQP", options={"ftol": 1e-15, "maxiter": 300})
+    assert r.success
+    assert cost(u[:, 0]) <= cost(r.x) + 1e-10
+    assert np.abs(u[:, 0] - r.x).max() < 1e-5

@@ -45,7 +45,9 @@ extern "C" {
 
 enum { USVMPC_MODEL_USV = 0,             /* `usv_model`              nx 5  nu 2           */
        USVMPC_MODEL_GUIDANCE_CA1 = 1,    /* `usv_model_guidance_ca1` nx 8  nu 1, soft h   */
-       USVMPC_MODEL_PF_CA = 2 };         /* `usv_model_pf_ca`        nx 14 nu 2, hard h   */
+       USVMPC_MODEL_PF_CA = 2,           /* `usv_model_pf_ca`        nx 14 nu 2, hard h   */
+       USVMPC_MODEL_GENERATED = 3 };     /* model compiled into THIS library from a symbolic definition
+                                            (mpc_collisionavoidance_amd/codegen.py); only in libraries built for it */
 
 enum { USVMPC_E_ARG = -1, USVMPC_E_FIELD = -2, USVMPC_E_STAGE = -3, USVMPC_E_SIZE = -4,
        USVMPC_E_HIP = -5, USVMPC_E_NODEVICE = -6 };

@@ -39,7 +39,6 @@ def lib_path():
     return os.environ.get("USVMPC_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libusvmpc.so")
 
 
-_lib = None
 # torch bundles its own HIP runtime under the same SONAME.  If torch is imported BEFORE this library is
 # loaded both share torch's copy and zero-copy tensors / RCCL on solver buffers work; the other order
 # leaves torch unable to initialise its device.  Recorded here so the torch helpers can say so.
@@ -52,46 +51,55 @@ EXPORTS = ["usvmpc_model_dims", "usvmpc_default_options", "usvmpc_create", "usvm
            "usvmpc_guidance_publish", "usvmpc_guidance_state", "usvmpc_device_bytes", "usvmpc_last_error"]
 
 
-def lib():
-    """Load libusvmpc.so; raises if it has not been built (no fallback)."""
-    global _lib
-    if _lib is None:
-        path = lib_path()
-        if not os.path.exists(path):
-            raise RuntimeError(
-                "HIP library %s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(there is no CPU fallback)" % path)
-        global loaded_before_torch
+_libs = {}
+
+
+def load(path):
+    """Load (once) a build of the solver library and declare its C ABI."""
+    global loaded_before_torch
+    path = os.path.abspath(path)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "HIP library %s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)" % path)
+    if not _libs:
         loaded_before_torch = "torch" not in sys.modules
-        L = C.CDLL(path)
-        L.usvmpc_model_dims.argtypes = [C.c_int, _ip, _ip]
-        L.usvmpc_default_options.argtypes = [C.POINTER(Desc)]
-        L.usvmpc_default_options.restype = None
-        L.usvmpc_create.argtypes = [C.POINTER(Desc), C.POINTER(C.c_void_p)]
-        L.usvmpc_destroy.argtypes = [C.c_void_p]
-        L.usvmpc_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _dp, C.c_size_t]
-        L.usvmpc_get.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _dp, C.c_size_t]
-        L.usvmpc_get_int.argtypes = [C.c_void_p, C.c_char_p, _ip]
-        L.usvmpc_solve.argtypes = [C.c_void_p, _ip]
-        L.usvmpc_solve_async.argtypes = [C.c_void_p]
-        L.usvmpc_sync.argtypes = [C.c_void_p]
-        L.usvmpc_get_device_ptr.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
-        L.usvmpc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-        L.usvmpc_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-        L.usvmpc_advance.argtypes = [C.c_void_p, C.c_double, C.c_ulonglong]
-        L.usvmpc_set_stream.argtypes = [C.c_void_p, C.c_void_p]
-        L.usvmpc_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
-        L.usvmpc_calibrate_traffic.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
-        L.usvmpc_guidance_reset.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
-        L.usvmpc_guidance_prepare.argtypes = [C.c_void_p, _dp, _dp, _dp, _ip, C.c_int]
-        L.usvmpc_guidance_publish.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _ip]
-        L.usvmpc_guidance_state.argtypes = [C.c_void_p, _ip, C.POINTER(C.c_float)]
-        L.usvmpc_device_bytes.argtypes = [C.c_void_p]
-        L.usvmpc_device_bytes.restype = C.c_size_t
-        L.usvmpc_last_error.argtypes = [C.c_void_p]
-        L.usvmpc_last_error.restype = C.c_char_p
-        _lib = L
-    return _lib
+    L = C.CDLL(path)
+    L.usvmpc_model_dims.argtypes = [C.c_int, _ip, _ip]
+    L.usvmpc_default_options.argtypes = [C.POINTER(Desc)]
+    L.usvmpc_default_options.restype = None
+    L.usvmpc_create.argtypes = [C.POINTER(Desc), C.POINTER(C.c_void_p)]
+    L.usvmpc_destroy.argtypes = [C.c_void_p]
+    L.usvmpc_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _dp, C.c_size_t]
+    L.usvmpc_get.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _dp, C.c_size_t]
+    L.usvmpc_get_int.argtypes = [C.c_void_p, C.c_char_p, _ip]
+    L.usvmpc_solve.argtypes = [C.c_void_p, _ip]
+    L.usvmpc_solve_async.argtypes = [C.c_void_p]
+    L.usvmpc_sync.argtypes = [C.c_void_p]
+    L.usvmpc_get_device_ptr.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    L.usvmpc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.usvmpc_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.usvmpc_advance.argtypes = [C.c_void_p, C.c_double, C.c_ulonglong]
+    L.usvmpc_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.usvmpc_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    L.usvmpc_calibrate_traffic.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+    L.usvmpc_guidance_reset.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
+    L.usvmpc_guidance_prepare.argtypes = [C.c_void_p, _dp, _dp, _dp, _ip, C.c_int]
+    L.usvmpc_guidance_publish.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _ip]
+    L.usvmpc_guidance_state.argtypes = [C.c_void_p, _ip, C.POINTER(C.c_float)]
+    L.usvmpc_device_bytes.argtypes = [C.c_void_p]
+    L.usvmpc_device_bytes.restype = C.c_size_t
+    L.usvmpc_last_error.argtypes = [C.c_void_p]
+    L.usvmpc_last_error.restype = C.c_char_p
+    _libs[path] = L
+    return L
+
+
+def lib():
+    """The stock library (hand-written models); raises if it has not been built (no fallback)."""
+    return load(lib_path())
 
 
 def _fill(dst, src, n, what="array"):
@@ -111,17 +119,24 @@ def default_options(d):
     return d
 
 
-def desc_from_ocp(ocp, batch=1, device=0):
+MODEL_GENERATED = 3
+
+
+def desc_from_ocp(ocp, batch=1, device=0, generated=False):
     """Translate an AcadosOcp look-alike into the C description; validates like acados'
-    make_consistent (dimension mismatches raise Exception)."""
+    make_consistent (dimension mismatches raise Exception).  generated: the model is compiled from its
+    symbolic definition (model id 3) instead of coming from the registry of hand-written models."""
     name = ocp.model.name
-    if name not in MODEL_IDS:
-        raise Exception("model '%s' is not in the registry %s" % (name, sorted(MODEL_IDS)))
-    mid = MODEL_IDS[name]
-    nx, nu = MODEL_DIMS[mid]
     opts, cost, con = ocp.solver_options, ocp.cost, ocp.constraints
-    if ocp.model.x.size()[0] != nx or ocp.model.u.size()[0] != nu:
-        raise Exception("model dimensions do not match registry entry '%s'" % name)
+    if generated:
+        mid, nx, nu = MODEL_GENERATED, ocp.model.x.size()[0], ocp.model.u.size()[0]
+    else:
+        if name not in MODEL_IDS:
+            raise Exception("model '%s' is not in the registry %s and carries no symbolic definition" % (name, sorted(MODEL_IDS)))
+        mid = MODEL_IDS[name]
+        nx, nu = MODEL_DIMS[mid]
+        if ocp.model.x.size()[0] != nx or ocp.model.u.size()[0] != nu:
+            raise Exception("model dimensions do not match registry entry '%s'" % name)
     for fld, want in (("cost_type", "LINEAR_LS"), ("cost_type_e", "LINEAR_LS")):
         if getattr(cost, fld) != want:
             raise Exception("only %s = %s is supported" % (fld, want))
@@ -179,6 +194,8 @@ def desc_from_ocp(ocp, batch=1, device=0):
             d.lsh[i], d.ush[i] = float(con.lsh[i]), float(con.ush[i])
             d.zl[i], d.zu[i] = float(cost.zl[i]), float(cost.zu[i])
             d.Zl[i], d.Zu[i] = float(cost.Zl[i]), float(cost.Zu[i])
+    if generated and d.soft == 0 and idxsh.size == 0:
+        pass
     if mid == 1 and K and not d.soft:
         raise Exception("usv_model_guidance_ca1 is built with soft obstacle rows")
     if mid == 2 and d.soft:

@@ -107,6 +107,7 @@ class AcadosOcpOptions:
         self.qp_solver_tol_eq = None
         self.qp_solver_tol_ineq = None
         self.qp_solver_tol_comp = None
+        self.model_source = None  # "symbolic": compile the model from its expressions even if the registry has it
 
 
 class AcadosOcp:
@@ -136,12 +137,27 @@ class BatchOcpSolver:
     def __init__(self, ocp, batch, device=0):
         self.ocp = ocp
         self.B = int(batch)
-        self._desc = _capi.desc_from_ocp(ocp, batch=self.B, device=device)
+        # Route: hand-written device model from the registry (by model name and dimensions), or - when the
+        # model carries a symbolic definition that the registry does not cover, or the caller asks for it
+        # with solver_options.model_source = "symbolic" - a library generated and compiled for this model,
+        # as acados does at this point.
+        from . import casadi_lite
+        m = ocp.model
+        symbolic = isinstance(getattr(m, "f_expl_expr", None), casadi_lite.MXVec)
+        known = m.name in _capi.MODEL_IDS and (m.x.size()[0], m.u.size()[0]) == _capi.MODEL_DIMS[_capi.MODEL_IDS[m.name]]
+        self.generated = symbolic and (not known or getattr(ocp.solver_options, "model_source", None) == "symbolic")
+        self._desc = _capi.desc_from_ocp(ocp, batch=self.B, device=device, generated=self.generated)
         self.N = self._desc.N
         self.K = self._desc.K
-        self.nx, self.nu = _capi.MODEL_DIMS[self._desc.model]
+        if self.generated:
+            from . import codegen, genbuild
+            info = codegen.analyse(m)
+            self.nx, self.nu = info.nx, info.nu
+            self._lib = _capi.load(genbuild.build_device_lib(info, (self.K + 15) // 16, bool(self._desc.soft)))
+        else:
+            self.nx, self.nu = _capi.MODEL_DIMS[self._desc.model]
+            self._lib = _capi.lib()
         self.ny, self.ny_e = self.nx + self.nu, self.nx
-        self._lib = _capi.lib()
         h = C.c_void_p()
         rc = self._lib.usvmpc_create(C.byref(self._desc), C.byref(h))
         if rc != 0:

@@ -1,0 +1,259 @@
+"""Device-code generation for symbolically defined models (casadi_lite expression graphs).
+
+What acados does with CasADi codegen (`<model>_expl_vde_forw`, `<model>_constr_h_fun_jac_uxt`) is done
+here for the batched kernels: from `model.x, model.u, model.p, model.f_expl_expr, model.con_h_expr` it emits
+
+  * a straight-line C function  fjvp(x, U, s, su, f, js):  f(x,u) and the directional derivative
+    Jx(x,u)·s + Ju(x,u)·su by forward-mode tangent propagation over the shared expression DAG
+    (sin/cos of one argument become one sincos); usable as plain C (oracle hook) and as the body of
+  * a device model struct `ModelGen` with the interface of csrc/models.hpp, including the structural
+    traits the kernels exploit: OUT_UNIT (f_j == 0) and IN_UNIT (variable appears in no right-hand side),
+    derived from the graph's dependency sets;
+  * the obstacle-row trait: `con_h_expr` must be rows sqrt((x_a - p_2i)^2 + (x_b - p_2i+1)^2) (what every
+    obstacle variant of the reference uses, e.g. scripts/usv_guidance_ca1/usv_model.py:133-140); the
+    kernels take (a, b) as IPX, IPY.  Anything else raises.
+"""
+import hashlib
+
+from . import casadi_lite as cl
+
+NX_MAX, NU_MAX, NZ_MAX, K_MAX = 14, 2, 16, 32
+
+
+class ModelInfo:
+    pass
+
+
+def _is_sq_diff(node, xs, ps):
+    """node == (x_a - p_m) * (x_a - p_m)  ->  (a, m) else None"""
+    if node.kind != "mul" or node.args[0] is not node.args[1]:
+        return None
+    d = node.args[0]
+    if d.kind != "sub" or d.args[0] not in xs or d.args[1] not in ps:
+        return None
+    return xs[d.args[0]], ps[d.args[1]]
+
+
+def analyse(model):
+    """model: object with x, u (or U), p, f_expl_expr, con_h_expr (may be None), name."""
+    x = cl.scalars(model.x)
+    u = cl.scalars(getattr(model, "u", None) if getattr(model, "u", None) is not None else getattr(model, "U"))
+    p = cl.scalars(getattr(model, "p", None))
+    f = cl.scalars(model.f_expl_expr)
+    h = cl.scalars(getattr(model, "con_h_expr", None))
+    nx, nu = len(x), len(u)
+    if len(f) != nx:
+        raise Exception("f_expl_expr has %d rows, the state has %d" % (len(f), nx))
+    if nx > NX_MAX or nu > NU_MAX or nx + nu > NZ_MAX or nu < 1:
+        raise Exception("model dimensions nx=%d nu=%d exceed the 16-lane kernels (nx<=14, nu<=2)" % (nx, nu))
+    for s in x + u + p:
+        if s.kind != "sym":
+            raise Exception("model.x / model.u / model.p must be vectors of symbols")
+    xs = {s: i for i, s in enumerate(x)}
+    us = {s: i for i, s in enumerate(u)}
+    ps = {s: i for i, s in enumerate(p)}
+    deps = cl.depends_on(f)
+    used = set()
+    for d in deps:
+        for s in d:
+            if s in ps:
+                raise Exception("the dynamics depend on the parameter '%s': only obstacle rows may use p" % s.name)
+            if s not in xs and s not in us:
+                raise Exception("the dynamics use the symbol '%s' which is neither a state nor a control" % s.name)
+            used.add(s)
+    info = ModelInfo()
+    info.name = getattr(model, "name", "model")
+    info.x, info.u, info.p, info.f, info.h = x, u, p, f, h
+    info.nx, info.nu, info.np = nx, nu, len(p)
+    info.out_unit = sum(1 << j for j, e in enumerate(f) if e.kind == "const" and e.value == 0.0)
+    info.in_unit = sum(1 << l for l, s in enumerate(u) if s not in used) | sum(1 << (nu + c) for c, s in enumerate(x) if s not in used)
+    # ---- obstacle rows
+    info.K, info.ipx, info.ipy = len(h), 0, 0
+    if h:
+        if len(p) != 2 * len(h) or len(h) > K_MAX:
+            raise Exception("obstacle rows need np = 2*nh parameters (ox_i, oy_i) and nh <= %d" % K_MAX)
+        for i, row in enumerate(h):
+            ok = row.kind == "sqrt" and row.args[0].kind == "add"
+            a = b = None
+            if ok:
+                a = _is_sq_diff(row.args[0].args[0], xs, ps)
+                b = _is_sq_diff(row.args[0].args[1], xs, ps)
+                ok = a is not None and b is not None and a[1] == 2 * i and b[1] == 2 * i + 1
+            if ok and i == 0:
+                info.ipx, info.ipy = a[0], b[0]
+            if not ok or (a[0], b[0]) != (info.ipx, info.ipy):
+                raise NotImplementedError("con_h_expr row %d is not a circular-obstacle distance "
+                                          "sqrt((x_a-p_%d)^2 + (x_b-p_%d)^2)" % (i, 2 * i, 2 * i + 1))
+    return info
+
+
+_C1 = {"sin": "sin", "cos": "cos", "tan": "tan", "sqrt": "sqrt", "fabs": "fabs", "exp": "exp", "log": "log", "tanh": "tanh"}
+_CMP = {"lt": "<", "le": "<=", "gt": ">", "ge": ">=", "eq": "==", "ne": "!="}
+
+
+def emit_fjvp_body(info):
+    """Statements computing f[] and js[] from x[], U[], s[], su[] (C / C++ compatible)."""
+    xs = {s: i for i, s in enumerate(info.x)}
+    us = {s: i for i, s in enumerate(info.u)}
+    order = cl.topo(info.f)
+    idx = {n.key: i for i, n in enumerate(order)}
+    has_t = {}
+    # arguments that appear under both sin and cos (or whose derivative needs the partner) share one sincos
+    trig_args = {}
+    for n in order:
+        if n.kind in ("sin", "cos"):
+            trig_args.setdefault(n.args[0].key, n.args[0])
+    lines = []
+    val, tan = {}, {}
+
+    def V(n):
+        return val[n.key]
+
+    def T(n):
+        return tan.get(n.key)
+
+    emitted_trig = set()
+    for n in order:
+        i = idx[n.key]
+        k = n.kind
+        if k == "sym":
+            if n in xs:
+                val[n.key], tan[n.key] = "x[%d]" % xs[n], "s[%d]" % xs[n]
+            else:
+                val[n.key], tan[n.key] = "U[%d]" % us[n], "su[%d]" % us[n]
+            has_t[n.key] = True
+            continue
+        if k == "const":
+            val[n.key] = repr(float(n.value)) if n.value == n.value and abs(n.value) != float("inf") else ("NAN" if n.value != n.value else ("INFINITY" if n.value > 0 else "-INFINITY"))
+            has_t[n.key] = False
+            continue
+        a = n.args[0]
+        b = n.args[1] if len(n.args) > 1 else None
+        ht = any(has_t[c.key] for c in n.args)
+        if k in ("lt", "le", "gt", "ge", "eq", "ne", "and", "or", "not", "sign"):
+            ht = False
+        has_t[n.key] = ht
+        v, d = "v%d" % i, "d%d" % i
+        if k in ("sin", "cos"):
+            ak = a.key
+            if ak not in emitted_trig:
+                j = idx[ak]
+                lines.append("double sn%d, cs%d; sincos(%s, &sn%d, &cs%d);" % (j, j, V(a), j, j))
+                emitted_trig.add(ak)
+            j = idx[ak]
+            val[n.key] = ("sn%d" if k == "sin" else "cs%d") % j
+            if ht:
+                lines.append("const double %s = %s * %s;" % (d, ("cs%d" % j) if k == "sin" else ("-sn%d" % j), T(a)))
+                tan[n.key] = d
+            continue
+        # ---- value
+        if k == "add": e = "%s + %s" % (V(a), V(b))
+        elif k == "sub": e = "%s - %s" % (V(a), V(b))
+        elif k == "mul": e = "%s * %s" % (V(a), V(b))
+        elif k == "div": e = "%s / %s" % (V(a), V(b))
+        elif k == "neg": e = "-%s" % V(a)
+        elif k == "pow": e = "pow(%s, %s)" % (V(a), V(b))
+        elif k in _C1: e = "%s(%s)" % (_C1[k], V(a))
+        elif k == "sign": e = "(double)((%s > 0.0) - (%s < 0.0))" % (V(a), V(a))
+        elif k == "atan2": e = "atan2(%s, %s)" % (V(a), V(b))
+        elif k == "fmin": e = "fmin(%s, %s)" % (V(a), V(b))
+        elif k == "fmax": e = "fmax(%s, %s)" % (V(a), V(b))
+        elif k in _CMP: e = "(%s %s %s ? 1.0 : 0.0)" % (V(a), _CMP[k], V(b))
+        elif k == "and": e = "((%s != 0.0 && %s != 0.0) ? 1.0 : 0.0)" % (V(a), V(b))
+        elif k == "or": e = "((%s != 0.0 || %s != 0.0) ? 1.0 : 0.0)" % (V(a), V(b))
+        elif k == "not": e = "(%s != 0.0 ? 0.0 : 1.0)" % V(a)
+        elif k == "if_else": e = "(%s != 0.0 ? %s : %s)" % (V(a), V(b), V(n.args[2]))
+        else:
+            raise NotImplementedError(k)
+        lines.append("const double %s = %s;" % (v, e))
+        val[n.key] = v
+        if not ht:
+            continue
+        # ---- tangent (only the operands that carry one)
+        ta, tb = T(a) if has_t[a.key] else None, (T(b) if (b is not None and has_t[b.key]) else None)
+        if k == "add": t = " + ".join(x for x in (ta, tb) if x)
+        elif k == "sub": t = (ta or "") + (" - %s" % tb if tb else "") if ta else "-%s" % tb
+        elif k == "mul":
+            parts = []
+            if ta: parts.append("%s * %s" % (ta, V(b)))
+            if tb: parts.append("%s * %s" % (V(a), tb))
+            t = " + ".join(parts)
+        elif k == "div":
+            if ta and tb: t = "(%s - %s * %s) / %s" % (ta, v, tb, V(b))
+            elif ta: t = "%s / %s" % (ta, V(b))
+            else: t = "-%s * %s / %s" % (v, tb, V(b))
+        elif k == "neg": t = "-%s" % ta
+        elif k == "pow":
+            if tb is None: t = "%s * pow(%s, %s - 1.0) * %s" % (V(b), V(a), V(b), ta)
+            elif ta is None: t = "%s * log(%s) * %s" % (v, V(a), tb)
+            else: t = "%s * (%s * log(%s) + %s * %s / %s)" % (v, tb, V(a), V(b), ta, V(a))
+        elif k == "tan": t = "%s * (1.0 + %s * %s)" % (ta, v, v)
+        elif k == "sqrt": t = "0.5 * %s / %s" % (ta, v)
+        elif k == "fabs": t = "(double)((%s > 0.0) - (%s < 0.0)) * %s" % (V(a), V(a), ta)
+        elif k == "exp": t = "%s * %s" % (v, ta)
+        elif k == "log": t = "%s / %s" % (ta, V(a))
+        elif k == "tanh": t = "(1.0 - %s * %s) * %s" % (v, v, ta)
+        elif k == "atan2":  # atan2(y=a, x=b)
+            num = []
+            if ta: num.append("%s * %s" % (V(b), ta))
+            if tb: num.append("- %s * %s" % (V(a), tb))
+            t = "(%s) / (%s * %s + %s * %s)" % (" ".join(num), V(a), V(a), V(b), V(b))
+        elif k in ("fmin", "fmax"):
+            cmp = "<=" if k == "fmin" else ">="
+            t = "(%s %s %s ? %s : %s)" % (V(a), cmp, V(b), ta or "0.0", tb or "0.0")
+        elif k == "if_else":
+            c2 = n.args[2]
+            tb2 = T(b) if has_t[b.key] else "0.0"
+            tc2 = T(c2) if has_t[c2.key] else "0.0"
+            t = "(%s != 0.0 ? %s : %s)" % (V(a), tb2, tc2)
+        else:
+            raise NotImplementedError(k)
+        lines.append("const double %s = %s;" % (d, t))
+        tan[n.key] = d
+    for j, e in enumerate(info.f):
+        lines.append("f[%d] = %s;" % (j, V(e)))
+        lines.append("js[%d] = %s;" % (j, T(e) if has_t[e.key] else "0.0"))
+    return lines
+
+
+def emit_device_header(info):
+    body = "\n        ".join(emit_fjvp_body(info))
+    return '''// generated by mpc_collisionavoidance_amd/codegen.py from the symbolic model '%(name)s' - do not edit
+#pragma once
+#include "lanes.hpp"
+#include <cmath>
+
+namespace usv {
+
+struct ModelGen {
+    static constexpr int ID = 3, NX = %(nx)d, NU = %(nu)d, IPX = %(ipx)d, IPY = %(ipy)d;
+    static constexpr unsigned OUT_UNIT = %(out)du, IN_UNIT = %(inn)du;
+    USV_DEV static void fjvp(const double *x, const double *U, const double *s, const double *su, double *f, double *js)
+    {
+        %(body)s
+    }
+};
+
+} // namespace usv
+''' % dict(name=info.name, nx=info.nx, nu=info.nu, ipx=info.ipx, ipy=info.ipy, out=info.out_unit, inn=info.in_unit, body=body)
+
+
+def emit_oracle_c(info):
+    """Plain C for the CPU oracle's generated-model hook (oracle/usv_oracle.c, model id 3)."""
+    body = "\n    ".join(emit_fjvp_body(info))
+    return '''/* generated by mpc_collisionavoidance_amd/codegen.py from the symbolic model '%(name)s' (test infrastructure) */
+#define _GNU_SOURCE
+#include <math.h>
+int usv_gen_nx(void) { return %(nx)d; }
+int usv_gen_nu(void) { return %(nu)d; }
+int usv_gen_ipx(void) { return %(ipx)d; }
+int usv_gen_ipy(void) { return %(ipy)d; }
+void usv_gen_fjvp(const double *x, const double *U, const double *s, const double *su, double *f, double *js)
+{
+    %(body)s
+}
+''' % dict(name=info.name, nx=info.nx, nu=info.nu, ipx=info.ipx, ipy=info.ipy, body=body)
+
+
+def digest(info):
+    return hashlib.sha256(emit_device_header(info).encode()).hexdigest()[:16]

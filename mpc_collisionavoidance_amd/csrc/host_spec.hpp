@@ -14,6 +14,9 @@ inline int model_dims(int model, int &nx, int &nu)
     case USVMPC_MODEL_USV: nx = 5; nu = 2; return 0;
     case USVMPC_MODEL_GUIDANCE_CA1: nx = 8; nu = 1; return 0;
     case USVMPC_MODEL_PF_CA: nx = 14; nu = 2; return 0;
+#ifdef USV_GEN_NX
+    case USVMPC_MODEL_GENERATED: nx = USV_GEN_NX; nu = USV_GEN_NU; return 0;
+#endif
     }
     return -1;
 }

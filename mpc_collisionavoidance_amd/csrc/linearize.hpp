@@ -59,34 +59,31 @@ struct Linearize {
 
         // ---- ERK4 + forward VDE for this lane's sensitivity column ----
         const double dt = S.dt;
-        double s0[NX], f[NX], js[NX], xs[NX], ss[NX], xa[NX], sa[NX];
+        double s0[NX], f[NX], js[NX], xs[NX], ss[NX], xa[NX], sa[NX], su[NU > 0 ? NU : 1];
+        sfor<0, NU>([&](auto l) { su[l] = (lane == l) ? 1.0 : 0.0; });
         sfor<0, NX>([&](auto i) { s0[i] = (lane == NU + i) ? 1.0 : 0.0; });
-        M::fjvp(x, U, s0, f, js);
-        M::ju_add(lane, js);
+        M::fjvp(x, U, s0, su, f, js);
         sfor<0, NX>([&](auto i) {
             xa[i] = f[i];
             sa[i] = js[i];
             xs[i] = fma(0.5 * dt, f[i], x[i]);
             ss[i] = fma(0.5 * dt, js[i], s0[i]);
         });
-        M::fjvp(xs, U, ss, f, js);
-        M::ju_add(lane, js);
+        M::fjvp(xs, U, ss, su, f, js);
         sfor<0, NX>([&](auto i) {
             xa[i] = fma(2.0, f[i], xa[i]);
             sa[i] = fma(2.0, js[i], sa[i]);
             xs[i] = fma(0.5 * dt, f[i], x[i]);
             ss[i] = fma(0.5 * dt, js[i], s0[i]);
         });
-        M::fjvp(xs, U, ss, f, js);
-        M::ju_add(lane, js);
+        M::fjvp(xs, U, ss, su, f, js);
         sfor<0, NX>([&](auto i) {
             xa[i] = fma(2.0, f[i], xa[i]);
             sa[i] = fma(2.0, js[i], sa[i]);
             xs[i] = fma(dt, f[i], x[i]);
             ss[i] = fma(dt, js[i], s0[i]);
         });
-        M::fjvp(xs, U, ss, f, js);
-        M::ju_add(lane, js);
+        M::fjvp(xs, U, ss, su, f, js);
         const double *xn = P.x + ((long)b * (N + 1) + k + 1) * NX;
         double bres = 0.0;
         sfor<0, NX>([&](auto i) {

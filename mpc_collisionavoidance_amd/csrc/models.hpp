@@ -1,8 +1,9 @@
 // models.hpp — the three in-scope USV models as device functions.
 //
-// Each model provides f(x,u) together with the directional derivative Jx(x)·s for ONE
-// sensitivity column s (the lane's own column of [dx+/du | dx+/dx]); the control Jacobian of
-// all three models is constant and is added by ju_add().  Formulas follow the reference's
+// Each model provides f(x,u) together with the directional derivative Jx(x)·s + Ju(x,u)·su for ONE
+// sensitivity column (s, su) (the lane's own column of [dx+/du | dx+/dx]; su is the unit vector of
+// the lane's control or zero).  Models generated from a symbolic definition (codegen.py) have the
+// same interface.  Formulas follow the reference's
 // CasADi definitions (paths relative to /root/reference/catkin_ws/src/nmpc_ca/scripts/):
 //   M0 usv_model              usv_acados/usv_model.py:61-122
 //   M1 usv_model_guidance_ca1 usv_guidance_ca1/usv_model.py:61-140
@@ -62,18 +63,13 @@ struct ModelM0 {
     static constexpr int ID = 0, NX = 5, NU = 2, IPX = 0, IPY = 0; // no obstacles (K = 0)
     // structural identities of the discrete map (see ModelM2): none for this model
     static constexpr unsigned OUT_UNIT = 0u, IN_UNIT = 0u;
-    USV_DEV static void fjvp(const double *x, const double *U, const double *s, double *f, double *js)
+    USV_DEV static void fjvp(const double *x, const double *U, const double *s, const double *su, double *f, double *js)
     {
         Dof3::eval(0.78, x[0], x[1], x[2], x[3], x[4], s[0], s[1], s[2], s[3], s[4], f, js);
         f[3] = U[0];
         f[4] = U[1];
-        js[3] = 0.0;
-        js[4] = 0.0;
-    }
-    USV_DEV static void ju_add(int lane, double *js)
-    {
-        js[3] += (lane == 0) ? 1.0 : 0.0;
-        js[4] += (lane == 1) ? 1.0 : 0.0;
+        js[3] = su[0];
+        js[4] = su[1];
     }
 };
 
@@ -83,7 +79,7 @@ struct ModelM1 {
     static constexpr unsigned OUT_UNIT = (1u << 0) | (1u << 1);
     static constexpr unsigned IN_UNIT = (1u << (NU + 2)) | (1u << (NU + 5)) | (1u << (NU + 6));
     // x = (u, v, ye, chie, psied, xned, yned, psi), T1 = 1
-    USV_DEV static void fjvp(const double *x, const double *U, const double *s, double *f, double *js)
+    USV_DEV static void fjvp(const double *x, const double *U, const double *s, const double *su, double *f, double *js)
     {
         const double u = x[0], v = x[1], chie = x[3], psied = x[4], psi = x[7];
         const double ue = u + 0.001;
@@ -107,12 +103,11 @@ struct ModelM1 {
         js[1] = 0.0;
         js[2] = sp * s[0] + cp * s[1] + (u * cp - v * sp) * dpsie;
         js[3] = s[4] - dpsie;
-        js[4] = 0.0;
+        js[4] = su[0];
         js[5] = cq * s[0] - sq * s[1] + (-u * sq - v * cq) * s[7];
         js[6] = sq * s[0] + cq * s[1] + (u * cq - v * sq) * s[7];
         js[7] = s[4] - dpsie;
     }
-    USV_DEV static void ju_add(int lane, double *js) { js[4] += (lane == 0) ? 1.0 : 0.0; }
 };
 
 struct ModelM2 {
@@ -128,7 +123,7 @@ struct ModelM2 {
     static constexpr unsigned IN_UNIT = (1u << (NU + 1)) | (1u << (NU + 2)) | (1u << (NU + 6)) | (1u << (NU + 7)) |
                                         (1u << (NU + 8)) | (1u << (NU + 10)) | (1u << (NU + 11));
     // x = (psi, sinpsi, cospsi, u, v, r, ye, x1, y1, ak, nedx, nedy, Tport, Tstbd), c = 1
-    USV_DEV static void fjvp(const double *x, const double *U, const double *s, double *f, double *js)
+    USV_DEV static void fjvp(const double *x, const double *U, const double *s, const double *su, double *f, double *js)
     {
         const double psi = x[0], u = x[3], v = x[4], r = x[5], ak = x[9];
         const double ue = u + .001;
@@ -171,13 +166,8 @@ struct ModelM2 {
         js[9] = 0.0;
         js[10] = dvx;
         js[11] = dvy;
-        js[12] = 0.0;
-        js[13] = 0.0;
-    }
-    USV_DEV static void ju_add(int lane, double *js)
-    {
-        js[12] += (lane == 0) ? 1.0 : 0.0;
-        js[13] += (lane == 1) ? 1.0 / 1.0 : 0.0;
+        js[12] = su[0];
+        js[13] = su[1] / 1.0;
     }
 };
 

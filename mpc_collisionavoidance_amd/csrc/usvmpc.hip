@@ -13,6 +13,9 @@
 #include "linearize.hpp"
 #include "models.hpp"
 #include "qp_ipm.hpp"
+#ifdef USV_GEN_MODEL_HEADER // a model generated from a symbolic definition (codegen.py): struct ModelGen
+#include USV_GEN_MODEL_HEADER
+#endif
 
 #include <cstdio>
 #include <cstring>
@@ -269,11 +272,16 @@ int launch_pair(usvmpc_handle *h)
 int launch(usvmpc_handle *h)
 {
     switch (h->desc.model) {
+#ifndef USV_GEN_ONLY
     case USVMPC_MODEL_USV: return launch_pair<ModelM0, 0, false>(h);
     case USVMPC_MODEL_GUIDANCE_CA1:
         return h->kch <= 1 ? launch_pair<ModelM1, 1, true>(h) : launch_pair<ModelM1, 2, true>(h);
     case USVMPC_MODEL_PF_CA:
         return h->kch <= 1 ? launch_pair<ModelM2, 1, false>(h) : launch_pair<ModelM2, 2, false>(h);
+#endif
+#ifdef USV_GEN_MODEL_HEADER
+    case USVMPC_MODEL_GENERATED: return launch_pair<ModelGen, USV_GEN_KCH, (USV_GEN_SOFT != 0)>(h);
+#endif
     }
     h->err = "unknown model";
     return USVMPC_E_ARG;
@@ -309,10 +317,23 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
         std::fprintf(stderr, "usvmpc_create: %s\n", err.c_str());
         return USVMPC_E_ARG;
     }
-    if ((d->model == USVMPC_MODEL_GUIDANCE_CA1) != (d->soft != 0) && d->K > 0) {
+    if (d->model != USVMPC_MODEL_GENERATED && (d->model == USVMPC_MODEL_GUIDANCE_CA1) != (d->soft != 0) && d->K > 0) {
         std::fprintf(stderr, "usvmpc_create: obstacle rows are soft for model 1 and hard for model 2\n");
         return USVMPC_E_ARG;
     }
+#ifdef USV_GEN_MODEL_HEADER
+    if (d->model == USVMPC_MODEL_GENERATED &&
+        ((S.K + LANES - 1) / LANES != USV_GEN_KCH || (S.K > 0 && (d->soft != 0) != (USV_GEN_SOFT != 0)))) {
+        std::fprintf(stderr, "usvmpc_create: this library was generated for %d obstacle chunk(s), soft = %d\n", USV_GEN_KCH, USV_GEN_SOFT);
+        return USVMPC_E_ARG;
+    }
+#endif
+#ifdef USV_GEN_ONLY
+    if (d->model != USVMPC_MODEL_GENERATED) {
+        std::fprintf(stderr, "usvmpc_create: this library only holds the generated model\n");
+        return USVMPC_E_ARG;
+    }
+#endif
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || d->device < 0 || d->device >= ndev) {
         std::fprintf(stderr, "usvmpc_create: no usable HIP device (count %d, requested %d); there is no CPU fallback\n",
@@ -327,6 +348,9 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->N = S.N; h->K = S.K; h->B = S.B; h->Bp = S.Bp;
     h->kch = d->model == USVMPC_MODEL_USV ? 0 : ((S.K + LANES - 1) / LANES > 1 ? 2 : 1);
     h->soft = d->soft != 0 || d->model == USVMPC_MODEL_GUIDANCE_CA1;
+#ifdef USV_GEN_MODEL_HEADER
+    if (d->model == USVMPC_MODEL_GENERATED) { h->kch = USV_GEN_KCH; h->soft = USV_GEN_SOFT != 0; }
+#endif
     h->device = d->device;
     h->nallocs = 0; h->bytes = 0; h->nsolves = 0; h->own_stream = true;
     std::memset(&h->ptrs, 0, sizeof(h->ptrs));

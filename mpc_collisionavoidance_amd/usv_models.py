@@ -19,7 +19,75 @@ import types
 import numpy as np
 import scipy.linalg
 
+from . import casadi_lite as ca
 from .acados_template import AcadosModel, AcadosOcp, AcadosOcpSolver, BatchOcpSolver, SymVec
+
+
+# ------------------------------------------------------------------------------------------ symbolic forms
+# The same three models written with the CasADi-style layer (casadi_lite), formula by formula as the
+# reference's usv_model.py files state them.  With `symbolic=True` the builders below attach these
+# expression graphs, and solver_options.model_source = "symbolic" makes the solver compile its device model
+# from them (codegen.py) instead of using the hand-written csrc/models.hpp - the route every other model file
+# of the reference takes.
+def _dof3_sym(c, u, v, r, Tport, Tstbd):
+    """usv_acados/usv_model.py:61-77,110-122"""
+    X_u_dot, Y_v_dot, Y_r_dot, N_v_dot, N_r_dot = -2.25, -23.13, -1.31, -16.41, -2.79
+    Yvv, Yvr, Nrv, Nrr = -99.99, -5.49, -8.8, -3.49
+    m, Iz, B = 30, 4.1, 0.41
+    Xu = ca.if_else(u > 1.25, 64.55, -25)
+    Xuu = ca.if_else(u > 1.25, -70.92, 0)
+    Yv = 0.5 * (-40 * 1000 * ca.fabs(v)) * (1.1 + 0.0045 * (1.01 / 0.09) - 0.1 * (0.27 / 0.09) + 0.016 * ((0.27 / 0.09) * (0.27 / 0.09)))
+    Nr = (-0.52) * ca.sqrt(u * u + v * v)
+    Tu = Tport + c * Tstbd
+    Tr = (Tport - c * Tstbd) * B / 2
+    return (
+        (Tu - (-m + 2 * Y_v_dot) * v - (Y_r_dot + N_v_dot) * r * r - (-Xu * u - Xuu * ca.fabs(u) * u)) / (m - X_u_dot),
+        (-(m - X_u_dot) * u * r - (-Yv - Yvv * ca.fabs(v) - Yvr * ca.fabs(r)) * v) / (m - Y_v_dot),
+        (Tr - (-2 * Y_v_dot * u * v - (Y_r_dot + N_v_dot) * r * u + X_u_dot * u * r) - (-Nr * r - Nrv * ca.fabs(v) * r - Nrr * ca.fabs(r) * r)) / (Iz - N_r_dot),
+    )
+
+
+def _distances(px, py, p, K):
+    return ca.vertcat(*[ca.sqrt((px - p[2 * i]) * (px - p[2 * i]) + (py - p[2 * i + 1]) * (py - p[2 * i + 1])) for i in range(K)])
+
+
+def _attach_symbolic(model, constraint, name, K):
+    if name == "usv_model":
+        u, v, r, Tport, Tstbd = (ca.MX.sym(n) for n in ("u", "v", "r", "Tport", "Tstbd"))
+        U0, U1 = ca.MX.sym("UTportdot"), ca.MX.sym("UTstbddot")
+        fu, fv, fr = _dof3_sym(0.78, u, v, r, Tport, Tstbd)
+        model.x, model.U, model.p = ca.vertcat(u, v, r, Tport, Tstbd), ca.vertcat(U0, U1), ca.vertcat([])
+        model.f_expl_expr = ca.vertcat(fu, fv, fr, U0, U1)
+        constraint.expr = None
+    elif name == "usv_model_guidance_ca1":
+        u, v, ye, chie, psied, xned, yned, psi = (ca.MX.sym(n) for n in ("u", "v", "ye", "chie", "psied", "xned", "yned", "psi"))
+        U = ca.MX.sym("Upsieddot")
+        p = [ca.MX.sym("o%d" % i) for i in range(2 * K)]
+        T1 = 1.0
+        beta = ca.atan2(v, u + 0.001)
+        psie = chie - beta
+        model.x, model.U, model.p = ca.vertcat(u, v, ye, chie, psied, xned, yned, psi), ca.vertcat(U), ca.vertcat(*p)
+        model.f_expl_expr = ca.vertcat(0, 0, u * ca.sin(psie) + v * ca.cos(psie), (psied - psie) / T1, U,
+                                       u * ca.cos(psi) - v * ca.sin(psi), u * ca.sin(psi) + v * ca.cos(psi), (psied - psie) / T1)
+        constraint.expr = _distances(xned, yned, p, K)
+    else:
+        names = ("psi", "sinpsi", "cospsi", "u", "v", "r", "ye", "x1", "y1", "ak", "nedx", "nedy", "Tport", "Tstbd")
+        psi, sinpsi, cospsi, u, v, r, ye, x1, y1, ak, nedx, nedy, Tport, Tstbd = (ca.MX.sym(n) for n in names)
+        U0, U1 = ca.MX.sym("UTportdot"), ca.MX.sym("UTstbddot")
+        p = [ca.MX.sym("o%d" % i) for i in range(2 * K)]
+        c = 1.0
+        fu, fv, fr = _dof3_sym(c, u, v, r, Tport, Tstbd)
+        chi = psi + ca.atan2(v, u + .001)
+        model.x = ca.vertcat(psi, sinpsi, cospsi, u, v, r, ye, x1, y1, ak, nedx, nedy, Tport, Tstbd)
+        model.U, model.p = ca.vertcat(U0, U1), ca.vertcat(*p)
+        model.f_expl_expr = ca.vertcat(
+            r, ca.cos(chi) * r, -ca.sin(chi) * r, fu, fv, fr,
+            -(u * ca.cos(psi) - v * ca.sin(psi)) * ca.sin(ak) + (u * ca.sin(psi) + v * ca.cos(psi)) * ca.cos(ak),
+            0, 0, 0, u * ca.cos(psi) - v * ca.sin(psi), u * ca.sin(psi) + v * ca.cos(psi), U0, U1 / c)
+        constraint.expr = _distances(nedx, nedy, p, K)
+    model.xdot = ca.MX.sym("xdot", len(model.x)) if len(model.x) > 1 else ca.vertcat(ca.MX.sym("xdot"))
+    model.z = ca.vertcat([])
+    model.f_impl_expr = model.xdot - model.f_expl_expr
 
 
 # ------------------------------------------------------------------------------------------ M0
@@ -64,8 +132,10 @@ def _common(model, constraint, N, Tf):
     return ocp
 
 
-def ocp_usv(Tf, N):
+def ocp_usv(Tf, N, symbolic=False):
     model, constraint = usv_model()
+    if symbolic:
+        _attach_symbolic(model, constraint, "usv_model", 0)
     ocp = _common(model, constraint, N, Tf)
     nx, nu = 5, 2
     ny = nx + nu
@@ -120,9 +190,11 @@ def usv_model_guidance_ca1(n_obstacles=8):
     return model, constraint
 
 
-def ocp_guidance_ca1(Tf, N, n_obstacles=8):
+def ocp_guidance_ca1(Tf, N, n_obstacles=8, symbolic=False):
     K = int(n_obstacles)
     model, constraint = usv_model_guidance_ca1(K)
+    if symbolic:
+        _attach_symbolic(model, constraint, "usv_model_guidance_ca1", K)
     ocp = _common(model, constraint, N, Tf)
     nx, nu = 8, 1
     ny = nx + nu
@@ -189,9 +261,11 @@ def usv_model_pf_ca(n_obstacles=4):
     return model, constraint
 
 
-def ocp_pf_ca(Tf, N, n_obstacles=4):
+def ocp_pf_ca(Tf, N, n_obstacles=4, symbolic=False):
     K = int(n_obstacles)
     model, constraint = usv_model_pf_ca(K)
+    if symbolic:
+        _attach_symbolic(model, constraint, "usv_model_pf_ca", K)
     ocp = _common(model, constraint, N, Tf)
     nx, nu = 14, 2
     ny = nx + nu
@@ -228,12 +302,17 @@ def ocp_pf_ca(Tf, N, n_obstacles=4):
 OCP_BUILDERS = {"usv_model": ocp_usv, "usv_model_guidance_ca1": ocp_guidance_ca1, "usv_model_pf_ca": ocp_pf_ca}
 
 
-def make_ocp(name, Tf, N, n_obstacles=None):
+def make_ocp(name, Tf, N, n_obstacles=None, symbolic=False):
+    """symbolic=True: attach the expression graphs and route the solver through the code generator."""
     if name == "usv_model":
-        return ocp_usv(Tf, N)[2]
-    if n_obstacles is None:
-        return OCP_BUILDERS[name](Tf, N)[2]
-    return OCP_BUILDERS[name](Tf, N, n_obstacles)[2]
+        ocp = ocp_usv(Tf, N, symbolic=symbolic)[2]
+    elif n_obstacles is None:
+        ocp = OCP_BUILDERS[name](Tf, N, symbolic=symbolic)[2]
+    else:
+        ocp = OCP_BUILDERS[name](Tf, N, n_obstacles, symbolic=symbolic)[2]
+    if symbolic:
+        ocp.solver_options.model_source = "symbolic"
+    return ocp
 
 
 def acados_settings(Tf, N, name="usv_model_guidance_ca1", n_obstacles=None, device=0):

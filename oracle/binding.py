@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libusv_oracle.so")
 
 NXM, NUM, NZM, KM, NYM = 14, 2, 16, 32, 16
-M0, M1, M2 = 0, 1, 2
+M0, M1, M2, MGEN = 0, 1, 2, 3
 RICCATI_SQRT, RICCATI_CLASSIC = 0, 1
 
 _dp = C.POINTER(C.c_double)
@@ -97,6 +97,8 @@ def lib():
         L.usv_qp_solve.argtypes = [C.POINTER(Qp), C.POINTER(Opts), C.POINTER(QpSol)]
         L.usv_rti.argtypes = [C.POINTER(Spec)] + [_dp] * 11
         L.usv_rti_batch.argtypes = [C.POINTER(Spec), C.c_int] + [_dp] * 7 + [_ip, _ip]
+        L.usv_oracle_register_generated.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.usv_oracle_register_generated.restype = None
         _fp = C.POINTER(C.c_float)
         L.usv_guidance_reset_ref.argtypes = [_dp, C.c_double, _ip, _fp]
         L.usv_guidance_reset_ref.restype = None
@@ -264,3 +266,57 @@ def guidance_publish(x1_psied, u0, ak, past_psied):
     h, r, s = C.c_double(), C.c_double(), C.c_double()
     lib().usv_guidance_publish_ref(float(x1_psied), float(u0), float(ak), C.byref(pp), C.byref(h), C.byref(r), C.byref(s))
     return dict(heading=h.value, r=r.value, speed=s.value, past_psied=pp.value)
+
+
+# ---- generated models (codegen.emit_oracle_c) and generic OCP -> Spec translation
+_gen_keep = []
+
+
+def register_generated(c_source, workdir):
+    """Compile the generated plain-C model, register it as model id MGEN. Returns (nx, nu)."""
+    import hashlib
+    tag = hashlib.sha256(c_source.encode()).hexdigest()[:12]
+    src = os.path.join(workdir, "gen_%s.c" % tag)
+    so = os.path.join(workdir, "gen_%s.so" % tag)
+    if not os.path.exists(so):
+        with open(src, "w") as f:
+            f.write(c_source)
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src, "-lm"])
+    G = C.CDLL(so)
+    _gen_keep.append(G)
+    fn = C.cast(G.usv_gen_fjvp, C.c_void_p)
+    nx, nu = G.usv_gen_nx(), G.usv_gen_nu()
+    lib().usv_oracle_register_generated(fn, nx, nu, G.usv_gen_ipx(), G.usv_gen_ipy())
+    return nx, nu
+
+
+def spec_from_ocp(ocp, model_id, **opts):
+    """Spec for any model id from an AcadosOcp look-alike (weights, selectors, bounds, soft data)."""
+    N, Tf = int(ocp.dims.N), float(ocp.solver_options.tf)
+    K = 0 if ocp.model.con_h_expr is None else ocp.model.con_h_expr.size()[0]
+    s = spec(model_id, N, Tf, K, **opts)
+    nx, nu = s.nx, s.nu
+    ny = nx + nu
+    for name, arr, n in (("W", ocp.cost.W, ny * ny), ("W_e", ocp.cost.W_e, nx * nx), ("Vx", ocp.cost.Vx, ny * nx),
+                         ("Vu", ocp.cost.Vu, ny * nu), ("Vx_e", ocp.cost.Vx_e, nx * nx)):
+        a = np.ascontiguousarray(arr, dtype=np.float64).reshape(-1)
+        assert a.size == n, name
+        dst = getattr(s, name)
+        for i in range(dst._length_):
+            dst[i] = a[i] if i < n else 0.0
+    con, cost = ocp.constraints, ocp.cost
+    idxbu = np.asarray(con.idxbu, dtype=int).reshape(-1)
+    s.nbu = idxbu.size
+    for i in range(s.nbu):
+        s.idxbu[i], s.lbu[i], s.ubu[i] = int(idxbu[i]), float(con.lbu[i]), float(con.ubu[i])
+    idxbx = np.asarray(con.idxbx, dtype=int).reshape(-1)
+    s.nbx = idxbx.size
+    for i in range(s.nbx):
+        s.idxbx[i], s.lbx[i], s.ubx[i] = int(idxbx[i]), float(con.lbx[i]), float(con.ubx[i])
+    s.soft = 1 if np.asarray(con.idxsh).size else 0
+    for i in range(K):
+        s.uh[i] = float(con.uh[i])
+        if s.soft:
+            s.lsh[i], s.ush[i] = float(con.lsh[i]), float(con.ush[i])
+            s.zl[i], s.zu[i], s.Zl[i], s.Zu[i] = float(cost.zl[i]), float(cost.zu[i]), float(cost.Zl[i]), float(cost.Zu[i])
+    return s

@@ -71,9 +71,18 @@ static void dof3(double c, double u, double v, double r, double Tp, double Ts, d
     }
 }
 
+static usv_fjvp_fn g_gen_fjvp = 0;
+static int g_gen_nx = 0, g_gen_nu = 0, g_gen_ipx = -1, g_gen_ipy = -1;
+
+void usv_oracle_register_generated(usv_fjvp_fn fn, int nx, int nu, int ipx, int ipy)
+{
+    g_gen_fjvp = fn; g_gen_nx = nx; g_gen_nu = nu; g_gen_ipx = ipx; g_gen_ipy = ipy;
+}
+
 int usv_model_dims(int model, int *nx, int *nu)
 {
     switch (model) {
+    case USV_MGEN: if (!g_gen_fjvp) return -1; *nx = g_gen_nx; *nu = g_gen_nu; return 0;
     case USV_M0: *nx = 5; *nu = 2; return 0;   /* usv_acados/usv_model.py:81-91 */
     case USV_M1: *nx = 8; *nu = 1; return 0;   /* usv_guidance_ca1/usv_model.py:65-77 */
     case USV_M2: *nx = 14; *nu = 2; return 0;  /* usv_pf_ca/usv_model.py:81-100 */
@@ -85,11 +94,17 @@ void usv_model_pos_idx(int model, int *ipx, int *ipy)
 {
     if (model == USV_M1) { *ipx = 5; *ipy = 6; }        /* xned, yned */
     else if (model == USV_M2) { *ipx = 10; *ipy = 11; } /* nedx, nedy */
+    else if (model == USV_MGEN) { *ipx = g_gen_ipx; *ipy = g_gen_ipy; }
     else { *ipx = -1; *ipy = -1; }
 }
 
 void usv_model_f(int model, const double *x, const double *U, double *f)
 {
+    if (model == USV_MGEN) {
+        double s[NXM] = {0}, su[NUM] = {0}, js[NXM];
+        g_gen_fjvp(x, U, s, su, f, js);
+        return;
+    }
     if (model == USV_M0) {
         /* usv_acados/usv_model.py:116-122, c = 0.78 (:77) */
         dof3(0.78, x[0], x[1], x[2], x[3], x[4], f, NULL);
@@ -140,6 +155,18 @@ void usv_model_jac(int model, const double *x, const double *U, double *Jx, doub
     usv_model_dims(model, &nx, &nu);
     for (i = 0; i < nx * nx; i++) Jx[i] = 0.0;
     for (i = 0; i < nx * nu; i++) Ju[i] = 0.0;
+    if (model == USV_MGEN) { /* dense Jacobians column by column from the generated tangent code */
+        int c, r;
+        for (c = 0; c < nx + nu; c++) {
+            double s[NXM] = {0}, su[NUM] = {0}, f[NXM], js[NXM];
+            if (c < nu) su[c] = 1.0; else s[c - nu] = 1.0;
+            g_gen_fjvp(x, U, s, su, f, js);
+            for (r = 0; r < nx; r++) {
+                if (c < nu) Ju[r * nu + c] = js[r]; else Jx[r * nx + (c - nu)] = js[r];
+            }
+        }
+        return;
+    }
     if (model == USV_M0) {
         double f3[3], J3[15];
         int a, b;
@@ -311,6 +338,7 @@ int usv_spec_defaults(usv_spec *s, int model, int N, double Tf, int K)
     if (usv_model_dims(model, &nx, &nu)) return -1;
     if (model == USV_M0) K = 0;
     if (K < 0 || K > KM || N < 1) return -1;
+    if (model == USV_MGEN && g_gen_ipx < 0 && K > 0) return -1;
     s->model = model;
     s->N = N;
     s->dt = Tf / N;
@@ -325,6 +353,7 @@ int usv_spec_defaults(usv_spec *s, int model, int N, double Tf, int K)
         s->Vx[i * nx + i] = 1.0;
         s->Vx_e[i * nx + i] = 1.0;
     }
+    if (model == USV_MGEN) return 0; /* dimensions only: weights / bounds come from the caller's OCP */
     if (model == USV_M0) {
         /* usv_acados/acados_settings.py:75-81,96-98,115-120; usv_model.py:129-139 */
         const double Q[5] = {1e3, 1e-3, 1e3, 1e-1, 1e-1}, R[2] = {1e-2, 1e-2};

@@ -50,7 +50,13 @@ extern "C" {
 #define USV_K_MAX 32
 #define USV_NY_MAX 16
 
-enum { USV_M0 = 0, USV_M1 = 1, USV_M2 = 2 };
+enum { USV_M0 = 0, USV_M1 = 1, USV_M2 = 2, USV_MGEN = 3 };
+
+/* Hook for a model generated from a symbolic definition (mpc_collisionavoidance_amd/codegen.py,
+ * emit_oracle_c): fjvp(x, U, s, su, f, js) = f and Jx s + Ju su.  Model id USV_MGEN then refers to it;
+ * usv_spec_defaults(USV_MGEN) only fills the dimensions, the caller supplies weights and bounds. */
+typedef void (*usv_fjvp_fn)(const double *, const double *, const double *, const double *, double *, double *);
+void usv_oracle_register_generated(usv_fjvp_fn fn, int nx, int nu, int ipx, int ipy);
 enum { USV_RICCATI_SQRT = 0, USV_RICCATI_CLASSIC = 1 };
 
 typedef struct usv_opts {

@@ -8,6 +8,9 @@
 #include "linearize.hpp"
 #include "models.hpp"
 #include "qp_ipm.hpp"
+#ifdef USV_GEN_MODEL_HEADER
+#include USV_GEN_MODEL_HEADER
+#endif
 
 #include <cstring>
 #include <vector>
@@ -150,8 +153,11 @@ extern "C" int usv_emu_solve(const usvmpc_desc *d, double *x, double *u, const d
     int nx, nu;
     model_dims(d->model, nx, nu);
     const int nz = nx + nu, N = S.N;
-    const int kch = (S.K + LANES - 1) / LANES;
-    const bool soft = d->soft != 0;
+    int kch = (S.K + LANES - 1) / LANES;
+    bool soft = d->soft != 0;
+#ifdef USV_GEN_MODEL_HEADER
+    if (d->model == USVMPC_MODEL_GENERATED) { kch = USV_GEN_KCH; soft = USV_GEN_SOFT != 0; }
+#endif
     const long stride = (long)S.Bp * LANES;
     std::vector<double> BAt((size_t)N * nx * stride), ABr((size_t)N * nz * stride), rb0((size_t)N * stride),
         gq((size_t)(N + 1) * stride), con((size_t)N * (kch ? kch : 1) * 4 * stride),
@@ -163,6 +169,10 @@ extern "C" int usv_emu_solve(const usvmpc_desc *d, double *x, double *u, const d
     P.sl = sl; P.su = su; P.pi = pi; P.status = status; P.qp_iter = qp_iter; P.qp_status = qp_status; P.res = res;
     P.BAt = BAt.data(); P.ABr = ABr.data(); P.rb0 = rb0.data(); P.gq = gq.data(); P.con = con.data(); P.ws = ws.data();
     const int phase = 3;
+#ifdef USV_GEN_MODEL_HEADER
+    if (d->model == USVMPC_MODEL_GENERATED) run_all<ModelGen, USV_GEN_KCH, (USV_GEN_SOFT != 0)>(P, S, phase);
+    else
+#endif
     if (d->model == USVMPC_MODEL_USV) run_all<ModelM0, 0, false>(P, S, phase);
     else if (d->model == USVMPC_MODEL_GUIDANCE_CA1) {
         if (!soft) return -2;

@@ -18,20 +18,6 @@ EMU = os.path.join(ROOT, "tests", "emu")
 CSRC = os.path.join(ROOT, "mpc_collisionavoidance_amd", "csrc")
 
 
-@pytest.fixture(scope="session")
-def emu():
-    out = os.path.join(EMU, "libusv_emu.so")
-    srcs = [os.path.join(EMU, "emu_driver.cpp"), os.path.join(EMU, "lanes.hpp")] + \
-           [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
-    if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + EMU, "-I" + CSRC, "-o", out,
-                               os.path.join(EMU, "emu_driver.cpp")])
-    lib = C.CDLL(out)
-    dp, ip = _capi._dp, _capi._ip
-    lib.usv_emu_solve.argtypes = [C.POINTER(_capi.Desc)] + [dp] * 10 + [ip] * 3 + [dp] * 4
-    return lib
-
-
 def _d(a):
     return a.ctypes.data_as(_capi._dp)
 

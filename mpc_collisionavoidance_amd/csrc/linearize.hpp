@@ -91,14 +91,16 @@ struct Linearize {
             sa[i] = fma(dt / 6.0, sa[i] + js[i], s0[i]);
             bres = (lane == NU + i) ? xnext - xn[i] : bres;
         });
-        // row r of [B A]' (coalesced) and, scattered, column r of the rows of [B A] that the
-        // forward sweep reads (lane nu+j gets d x+_j / d z_r)
-        // planes that are structurally unit vectors (M::OUT_UNIT / M::IN_UNIT) are not materialised
+        // row r of [B A]' (coalesced) and - only for models whose forward sweep is cheaper on the rows of
+        // [B A] (fwd_rows<M>, qp_ipm.hpp) - scattered, column r of those rows (lane nu+j gets d x+_j / d z_r).
+        // Planes that are structurally unit vectors (M::OUT_UNIT / M::IN_UNIT) are not materialised.
         const bool in_unit = ((M::IN_UNIT >> lane) & 1u) != 0u;
         sfor<0, NX>([&](auto i) {
             if constexpr (((M::OUT_UNIT >> i) & 1u) == 0u)
                 P.BAt[((long)k * NX + i) * stride + gl] = (lane < NZ) ? sa[i] : 0.0;
-            if (lane < NZ && !in_unit) P.ABr[((long)k * NZ + lane) * stride + g * LANES + NU + i] = sa[i];
+            if constexpr (fwd_rows<M>()) {
+                if (lane < NZ && !in_unit) P.ABr[((long)k * NZ + lane) * stride + g * LANES + NU + i] = sa[i];
+            }
         });
         P.rb0[(long)k * stride + gl] = xlane ? bres : 0.0;
 

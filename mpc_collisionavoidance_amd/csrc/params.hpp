@@ -29,6 +29,16 @@ struct DevSpec {
 };
 
 // Device pointers of one solver handle.
+// Which copy of the stage matrix the forward sweeps stream: the rows of [B A] (a second, transposed set
+// of planes written by the lineariser; one plane per column that is not a unit vector) or the [B A]'
+// planes of the backward sweeps (one per row that is not a unit vector, reduced across the lanes).
+// The cheaper one in bytes wins; on a tie the single copy.
+template <class M>
+constexpr bool fwd_rows()
+{
+    return (M::NX + M::NU - __builtin_popcount(M::IN_UNIT)) < (M::NX - __builtin_popcount(M::OUT_UNIT));
+}
+
 struct DevPtrs {
     const DevSpec *spec;
     const int *perm;      // [B] group -> instance (difficulty binning); nullptr = identity
@@ -49,7 +59,7 @@ struct DevPtrs {
     // linearisation output, lane-major planes: element (k, e) of group g, lane r at
     // ((k*E + e) * Bp + g) * 16 + r
     double *BAt;          // [N][nx]   row r of [B A]'   (lane r = variable r of [u;x])
-    double *ABr;          // [N][nz]   row j of [B A]    (lane nu+j = state j)
+    double *ABr;          // [N][nz]   row j of [B A] (lane nu+j = state j); only if fwd_rows<M>(), else nullptr
     double *rb0;          // [N]       dynamics residual b_k (x lanes)
     double *gq;           // [N+1]     cost gradient
     double *con;          // [N][KCH][4] obstacle rows: cx, cy, lg, ug (lane i = obstacle c*16+i)

@@ -140,6 +140,7 @@ template <class M, int KCH, bool SOFT, bool HDIAG>
 struct QpIpm {
     static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
     static constexpr int PXL = NU + M::IPX, PYL = NU + M::IPY;
+    static constexpr bool FWD_ROWS = fwd_rows<M>();
     // plane map of the per-stage workspace window
     enum : int { P_Z = 0, P_ZB, P_RB, P_RG, P_DZA, P_DZ, P_DX0, P_PB, P_LUV, P_PI,
                  P_BLL, P_BLU, P_BTL, P_BTU, P_OBS };
@@ -630,15 +631,25 @@ struct QpIpm {
         for (int k = 0; k <= N; k++) {
             const StageIn in = nxt;
             const Planes W = ws(k);
-            // this stage's rows of [B A] and the next stage's small planes: both in flight during
-            // the gain / row computations below
-            double abr[NZ];
+            // this stage's matrix planes and the next stage's small planes: both in flight during the gain /
+            // row computations below.  FWD_ROWS: the rows of [B A] (ABr, one plane per non-unit column);
+            // otherwise the [B A]' planes the backward sweeps read (one per non-unit row).
+            constexpr int NMAT = FWD_ROWS ? NZ : NX;
+            double mat[NMAT];
             if (k < N) {
-                const Planes AB(P.ABr + (long)k * NZ * stride, stride, NZ, gl);
-                sfor<0, NZ>([&](auto c) {
-                    if constexpr (((M::IN_UNIT >> c) & 1u) != 0u) abr[c] = (lane == c) ? 1.0 : 0.0;
-                    else abr[c] = AB.ld(c);
-                });
+                if constexpr (FWD_ROWS) {
+                    const Planes AB(P.ABr + (long)k * NZ * stride, stride, NZ, gl);
+                    sfor<0, NZ>([&](auto c) {
+                        if constexpr (((M::IN_UNIT >> c) & 1u) != 0u) mat[c] = (lane == c) ? 1.0 : 0.0;
+                        else mat[c] = AB.ld(c);
+                    });
+                } else {
+                    const Planes BT(P.BAt + (long)k * NX * stride, stride, NX, gl);
+                    sfor<0, NX>([&](auto j) {
+                        if constexpr (((M::OUT_UNIT >> j) & 1u) == 0u) mat[j] = BT.ld(j);
+                        else mat[j] = 0.0;
+                    });
+                }
                 load_in<SW>(k + 1, nxt);
             }
             double dz;
@@ -697,7 +708,20 @@ struct QpIpm {
             W.st(FINAL ? P_DZ : P_DZA, dz);
             if (k < N) {
                 double dxn = in.rb;
-                sfor<0, NZ>([&](auto c) { lanes::fma_bc<c>(dxn, dz, abr[c]); });
+                if constexpr (FWD_ROWS) {
+                    sfor<0, NZ>([&](auto c) { lanes::fma_bc<c>(dxn, dz, mat[c]); });
+                } else {
+                    // dx+_j = b_j + sum_c [B A][j][c] dz_c: lane c holds [B A][j][c] in plane j, so the row sum
+                    // is a group reduction delivered to lane nu+j (no transposed copy of the matrix in HBM)
+                    sfor<0, NX>([&](auto j) {
+                        if constexpr (((M::OUT_UNIT >> j) & 1u) != 0u) {
+                            dxn += (lane == NU + j) ? dz : 0.0;
+                        } else {
+                            const double sj = lanes::gsum(mat[j] * dz);
+                            dxn += (lane == NU + j) ? sj : 0.0;
+                        }
+                    });
+                }
                 dzx = xlane ? dxn : 0.0;
             }
         }

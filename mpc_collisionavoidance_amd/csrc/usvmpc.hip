@@ -269,6 +269,22 @@ int launch_pair(usvmpc_handle *h)
     return 0;
 }
 
+// does this model's forward sweep stream the rows of [B A] (a second set of matrix planes)?
+bool model_fwd_rows(int model)
+{
+    switch (model) {
+#ifndef USV_GEN_ONLY
+    case USVMPC_MODEL_USV: return fwd_rows<ModelM0>();
+    case USVMPC_MODEL_GUIDANCE_CA1: return fwd_rows<ModelM1>();
+    case USVMPC_MODEL_PF_CA: return fwd_rows<ModelM2>();
+#endif
+#ifdef USV_GEN_MODEL_HEADER
+    case USVMPC_MODEL_GENERATED: return fwd_rows<ModelGen>();
+#endif
+    }
+    return false;
+}
+
 int launch(usvmpc_handle *h)
 {
     switch (h->desc.model) {
@@ -395,7 +411,8 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->gd_ready = false; h->gd_npts_cap = 0; h->gd_psi = nullptr;
     std::memset(&h->gd, 0, sizeof(h->gd));
     TRY_C(dev_alloc(h, &P.BAt, N * h->nx * stride, true));
-    TRY_C(dev_alloc(h, &P.ABr, N * h->nz * stride, true)); // u lanes / idle lanes stay zero
+    P.ABr = nullptr;
+    if (model_fwd_rows(d->model)) TRY_C(dev_alloc(h, &P.ABr, N * h->nz * stride, true)); // u lanes / idle lanes stay zero
     TRY_C(dev_alloc(h, &P.rb0, N * stride, true));
     TRY_C(dev_alloc(h, &P.gq, (N + 1) * stride, true));
     TRY_C(dev_alloc(h, &P.con, N * kch * 4 * stride, true));

@@ -69,6 +69,11 @@ def main():
     wl = scenario.make_batch(name, N, K, B, seed=1234 + rank)
     solver = BatchOcpSolver(ocp, B, device=local_rank)
     scenario.load_into(solver, wl)
+    if K > 0:
+        # the obstacle set of this workload is the same on every stage (as the reference's callers set it:
+        # usv_pf_ca/main.py sets one pobs on all stages); the solver then keeps it in registers
+        assert float(np.ptp(wl["p"], axis=1).max()) == 0.0 and float(np.ptp(wl["lh"], axis=1).max()) == 0.0
+        solver.set_option("static_obstacles", 1)
     nx, nu = solver.nx, solver.nu
 
     def barrier():
@@ -159,7 +164,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE.json configs[2]: batch=%d per GPU, %s, N=%d, %d obstacles, dt=%g s, GN SQP-RTI, "
+                "workload": "BASELINE.json configs[2]: batch=%d per GPU, %s, N=%d, %d static obstacles, dt=%g s, GN SQP-RTI, "
                             "closed loop x0<-x1+N(0,%g), seed 1234+rank" % (B, name, N, K, dt, args.sigma),
                 "model": name, "batch_per_gpu": B, "global_batch": world * B, "horizon": N, "obstacles": K,
                 "parallelism": "batch-sharded x%d, no collective" % world,

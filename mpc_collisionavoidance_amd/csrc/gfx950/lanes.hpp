@@ -57,6 +57,17 @@ USV_DEV void fma_bc(double &c, double b_remote, double a_own)
 #endif
 }
 
+// value held by lane `src` (0..15, run-time, may differ per lane) of this group: ds_bpermute_b32 goes
+// through the LDS crossbar but touches no LDS memory
+USV_DEV double gather(double v, int src)
+{
+    const int addr = (int)((((unsigned)threadIdx.x & 48u) | ((unsigned)src & 15u)) << 2);
+    const long l = __builtin_bit_cast(long, v);
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)l);
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, (int)(l >> 32));
+    return __builtin_bit_cast(double, ((long)(unsigned)lo) | ((long)hi << 32));
+}
+
 // rotate right by N lanes within the group (DPP row_ror:N)
 template <int N>
 USV_DEV double ror(double v)

@@ -91,6 +91,32 @@ inline std::string build_spec(const usvmpc_desc &d, DevSpec &S)
         S.zl[i] = S.dt * d.zl[i]; S.zu[i] = S.dt * d.zu[i];
         S.Zl[i] = S.dt * d.Zl[i]; S.Zu[i] = S.dt * d.Zu[i];
     }
+    {   // Box rows ride in the idle lanes (>= k_last) of the last obstacle chunk; rows that do not fit there
+        // are stored densely (four values in four consecutive lanes, from lane 0) in one plane.  The two lane
+        // sets must be disjoint (one gather serves both), which bounds the dense rows by k_last / 4.
+        const int kch = (d.K + LANES - 1) / LANES;
+        const int k_last = d.K - (kch - 1) * LANES;
+        int nb = 0;
+        for (int r = 0; r < LANES; r++) nb += S.has_b[r];
+        const int nslot = kch > 0 ? LANES - k_last : 0;
+        const int ndense = nb > nslot ? nb - nslot : 0;
+        S.boxpack_ok = (kch > 0 && nb > 0 && ndense <= 4 && 4 * ndense <= k_last) ? 1 : 0;
+        S.boxpack = S.boxpack_ok;
+        if (S.boxpack_ok) {
+            S.box_dense = ndense > 0;
+            int slot = k_last, j = 0;
+            for (int r = 0; r < LANES; r++) {
+                if (!S.has_b[r]) continue;
+                if (slot < LANES) {
+                    S.box_slot[r] = slot; S.box_step[r] = 0; S.slot_var[slot] = r; S.slot_is[slot] = 1; slot++;
+                } else {
+                    S.box_slot[r] = 4 * j; S.box_step[r] = 1;
+                    for (int e = 0; e < 4; e++) { S.slot_var[4 * j + e] = r; S.slot_is[4 * j + e] = 2; }
+                    j++;
+                }
+            }
+        }
+    }
     S.hdiag = 1;
     for (int i = 0; i < LANES; i++)
         for (int j = 0; j < LANES; j++)

@@ -1,6 +1,6 @@
 // linearize.hpp — preparation phase of one SQP-RTI iteration, one 16-lane group per
 // (instance, stage) pair.  Replaces acados' sim_erk (+ generated *_expl_vde_forw),
-// ocp_nlp_cost_ls and ocp_nlp_constraints_bgh evaluation for the reference's OCPs
+// ocp_nlp_cost_ls evaluation (the bgh obstacle rows are evaluated in qp_ipm.hpp) for the reference's OCPs
 // (/root/reference/catkin_ws/src/nmpc_ca/scripts/usv_guidance_ca1/acados_settings.py:83-194).
 //
 // Lane r (variable r of [u;x]) integrates ITS OWN column of the forward sensitivities
@@ -103,27 +103,7 @@ struct Linearize {
             }
         });
         P.rb0[(long)k * stride + gl] = xlane ? bres : 0.0;
-
-        // ---- obstacle rows: h_i = |pos - o_i|, gradient, bounds relative to h ----
-        if constexpr (KCH > 0) {
-            const double px = x[M::IPX], py = x[M::IPY];
-            const int kp = S.p_static ? 0 : k;
-            const double *pk = P.p + ((long)b * (N + 1) + kp) * 2 * K;
-            const double *lhk = P.lh + ((long)b * N + kp) * K;
-            sfor<0, KCH>([&](auto c) {
-                const int i = c * LANES + lane;
-                const bool act = i < K;
-                const int ii = act ? i : 0;
-                const double dx = px - pk[2 * ii], dy = py - pk[2 * ii + 1];
-                const double d = sqrt(dx * dx + dy * dy);
-                const double id = 1.0 / d;
-                double *cp = P.con + (((long)k * KCH + c) * 4) * stride + gl;
-                cp[0 * stride] = act ? dx * id : 0.0;
-                cp[1 * stride] = act ? dy * id : 0.0;
-                cp[2 * stride] = act ? lhk[ii] - d : -1.0;
-                cp[3 * stride] = act ? S.uh[ii] - d : 1.0;
-            });
-        }
+        // (obstacle rows are linearised inside the QP kernel from the iterate and (p, lh): QpIpm::obs_geom)
     }
 };
 

@@ -15,6 +15,14 @@ struct DevSpec {
     double Me[LANES * LANES];  // Vx_e' W_e at the x rows (nz x ny_e)
     double lb[LANES], ub[LANES];  // box bounds per variable of [u;x]
     int has_b[LANES];             // 1: variable carries a box constraint
+    // Box rows packed into the last obstacle chunk's (lambda, t) planes + at most one dense plane (qp_ipm.hpp):
+    int boxpack;                  // 1: packing in use (option "pack_box_rows" toggles it when boxpack_ok)
+    int boxpack_ok;               //    whether the rows fit at all
+    int box_dense;                // 1: some rows are dense (plane P_BLL is in use)
+    int box_slot[LANES];          // variable r -> lane its value 0 is stored in
+    int box_step[LANES];          // variable r -> 0 (slot row: all four values in that lane) | 1 (dense row)
+    int slot_var[LANES];          // lane L -> variable whose row (or row element) it stores
+    int slot_is[LANES];           // lane L: 0 nothing, 1 slot lane, 2 dense lane
     double uh[KMAX];
     double lsl[KMAX], lsu[KMAX];  // lower bounds of the soft slacks (lsh, ush)
     double zl[KMAX], zu[KMAX], Zl[KMAX], Zu[KMAX];  // slack penalties, already scaled by dt
@@ -62,7 +70,6 @@ struct DevPtrs {
     double *ABr;          // [N][nz]   row j of [B A] (lane nu+j = state j); only if fwd_rows<M>(), else nullptr
     double *rb0;          // [N]       dynamics residual b_k (x lanes)
     double *gq;           // [N+1]     cost gradient
-    double *con;          // [N][KCH][4] obstacle rows: cx, cy, lg, ug (lane i = obstacle c*16+i)
     // QP workspace, lane-major planes [N+1][NPL]
     double *ws;
 };

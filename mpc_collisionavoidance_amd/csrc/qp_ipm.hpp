@@ -136,8 +136,9 @@ struct RowCalc {
     }
 };
 
-template <class M, int KCH, bool SOFT, bool HDIAG>
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK>
 struct QpIpm {
+    static_assert(!PACK || KCH > 0, "box rows are packed into obstacle planes");
     static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
     static constexpr int PXL = NU + M::IPX, PYL = NU + M::IPY;
     static constexpr bool FWD_ROWS = fwd_rows<M>();
@@ -159,10 +160,23 @@ struct QpIpm {
     unsigned gl;
     bool xlane, ulane, valid, isPX, isPY;
     // per-lane constants, read once: box bounds of this lane's variable, Hessian diagonal
+    // PACK: the box rows' (lambda_l, lambda_u, t_l, t_u) do not get four planes of their own.  A *slot* row
+    // lives in an idle lane (>= K_last) of the last obstacle chunk's four (lambda, t) planes; rows that do not
+    // fit there are *dense*: their four values sit in four consecutive lanes of ONE plane (P_BLL).  Slot lanes
+    // and dense lanes are disjoint (host_spec.hpp), so one run-time gather per value serves both kinds.
+    //   bsrc   : lane this variable's value 0 comes from (slot lane, or first of the four dense lanes)
+    //   bstep  : 0 for a slot row, 1 for a dense row (value e comes from lane bsrc + e*bstep)
+    //   ssrc   : variable whose row this lane stores (as slot lane or as dense lane)
+    //   isslot / isdense : what this lane stores
+    bool isslot, isdense, anydense;
+    int bsrc, bstep, ssrc;
     bool hasb;
     double lbv, ubv, hd_stage, hd_term;
     double c_zl[KCH > 0 ? KCH : 1], c_zu[KCH > 0 ? KCH : 1], c_Zl[KCH > 0 ? KCH : 1], c_Zu[KCH > 0 ? KCH : 1],
         c_bsl[KCH > 0 ? KCH : 1], c_bsu[KCH > 0 ? KCH : 1];
+    // obstacle data of this lane's row(s): upper bound, and - when the obstacle set is the same on every
+    // stage (DevSpec::p_static, what the reference's callers do) - centre and lower bound held in registers
+    double c_uh[KCH > 0 ? KCH : 1], c_ox[KCH > 0 ? KCH : 1], c_oy[KCH > 0 ? KCH : 1], c_lh[KCH > 0 ? KCH : 1];
 
     USV_DEV QpIpm(const DevPtrs &P_, long g_) : P(P_), S(*P_.spec)
     {
@@ -181,10 +195,26 @@ struct QpIpm {
         isPX = KCH > 0 && lane == PXL;
         isPY = KCH > 0 && lane == PYL;
         hasb = S.has_b[lane] != 0;
+        isslot = PACK && S.slot_is[lane] == 1;
+        isdense = PACK && S.slot_is[lane] == 2;
+        anydense = PACK && S.box_dense != 0; // wave-uniform
+        bsrc = S.box_slot[lane];
+        bstep = S.box_step[lane];
+        ssrc = S.slot_var[lane];
         lbv = S.lb[lane];
         ubv = S.ub[lane];
         hd_stage = S.Hc[lane * LANES + lane];
         hd_term = S.He[lane * LANES + lane];
+        if constexpr (KCH > 0) {
+            sfor<0, KCH>([&](auto c) {
+                const int i = c * LANES + lane;
+                const int ii = i < S.K ? i : 0;
+                c_uh[c] = S.uh[ii];
+                c_ox[c] = P.p[(long)b * (N + 1) * 2 * S.K + 2 * ii];
+                c_oy[c] = P.p[(long)b * (N + 1) * 2 * S.K + 2 * ii + 1];
+                c_lh[c] = P.lh[(long)b * N * S.K + ii];
+            });
+        }
         if constexpr (KCH > 0 && SOFT) {
             sfor<0, KCH>([&](auto c) {
                 const int i = c * LANES + lane;
@@ -197,11 +227,6 @@ struct QpIpm {
     }
 
     USV_DEV Planes ws(int k) const { return Planes(P.ws + (long)k * NPL * stride, stride, NPL, gl); }
-    USV_DEV Planes conw(int k) const
-    {
-        return Planes(P.con + (long)k * (KCH > 0 ? KCH : 1) * 4 * stride, stride, (KCH > 0 ? KCH : 1) * 4, gl);
-    }
-
     // iterate value of this lane's variable at stage k (caller-visible arrays)
     USV_DEV double zbar(int k) const
     {
@@ -217,59 +242,66 @@ struct QpIpm {
         r.dl = r.act ? lbv - zb : -1.0;
         r.du = r.act ? ubv - zb : 1.0;
     }
-    // loads are unconditional (every lane reads its slot, inactive lanes are neutralised by
-    // selects): no data-dependent branch sits between the loads of a stage, so they all issue
-    // back to back and their latencies overlap
-    USV_DEV void box_load(const Planes &W, int k, double zb, BoxRow &r) const
-    {
-        r.neutral();
-        box_data(k, zb, r);
-        const double a0 = W.ld(P_BLL), a1 = W.ld(P_BLU), a2 = W.ld(P_BTL), a3 = W.ld(P_BTU);
-        r.ll = r.act ? a0 : 0.0; r.lu = r.act ? a1 : 0.0; r.tl = r.act ? a2 : 1.0; r.tu = r.act ? a3 : 1.0;
-    }
     USV_DEV static void box_store(const Planes &W, const BoxRow &r)
     {
         W.st(P_BLL, r.ll); W.st(P_BLU, r.lu); W.st(P_BTL, r.tl); W.st(P_BTU, r.tu);
     }
-    // obstacle chunk c at stage k: constants (cx, cy) + row data
-    USV_DEV void obs_data(int k, int c, ObsRow &r, double &cx, double &cy) const
+    // Obstacle chunk c at stage k.  The row h_i = |pos - o_i| >= lh_i is linearised here, from the iterate's
+    // position (the px / py lanes of zb) and the obstacle data, instead of being streamed from planes written
+    // by the lineariser: a square root and a few multiplies replace four plane reads per sweep.
+    // raw = (ox, oy, lh) of this lane's obstacle at this stage.
+    template <int C>
+    USV_DEV void obs_geom(int k, double zb, const double *raw, ObsRow &r, double &cx, double &cy) const
     {
-        const int i = c * LANES + lane;
+        const int i = C * LANES + lane;
         const bool stage_ok = (k >= 1 && k < N); // wave-uniform
         r.act = stage_ok && i < S.K;
-        cx = 0.0; cy = 0.0; r.dl = -1.0; r.du = 1.0;
-        if (stage_ok) {
-            const Planes C = conw(k);
-            const double a0 = C.ld(c * 4 + 0), a1 = C.ld(c * 4 + 1), a2 = C.ld(c * 4 + 2), a3 = C.ld(c * 4 + 3);
-            cx = r.act ? a0 : 0.0; cy = r.act ? a1 : 0.0; r.dl = r.act ? a2 : -1.0; r.du = r.act ? a3 : 1.0;
-        }
+        const double dx = lanes::bcast<PXL>(zb) - raw[0], dy = lanes::bcast<PYL>(zb) - raw[1];
+        const double d2 = dx * dx + dy * dy;
+        const double id = lanes::frsqrt(d2);
+        const double d = d2 * id;
+        cx = r.act ? dx * id : 0.0; cy = r.act ? dy * id : 0.0;
+        r.dl = r.act ? raw[2] - d : -1.0; r.du = r.act ? c_uh[C] - d : 1.0;
         if constexpr (SOFT) {
-            r.zl = c_zl[c]; r.zu = c_zu[c]; r.Zl = c_Zl[c]; r.Zu = c_Zu[c]; r.bsl = c_bsl[c]; r.bsu = c_bsu[c];
+            r.zl = c_zl[C]; r.zu = c_zu[C]; r.Zl = c_Zl[C]; r.Zu = c_Zu[C]; r.bsl = c_bsl[C]; r.bsu = c_bsu[C];
         }
     }
-    USV_DEV void obs_load(const Planes &W, int k, int c, ObsRow &r, double &cx, double &cy) const
+    // (ox, oy, lh) of this lane's obstacle in chunk c at stage k, from the caller-visible arrays
+    template <int C>
+    USV_DEV void obs_raw(int k, double *raw) const
     {
-        r.neutral();
-        obs_data(k, c, r, cx, cy);
-        if (k >= 1 && k < N) { // wave-uniform
-            const int p0 = P_OBS + c * OBSN;
-            const double a0 = W.ld(p0), a1 = W.ld(p0 + 1), a2 = W.ld(p0 + 2), a3 = W.ld(p0 + 3);
-            r.ll = r.act ? a0 : 0.0; r.lu = r.act ? a1 : 0.0; r.tl = r.act ? a2 : 1.0; r.tu = r.act ? a3 : 1.0;
-            if constexpr (SOFT) {
-                const double b0 = W.ld(p0 + 4), b1 = W.ld(p0 + 5), b2 = W.ld(p0 + 6), b3 = W.ld(p0 + 7),
-                             b4 = W.ld(p0 + 8), b5 = W.ld(p0 + 9);
-                r.sl = r.act ? b0 : 0.0; r.su = r.act ? b1 : 0.0; r.lsl = r.act ? b2 : 0.0; r.lsu = r.act ? b3 : 0.0;
-                r.tsl = r.act ? b4 : 1.0; r.tsu = r.act ? b5 : 1.0;
-            }
+        if (S.p_static) { // wave-uniform
+            raw[0] = c_ox[C]; raw[1] = c_oy[C]; raw[2] = c_lh[C];
+        } else {
+            const int i = C * LANES + lane;
+            const int ii = i < S.K ? i : 0;
+            const int kl = k < N ? k : N - 1;
+            const double *pk = P.p + ((long)b * (N + 1) + k) * 2 * S.K;
+            raw[0] = pk[2 * ii]; raw[1] = pk[2 * ii + 1];
+            raw[2] = P.lh[((long)b * N + kl) * S.K + ii];
         }
     }
-    USV_DEV static void obs_store(const Planes &W, int c, const ObsRow &r)
+    // pk: the box rows gathered to their storage lanes (PACK, last chunk), else nullptr
+    USV_DEV void obs_store(const Planes &W, int c, const ObsRow &r, const double *pk = nullptr) const
     {
         const int p0 = P_OBS + c * OBSN;
-        W.st(p0, r.ll); W.st(p0 + 1, r.lu); W.st(p0 + 2, r.tl); W.st(p0 + 3, r.tu);
+        const bool sel = PACK && pk != nullptr && isslot;
+        W.st(p0, sel ? pk[0] : r.ll); W.st(p0 + 1, sel ? pk[1] : r.lu);
+        W.st(p0 + 2, sel ? pk[2] : r.tl); W.st(p0 + 3, sel ? pk[3] : r.tu);
         if constexpr (SOFT) {
             W.st(p0 + 4, r.sl); W.st(p0 + 5, r.su); W.st(p0 + 6, r.lsl); W.st(p0 + 7, r.lsu);
             W.st(p0 + 8, r.tsl); W.st(p0 + 9, r.tsu);
+        }
+    }
+    // box row values delivered to the lanes that store them (call under wave-uniform control flow)
+    USV_DEV void box_pack(const Planes &W, const BoxRow &r, double *pk, bool do_store) const
+    {
+        pk[0] = lanes::gather(r.ll, ssrc); pk[1] = lanes::gather(r.lu, ssrc);
+        pk[2] = lanes::gather(r.tl, ssrc); pk[3] = lanes::gather(r.tu, ssrc);
+        if (anydense) { // wave-uniform: the dense plane, value (lane & 3) of the row this lane belongs to
+            const int e = lane & 3;
+            const double v = e == 0 ? pk[0] : (e == 1 ? pk[1] : (e == 2 ? pk[2] : pk[3]));
+            if (do_store && isdense) W.st(P_BLL, v);
         }
     }
     USV_DEV static double obs_dot(double cx, double cy, double vec)
@@ -293,20 +325,23 @@ struct QpIpm {
             box_data(k, zb, r);
             r.tl = fmax(0.0 - r.dl, S.thr0); r.tu = fmax(r.du - 0.0, S.thr0);
             r.ll = S.mu0 / r.tl; r.lu = S.mu0 / r.tu;
-            box_store(W, r);
+            double pk[4];
+            if constexpr (PACK) box_pack(W, r, pk, true);
+            else box_store(W, r);
             if constexpr (KCH > 0) {
                 sfor<0, KCH>([&](auto c) {
                     ObsRow o;
-                    double cx, cy;
+                    double cx, cy, raw[3];
                     o.neutral();
-                    obs_data(k, c, o, cx, cy);
+                    obs_raw<c>(k, raw);
+                    obs_geom<c>(k, zb, raw, o, cx, cy);
                     o.tl = fmax(0.0 - o.dl, S.thr0); o.tu = fmax(o.du - 0.0, S.thr0);
                     o.ll = S.mu0 / o.tl; o.lu = S.mu0 / o.tu;
                     if constexpr (SOFT) {
                         o.tsl = fmax(0.0 - o.bsl, S.thr0); o.tsu = fmax(0.0 - o.bsu, S.thr0);
                         o.lsl = S.mu0 / o.tsl; o.lsu = S.mu0 / o.tsu;
                     }
-                    obs_store(W, c, o);
+                    obs_store(W, c, o, (PACK && c == KCH - 1) ? pk : nullptr);
                 });
             }
         }
@@ -337,7 +372,7 @@ struct QpIpm {
         double lzu[NU];
         double box[4];
         double obs[KCH > 0 ? KCH : 1][OBSN];
-        double con[KCH > 0 ? KCH : 1][4];
+        double raw[KCH > 0 ? KCH : 1][3];
     };
     enum : int { SW_BACK_A = 0, SW_FWD_A = 1, SW_BACK_B = 2, SW_FWD_B = 3 };
 
@@ -363,14 +398,19 @@ struct QpIpm {
             else sfor<0, NU>([&](auto l) { in.lzu[l] = 1.0; });
         }
         if constexpr (SW == SW_FWD_A || SW == SW_FWD_B) in.luv = (k < N) ? W.ld(P_LUV) : 0.0;
-        in.box[0] = W.ld(P_BLL); in.box[1] = W.ld(P_BLU); in.box[2] = W.ld(P_BTL); in.box[3] = W.ld(P_BTU);
+        if constexpr (PACK) {
+            in.box[0] = (anydense && k < N) ? W.ld(P_BLL) : 0.0; // wave-uniform
+        } else {
+            in.box[0] = W.ld(P_BLL); in.box[1] = W.ld(P_BLU); in.box[2] = W.ld(P_BTL); in.box[3] = W.ld(P_BTU);
+        }
         if constexpr (KCH > 0) {
             if (k >= 1 && k < N) { // wave-uniform
-                const Planes C = conw(k);
                 sfor<0, KCH>([&](auto c) {
                     sfor<0, OBSN>([&](auto e) { in.obs[c][e] = W.ld(P_OBS + c * OBSN + e); });
-                    sfor<0, 4>([&](auto e) { in.con[c][e] = C.ld(c * 4 + e); });
+                    obs_raw<c>(k, in.raw[c]);
                 });
+            } else if (PACK && k == 0) { // the input bounds of stage 0 live there too
+                sfor<0, 4>([&](auto e) { in.obs[KCH - 1][e] = W.ld(P_OBS + (KCH - 1) * OBSN + e); });
             }
         }
     }
@@ -378,25 +418,39 @@ struct QpIpm {
     {
         r.neutral();
         box_data(k, in.zb, r);
-        r.ll = r.act ? in.box[0] : 0.0; r.lu = r.act ? in.box[1] : 0.0;
-        r.tl = r.act ? in.box[2] : 1.0; r.tu = r.act ? in.box[3] : 1.0;
+        double b0, b1, b2, b3;
+        if constexpr (PACK) {
+            constexpr int CL = KCH > 0 ? KCH - 1 : 0;
+            // every lane offers what a reader would want from it: a slot lane its obstacle-plane values, any
+            // other lane the dense plane's value
+            b0 = lanes::gather(isslot ? in.obs[CL][0] : in.box[0], bsrc);
+            b1 = lanes::gather(isslot ? in.obs[CL][1] : in.box[0], bsrc + bstep);
+            b2 = lanes::gather(isslot ? in.obs[CL][2] : in.box[0], bsrc + 2 * bstep);
+            b3 = lanes::gather(isslot ? in.obs[CL][3] : in.box[0], bsrc + 3 * bstep);
+        } else {
+            b0 = in.box[0]; b1 = in.box[1]; b2 = in.box[2]; b3 = in.box[3];
+        }
+        r.ll = r.act ? b0 : 0.0; r.lu = r.act ? b1 : 0.0;
+        r.tl = r.act ? b2 : 1.0; r.tu = r.act ? b3 : 1.0;
     }
     template <int C>
     USV_DEV void obs_from(const StageIn &in, int k, ObsRow &r, double &cx, double &cy) const
     {
-        const int i = C * LANES + lane;
-        const bool stage_ok = (k >= 1 && k < N);
         r.neutral();
-        r.act = stage_ok && i < S.K;
-        cx = r.act ? in.con[C][0] : 0.0; cy = r.act ? in.con[C][1] : 0.0;
-        r.dl = r.act ? in.con[C][2] : -1.0; r.du = r.act ? in.con[C][3] : 1.0;
+        if (k >= 1 && k < N) { // wave-uniform
+            obs_geom<C>(k, in.zb, in.raw[C], r, cx, cy);
+        } else {
+            r.act = false; cx = 0.0; cy = 0.0;
+            if constexpr (SOFT) {
+                r.zl = c_zl[C]; r.zu = c_zu[C]; r.Zl = c_Zl[C]; r.Zu = c_Zu[C]; r.bsl = c_bsl[C]; r.bsu = c_bsu[C];
+            }
+        }
         r.ll = r.act ? in.obs[C][0] : 0.0; r.lu = r.act ? in.obs[C][1] : 0.0;
         r.tl = r.act ? in.obs[C][2] : 1.0; r.tu = r.act ? in.obs[C][3] : 1.0;
         if constexpr (SOFT) {
             r.sl = r.act ? in.obs[C][4] : 0.0; r.su = r.act ? in.obs[C][5] : 0.0;
             r.lsl = r.act ? in.obs[C][6] : 0.0; r.lsu = r.act ? in.obs[C][7] : 0.0;
             r.tsl = r.act ? in.obs[C][8] : 1.0; r.tsu = r.act ? in.obs[C][9] : 1.0;
-            r.zl = c_zl[C]; r.zu = c_zu[C]; r.Zl = c_Zl[C]; r.Zu = c_Zu[C]; r.bsl = c_bsl[C]; r.bsu = c_bsu[C];
         }
     }
 
@@ -442,9 +496,11 @@ struct QpIpm {
                     chain(br, z, true, dzap, sigmu_prev, Ghb, gamb);
                     br.expand(dzp);
                     br.apply(a_prev);
-                    box_store(W, br);
+                    if constexpr (!PACK) box_store(W, br);
                 }
             }
+            double pk[4];
+            if constexpr (FACT && PACK) box_pack(W, br, pk, pend);
             const double znew = (FACT && pend) ? z + a_prev * dzp : z;
             chain(br, znew, !FACT, dza, sigmu, Ghb, gamb);
             double Sxx = 0.0, Sxy = 0.0, Syy = 0.0, gx = 0.0, gy = 0.0, lx = 0.0, ly = 0.0;
@@ -459,8 +515,9 @@ struct QpIpm {
                             chain(o, vo, true, wap, sigmu_prev, Gh, gam);
                             o.expand(wp);
                             o.apply(a_prev);
-                            obs_store(W, c, o);
                         }
+                        const bool slot_here = c == KCH - 1 && isslot;
+                        if (pend && (o.act || slot_here)) obs_store(W, c, o, (PACK && c == KCH - 1) ? pk : nullptr);
                     }
                     const double v = obs_dot(cx, cy, znew);
                     const double wa = FACT ? 0.0 : obs_dot(cx, cy, dza);

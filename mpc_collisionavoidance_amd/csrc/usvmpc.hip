@@ -3,7 +3,7 @@
 // Two kernels per SQP-RTI iteration:
 //   usv_linearize<M,KCH>      one 16-lane group per (instance, stage): ERK4 + forward VDE, GN
 //                             gradient, obstacle rows                       (linearize.hpp)
-//   usv_qp_rti<M,KCH,SOFT>    one 16-lane group per instance: Riccati-IPM QP + RTI step
+//   usv_qp_rti<M,KCH,SOFT,..> one 16-lane group per instance: Riccati-IPM QP + RTI step
 //                             (qp_ipm.hpp)
 // Both are FP64 VALU + DPP kernels: no LDS, no MFMA (blocks are at most 16x16).
 #include "gfx950/lanes.hpp"
@@ -32,12 +32,12 @@ __global__ void __launch_bounds__(256, 2) usv_linearize(DevPtrs P, long ngroups)
     Linearize<M, KCH>::run(P, gid);
 }
 
-template <class M, int KCH, bool SOFT, bool HDIAG>
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK>
 __global__ void __launch_bounds__(64, 2) usv_qp_rti(DevPtrs P, long ngroups)
 {
     const long gid = lanes::group_linear();
     if (gid >= ngroups) return;
-    QpIpm<M, KCH, SOFT, HDIAG> q(P, gid);
+    QpIpm<M, KCH, SOFT, HDIAG, PACK> q(P, gid);
     q.solve();
 }
 
@@ -259,10 +259,16 @@ int launch_pair(usvmpc_handle *h)
     hipLaunchKernelGGL((usv_linearize<M, KCH>), dim3((unsigned)lin_grid), dim3(lin_block), 0, h->stream, h->ptrs, lin_groups);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[1], h->stream));
-    if (h->spec.hdiag)
-        hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true>), dim3((unsigned)qp_grid), dim3(qp_block), 0, h->stream, h->ptrs, qp_groups);
-    else
-        hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false>), dim3((unsigned)qp_grid), dim3(qp_block), 0, h->stream, h->ptrs, qp_groups);
+    constexpr bool CANPACK = KCH > 0;
+    const bool pack = CANPACK && h->spec.boxpack != 0;
+    const dim3 qg((unsigned)qp_grid), qb(qp_block);
+    if (h->spec.hdiag) {
+        if (pack) hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, CANPACK>), qg, qb, 0, h->stream, h->ptrs, qp_groups);
+        else hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups);
+    } else {
+        if (pack) hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, CANPACK>), qg, qb, 0, h->stream, h->ptrs, qp_groups);
+        else hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups);
+    }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[2], h->stream));
     h->nsolves++;
@@ -415,7 +421,6 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     if (model_fwd_rows(d->model)) TRY_C(dev_alloc(h, &P.ABr, N * h->nz * stride, true)); // u lanes / idle lanes stay zero
     TRY_C(dev_alloc(h, &P.rb0, N * stride, true));
     TRY_C(dev_alloc(h, &P.gq, (N + 1) * stride, true));
-    TRY_C(dev_alloc(h, &P.con, N * kch * 4 * stride, true));
     TRY_C(dev_alloc(h, &P.ws, (N + 1) * (size_t)ws_planes(h->nx, h->nu, h->kch, h->soft) * stride, true));
     HIP_C(hipDeviceSynchronize());
 #undef TRY_C
@@ -546,8 +551,9 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         if (!h->sort_enabled) h->ptrs.perm = nullptr;
         return 0;
     }
-    if (s == "static_obstacles") {
-        h->spec.p_static = value != 0.0;
+    if (s == "static_obstacles" || s == "pack_box_rows") {
+        if (s == "static_obstacles") h->spec.p_static = value != 0.0;
+        else h->spec.boxpack = (value != 0.0 && h->spec.boxpack_ok) ? 1 : 0;
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipMemcpyAsync(h->d_spec, &h->spec, sizeof(DevSpec), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -109,11 +109,11 @@ void lin_body(void *a)
     Job *j = (Job *)a;
     Linearize<M, KCH>::run(*j->P, j->gid);
 }
-template <class M, int KCH, bool SOFT, bool HDIAG>
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK>
 void qp_body(void *a)
 {
     Job *j = (Job *)a;
-    QpIpm<M, KCH, SOFT, HDIAG> q(*j->P, j->gid);
+    QpIpm<M, KCH, SOFT, HDIAG, PACK> q(*j->P, j->gid);
     q.solve();
 }
 
@@ -128,8 +128,10 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase)
     if (phase & 2)
         for (long g = 0; g < S.Bp; g++) {
             Job j{&P, g};
-            if (S.hdiag) lanes::run_group(g, &qp_body<M, KCH, SOFT, true>, &j);
-            else lanes::run_group(g, &qp_body<M, KCH, SOFT, false>, &j);
+            constexpr bool CANPACK = KCH > 0;
+            const bool pack = CANPACK && S.boxpack != 0;
+            if (S.hdiag) lanes::run_group(g, pack ? &qp_body<M, KCH, SOFT, true, CANPACK> : &qp_body<M, KCH, SOFT, true, false>, &j);
+            else lanes::run_group(g, pack ? &qp_body<M, KCH, SOFT, false, CANPACK> : &qp_body<M, KCH, SOFT, false, false>, &j);
         }
 }
 
@@ -160,14 +162,14 @@ extern "C" int usv_emu_solve(const usvmpc_desc *d, double *x, double *u, const d
 #endif
     const long stride = (long)S.Bp * LANES;
     std::vector<double> BAt((size_t)N * nx * stride), ABr((size_t)N * nz * stride), rb0((size_t)N * stride),
-        gq((size_t)(N + 1) * stride), con((size_t)N * (kch ? kch : 1) * 4 * stride),
+        gq((size_t)(N + 1) * stride),
         ws((size_t)(N + 1) * ws_planes(nx, nu, kch, soft) * stride);
     DevPtrs P;
     std::memset(&P, 0, sizeof(P));
     P.spec = &S;
     P.x = x; P.u = u; P.x0 = x0; P.yref = yref; P.yref_e = yref_e; P.p = p; P.lh = lh;
     P.sl = sl; P.su = su; P.pi = pi; P.status = status; P.qp_iter = qp_iter; P.qp_status = qp_status; P.res = res;
-    P.BAt = BAt.data(); P.ABr = ABr.data(); P.rb0 = rb0.data(); P.gq = gq.data(); P.con = con.data(); P.ws = ws.data();
+    P.BAt = BAt.data(); P.ABr = ABr.data(); P.rb0 = rb0.data(); P.gq = gq.data(); P.ws = ws.data();
     const int phase = 3;
 #ifdef USV_GEN_MODEL_HEADER
     if (d->model == USVMPC_MODEL_GENERATED) run_all<ModelGen, USV_GEN_KCH, (USV_GEN_SOFT != 0)>(P, S, phase);

@@ -51,6 +51,8 @@ inline double bcast(double v) { return exchange(v, K); }
 template <int K>
 inline void fma_bc(double &c, double b_remote, double a_own) { c = std::fma(bcast<K>(b_remote), a_own, c); }
 
+inline double gather(double v, int src) { return exchange(v, src); }
+
 template <int N>
 inline double ror(double v) { return exchange(v, (g_emu.cur - N) & 15); }
 

@@ -45,7 +45,10 @@ def emu_rti(emu, desc, wl, x, u, dbg=False):
 
 
 CASES = [("usv_model", 8, 0, 3), ("usv_model_guidance_ca1", 8, 5, 3), ("usv_model_pf_ca", 8, 4, 5),
-         ("usv_model_guidance_ca1", 6, 20, 2), ("usv_model_pf_ca", 6, 18, 2)]
+         ("usv_model_guidance_ca1", 6, 20, 2), ("usv_model_pf_ca", 6, 18, 2),
+         # box rows packed into the idle obstacle lanes (+ dense plane): 4 slots + 3 dense, no fit, full chunk, 6 + 1
+         ("usv_model_pf_ca", 5, 12, 2), ("usv_model_pf_ca", 5, 14, 2), ("usv_model_guidance_ca1", 5, 16, 2),
+         ("usv_model_pf_ca", 5, 10, 2)]
 
 
 @pytest.mark.parametrize("name,N,K,B", CASES)

@@ -15,6 +15,9 @@ wl = scenario.make_batch(name, N, K if name != "usv_model" else 0, B, dt=dt)
 t0 = time.time()
 s = BatchOcpSolver(ocp, B)
 scenario.load_into(s, wl)
+import os
+if os.environ.get("USV_STATIC"): s.set_option("static_obstacles", 1)
+if os.environ.get("USV_NOPACK"): s.set_option("pack_box_rows", 0)
 print("setup %.2fs, device MB %.1f" % (time.time() - t0, s.device_bytes() / 1e6), flush=True)
 for it in range(iters):
     t0 = time.time()

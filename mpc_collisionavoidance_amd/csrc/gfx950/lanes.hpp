@@ -24,14 +24,13 @@ USV_DEV long group_linear() { return (long)blockIdx.x * (long)(blockDim.x >> 4) 
 template <int CTRL>
 USV_DEV double dpp_mov(double v)
 {
-    const long l = __builtin_bit_cast(long, v);
-    int lo = (int)l, hi = (int)(l >> 32);
     // bound_ctrl:1 - every lane of the row is written and no source lane is ever masked off (control
-    // flow around these ops is wave-uniform), so there is no `old` value to preserve and the
-    // compiler needs no zero-initialising v_mov in front of each DPP move
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-    return __builtin_bit_cast(double, ((long)(unsigned)lo) | ((long)hi << 32));
+    // flow around these ops is wave-uniform), so there is no `old` value to preserve.
+    // 64-bit operand: row_newbcast is a legal DP-ALU DPP control on gfx950 and becomes ONE v_mov_b64_dpp;
+    // the rotations are not and are split by the compiler into two v_mov_b32_dpp.
+    const long l = __builtin_bit_cast(long, v);
+    const long r = __builtin_amdgcn_update_dpp(0L, l, CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, r);
 }
 
 // value held by lane K of this group, delivered to all 16 lanes (DPP row_newbcast:K)

@@ -139,6 +139,6 @@ inline void default_options(usvmpc_desc &d)
 }
 
 // planes of the QP workspace per stage for a (model, KCH, soft) combination (see qp_ipm.hpp)
-inline int ws_planes(int nx, int nu, int kch, bool soft) { (void)nx; return 14 + kch * (soft ? 10 : 4) + nu; }
+inline int ws_planes(int nx, int nu, int kch, bool soft) { (void)nx; return 11 + kch * (soft ? 10 : 4) + nu; }
 
 } // namespace usv

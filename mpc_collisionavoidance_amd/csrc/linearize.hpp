@@ -6,7 +6,8 @@
 // Lane r (variable r of [u;x]) integrates ITS OWN column of the forward sensitivities
 // S = [dx+/du | dx+/dx] through the 4 RK stages (the VDE is linear in S column by column), while
 // every lane carries the nominal RK stage points.  The lane therefore ends up holding row r of
-// [B A]' — exactly the operand layout of the Riccati recursion (qp_ipm.hpp) — with no transpose.
+// [B A]' — exactly the operand layout of the Riccati recursion (qp_ipm.hpp) — with no transpose; the
+// informative entries are then packed densely for HBM (MatPack, params.hpp).
 #pragma once
 #include "lanes.hpp"
 #include "params.hpp"
@@ -91,16 +92,23 @@ struct Linearize {
             sa[i] = fma(dt / 6.0, sa[i] + js[i], s0[i]);
             bres = (lane == NU + i) ? xnext - xn[i] : bres;
         });
-        // row r of [B A]' (coalesced) and - only for models whose forward sweep is cheaper on the rows of
-        // [B A] (fwd_rows<M>, qp_ipm.hpp) - scattered, column r of those rows (lane nu+j gets d x+_j / d z_r).
-        // Planes that are structurally unit vectors (M::OUT_UNIT / M::IN_UNIT) are not materialised.
-        const bool in_unit = ((M::IN_UNIT >> lane) & 1u) != 0u;
-        sfor<0, NX>([&](auto i) {
-            if constexpr (((M::OUT_UNIT >> i) & 1u) == 0u)
-                P.BAt[((long)k * NX + i) * stride + gl] = (lane < NZ) ? sa[i] : 0.0;
-            if constexpr (fwd_rows<M>()) {
-                if (lane < NZ && !in_unit) P.ABr[((long)k * NZ + lane) * stride + g * LANES + NU + i] = sa[i];
-            }
+        // lane r now holds row r of [B A]' (sa[i] = d x+_i / d z_r).  Its informative entries are packed into
+        // MatPack<M>::NPK planes: lane L of plane q stores entry (jj, ci) = divmod(16 q + L, NC), i.e. sa[row jj]
+        // as held by the lane of column ci - a lane gather per row that the plane touches.
+        using MP = MatPack<M>;
+        sfor<0, MP::NPK>([&](auto q) {
+            const int sidx = 16 * q + lane;
+            const int jj_l = sidx / MP::NC, ci_l = sidx - jj_l * MP::NC;
+            int c_l = 0; // lane that owns column ci_l
+            sfor<0, MP::NC>([&](auto ci) { c_l = (ci_l == ci) ? MP::nth(MP::CMASK, ci) : c_l; });
+            double val = 0.0;
+            constexpr int jj0 = (16 * q) / MP::NC;
+            constexpr int jj1 = ((16 * q + 15) / MP::NC < MP::NR - 1) ? (16 * q + 15) / MP::NC : MP::NR - 1;
+            sfor<jj0, jj1 + 1>([&](auto jj) {
+                const double gth = lanes::gather(sa[MP::nth(MP::RMASK, jj)], c_l);
+                val = (jj_l == jj) ? gth : val;
+            });
+            P.BAp[((long)k * MP::NPK + q) * stride + gl] = val;
         });
         P.rb0[(long)k * stride + gl] = xlane ? bres : 0.0;
         // (obstacle rows are linearised inside the QP kernel from the iterate and (p, lh): QpIpm::obs_geom)

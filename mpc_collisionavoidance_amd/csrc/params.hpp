@@ -36,17 +36,31 @@ struct DevSpec {
     double mu0, thr0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min;
 };
 
-// Device pointers of one solver handle.
-// Which copy of the stage matrix the forward sweeps stream: the rows of [B A] (a second, transposed set
-// of planes written by the lineariser; one plane per column that is not a unit vector) or the [B A]'
-// planes of the backward sweeps (one per row that is not a unit vector, reduced across the lanes).
-// The cheaper one in bytes wins; on a tie the single copy.
+// How the stage matrix [B A] (nx x nz) is kept in HBM.  Rows that are unit vectors (M::OUT_UNIT: x+_j = x_j)
+// and columns that are unit vectors (M::IN_UNIT: the variable feeds no right-hand side) carry no information,
+// and nz is usually below 16, so a plane per row would be mostly padding.  The NR x NC informative entries are
+// stored as one row-major stream, 16 per plane: entry (jj, ci) sits in plane (jj*NC + ci) / 16, lane
+// (jj*NC + ci) % 16.  The lineariser packs with lane gathers, the sweeps unpack the same way (qp_ipm.hpp).
 template <class M>
-constexpr bool fwd_rows()
-{
-    return (M::NX + M::NU - __builtin_popcount(M::IN_UNIT)) < (M::NX - __builtin_popcount(M::OUT_UNIT));
-}
+struct MatPack {
+    static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
+    static constexpr unsigned RMASK = ((1u << NX) - 1u) & ~M::OUT_UNIT; // rows stored
+    static constexpr unsigned CMASK = ((1u << NZ) - 1u) & ~M::IN_UNIT;  // columns (variables of [u;x]) stored
+    static constexpr int NR = __builtin_popcount(RMASK), NC = __builtin_popcount(CMASK);
+    static constexpr int NPK = (NR * NC + 15) / 16;                     // planes per stage
+    static constexpr int nth(unsigned mask, int i)                      // position of the i-th set bit
+    {
+        for (int b = 0; b < 32; b++)
+            if ((mask >> b) & 1u) {
+                if (i == 0) return b;
+                i--;
+            }
+        return 0;
+    }
+    static constexpr int rank(unsigned mask, int b) { return __builtin_popcount(mask & ((1u << b) - 1u)); }
+};
 
+// Device pointers of one solver handle.
 struct DevPtrs {
     const DevSpec *spec;
     const int *perm;      // [B] group -> instance (difficulty binning); nullptr = identity
@@ -66,8 +80,7 @@ struct DevPtrs {
     double *res;          // [B][4]      final QP residuals (stat, eq, ineq, comp)
     // linearisation output, lane-major planes: element (k, e) of group g, lane r at
     // ((k*E + e) * Bp + g) * 16 + r
-    double *BAt;          // [N][nx]   row r of [B A]'   (lane r = variable r of [u;x])
-    double *ABr;          // [N][nz]   row j of [B A] (lane nu+j = state j); only if fwd_rows<M>(), else nullptr
+    double *BAp;          // [N][NPK]  the informative entries of [B A], packed (MatPack)
     double *rb0;          // [N]       dynamics residual b_k (x lanes)
     double *gq;           // [N+1]     cost gradient
     // QP workspace, lane-major planes [N+1][NPL]

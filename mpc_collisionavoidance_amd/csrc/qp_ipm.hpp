@@ -141,13 +141,16 @@ struct QpIpm {
     static_assert(!PACK || KCH > 0, "box rows are packed into obstacle planes");
     static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
     static constexpr int PXL = NU + M::IPX, PYL = NU + M::IPY;
-    static constexpr bool FWD_ROWS = fwd_rows<M>();
+    using MP = MatPack<M>;
     // plane map of the per-stage workspace window
-    enum : int { P_Z = 0, P_ZB, P_RB, P_RG, P_DZA, P_DZ, P_DX0, P_PB, P_LUV, P_PI,
-                 P_BLL, P_BLU, P_BTL, P_BTU, P_OBS };
+    // P_PB holds (l_u | P b): the u lanes carry the gain rhs, the x lanes P_{k+1} b_k;  P_PI holds (r_g | pi):
+    // stationarity residual on the u lanes, dynamics multiplier on the x lanes (u and x lanes are disjoint)
+    enum : int { P_Z = 0, P_ZB, P_DZA, P_DZ, P_DX0, P_PB, P_PI, P_BLL, P_BLU, P_BTL, P_BTU, P_OBS };
     static constexpr int OBSN = SOFT ? 10 : 4;
     static constexpr int P_LZU = P_OBS + KCH * OBSN;
     static constexpr int NPL = P_LZU + NU;
+
+    static constexpr bool out_unit(int j) { return ((M::OUT_UNIT >> j) & 1u) != 0u; }
 
     using BoxRow = RowCalc<false>;
     using ObsRow = RowCalc<SOFT>;
@@ -155,6 +158,7 @@ struct QpIpm {
 
     const DevPtrs &P;
     const DevSpec &S;
+    double rbscale; // product of (1 - alpha) over the steps taken: scales the dynamics residual
     int lane, N;
     long g, b, stride;
     unsigned gl;
@@ -168,6 +172,11 @@ struct QpIpm {
     //   bstep  : 0 for a slot row, 1 for a dense row (value e comes from lane bsrc + e*bstep)
     //   ssrc   : variable whose row this lane stores (as slot lane or as dense lane)
     //   isslot / isdense : what this lane stores
+    bool ounit; // this lane is the state of a structurally unit row of [A B] (M::OUT_UNIT)
+    // packed matrix planes (MatPack): this lane's column is stored / is a unit column; its index among the
+    // stored columns
+    bool mstored, munit;
+    int mci;
     bool isslot, isdense, anydense;
     int bsrc, bstep, ssrc;
     bool hasb;
@@ -195,6 +204,10 @@ struct QpIpm {
         isPX = KCH > 0 && lane == PXL;
         isPY = KCH > 0 && lane == PYL;
         hasb = S.has_b[lane] != 0;
+        ounit = xlane && ((M::OUT_UNIT >> (xlane ? lane - NU : 0)) & 1u) != 0u;
+        mstored = ((MP::CMASK >> lane) & 1u) != 0u;
+        munit = xlane && !mstored;
+        mci = mstored ? MP::rank(MP::CMASK, lane) : 0;
         isslot = PACK && S.slot_is[lane] == 1;
         isdense = PACK && S.slot_is[lane] == 2;
         anydense = PACK && S.box_dense != 0; // wave-uniform
@@ -304,6 +317,32 @@ struct QpIpm {
             if (do_store && isdense) W.st(P_BLL, v);
         }
     }
+    // Row j of [B A]' for every stored row (bat[j]: lane r = d x+_j / d z_r) from the packed planes of stage k.
+    // mat_issue puts the plane loads in flight, mat_unpack (call under wave-uniform control flow) distributes.
+    USV_DEV void mat_issue(int k, double *pk) const
+    {
+        const Planes BP(P.BAp + (long)k * MP::NPK * stride, stride, MP::NPK, gl);
+        sfor<0, MP::NPK>([&](auto q) { pk[q] = BP.ld(q); });
+    }
+    USV_DEV void mat_unpack(const double *pk, double *bat) const
+    {
+        sfor<0, NX>([&](auto j) {
+            if constexpr (out_unit(j)) {
+                bat[j] = 0.0; // never read: unit rows are handled structurally
+            } else {
+                constexpr int s0 = MP::rank(MP::RMASK, j) * MP::NC;
+                constexpr int q0 = s0 / 16, q1 = (s0 + MP::NC - 1) / 16;
+                const int pos = s0 + mci;
+                double v = lanes::gather(pk[q0], pos & 15);
+                if constexpr (q1 != q0) {
+                    const double v1 = lanes::gather(pk[q1], pos & 15);
+                    v = (pos >> 4) == q0 ? v : v1;
+                }
+                // a unit column holds the identity entry of its own state row, idle lanes hold zero
+                bat[j] = mstored ? v : ((munit && lane == NU + j) ? 1.0 : 0.0);
+            }
+        });
+    }
     USV_DEV static double obs_dot(double cx, double cy, double vec)
     {
         return cx * lanes::bcast<PXL>(vec) + cy * lanes::bcast<PYL>(vec);
@@ -312,13 +351,11 @@ struct QpIpm {
     // ------------------------------------------------------------------ cold start
     USV_DEV void init()
     {
-        const Planes RB0(P.rb0, stride, N, gl);
         for (int k = 0; k <= N; k++) {
             const Planes W = ws(k);
             const double zb = zbar(k);
             W.st(P_Z, 0.0);
             W.st(P_ZB, zb);
-            W.st(P_RB, (k < N) ? RB0.ld(k) : 0.0);
             if (k == 0) W.st(P_DX0, xlane ? P.x0[(long)b * NX + (lane - NU)] - zb : 0.0);
             BoxRow r;
             r.neutral();
@@ -382,7 +419,9 @@ struct QpIpm {
         const Planes W = ws(k);
         in.z = W.ld(P_Z);
         in.zb = W.ld(P_ZB);
-        if constexpr (SW != SW_BACK_B) in.rb = (k < N) ? W.ld(P_RB) : 0.0;
+        // b_k of the current iterate = rbscale * (residual of the linearisation point): the forward sweeps
+        // enforce the linearised dynamics, so every step scales it by (1 - alpha) and it is never rewritten
+        if constexpr (SW != SW_BACK_B) in.rb = (k < N) ? Planes(P.rb0, stride, N, gl).ld(k) * rbscale : 0.0;
         if constexpr (SW == SW_BACK_A) {
             in.dz = W.ld(P_DZ);
             in.dza = W.ld(P_DZA);
@@ -390,14 +429,14 @@ struct QpIpm {
         }
         if constexpr (SW == SW_BACK_B || SW == SW_FWD_B) in.dza = W.ld(P_DZA);
         if constexpr (SW == SW_BACK_B) {
-            in.rg = W.ld(P_RG);
+            in.rg = W.ld(P_PI);
             in.pb = (k < N) ? W.ld(P_PB) : 0.0;
         }
         if constexpr (SW != SW_BACK_A) {
             if (k < N) sfor<0, NU>([&](auto l) { in.lzu[l] = W.ld(P_LZU + l); });
             else sfor<0, NU>([&](auto l) { in.lzu[l] = 1.0; });
         }
-        if constexpr (SW == SW_FWD_A || SW == SW_FWD_B) in.luv = (k < N) ? W.ld(P_LUV) : 0.0;
+        if constexpr (SW == SW_FWD_A || SW == SW_FWD_B) in.luv = (k < N) ? W.ld(P_PB) : 0.0; // u lanes matter
         if constexpr (PACK) {
             in.box[0] = (anydense && k < N) ? W.ld(P_BLL) : 0.0; // wave-uniform
         } else {
@@ -464,23 +503,18 @@ struct QpIpm {
         constexpr int SW = FACT ? SW_BACK_A : SW_BACK_B;
         double Pn[NX], pn = 0.0, pin = 0.0;
         sfor<0, NX>([&](auto c) { Pn[c] = 0.0; });
-        if (FACT) { nm.rg = nm.rb = nm.rd = nm.rm = nm.musum = nm.nan = 0.0; }
+        if (FACT) {
+            nm.rg = nm.rb = nm.rd = nm.rm = nm.musum = nm.nan = 0.0;
+            rbscale = pend ? rbscale * (1.0 - a_prev) : rbscale; // the step applied in this sweep
+        }
         StageIn nxt;
         load_in<SW>(N, nxt);
         for (int k = N; k >= 0; k--) {
             const StageIn in = nxt;
             const Planes W = ws(k);
-            // this stage's [B A]' rows: in flight while the rows below are processed
-            double bat[NX];
-            if (k < N) {
-                const Planes BT(P.BAt + (long)k * NX * stride, stride, NX, gl);
-                sfor<0, NX>([&](auto j) {
-                    if constexpr (((M::OUT_UNIT >> j) & 1u) != 0u) bat[j] = (lane == NU + j) ? 1.0 : 0.0;
-                    else bat[j] = BT.ld(j);
-                });
-            } else {
-                sfor<0, NX>([&](auto j) { bat[j] = 0.0; });
-            }
+            // this stage's packed [B A] planes: in flight while the rows below are processed
+            double mpk[MP::NPK];
+            if (k < N) mat_issue(k, mpk);
             double z = in.z;
             const double *Hrow = (k < N ? S.Hc : S.He) + lane * LANES; // only read when !HDIAG
             const double hd = (k < N) ? hd_stage : hd_term;
@@ -549,12 +583,12 @@ struct QpIpm {
                 }
             }
             z = znew;
-            if (FACT && pend) {
-                W.st(P_Z, z);
-                if (k < N) { rb = (1.0 - a_prev) * rb; W.st(P_RB, rb); }
-            }
+            if (FACT && pend) W.st(P_Z, z);
             // ---- next stage's planes go in flight before the matrix work of this one
             if (k > 0) load_in<SW>(k - 1, nxt);
+            double bat[NX];
+            if (k < N) mat_unpack(mpk, bat); // wave-uniform
+            else sfor<0, NX>([&](auto j) { bat[j] = 0.0; });
 
             double rg, pik = 0.0;
             if (FACT) {
@@ -563,13 +597,15 @@ struct QpIpm {
                 double t = in.gq;
                 if constexpr (HDIAG) t = fma(hd, z, t);
                 else sfor<0, NZ>([&](auto c) { lanes::fma_bc<c>(t, z, Hrow[c]); });
-                sfor<0, NX>([&](auto j) { lanes::fma_bc<NU + j>(t, pin, bat[j]); });
+                sfor<0, NX>([&](auto j) {
+                    if constexpr (!out_unit(j)) lanes::fma_bc<NU + j>(t, pin, bat[j]);
+                });
+                if constexpr (M::OUT_UNIT != 0u) t += ounit ? pin : 0.0;
                 t -= br.act ? br.ll - br.lu : 0.0;
                 t -= isPX ? lx : (isPY ? ly : 0.0);
                 pik = xlane ? t : 0.0;
                 rg = (ulane && k < N) ? t : 0.0;
-                W.st(P_RG, rg);
-                W.st(P_PI, pik);
+                W.st(P_PI, rg + pik); // rg lives on the u lanes, pik on the x lanes
                 nm.rg = fmax(nm.rg, fabs(rg));
                 nm.nan = fma(0.0, t, nm.nan);
                 if (br.act) {
@@ -580,7 +616,7 @@ struct QpIpm {
                 }
                 nm.rb = fmax(nm.rb, fabs(rb));
             } else {
-                rg = in.rg;
+                rg = (ulane && k < N) ? in.rg : 0.0;
             }
             const double gt = rg + gamb + (isPX ? gx : (isPY ? gy : 0.0));
 
@@ -598,7 +634,11 @@ struct QpIpm {
                     double T[NX];
                     sfor<0, NX>([&](auto c) {
                         double a = 0.0;
-                        sfor<0, NX>([&](auto j) { lanes::fma_bc<NU + j>(a, Pn[c], bat[j]); });
+                        sfor<0, NX>([&](auto j) {
+                            if constexpr (!out_unit(j)) lanes::fma_bc<NU + j>(a, Pn[c], bat[j]);
+                        });
+                        // unit rows of [A B] (x+_j = x_j): row nu+j of T receives row j of P, which that lane owns
+                        if constexpr (M::OUT_UNIT != 0u) a += ounit ? Pn[c] : 0.0;
                         T[c] = a;
                     });
                     // P_{k+1} b_k (needs the old P before it is overwritten)
@@ -614,7 +654,10 @@ struct QpIpm {
                             if constexpr (c == PXL) a += isPX ? Sxx : (isPY ? Sxy : 0.0);
                             if constexpr (c == PYL) a += isPX ? Sxy : (isPY ? Syy : 0.0);
                         }
-                        sfor<0, NX>([&](auto j) { lanes::fma_bc<c>(a, bat[j], T[j]); });
+                        sfor<0, NX>([&](auto j) {
+                            if constexpr (!out_unit(j)) lanes::fma_bc<c>(a, bat[j], T[j]);
+                            else if constexpr (c == NU + j) a += T[j]; // column nu+j of a unit row is e_j
+                        });
                         Gr[c] = a;
                     });
                     // Cholesky of the leading nu columns, all rows at once
@@ -630,10 +673,9 @@ struct QpIpm {
                         sfor<0, NU>([&](auto l) { lanes::fma_bc<NU + c>(a, Lzu[l], -Lzu[l]); });
                         Pn[c] = xlane ? a : 0.0;
                     });
-                    W.st(P_PB, Pb);
                     sfor<0, NU>([&](auto l) { W.st(P_LZU + l, Lzu[l]); });
                 } else {
-                    Pb = in.pb;
+                    Pb = xlane ? in.pb : 0.0;
                     sfor<0, NU>([&](auto l) {
                         Lzu[l] = in.lzu[l];
                         iLd[l] = lanes::frcp(lanes::bcast<l>(Lzu[l]));
@@ -642,7 +684,10 @@ struct QpIpm {
                 // vector recursion
                 const double h = Pb + pn;
                 double rq = gt;
-                sfor<0, NX>([&](auto j) { lanes::fma_bc<NU + j>(rq, h, bat[j]); });
+                sfor<0, NX>([&](auto j) {
+                    if constexpr (!out_unit(j)) lanes::fma_bc<NU + j>(rq, h, bat[j]);
+                });
+                if constexpr (M::OUT_UNIT != 0u) rq += ounit ? h : 0.0;
                 double lu[NU], luv = 0.0;
                 sfor<0, NU>([&](auto l) {
                     double a = lanes::bcast<l>(rq);
@@ -653,7 +698,7 @@ struct QpIpm {
                 pv = rq;
                 sfor<0, NU>([&](auto l) { pv -= Lzu[l] * lu[l]; });
                 pv = xlane ? pv : 0.0;
-                W.st(P_LUV, luv);
+                W.st(P_PB, luv + Pb); // luv is non-zero on the u lanes only, Pb on the x lanes only
             }
             pn = pv;
             pin = pik;
@@ -688,25 +733,11 @@ struct QpIpm {
         for (int k = 0; k <= N; k++) {
             const StageIn in = nxt;
             const Planes W = ws(k);
-            // this stage's matrix planes and the next stage's small planes: both in flight during the gain /
-            // row computations below.  FWD_ROWS: the rows of [B A] (ABr, one plane per non-unit column);
-            // otherwise the [B A]' planes the backward sweeps read (one per non-unit row).
-            constexpr int NMAT = FWD_ROWS ? NZ : NX;
-            double mat[NMAT];
+            // this stage's packed [B A] planes and the next stage's small planes: both in flight during the
+            // gain / row computations below
+            double mpk[MP::NPK];
             if (k < N) {
-                if constexpr (FWD_ROWS) {
-                    const Planes AB(P.ABr + (long)k * NZ * stride, stride, NZ, gl);
-                    sfor<0, NZ>([&](auto c) {
-                        if constexpr (((M::IN_UNIT >> c) & 1u) != 0u) mat[c] = (lane == c) ? 1.0 : 0.0;
-                        else mat[c] = AB.ld(c);
-                    });
-                } else {
-                    const Planes BT(P.BAt + (long)k * NX * stride, stride, NX, gl);
-                    sfor<0, NX>([&](auto j) {
-                        if constexpr (((M::OUT_UNIT >> j) & 1u) == 0u) mat[j] = BT.ld(j);
-                        else mat[j] = 0.0;
-                    });
-                }
+                mat_issue(k, mpk);
                 load_in<SW>(k + 1, nxt);
             }
             double dz;
@@ -764,21 +795,19 @@ struct QpIpm {
             }
             W.st(FINAL ? P_DZ : P_DZA, dz);
             if (k < N) {
+                // dx+_j = b_j + sum_c [B A][j][c] dz_c: lane c holds [B A][j][c] in bat[j], so the row sum is a
+                // group reduction delivered to lane nu+j (no transposed copy of the matrix in HBM)
+                double bat[NX];
+                mat_unpack(mpk, bat);
                 double dxn = in.rb;
-                if constexpr (FWD_ROWS) {
-                    sfor<0, NZ>([&](auto c) { lanes::fma_bc<c>(dxn, dz, mat[c]); });
-                } else {
-                    // dx+_j = b_j + sum_c [B A][j][c] dz_c: lane c holds [B A][j][c] in plane j, so the row sum
-                    // is a group reduction delivered to lane nu+j (no transposed copy of the matrix in HBM)
-                    sfor<0, NX>([&](auto j) {
-                        if constexpr (((M::OUT_UNIT >> j) & 1u) != 0u) {
-                            dxn += (lane == NU + j) ? dz : 0.0;
-                        } else {
-                            const double sj = lanes::gsum(mat[j] * dz);
-                            dxn += (lane == NU + j) ? sj : 0.0;
-                        }
-                    });
-                }
+                sfor<0, NX>([&](auto j) {
+                    if constexpr (out_unit(j)) {
+                        dxn += (lane == NU + j) ? dz : 0.0;
+                    } else {
+                        const double sj = lanes::gsum(bat[j] * dz);
+                        dxn += (lane == NU + j) ? sj : 0.0;
+                    }
+                });
                 dzx = xlane ? dxn : 0.0;
             }
         }
@@ -790,6 +819,7 @@ struct QpIpm {
     USV_DEV void solve()
     {
         init();
+        rbscale = 1.0;
         bool done = false, pend = false;
         int status = 1, iters = 0;
         Norms nm;

@@ -275,20 +275,20 @@ int launch_pair(usvmpc_handle *h)
     return 0;
 }
 
-// does this model's forward sweep stream the rows of [B A] (a second set of matrix planes)?
-bool model_fwd_rows(int model)
+// planes per stage of the packed [B A] for this model (MatPack)
+int model_mat_planes(int model)
 {
     switch (model) {
 #ifndef USV_GEN_ONLY
-    case USVMPC_MODEL_USV: return fwd_rows<ModelM0>();
-    case USVMPC_MODEL_GUIDANCE_CA1: return fwd_rows<ModelM1>();
-    case USVMPC_MODEL_PF_CA: return fwd_rows<ModelM2>();
+    case USVMPC_MODEL_USV: return MatPack<ModelM0>::NPK;
+    case USVMPC_MODEL_GUIDANCE_CA1: return MatPack<ModelM1>::NPK;
+    case USVMPC_MODEL_PF_CA: return MatPack<ModelM2>::NPK;
 #endif
 #ifdef USV_GEN_MODEL_HEADER
-    case USVMPC_MODEL_GENERATED: return fwd_rows<ModelGen>();
+    case USVMPC_MODEL_GENERATED: return MatPack<ModelGen>::NPK;
 #endif
     }
-    return false;
+    return 0;
 }
 
 int launch(usvmpc_handle *h)
@@ -416,9 +416,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->sort_enabled = true;
     h->gd_ready = false; h->gd_npts_cap = 0; h->gd_psi = nullptr;
     std::memset(&h->gd, 0, sizeof(h->gd));
-    TRY_C(dev_alloc(h, &P.BAt, N * h->nx * stride, true));
-    P.ABr = nullptr;
-    if (model_fwd_rows(d->model)) TRY_C(dev_alloc(h, &P.ABr, N * h->nz * stride, true)); // u lanes / idle lanes stay zero
+    TRY_C(dev_alloc(h, &P.BAp, N * (size_t)model_mat_planes(d->model) * stride, true));
     TRY_C(dev_alloc(h, &P.rb0, N * stride, true));
     TRY_C(dev_alloc(h, &P.gq, (N + 1) * stride, true));
     TRY_C(dev_alloc(h, &P.ws, (N + 1) * (size_t)ws_planes(h->nx, h->nu, h->kch, h->soft) * stride, true));

@@ -117,6 +117,31 @@ void qp_body(void *a)
     q.solve();
 }
 
+double *g_dbg_BAt = nullptr; // [N][nx][Bp*16]: the packed planes expanded back to one plane per row (inspection)
+
+template <class M>
+void expand_packed(const DevPtrs &P, const DevSpec &S)
+{
+    using MP = MatPack<M>;
+    const long stride = (long)S.Bp * LANES;
+    for (int k = 0; k < S.N; k++)
+        for (int j = 0; j < M::NX; j++) {
+            if (!((MP::RMASK >> j) & 1u)) continue; // unit rows are not stored: left at zero
+            const int jj = MP::rank(MP::RMASK, j);
+            for (long g = 0; g < S.Bp; g++)
+                for (int c = 0; c < MP::NZ; c++) {
+                    double v;
+                    if ((MP::CMASK >> c) & 1u) {
+                        const int pos = jj * MP::NC + MP::rank(MP::CMASK, c);
+                        v = P.BAp[((long)k * MP::NPK + pos / 16) * stride + g * LANES + pos % 16];
+                    } else {
+                        v = (c == M::NU + j) ? 1.0 : 0.0;
+                    }
+                    g_dbg_BAt[((long)k * M::NX + j) * stride + g * LANES + c] = v;
+                }
+        }
+}
+
 template <class M, int KCH, bool SOFT>
 void run_all(const DevPtrs &P, const DevSpec &S, int phase)
 {
@@ -125,6 +150,7 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase)
             Job j{&P, gid};
             lanes::run_group(gid, &lin_body<M, KCH, SOFT>, &j);
         }
+    if ((phase & 1) && g_dbg_BAt) expand_packed<M>(P, S);
     if (phase & 2)
         for (long g = 0; g < S.Bp; g++) {
             Job j{&P, g};
@@ -161,7 +187,7 @@ extern "C" int usv_emu_solve(const usvmpc_desc *d, double *x, double *u, const d
     if (d->model == USVMPC_MODEL_GENERATED) { kch = USV_GEN_KCH; soft = USV_GEN_SOFT != 0; }
 #endif
     const long stride = (long)S.Bp * LANES;
-    std::vector<double> BAt((size_t)N * nx * stride), ABr((size_t)N * nz * stride), rb0((size_t)N * stride),
+    std::vector<double> BAp((size_t)N * 16 * stride), rb0((size_t)N * stride), // 16 >= MatPack::NPK of any model
         gq((size_t)(N + 1) * stride),
         ws((size_t)(N + 1) * ws_planes(nx, nu, kch, soft) * stride);
     DevPtrs P;
@@ -169,8 +195,9 @@ extern "C" int usv_emu_solve(const usvmpc_desc *d, double *x, double *u, const d
     P.spec = &S;
     P.x = x; P.u = u; P.x0 = x0; P.yref = yref; P.yref_e = yref_e; P.p = p; P.lh = lh;
     P.sl = sl; P.su = su; P.pi = pi; P.status = status; P.qp_iter = qp_iter; P.qp_status = qp_status; P.res = res;
-    P.BAt = BAt.data(); P.ABr = ABr.data(); P.rb0 = rb0.data(); P.gq = gq.data(); P.ws = ws.data();
+    P.BAp = BAp.data(); P.rb0 = rb0.data(); P.gq = gq.data(); P.ws = ws.data();
     const int phase = 3;
+    g_dbg_BAt = dbg_BAt;
 #ifdef USV_GEN_MODEL_HEADER
     if (d->model == USVMPC_MODEL_GENERATED) run_all<ModelGen, USV_GEN_KCH, (USV_GEN_SOFT != 0)>(P, S, phase);
     else
@@ -185,7 +212,6 @@ extern "C" int usv_emu_solve(const usvmpc_desc *d, double *x, double *u, const d
         if (kch <= 1) run_all<ModelM2, 1, false>(P, S, phase);
         else run_all<ModelM2, 2, false>(P, S, phase);
     }
-    if (dbg_BAt) std::memcpy(dbg_BAt, BAt.data(), BAt.size() * sizeof(double));
     if (dbg_rb0) std::memcpy(dbg_rb0, rb0.data(), rb0.size() * sizeof(double));
     if (dbg_gq) std::memcpy(dbg_gq, gq.data(), gq.size() * sizeof(double));
     return 0;

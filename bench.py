@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak
 
 
 def algorithmic_bytes(nx, nu, N, K):
@@ -128,20 +129,38 @@ def main():
         except Exception:
             traffic = None
 
+    # the algorithmic FP64 flop count of one solve (dense count, no sparsity credit), with the
+    # measured mean IPM iteration count
+    nz_, nh_ = nx + nu, K
+    c_f = {"usv_model": 60, "usv_model_guidance_ca1": 60, "usv_model_pf_ca": 150}.get(name, 100)
+    n_ipm = float(qi.mean()) + 1.0  # factorisations = iterations + the final residual pass
+    falg = N * (4 * (2 * nx * nx * nz_ + c_f) + 8 * nx * (nz_ + 1)) + \
+        n_ipm * N * (nx * nx * (nz_ + 1) + nx * nz_ * (nz_ + 1) + nz_ ** 3 / 3.0 + nh_ * nz_ * (nz_ + 1) + 8 * nz_ * nz_)
+    fp64_tflops = falg * B / qp_avg_s / 1e12
+
     # ---- CPU baseline + parity spot check (rank 0, single GPU runs only)
     if rank == 0 and args.gpus == 1 and args.cpu_sample != 0:
         from oracle import binding as ob
         per_solve_ms = {"usv_model": 0.12, "usv_model_guidance_ca1": 1.2, "usv_model_pf_ca": 3.5}[name] * N / 40.0
-        S = args.cpu_sample if args.cpu_sample > 0 else int(max(64, min(B, 15000.0 / per_solve_ms)))
+        cores = os.cpu_count() or 1
+        S1 = int(max(32, min(B, 4000.0 / per_solve_ms)))               # ~4 s on one core
+        S = args.cpu_sample if args.cpu_sample > 0 else int(min(B, max(64, 12000.0 / per_solve_ms * cores)))  # ~12 s on all
         S = min(S, B)
         spec = ob.spec(_ID[name], N, N * dt, K)
+        x1, u1 = wl["x_init"][:S1].copy(), wl["u_init"][:S1].copy()
+        c0 = time.perf_counter()
+        ob.rti_batch(spec, x1, u1, wl["x0"][:S1], wl["yref"][:S1], wl["yref_e"][:S1], wl["p"][:S1], wl["lh"][:S1])
+        c1sec = time.perf_counter() - c0
         xo, uo = wl["x_init"][:S].copy(), wl["u_init"][:S].copy()
         c0 = time.perf_counter()
-        sto, ito = ob.rti_batch(spec, xo, uo, wl["x0"][:S], wl["yref"][:S], wl["yref_e"][:S], wl["p"][:S], wl["lh"][:S])
+        sto, ito = ob.rti_batch(spec, xo, uo, wl["x0"][:S], wl["yref"][:S], wl["yref_e"][:S], wl["p"][:S], wl["lh"][:S],
+                                threads=cores)
         csec = time.perf_counter() - c0
-        cpu_baseline = {"value": S / csec, "unit": "solves/s", "cores": 1, "kind": "port",
-                        "sample": "first %d instances of the same batch, 1 RTI iteration from the same initial "
-                                  "guess, oracle/usv_oracle.c single thread (%.1f s)" % (S, csec)}
+        cpu_baseline = {"value": S / csec, "unit": "solves/s", "cores": cores, "kind": "port",
+                        "single_core_value": S1 / c1sec, "single_instance_latency_ms": c1sec / S1 * 1e3,
+                        "sample": "first %d instances of the same batch, 1 RTI iteration from the same initial guess, "
+                                  "oracle/usv_oracle.c, one instance per OpenMP thread on %d threads (%.1f s); "
+                                  "single-core figure from the first %d instances (%.1f s)" % (S, cores, csec, S1, c1sec)}
         if first_x is not None:
             ok = (sto == 0) & (ito < spec.opts.qp_iter_max) & (first_qs[:S] == 0)
             ex = float(np.abs(first_x[:S][ok] - xo[ok]).max() / max(1.0, np.abs(xo).max()))
@@ -173,10 +192,15 @@ def main():
                 "bound": "hbm", "kernel": "usv_qp_rti",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "algorithmic_bytes_per_solve": balg,
+                "traffic_GBs": (traffic / qp_avg_s / 1e9) if traffic else None,
+                "traffic_frac": (traffic / qp_avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "fp64_alg_tflops": fp64_tflops, "fp64_frac": fp64_tflops / FP64_PEAK_TFLOPS,
+                "algorithmic_bytes_per_solve": balg, "algorithmic_flops_per_solve": falg,
                 "kernel_ms": {"usv_linearize": float(lin_ms.mean()), "usv_qp_rti": float(qp_ms.mean())},
-                "note": "latency/VALU-bound FP64 kernel: the algorithmic bytes are tiny against HBM peak "
-                        "(see DESIGN.md); `traffic` is the measured scratch-plane streaming per launch",
+                "note": "`achieved` is SURVEY 8(d)'s algorithmic bytes / kernel time (structurally tiny for this path); "
+                        "`traffic` is the measured HBM streaming of the per-stage planes per launch (rocprofv3 PMC, "
+                        "profiles/pmc_traffic.json) and traffic_GBs / traffic_frac its rate; fp64_* from the "
+                        "algorithmic flop count.  See DESIGN.md section 4.",
             },
             "cpu_baseline": cpu_baseline,
             "workload_stats": {

@@ -97,6 +97,7 @@ def lib():
         L.usv_qp_solve.argtypes = [C.POINTER(Qp), C.POINTER(Opts), C.POINTER(QpSol)]
         L.usv_rti.argtypes = [C.POINTER(Spec)] + [_dp] * 11
         L.usv_rti_batch.argtypes = [C.POINTER(Spec), C.c_int] + [_dp] * 7 + [_ip, _ip]
+        L.usv_rti_batch_mt.argtypes = [C.POINTER(Spec), C.c_int] + [_dp] * 7 + [_ip, _ip, C.c_int]
         L.usv_oracle_register_generated.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.usv_oracle_register_generated.restype = None
         _fp = C.POINTER(C.c_float)
@@ -221,16 +222,21 @@ def rti(s, x, u, x0, yref, yref_e, p, lh):
                 status=st, qp_iter=int(info[0]), qp_status=int(info[1]), res=info[2:6].copy())
 
 
-def rti_batch(s, x, u, x0, yref, yref_e, p, lh):
-    """In-place batched RTI over leading batch axis (row-major per instance)."""
+def rti_batch(s, x, u, x0, yref, yref_e, p, lh, threads=1):
+    """In-place batched RTI over leading batch axis (row-major per instance); threads > 1 (or 0 = all cores)
+    distributes the instances over OpenMP threads."""
     B = x.shape[0]
     for a in (x, u):
         assert a.dtype == np.float64 and a.flags.c_contiguous
     x0, yref, yref_e, p, lh = map(_arr, (x0, yref, yref_e, p, lh))
     status = np.zeros(B, dtype=np.int32)
     it = np.zeros(B, dtype=np.int32)
-    lib().usv_rti_batch(C.byref(s), B, _d(x), _d(u), _d(x0), _d(yref), _d(yref_e), _d(p), _d(lh),
-                        status.ctypes.data_as(_ip), it.ctypes.data_as(_ip))
+    if threads == 1:
+        lib().usv_rti_batch(C.byref(s), B, _d(x), _d(u), _d(x0), _d(yref), _d(yref_e), _d(p), _d(lh),
+                            status.ctypes.data_as(_ip), it.ctypes.data_as(_ip))
+    else:
+        lib().usv_rti_batch_mt(C.byref(s), B, _d(x), _d(u), _d(x0), _d(yref), _d(yref_e), _d(p), _d(lh),
+                               status.ctypes.data_as(_ip), it.ctypes.data_as(_ip), int(threads))
     return status, it
 
 

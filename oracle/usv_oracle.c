@@ -5,6 +5,9 @@
  * /root/reference/catkin_ws/src/nmpc_ca/scripts/).
  */
 #include "usv_oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1198,6 +1201,32 @@ int usv_rti_batch(const usv_spec *s, int B, double *x, double *u, const double *
 {
     const int N = s->N, nx = s->nx, nu = s->nu, K = s->K;
     int b, worst = 0;
+    for (b = 0; b < B; b++) {
+        double info[8];
+        const int st = usv_rti(s, x + (size_t)b * (N + 1) * nx, u + (size_t)b * N * nu, x0 + (size_t)b * nx,
+                               yref + (size_t)b * N * s->ny, yref_e + (size_t)b * s->ny_e,
+                               p + (size_t)b * (N + 1) * 2 * K, lh + (size_t)b * N * K, NULL, NULL, NULL, info);
+        if (status) status[b] = st;
+        if (qp_iter) qp_iter[b] = (int)info[0];
+        if (st > worst) worst = st;
+    }
+    return worst;
+}
+
+/* All-core variant of the batch driver (one instance per thread, OpenMP dynamic schedule): the CPU
+ * baseline bench.py times next to the GPU run.  nthreads <= 0: the OpenMP default. */
+int usv_rti_batch_mt(const usv_spec *s, int B, double *x, double *u, const double *x0,
+                     const double *yref, const double *yref_e, const double *p, const double *lh,
+                     int *status, int *qp_iter, int nthreads)
+{
+    const int N = s->N, nx = s->nx, nu = s->nu, K = s->K;
+    int b, worst = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(dynamic, 4) reduction(max : worst)
     for (b = 0; b < B; b++) {
         double info[8];
         const int st = usv_rti(s, x + (size_t)b * (N + 1) * nx, u + (size_t)b * N * nu, x0 + (size_t)b * nx,

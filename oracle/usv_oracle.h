@@ -161,6 +161,11 @@ int usv_rti_batch(const usv_spec *s, int B, double *x, double *u, const double *
                   const double *yref, const double *yref_e, const double *p, const double *lh,
                   int *status, int *qp_iter);
 
+/* The same, instances distributed over nthreads OpenMP threads (<= 0: default). */
+int usv_rti_batch_mt(const usv_spec *s, int B, double *x, double *u, const double *x0,
+                     const double *yref, const double *yref_e, const double *p, const double *lh,
+                     int *status, int *qp_iter, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

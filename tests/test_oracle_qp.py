@@ -268,3 +268,19 @@ def test_rti_iterations_converge_to_the_nonlinear_ocp_optimum(oracle):
     assert r.success
     assert cost(u[:, 0]) <= cost(r.x) + 1e-10
     assert np.abs(u[:, 0] - r.x).max() < 1e-5
+
+
+def test_threaded_batch_driver_is_bit_identical(oracle):
+    """usv_rti_batch_mt (the all-core CPU baseline of bench.py) distributes instances over OpenMP threads and
+    must return exactly what the sequential driver returns."""
+    from mpc_collisionavoidance_amd import scenario
+    name, N, K, B = "usv_model_guidance_ca1", 10, 4, 24
+    wl = scenario.make_batch(name, N, K, B, seed=77)
+    spec = oracle.spec(1, N, N * scenario.DT[name], K)
+    out = []
+    for th in (1, 4):
+        x, u = wl["x_init"].copy(), wl["u_init"].copy()
+        st, it = oracle.rti_batch(spec, x, u, wl["x0"], wl["yref"], wl["yref_e"], wl["p"], wl["lh"], threads=th)
+        out.append((x, u, st, it))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)

@@ -74,6 +74,12 @@ typedef struct usvmpc_desc {
     double zl[USVMPC_K_MAX], zu[USVMPC_K_MAX], Zl[USVMPC_K_MAX], Zu[USVMPC_K_MAX];
     int qp_iter_max;
     double mu0, thr0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min;
+    /* integrator: RK4 steps per shooting interval (acados sim_method_num_steps; 0 is read as 1) */
+    int sim_num_steps;
+    /* full SQP only (usvmpc_solve_sqp): nlp_solver_max_iter (0 is read as 100) and the exit tolerances on
+     * the NLP residuals stat / eq / ineq / comp (0 is read as 1e-6, the acados default) */
+    int nlp_max_iter;
+    double nlp_tol_stat, nlp_tol_eq, nlp_tol_ineq, nlp_tol_comp;
 } usvmpc_desc;
 
 typedef struct usvmpc_handle usvmpc_handle;
@@ -92,14 +98,23 @@ int usvmpc_destroy(usvmpc_handle *h);
  * ("yref" with stage -1 covers stages 0..N-1 only). */
 int usvmpc_set(usvmpc_handle *h, const char *field, int stage, const double *v, size_t n);
 /* fields: "x", "u", "pi" (stage 1..N), "sl", "su" (stage 0..N-1, n = K), "res" (stage ignored,
- * n = 4: QP residuals stat/eq/ineq/comp); same stage = -1 convention. */
+ * n = 4: QP residuals stat/eq/ineq/comp), "nlp_res" (the same for the NLP, full SQP only); same stage = -1
+ * convention. */
 int usvmpc_get(usvmpc_handle *h, const char *field, int stage, double *out, size_t n);
-/* integer per-instance results: "status" (0 | 4), "qp_status" (0 ok,1 max iter,2 min step,
- * 3 nan), "qp_iter" */
+/* integer per-instance results: "status" (0 | 4; after usvmpc_solve_sqp 0 | 2 | 4), "qp_status" (0 ok,
+ * 1 max iter,2 min step, 3 nan), "qp_iter", "sqp_iter" */
 int usvmpc_get_int(usvmpc_handle *h, const char *field, int *out);
 
 /* One SQP-RTI iteration for every instance; returns the worst status. status may be NULL. */
 int usvmpc_solve(usvmpc_handle *h, int *status);
+/* Full SQP (acados nlp_solver_type "SQP": the option the reference's settings files mention but leave
+ * commented, scripts/usv_guidance_ca1/acados_settings.py:192-204; used by scripts/race_cars/
+ * acados_settings_dev.py:157): per instance, linearise - test the NLP residuals - solve the QP - full step,
+ * until the residuals are below the tolerances (status 0), nlp_max_iter QPs have been solved (2) or a QP
+ * fails (4).  Converged instances are frozen while the rest of the batch continues.  The multipliers of
+ * the last QP are kept between calls, so a call from a converged point returns after 0 iterations.  Afterwards
+ * usvmpc_get_int "sqp_iter" and usvmpc_get "nlp_res" (n = 4) describe the run. */
+int usvmpc_solve_sqp(usvmpc_handle *h, int *status);
 /* Enqueue one RTI iteration on the handle's stream without synchronising or reading back */
 int usvmpc_solve_async(usvmpc_handle *h);
 int usvmpc_sync(usvmpc_handle *h);

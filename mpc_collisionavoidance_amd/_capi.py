@@ -31,7 +31,10 @@ class Desc(C.Structure):
                 ("zl", C.c_double * KM), ("zu", C.c_double * KM), ("Zl", C.c_double * KM), ("Zu", C.c_double * KM),
                 ("qp_iter_max", C.c_int), ("mu0", C.c_double), ("thr0", C.c_double),
                 ("tol_stat", C.c_double), ("tol_eq", C.c_double), ("tol_ineq", C.c_double),
-                ("tol_comp", C.c_double), ("alpha_min", C.c_double)]
+                ("tol_comp", C.c_double), ("alpha_min", C.c_double),
+                ("sim_num_steps", C.c_int), ("nlp_max_iter", C.c_int),
+                ("nlp_tol_stat", C.c_double), ("nlp_tol_eq", C.c_double), ("nlp_tol_ineq", C.c_double),
+                ("nlp_tol_comp", C.c_double)]
 
 
 def lib_path():
@@ -45,7 +48,7 @@ def lib_path():
 loaded_before_torch = False
 
 EXPORTS = ["usvmpc_model_dims", "usvmpc_default_options", "usvmpc_create", "usvmpc_destroy",
-           "usvmpc_set", "usvmpc_get", "usvmpc_get_int", "usvmpc_solve", "usvmpc_solve_async",
+           "usvmpc_set", "usvmpc_get", "usvmpc_get_int", "usvmpc_solve", "usvmpc_solve_sqp", "usvmpc_solve_async",
            "usvmpc_sync", "usvmpc_get_device_ptr", "usvmpc_last_kernel_ms", "usvmpc_kernel_ms",
            "usvmpc_advance", "usvmpc_set_stream", "usvmpc_set_option", "usvmpc_calibrate_traffic", "usvmpc_guidance_reset", "usvmpc_guidance_prepare",
            "usvmpc_guidance_publish", "usvmpc_guidance_state", "usvmpc_device_bytes", "usvmpc_last_error"]
@@ -76,6 +79,7 @@ def load(path):
     L.usvmpc_get.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _dp, C.c_size_t]
     L.usvmpc_get_int.argtypes = [C.c_void_p, C.c_char_p, _ip]
     L.usvmpc_solve.argtypes = [C.c_void_p, _ip]
+    L.usvmpc_solve_sqp.argtypes = [C.c_void_p, _ip]
     L.usvmpc_solve_async.argtypes = [C.c_void_p]
     L.usvmpc_sync.argtypes = [C.c_void_p]
     L.usvmpc_get_device_ptr.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
@@ -116,6 +120,9 @@ def default_options(d):
     d.mu0, d.thr0 = 10.0, 0.1
     d.tol_stat, d.tol_eq, d.tol_ineq, d.tol_comp = 1e-6, 1e-8, 1e-8, 1e-8
     d.alpha_min = 1e-12
+    d.sim_num_steps = 1
+    d.nlp_max_iter = 100
+    d.nlp_tol_stat = d.nlp_tol_eq = d.nlp_tol_ineq = d.nlp_tol_comp = 1e-6
     return d
 
 
@@ -140,8 +147,10 @@ def desc_from_ocp(ocp, batch=1, device=0, generated=False):
     for fld, want in (("cost_type", "LINEAR_LS"), ("cost_type_e", "LINEAR_LS")):
         if getattr(cost, fld) != want:
             raise Exception("only %s = %s is supported" % (fld, want))
-    if opts.nlp_solver_type not in ("SQP_RTI",):
-        raise Exception("nlp_solver_type must be SQP_RTI")
+    if opts.nlp_solver_type not in ("SQP_RTI", "SQP"):
+        raise Exception("nlp_solver_type must be SQP_RTI or SQP")
+    if getattr(opts, "sim_method_num_stages", 4) not in (None, 4):
+        raise Exception("sim_method_num_stages must be 4 (the ERK4 tableau); use sim_method_num_steps to refine")
     if opts.integrator_type != "ERK" or opts.hessian_approx != "GAUSS_NEWTON":
         raise Exception("integrator_type must be ERK and hessian_approx GAUSS_NEWTON")
     if opts.qp_solver not in ("PARTIAL_CONDENSING_HPIPM", "FULL_CONDENSING_HPIPM"):
@@ -205,5 +214,15 @@ def desc_from_ocp(ocp, batch=1, device=0, generated=False):
     for src, dst in (("qp_solver_tol_stat", "tol_stat"), ("qp_solver_tol_eq", "tol_eq"),
                      ("qp_solver_tol_ineq", "tol_ineq"), ("qp_solver_tol_comp", "tol_comp")):
         if getattr(opts, src) is not None:
+            setattr(d, dst, float(getattr(opts, src)))
+    if getattr(opts, "sim_method_num_steps", None) is not None:
+        d.sim_num_steps = int(opts.sim_method_num_steps)
+        if d.sim_num_steps < 1:
+            raise Exception("sim_method_num_steps must be >= 1")
+    if getattr(opts, "nlp_solver_max_iter", None) is not None:
+        d.nlp_max_iter = int(opts.nlp_solver_max_iter)
+    for src, dst in (("nlp_solver_tol_stat", "nlp_tol_stat"), ("nlp_solver_tol_eq", "nlp_tol_eq"),
+                     ("nlp_solver_tol_ineq", "nlp_tol_ineq"), ("nlp_solver_tol_comp", "nlp_tol_comp")):
+        if getattr(opts, src, None) is not None:
             setattr(d, dst, float(getattr(opts, src)))
     return d

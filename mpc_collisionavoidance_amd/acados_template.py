@@ -107,6 +107,15 @@ class AcadosOcpOptions:
         self.qp_solver_tol_eq = None
         self.qp_solver_tol_ineq = None
         self.qp_solver_tol_comp = None
+        # integrator refinement and full SQP (the knobs scripts/usv_guidance_ca1/acados_settings.py:192-204
+        # mentions and leaves commented; scripts/race_cars/acados_settings_dev.py:157-164 sets them)
+        self.sim_method_num_stages = 4
+        self.sim_method_num_steps = 1
+        self.nlp_solver_max_iter = 100
+        self.nlp_solver_tol_stat = None
+        self.nlp_solver_tol_eq = None
+        self.nlp_solver_tol_ineq = None
+        self.nlp_solver_tol_comp = None
         self.model_source = None  # "symbolic": compile the model from its expressions even if the registry has it
 
 
@@ -210,9 +219,9 @@ class BatchOcpSolver:
         self._check(self._lib.usvmpc_set(self._h, field.encode(), -1, a.ctypes.data_as(_capi._dp), n))
 
     def get(self, field, stage):
-        if field == "res":
+        if field in ("res", "nlp_res"):
             out = np.zeros((self.B, 4))
-            self._check(self._lib.usvmpc_get(self._h, b"res", 0, out.ctypes.data_as(_capi._dp), 4))
+            self._check(self._lib.usvmpc_get(self._h, field.encode(), 0, out.ctypes.data_as(_capi._dp), 4))
             return out
         n, _ = self._field(field, stage)
         out = np.zeros((self.B, n))
@@ -234,6 +243,14 @@ class BatchOcpSolver:
         """One SQP-RTI iteration for every instance. Returns the per-instance status array."""
         st = np.zeros(self.B, dtype=np.int32)
         self._check(self._lib.usvmpc_solve(self._h, st.ctypes.data_as(_capi._ip)))
+        return st
+
+    def solve_sqp(self):
+        """Full SQP for every instance (nlp_solver_type "SQP"): iterate until the NLP residuals are below
+        nlp_solver_tol_* (status 0), nlp_solver_max_iter QPs were solved (2) or a QP failed (4).  Converged
+        instances are frozen while the others continue.  get_int("sqp_iter") / get("nlp_res", 0) describe the run."""
+        st = np.zeros(self.B, dtype=np.int32)
+        self._check(self._lib.usvmpc_solve_sqp(self._h, st.ctypes.data_as(_capi._ip)))
         return st
 
     def solve_async(self):
@@ -293,6 +310,7 @@ class AcadosOcpSolver:
         self._b = BatchOcpSolver(acados_ocp, 1, device=device)
         self.N = self._b.N
         self.status = 0
+        self._sqp = acados_ocp.solver_options.nlp_solver_type == "SQP"
 
     def _vec(self, value, n, field):
         a = np.ascontiguousarray(value, dtype=np.float64).reshape(-1)
@@ -337,7 +355,10 @@ class AcadosOcpSolver:
             raise Exception("AcadosOcpSolver.constraints_set(): {} is not a valid argument.".format(field_))
 
     def solve(self):
-        self.status = int(self._b.solve()[0])
+        if self._sqp:
+            self.status = int(self._b.solve_sqp()[0])
+        else:
+            self.status = int(self._b.solve()[0])
         return self.status
 
     def get(self, stage_, field_):
@@ -350,6 +371,8 @@ class AcadosOcpSolver:
     def get_stats(self, field_):
         if field_ == "qp_iter":
             return int(self._b.get_int("qp_iter")[0])
-        if field_ == "residuals":
-            return self._b.get("res", 0)[0].copy()
+        if field_ == "sqp_iter":
+            return int(self._b.get_int("sqp_iter")[0]) if self._sqp else 1
+        if field_ == "residuals":  # acados: the NLP residuals for SQP; the QP's for an RTI iteration
+            return self._b.get("nlp_res" if self._sqp else "res", 0)[0].copy()
         raise Exception("AcadosOcpSolver.get_stats(): {} is not a valid argument.".format(field_))

@@ -101,6 +101,9 @@ USV_DEV double gmin(double v)
     return v;
 }
 
+// one more in a global counter
+USV_DEV void count_one(int *p) { atomicAdd(p, 1); }
+
 // true if the predicate holds in any lane of the wave (four instances)
 USV_DEV bool wave_any(bool p) { return __any((int)p) != 0; }
 

@@ -127,6 +127,13 @@ inline std::string build_spec(const usvmpc_desc &d, DevSpec &S)
     S.tol_stat = d.tol_stat; S.tol_eq = d.tol_eq; S.tol_ineq = d.tol_ineq; S.tol_comp = d.tol_comp;
     S.alpha_min = d.alpha_min;
     if (S.iter_max < 1) return "qp_iter_max must be >= 1";
+    if (d.sim_num_steps < 0 || d.sim_num_steps > 64) return "sim_num_steps out of range (1..64)";
+    S.sim_steps = d.sim_num_steps > 0 ? d.sim_num_steps : 1;
+    S.nlp_tol[0] = d.nlp_tol_stat > 0.0 ? d.nlp_tol_stat : 1e-6;
+    S.nlp_tol[1] = d.nlp_tol_eq > 0.0 ? d.nlp_tol_eq : 1e-6;
+    S.nlp_tol[2] = d.nlp_tol_ineq > 0.0 ? d.nlp_tol_ineq : 1e-6;
+    S.nlp_tol[3] = d.nlp_tol_comp > 0.0 ? d.nlp_tol_comp : 1e-6;
+    if (d.nlp_max_iter < 0) return "nlp_max_iter must be >= 0";
     return "";
 }
 
@@ -136,6 +143,9 @@ inline void default_options(usvmpc_desc &d)
     d.mu0 = 10.0; d.thr0 = 0.1;
     d.tol_stat = 1e-6; d.tol_eq = 1e-8; d.tol_ineq = 1e-8; d.tol_comp = 1e-8;
     d.alpha_min = 1e-12;
+    d.sim_num_steps = 1;
+    d.nlp_max_iter = 100;
+    d.nlp_tol_stat = d.nlp_tol_eq = d.nlp_tol_ineq = d.nlp_tol_comp = 1e-6;
 }
 
 // planes of the QP workspace per stage for a (model, KCH, soft) combination (see qp_ipm.hpp)

@@ -58,40 +58,44 @@ struct Linearize {
         }
         if (k == N) return; // wave-uniform
 
-        // ---- ERK4 + forward VDE for this lane's sensitivity column ----
-        const double dt = S.dt;
+        // ---- ERK4 + forward VDE for this lane's sensitivity column; sim_steps steps of size dt / sim_steps
+        // (acados sim_method_num_steps; the reference leaves it at 1): the column is simply carried on ----
+        const double dt = S.dt / (double)S.sim_steps;
         double s0[NX], f[NX], js[NX], xs[NX], ss[NX], xa[NX], sa[NX], su[NU > 0 ? NU : 1];
         sfor<0, NU>([&](auto l) { su[l] = (lane == l) ? 1.0 : 0.0; });
         sfor<0, NX>([&](auto i) { s0[i] = (lane == NU + i) ? 1.0 : 0.0; });
-        M::fjvp(x, U, s0, su, f, js);
-        sfor<0, NX>([&](auto i) {
-            xa[i] = f[i];
-            sa[i] = js[i];
-            xs[i] = fma(0.5 * dt, f[i], x[i]);
-            ss[i] = fma(0.5 * dt, js[i], s0[i]);
-        });
-        M::fjvp(xs, U, ss, su, f, js);
-        sfor<0, NX>([&](auto i) {
-            xa[i] = fma(2.0, f[i], xa[i]);
-            sa[i] = fma(2.0, js[i], sa[i]);
-            xs[i] = fma(0.5 * dt, f[i], x[i]);
-            ss[i] = fma(0.5 * dt, js[i], s0[i]);
-        });
-        M::fjvp(xs, U, ss, su, f, js);
-        sfor<0, NX>([&](auto i) {
-            xa[i] = fma(2.0, f[i], xa[i]);
-            sa[i] = fma(2.0, js[i], sa[i]);
-            xs[i] = fma(dt, f[i], x[i]);
-            ss[i] = fma(dt, js[i], s0[i]);
-        });
-        M::fjvp(xs, U, ss, su, f, js);
+        for (int step = 0; step < S.sim_steps; step++) { // wave-uniform
+            M::fjvp(x, U, s0, su, f, js);
+            sfor<0, NX>([&](auto i) {
+                xa[i] = f[i];
+                sa[i] = js[i];
+                xs[i] = fma(0.5 * dt, f[i], x[i]);
+                ss[i] = fma(0.5 * dt, js[i], s0[i]);
+            });
+            M::fjvp(xs, U, ss, su, f, js);
+            sfor<0, NX>([&](auto i) {
+                xa[i] = fma(2.0, f[i], xa[i]);
+                sa[i] = fma(2.0, js[i], sa[i]);
+                xs[i] = fma(0.5 * dt, f[i], x[i]);
+                ss[i] = fma(0.5 * dt, js[i], s0[i]);
+            });
+            M::fjvp(xs, U, ss, su, f, js);
+            sfor<0, NX>([&](auto i) {
+                xa[i] = fma(2.0, f[i], xa[i]);
+                sa[i] = fma(2.0, js[i], sa[i]);
+                xs[i] = fma(dt, f[i], x[i]);
+                ss[i] = fma(dt, js[i], s0[i]);
+            });
+            M::fjvp(xs, U, ss, su, f, js);
+            sfor<0, NX>([&](auto i) {
+                x[i] = fma(dt / 6.0, xa[i] + f[i], x[i]);
+                sa[i] = fma(dt / 6.0, sa[i] + js[i], s0[i]);
+                s0[i] = sa[i];
+            });
+        }
         const double *xn = P.x + ((long)b * (N + 1) + k + 1) * NX;
         double bres = 0.0;
-        sfor<0, NX>([&](auto i) {
-            const double xnext = fma(dt / 6.0, xa[i] + f[i], x[i]);
-            sa[i] = fma(dt / 6.0, sa[i] + js[i], s0[i]);
-            bres = (lane == NU + i) ? xnext - xn[i] : bres;
-        });
+        sfor<0, NX>([&](auto i) { bres = (lane == NU + i) ? x[i] - xn[i] : bres; });
         // lane r now holds row r of [B A]' (sa[i] = d x+_i / d z_r).  Its informative entries are packed into
         // MatPack<M>::NPK planes: lane L of plane q stores entry (jj, ci) = divmod(16 q + L, NC), i.e. sa[row jj]
         // as held by the lane of column ci - a lane gather per row that the plane touches.

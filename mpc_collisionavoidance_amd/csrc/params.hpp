@@ -34,6 +34,8 @@ struct DevSpec {
     int hdiag;                    // 1: Hc and He are diagonal (true for every OCP of the reference)
     int iter_max;
     double mu0, thr0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min;
+    int sim_steps;                // RK4 steps per shooting interval (sim_method_num_steps)
+    double nlp_tol[4];            // full SQP: exit tolerances on the NLP residuals (stat, eq, ineq, comp)
 };
 
 // How the stage matrix [B A] (nx x nz) is kept in HBM.  Rows that are unit vectors (M::OUT_UNIT: x+_j = x_j)
@@ -78,6 +80,11 @@ struct DevPtrs {
     int *qp_iter;         // [B]
     int *qp_status;       // [B]   0 ok, 1 max iter, 2 min step, 3 nan
     double *res;          // [B][4]      final QP residuals (stat, eq, ineq, comp)
+    // full SQP (usvmpc_solve_sqp): per-instance state between the iterations of one call
+    double *nlp_res;      // [B][4]      NLP residuals of the current iterate (stat, eq, ineq, comp)
+    int *sqp_iter;        // [B]         SQP iterations taken
+    int *sqp_state;       // [B]         -1 running, else the final acados status (0 converged, 2 max iter, 4 QP failure)
+    int *sqp_running;     // [1]         instances still running after the last launch
     // linearisation output, lane-major planes: element (k, e) of group g, lane r at
     // ((k*E + e) * Bp + g) * 16 + r
     double *BAp;          // [N][NPK]  the informative entries of [B A], packed (MatPack)

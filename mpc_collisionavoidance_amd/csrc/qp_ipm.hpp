@@ -159,6 +159,7 @@ struct QpIpm {
     const DevPtrs &P;
     const DevSpec &S;
     double rbscale; // product of (1 - alpha) over the steps taken: scales the dynamics residual
+    bool keep;      // full SQP: this instance is finished, its workspace (multipliers of the last QP) must survive
     int lane, N;
     long g, b, stride;
     unsigned gl;
@@ -349,22 +350,25 @@ struct QpIpm {
     }
 
     // ------------------------------------------------------------------ cold start
+    // (an instance that a full SQP has frozen keeps the multipliers of its last QP: keep)
     USV_DEV void init()
     {
         for (int k = 0; k <= N; k++) {
             const Planes W = ws(k);
             const double zb = zbar(k);
-            W.st(P_Z, 0.0);
-            W.st(P_ZB, zb);
-            if (k == 0) W.st(P_DX0, xlane ? P.x0[(long)b * NX + (lane - NU)] - zb : 0.0);
+            if (!keep) {
+                W.st(P_Z, 0.0);
+                W.st(P_ZB, zb);
+                if (k == 0) W.st(P_DX0, xlane ? P.x0[(long)b * NX + (lane - NU)] - zb : 0.0);
+            }
             BoxRow r;
             r.neutral();
             box_data(k, zb, r);
             r.tl = fmax(0.0 - r.dl, S.thr0); r.tu = fmax(r.du - 0.0, S.thr0);
             r.ll = S.mu0 / r.tl; r.lu = S.mu0 / r.tu;
             double pk[4];
-            if constexpr (PACK) box_pack(W, r, pk, true);
-            else box_store(W, r);
+            if constexpr (PACK) box_pack(W, r, pk, !keep);
+            else if (!keep) box_store(W, r);
             if constexpr (KCH > 0) {
                 sfor<0, KCH>([&](auto c) {
                     ObsRow o;
@@ -378,7 +382,7 @@ struct QpIpm {
                         o.tsl = fmax(0.0 - o.bsl, S.thr0); o.tsu = fmax(0.0 - o.bsu, S.thr0);
                         o.lsl = S.mu0 / o.tsl; o.lsu = S.mu0 / o.tsu;
                     }
-                    obs_store(W, c, o, (PACK && c == KCH - 1) ? pk : nullptr);
+                    if (!keep) obs_store(W, c, o, (PACK && c == KCH - 1) ? pk : nullptr);
                 });
             }
         }
@@ -605,7 +609,7 @@ struct QpIpm {
                 t -= isPX ? lx : (isPY ? ly : 0.0);
                 pik = xlane ? t : 0.0;
                 rg = (ulane && k < N) ? t : 0.0;
-                W.st(P_PI, rg + pik); // rg lives on the u lanes, pik on the x lanes
+                if (!keep) W.st(P_PI, rg + pik); // rg lives on the u lanes, pik on the x lanes
                 nm.rg = fmax(nm.rg, fabs(rg));
                 nm.nan = fma(0.0, t, nm.nan);
                 if (br.act) {
@@ -815,12 +819,114 @@ struct QpIpm {
         if (!FINAL) { S1 = lanes::gsum(s1); S2 = lanes::gsum(s2); }
     }
 
-    // ------------------------------------------------------------------ driver
-    USV_DEV void solve()
+    // ------------------------------------------------------------------ NLP residuals (full SQP only)
+    // Inf-norms of the KKT residuals of the NLP at the iterate the lineariser has just been run on, with the
+    // multipliers and slacks the previous QP left in the workspace (acados ocp_nlp_res_compute): because the
+    // QP is the linearisation AT this iterate, they are the QP's residuals at dz = 0.  first: no QP has been
+    // solved yet in this call, all multipliers / slacks are zero.  One backward sweep, no prefetching.
+    USV_DEV void nlp_residual(bool first, double *res) const
     {
+        double rg = 0.0, rbn = 0.0, rd = 0.0, rm = 0.0, pin = 0.0;
+        for (int k = N; k >= 0; k--) {
+            const Planes W = ws(k);
+            StageIn in;
+            in.zb = zbar(k);
+            sfor<0, 4>([&](auto e) { in.box[e] = 0.0; });
+            if constexpr (KCH > 0) sfor<0, KCH>([&](auto c) { sfor<0, OBSN>([&](auto e) { in.obs[c][e] = 0.0; }); });
+            if (!first) { // wave-uniform
+                if constexpr (PACK) {
+                    in.box[0] = (anydense && k < N) ? W.ld(P_BLL) : 0.0;
+                } else {
+                    in.box[0] = W.ld(P_BLL); in.box[1] = W.ld(P_BLU); in.box[2] = W.ld(P_BTL); in.box[3] = W.ld(P_BTU);
+                }
+                if constexpr (KCH > 0) {
+                    if (k >= 1 && k < N) {
+                        sfor<0, KCH>([&](auto c) { sfor<0, OBSN>([&](auto e) { in.obs[c][e] = W.ld(P_OBS + c * OBSN + e); }); });
+                    } else if (PACK && k == 0) {
+                        sfor<0, 4>([&](auto e) { in.obs[KCH - 1][e] = W.ld(P_OBS + (KCH - 1) * OBSN + e); });
+                    }
+                }
+            }
+            if constexpr (KCH > 0) {
+                if (k >= 1 && k < N) sfor<0, KCH>([&](auto c) { obs_raw<c>(k, in.raw[c]); });
+            }
+            double bat[NX], mpk[MP::NPK];
+            if (k < N) { mat_issue(k, mpk); mat_unpack(mpk, bat); }
+            else sfor<0, NX>([&](auto j) { bat[j] = 0.0; });
+            // rows: with no multipliers yet lambda = t = 0 (box_from / obs_from deliver 0 / 1 for inactive rows)
+            BoxRow br;
+            box_from(in, k, br);
+            if (first) { br.tl = 0.0; br.tu = 0.0; }
+            if (br.act) {
+                rd = fmax(rd, fmax(fabs(-br.dl - br.tl), fabs(br.du - br.tu)));
+                rm = fmax(rm, fmax(br.ll * br.tl, br.lu * br.tu));
+            }
+            double lx = 0.0, ly = 0.0;
+            if constexpr (KCH > 0) {
+                sfor<0, KCH>([&](auto c) {
+                    ObsRow o;
+                    double cx, cy;
+                    obs_from<c>(in, k, o, cx, cy);
+                    if (first) { o.tl = 0.0; o.tu = 0.0; if constexpr (SOFT) { o.tsl = 0.0; o.tsu = 0.0; } }
+                    if (o.act) {
+                        rd = fmax(rd, fmax(fabs(o.sl - o.dl - o.tl), fabs(o.du + o.su - o.tu)));
+                        rm = fmax(rm, fmax(o.ll * o.tl, o.lu * o.tu));
+                        lx += (o.ll - o.lu) * cx; ly += (o.ll - o.lu) * cy;
+                        if constexpr (SOFT) {
+                            rg = fmax(rg, fmax(fabs(o.Zl * o.sl + o.zl - o.ll - o.lsl), fabs(o.Zu * o.su + o.zu - o.lu - o.lsu)));
+                            rd = fmax(rd, fmax(fabs(o.sl - o.bsl - o.tsl), fabs(o.su - o.bsu - o.tsu)));
+                            rm = fmax(rm, fmax(o.lsl * o.tsl, o.lsu * o.tsu));
+                        }
+                    }
+                });
+                lx = lanes::gsum(lx); ly = lanes::gsum(ly);
+            }
+            // stationarity: g + [B A]' pi_{k+1} - C'(ll - lu) (- pi_k on the x lanes)
+            double t = Planes(P.gq, stride, N + 1, gl).ld(k);
+            sfor<0, NX>([&](auto j) {
+                if constexpr (!out_unit(j)) lanes::fma_bc<NU + j>(t, pin, bat[j]);
+            });
+            if constexpr (M::OUT_UNIT != 0u) t += ounit ? pin : 0.0;
+            t -= br.act ? br.ll - br.lu : 0.0;
+            t -= isPX ? lx : (isPY ? ly : 0.0);
+            const double pik = (xlane && !first) ? W.ld(P_PI) : 0.0;
+            if (xlane && k >= 1) rg = fmax(rg, fabs(t - pik));
+            if (ulane && k < N) rg = fmax(rg, fabs(t));
+            if (k < N) rbn = fmax(rbn, xlane ? fabs(Planes(P.rb0, stride, N, gl).ld(k)) : 0.0);
+            if (k == 0) rbn = fmax(rbn, xlane ? fabs(P.x0[(long)b * NX + (lane - NU)] - in.zb) : 0.0);
+            pin = pik;
+        }
+        res[0] = lanes::gmax(rg); res[1] = lanes::gmax(rbn); res[2] = lanes::gmax(rd); res[3] = lanes::gmax(rm);
+    }
+
+    // ------------------------------------------------------------------ driver
+    // phase 0: one SQP-RTI iteration.  phase 1 / 2: one iteration of the full SQP (first / later): test the NLP
+    // residuals, and unless the instance has converged (or finished earlier) solve the QP and take the step.
+    USV_DEV void solve(int phase)
+    {
+        bool frozen = false;
+        keep = false;
+        if (phase > 0) {
+            const bool real0 = g < S.B;
+            frozen = !real0 || P.sqp_state[b] >= 0;
+            if (!lanes::wave_any(!frozen)) return;
+            double nr[4];
+            nlp_residual(phase == 1, nr);
+            if (!frozen) {
+                const bool conv = nr[0] <= S.nlp_tol[0] && nr[1] <= S.nlp_tol[1] && nr[2] <= S.nlp_tol[2] && nr[3] <= S.nlp_tol[3];
+                if (lane == 0) {
+                    P.nlp_res[b * 4 + 0] = nr[0]; P.nlp_res[b * 4 + 1] = nr[1];
+                    P.nlp_res[b * 4 + 2] = nr[2]; P.nlp_res[b * 4 + 3] = nr[3];
+                    if (conv) P.sqp_state[b] = 0;
+                }
+                frozen = conv;
+            }
+            if (!lanes::wave_any(!frozen)) return;
+        }
+        keep = frozen;
         init();
         rbscale = 1.0;
-        bool done = false, pend = false;
+        bool done = frozen, pend = false;
         int status = 1, iters = 0;
         Norms nm;
         double res0 = 0, res1 = 0, res2 = 0, res3 = 0;
@@ -868,7 +974,7 @@ struct QpIpm {
         }
         // ---- RTI step + outputs
         const bool ok = (status == 0 || status == 1);
-        const bool real = g < S.B;
+        const bool real = g < S.B && !frozen;
         for (int k = 0; k <= N; k++) {
             const Planes W = ws(k);
             const double z = W.ld(P_Z);
@@ -896,6 +1002,11 @@ struct QpIpm {
             P.qp_iter[b] = iters;
             P.res[b * 4 + 0] = res0; P.res[b * 4 + 1] = res1; P.res[b * 4 + 2] = res2; P.res[b * 4 + 3] = res3;
             P.qp_status[b] = status;
+            if (phase > 0) {
+                P.sqp_iter[b] += 1;
+                if (!ok) P.sqp_state[b] = 4;
+                else lanes::count_one(P.sqp_running);
+            }
         }
     }
 };

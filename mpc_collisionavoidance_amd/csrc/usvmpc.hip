@@ -33,12 +33,24 @@ __global__ void __launch_bounds__(256, 2) usv_linearize(DevPtrs P, long ngroups)
 }
 
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK>
-__global__ void __launch_bounds__(64, 2) usv_qp_rti(DevPtrs P, long ngroups)
+__global__ void __launch_bounds__(64, 2) usv_qp_rti(DevPtrs P, long ngroups, int phase)
 {
     const long gid = lanes::group_linear();
     if (gid >= ngroups) return;
     QpIpm<M, KCH, SOFT, HDIAG, PACK> q(P, gid);
-    q.solve();
+    q.solve(phase);
+}
+
+// full SQP bookkeeping: start of a call (everything running) and end (still running = max iterations)
+__global__ void usv_sqp_begin(DevPtrs P, int B)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { P.sqp_state[i] = -1; P.sqp_iter[i] = 0; }
+}
+__global__ void usv_sqp_end(DevPtrs P, int B)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) P.status[i] = P.sqp_state[i] < 0 ? 2 : P.sqp_state[i];
 }
 
 // Closed-loop hand-over between two ticks, as the reference's callers do it on the host
@@ -191,6 +203,7 @@ int lookup(usvmpc_handle *h, const char *f, int stage, bool set, Field &o)
     else if (!set && s == "sl") o = {P.sl, h->K, N, 0};
     else if (!set && s == "su") o = {P.su, h->K, N, 0};
     else if (!set && s == "res") o = {P.res, 4, 1, 0};
+    else if (!set && s == "nlp_res") o = {P.nlp_res, 4, 1, 0};
     else {
         h->err = "unknown field '" + s + "'";
         return USVMPC_E_FIELD;
@@ -203,7 +216,8 @@ int copy_field(usvmpc_handle *h, const char *field, int stage, double *host, siz
     if (!h) return USVMPC_E_ARG;
     if (!host) { h->err = "null buffer"; return USVMPC_E_ARG; }
     Field f;
-    if (std::string(field ? field : "") == "res" || std::string(field ? field : "") == "x0" ||
+    if (std::string(field ? field : "") == "res" || std::string(field ? field : "") == "nlp_res" ||
+        std::string(field ? field : "") == "x0" ||
         std::string(field ? field : "") == "yref_e")
         stage = stage < 0 ? -1 : 0;
     int rc = lookup(h, field, stage, set, f);
@@ -239,7 +253,7 @@ int copy_field(usvmpc_handle *h, const char *field, int stage, double *host, siz
 }
 
 template <class M, int KCH, bool SOFT>
-int launch_pair(usvmpc_handle *h)
+int launch_pair(usvmpc_handle *h, int phase)
 {
     const long lin_groups = (long)(h->N + 1) * h->Bp;
     const long qp_groups = h->Bp;
@@ -247,7 +261,9 @@ int launch_pair(usvmpc_handle *h)
     const long lin_grid = (lin_groups * LANES + lin_block - 1) / lin_block;
     const long qp_grid = (qp_groups * LANES + qp_block - 1) / qp_block;
     hipEvent_t *ev = h->ev[h->nsolves % usvmpc_handle::RING];
-    if (h->sort_enabled && h->nsolves > 0) {
+    // (the later iterations of a full SQP read the multipliers the previous launch left in the group-indexed
+    // workspace: the group -> instance map must not change inside one SQP call)
+    if (h->sort_enabled && h->nsolves > 0 && phase != 2) {
         const int B = h->B;
         hipLaunchKernelGGL(usv_sort_hist, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_iter, B, h->d_hist);
         hipLaunchKernelGGL(usv_sort_scan, dim3(1), dim3(64), 0, h->stream, h->d_hist, h->d_cursor);
@@ -263,11 +279,11 @@ int launch_pair(usvmpc_handle *h)
     const bool pack = CANPACK && h->spec.boxpack != 0;
     const dim3 qg((unsigned)qp_grid), qb(qp_block);
     if (h->spec.hdiag) {
-        if (pack) hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, CANPACK>), qg, qb, 0, h->stream, h->ptrs, qp_groups);
-        else hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups);
+        if (pack) hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, CANPACK>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
+        else hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
     } else {
-        if (pack) hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, CANPACK>), qg, qb, 0, h->stream, h->ptrs, qp_groups);
-        else hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups);
+        if (pack) hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, CANPACK>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
+        else hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
     }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[2], h->stream));
@@ -291,18 +307,18 @@ int model_mat_planes(int model)
     return 0;
 }
 
-int launch(usvmpc_handle *h)
+int launch(usvmpc_handle *h, int phase = 0)
 {
     switch (h->desc.model) {
 #ifndef USV_GEN_ONLY
-    case USVMPC_MODEL_USV: return launch_pair<ModelM0, 0, false>(h);
+    case USVMPC_MODEL_USV: return launch_pair<ModelM0, 0, false>(h, phase);
     case USVMPC_MODEL_GUIDANCE_CA1:
-        return h->kch <= 1 ? launch_pair<ModelM1, 1, true>(h) : launch_pair<ModelM1, 2, true>(h);
+        return h->kch <= 1 ? launch_pair<ModelM1, 1, true>(h, phase) : launch_pair<ModelM1, 2, true>(h, phase);
     case USVMPC_MODEL_PF_CA:
-        return h->kch <= 1 ? launch_pair<ModelM2, 1, false>(h) : launch_pair<ModelM2, 2, false>(h);
+        return h->kch <= 1 ? launch_pair<ModelM2, 1, false>(h, phase) : launch_pair<ModelM2, 2, false>(h, phase);
 #endif
 #ifdef USV_GEN_MODEL_HEADER
-    case USVMPC_MODEL_GENERATED: return launch_pair<ModelGen, USV_GEN_KCH, (USV_GEN_SOFT != 0)>(h);
+    case USVMPC_MODEL_GENERATED: return launch_pair<ModelGen, USV_GEN_KCH, (USV_GEN_SOFT != 0)>(h, phase);
 #endif
     }
     h->err = "unknown model";
@@ -410,6 +426,10 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     TRY_C(dev_alloc(h, &P.qp_iter, B, true));
     TRY_C(dev_alloc(h, &P.qp_status, B, true));
     TRY_C(dev_alloc(h, &P.res, B * 4, true));
+    TRY_C(dev_alloc(h, &P.nlp_res, B * 4, true));
+    TRY_C(dev_alloc(h, &P.sqp_iter, B, true));
+    TRY_C(dev_alloc(h, &P.sqp_state, B, true));
+    TRY_C(dev_alloc(h, &P.sqp_running, 1, true));
     TRY_C(dev_alloc(h, &h->d_perm, B, true));
     TRY_C(dev_alloc(h, &h->d_hist, SORT_BINS, true));
     TRY_C(dev_alloc(h, &h->d_cursor, SORT_BINS, true));
@@ -454,7 +474,8 @@ int usvmpc_get_int(usvmpc_handle *h, const char *field, int *out)
 {
     if (!h || !out) return USVMPC_E_ARG;
     const std::string s(field ? field : "");
-    const int *src = s == "status" ? h->ptrs.status : s == "qp_iter" ? h->ptrs.qp_iter : s == "qp_status" ? h->ptrs.qp_status : nullptr;
+    const int *src = s == "status" ? h->ptrs.status : s == "qp_iter" ? h->ptrs.qp_iter : s == "qp_status" ? h->ptrs.qp_status
+                     : s == "sqp_iter" ? h->ptrs.sqp_iter : nullptr;
     if (!src) { h->err = "unknown integer field '" + s + "'"; return USVMPC_E_FIELD; }
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(out, src, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -488,6 +509,37 @@ int usvmpc_solve(usvmpc_handle *h, int *status)
         rc = usvmpc_get_int(h, "status", status);
         if (rc) return rc;
         for (int b = 0; b < h->B; b++) worst = status[b] > worst ? status[b] : worst;
+    }
+    return worst;
+}
+
+int usvmpc_solve_sqp(usvmpc_handle *h, int *status)
+{
+    if (!h) return USVMPC_E_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int B = h->B;
+    const int max_iter = h->desc.nlp_max_iter > 0 ? h->desc.nlp_max_iter : 100;
+    hipLaunchKernelGGL(usv_sqp_begin, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs, B);
+    HIP_TRY(h, hipGetLastError());
+    for (int it = 0; it < max_iter; it++) {
+        HIP_TRY(h, hipMemsetAsync(h->ptrs.sqp_running, 0, sizeof(int), h->stream));
+        // the very first launch of a handle has no multipliers yet; afterwards the workspace holds those of the
+        // last QP of every instance (acados likewise keeps nlp_out between calls)
+        const int rc = launch(h, (it == 0 && h->nsolves == 0) ? 1 : 2);
+        if (rc) return rc;
+        int running = 0;
+        HIP_TRY(h, hipMemcpyAsync(&running, h->ptrs.sqp_running, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (running == 0) break; // every instance has converged or failed
+    }
+    hipLaunchKernelGGL(usv_sqp_end, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs, B);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    int worst = 0;
+    if (status) {
+        const int rc = usvmpc_get_int(h, "status", status);
+        if (rc) return rc;
+        for (int b = 0; b < B; b++) worst = status[b] > worst ? status[b] : worst;
     }
     return worst;
 }

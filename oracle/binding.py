@@ -38,7 +38,7 @@ class Spec(C.Structure):
                 ("uh", C.c_double * KM), ("soft", C.c_int),
                 ("lsh", C.c_double * KM), ("ush", C.c_double * KM),
                 ("zl", C.c_double * KM), ("zu", C.c_double * KM), ("Zl", C.c_double * KM), ("Zu", C.c_double * KM),
-                ("opts", Opts)]
+                ("opts", Opts), ("sim_steps", C.c_int), ("nlp_max_iter", C.c_int), ("nlp_tol", C.c_double * 4)]
 
 
 class Qp(C.Structure):
@@ -97,6 +97,9 @@ def lib():
         L.usv_qp_solve.argtypes = [C.POINTER(Qp), C.POINTER(Opts), C.POINTER(QpSol)]
         L.usv_rti.argtypes = [C.POINTER(Spec)] + [_dp] * 11
         L.usv_rti_batch.argtypes = [C.POINTER(Spec), C.c_int] + [_dp] * 7 + [_ip, _ip]
+        L.usv_erk_sens.argtypes = [C.c_int, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _dp]
+        L.usv_erk_sens.restype = None
+        L.usv_sqp_batch.argtypes = [C.POINTER(Spec), C.c_int] + [_dp] * 7 + [_ip, _ip, _dp]
         L.usv_rti_batch_mt.argtypes = [C.POINTER(Spec), C.c_int] + [_dp] * 7 + [_ip, _ip, C.c_int]
         L.usv_oracle_register_generated.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.usv_oracle_register_generated.restype = None
@@ -131,7 +134,13 @@ def spec(model, N, Tf, K=0, **opts):
     if lib().usv_spec_defaults(C.byref(s), model, N, float(Tf), K) != 0:
         raise ValueError("bad spec")
     for k, v in opts.items():
-        setattr(s.opts, k, v)
+        if k in ("sim_steps", "nlp_max_iter"):
+            setattr(s, k, int(v))
+        elif k == "nlp_tol":
+            for i in range(4):
+                s.nlp_tol[i] = float(v[i] if np.ndim(v) else v)
+        else:
+            setattr(s.opts, k, v)
     return s
 
 
@@ -238,6 +247,26 @@ def rti_batch(s, x, u, x0, yref, yref_e, p, lh, threads=1):
         lib().usv_rti_batch_mt(C.byref(s), B, _d(x), _d(u), _d(x0), _d(yref), _d(yref_e), _d(p), _d(lh),
                                status.ctypes.data_as(_ip), it.ctypes.data_as(_ip), int(threads))
     return status, it
+
+
+def erk_sens(model, dt, steps, x, u):
+    nx, nu = dims(model)
+    x, u = _arr(x), _arr(u if nu else np.zeros(1))
+    xn, A, B = np.zeros(nx), np.zeros((nx, nx)), np.zeros((nx, max(nu, 1)))
+    lib().usv_erk_sens(model, float(dt), int(steps), _d(x), _d(u), _d(xn), _d(A), _d(B))
+    return xn, A, B[:, :nu]
+
+
+def sqp_batch(s, x, u, x0, yref, yref_e, p, lh):
+    """In-place batched full SQP; returns (status, sqp_iter, nlp_res[B,4])."""
+    B = x.shape[0]
+    for a in (x, u):
+        assert a.dtype == np.float64 and a.flags.c_contiguous
+    x0, yref, yref_e, p, lh = map(_arr, (x0, yref, yref_e, p, lh))
+    status, it, res = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32), np.zeros((B, 4))
+    lib().usv_sqp_batch(C.byref(s), B, _d(x), _d(u), _d(x0), _d(yref), _d(yref_e), _d(p), _d(lh),
+                        status.ctypes.data_as(_ip), it.ctypes.data_as(_ip), _d(res))
+    return status, it, res
 
 
 # ---- reference ROS-node arithmetic either side of the solve (usv_guidance_oracle.c)

@@ -284,38 +284,51 @@ static void vde(int model, int nx, int nu, const double *x, const double *S, con
         }
 }
 
+/* one RK4 step of the augmented system, in place on (x, S) */
+static void rk4_step(int model, int nx, int nu, double h, double *x, double *S, const double *u)
+{
+    const int nz = nx + nu, ns = nx * nz;
+    int i;
+    double xs[NXM], Ss[NXM * NZM];
+    double k1x[NXM], k2x[NXM], k3x[NXM], k4x[NXM];
+    double k1S[NXM * NZM], k2S[NXM * NZM], k3S[NXM * NZM], k4S[NXM * NZM];
+    vde(model, nx, nu, x, S, u, k1x, k1S);
+    for (i = 0; i < nx; i++) xs[i] = x[i] + 0.5 * h * k1x[i];
+    for (i = 0; i < ns; i++) Ss[i] = S[i] + 0.5 * h * k1S[i];
+    vde(model, nx, nu, xs, Ss, u, k2x, k2S);
+    for (i = 0; i < nx; i++) xs[i] = x[i] + 0.5 * h * k2x[i];
+    for (i = 0; i < ns; i++) Ss[i] = S[i] + 0.5 * h * k2S[i];
+    vde(model, nx, nu, xs, Ss, u, k3x, k3S);
+    for (i = 0; i < nx; i++) xs[i] = x[i] + h * k3x[i];
+    for (i = 0; i < ns; i++) Ss[i] = S[i] + h * k3S[i];
+    vde(model, nx, nu, xs, Ss, u, k4x, k4S);
+    for (i = 0; i < nx; i++) x[i] += h / 6.0 * (k1x[i] + 2.0 * k2x[i] + 2.0 * k3x[i] + k4x[i]);
+    for (i = 0; i < ns; i++) S[i] += h / 6.0 * (k1S[i] + 2.0 * k2S[i] + 2.0 * k3S[i] + k4S[i]);
+}
+
+/* `steps` RK4 steps of size dt/steps over one shooting interval (acados sim_method_num_steps) */
+void usv_erk_sens(int model, double dt, int steps, const double *x, const double *u, double *xn,
+                  double *A, double *B)
+{
+    int nx, nu, nz, i, j, n;
+    double S[NXM * NZM];
+    usv_model_dims(model, &nx, &nu);
+    nz = nx + nu;
+    if (steps < 1) steps = 1;
+    for (i = 0; i < nx * nz; i++) S[i] = 0.0;
+    for (i = 0; i < nx; i++) { S[i * nz + i] = 1.0; xn[i] = x[i]; }
+    for (n = 0; n < steps; n++) rk4_step(model, nx, nu, dt / steps, xn, S, u);
+    for (i = 0; i < nx; i++)
+        for (j = 0; j < nz; j++) {
+            if (j < nx) A[i * nx + j] = S[i * nz + j];
+            else B[i * nu + (j - nx)] = S[i * nz + j];
+        }
+}
+
 void usv_rk4_sens(int model, double dt, const double *x, const double *u, double *xn, double *A,
                   double *B)
 {
-    int nx, nu, nz, i, j, n, ns;
-    double S0[NXM * NZM], xs[NXM], Ss[NXM * NZM];
-    double k1x[NXM], k2x[NXM], k3x[NXM], k4x[NXM];
-    double k1S[NXM * NZM], k2S[NXM * NZM], k3S[NXM * NZM], k4S[NXM * NZM];
-    usv_model_dims(model, &nx, &nu);
-    nz = nx + nu;
-    ns = nx * nz;
-    for (i = 0; i < ns; i++) S0[i] = 0.0;
-    for (i = 0; i < nx; i++) S0[i * nz + i] = 1.0;
-    vde(model, nx, nu, x, S0, u, k1x, k1S);
-    for (i = 0; i < nx; i++) xs[i] = x[i] + 0.5 * dt * k1x[i];
-    for (i = 0; i < ns; i++) Ss[i] = S0[i] + 0.5 * dt * k1S[i];
-    vde(model, nx, nu, xs, Ss, u, k2x, k2S);
-    for (i = 0; i < nx; i++) xs[i] = x[i] + 0.5 * dt * k2x[i];
-    for (i = 0; i < ns; i++) Ss[i] = S0[i] + 0.5 * dt * k2S[i];
-    vde(model, nx, nu, xs, Ss, u, k3x, k3S);
-    for (i = 0; i < nx; i++) xs[i] = x[i] + dt * k3x[i];
-    for (i = 0; i < ns; i++) Ss[i] = S0[i] + dt * k3S[i];
-    vde(model, nx, nu, xs, Ss, u, k4x, k4S);
-    for (i = 0; i < nx; i++) xn[i] = x[i] + dt / 6.0 * (k1x[i] + 2.0 * k2x[i] + 2.0 * k3x[i] + k4x[i]);
-    for (i = 0; i < nx; i++)
-        for (j = 0; j < nz; j++) {
-            n = i * nz + j;
-            {
-                const double s = S0[n] + dt / 6.0 * (k1S[n] + 2.0 * k2S[n] + 2.0 * k3S[n] + k4S[n]);
-                if (j < nx) A[i * nx + j] = s;
-                else B[i * nu + (j - nx)] = s;
-            }
-        }
+    usv_erk_sens(model, dt, 1, x, u, xn, A, B);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -351,6 +364,9 @@ int usv_spec_defaults(usv_spec *s, int model, int N, double Tf, int K)
     s->ny = nx + nu;
     s->ny_e = nx;
     usv_opts_defaults(&s->opts);
+    s->sim_steps = 1;
+    s->nlp_max_iter = 100;
+    s->nlp_tol[0] = s->nlp_tol[1] = s->nlp_tol[2] = s->nlp_tol[3] = 1e-6;
     /* Vx = [I;0], Vx_e = I : e.g. usv_guidance_ca1/acados_settings.py:92-103 */
     for (i = 0; i < nx; i++) {
         s->Vx[i * nx + i] = 1.0;
@@ -523,7 +539,7 @@ void usv_linearize(const usv_spec *s, const double *x, const double *u, const do
     for (i = 0; i < nx; i++) q->dx0[i] = x0[i] - x[i];
     for (k = 0; k < N; k++) {
         double xn[NXM];
-        usv_rk4_sens(s->model, s->dt, x + k * nx, u + k * nu, xn, q->A + (size_t)k * nx * nx,
+        usv_erk_sens(s->model, s->dt, s->sim_steps, x + k * nx, u + k * nu, xn, q->A + (size_t)k * nx * nx,
                      q->B + (size_t)k * nx * nu);
         for (i = 0; i < nx; i++) q->b[k * nx + i] = xn[i] - x[(k + 1) * nx + i];
         ls_cost(nx, nu, ny, s->dt, s->W, s->Vx, s->Vu, x + k * nx, u + k * nu, yref + k * ny,
@@ -1153,6 +1169,150 @@ int usv_qp_solve(const usv_qp *q, const usv_opts *o, usv_qp_sol *sol)
     free(w.st);
     (void)nu;
     return status;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * 5b. Pieces of the full SQP (acados ocp_nlp_sqp + ocp_nlp_res_compute restated).
+ * ---------------------------------------------------------------------------------------- */
+static void load_rows(ipm_ws *w, const usv_qp_sol *sol)
+{
+    const usv_qp *q = w->q;
+    const int N = q->N, K = q->K;
+    int k, i;
+    for (k = 0; k <= N; k++) {
+        stage_t *s = &w->st[k];
+        int m = 0;
+        if (k < N)
+            for (i = 0; i < q->nbu; i++, m++) {
+                s->r[m].ll = sol->lam_bu[k * 2 * q->nbu + i]; s->r[m].lu = sol->lam_bu[k * 2 * q->nbu + q->nbu + i];
+                s->r[m].tl = sol->t_bu[k * 2 * q->nbu + i]; s->r[m].tu = sol->t_bu[k * 2 * q->nbu + q->nbu + i];
+            }
+        if (k >= 1 && k < N) {
+            for (i = 0; i < q->nbx; i++, m++) {
+                s->r[m].ll = sol->lam_bx[k * 2 * q->nbx + i]; s->r[m].lu = sol->lam_bx[k * 2 * q->nbx + q->nbx + i];
+                s->r[m].tl = sol->t_bx[k * 2 * q->nbx + i]; s->r[m].tu = sol->t_bx[k * 2 * q->nbx + q->nbx + i];
+            }
+            for (i = 0; i < K; i++, m++) {
+                s->r[m].ll = sol->lam_g[k * 2 * K + i]; s->r[m].lu = sol->lam_g[k * 2 * K + K + i];
+                s->r[m].tl = sol->t_g[k * 2 * K + i]; s->r[m].tu = sol->t_g[k * 2 * K + K + i];
+                s->r[m].sl = sol->sl[k * K + i]; s->r[m].su = sol->su[k * K + i];
+                s->r[m].lsl = sol->lam_s[k * 2 * K + i]; s->r[m].lsu = sol->lam_s[k * 2 * K + K + i];
+                s->r[m].tsl = sol->t_s[k * 2 * K + i]; s->r[m].tsu = sol->t_s[k * 2 * K + K + i];
+            }
+        }
+    }
+}
+
+/* Dynamics multipliers by the adjoint recursion pi_k = (H z + g - C'(ll - lu))_x + A_k' pi_{k+1} at the QP
+ * solution held in `sol` (what the device kernel carries instead of pi += alpha dpi; the two agree to the QP's
+ * stationarity tolerance).  Overwrites sol->pi. */
+void usv_qp_adjoint_pi(const usv_qp *q, usv_qp_sol *sol)
+{
+    const int N = q->N, nx = q->nx, nu = q->nu, nz = q->nz;
+    ipm_ws w;
+    int k, i, j;
+    w.q = q;
+    w.st = (stage_t *)calloc((size_t)N + 1, sizeof(stage_t));
+    build_rows(&w);
+    load_rows(&w, sol);
+    for (k = N; k >= 1; k--) {
+        stage_t *s = &w.st[k];
+        const double *H = q->H + (size_t)k * nz * nz;
+        const double *z = sol->dz + (size_t)k * nz;
+        double t[NZM];
+        for (i = 0; i < nz; i++) {
+            double a = q->g[k * nz + i];
+            for (j = 0; j < nz; j++) a += H[i * nz + j] * z[j];
+            t[i] = a;
+        }
+        if (k < N) {
+            const double *A = q->A + (size_t)k * nx * nx;
+            for (j = 0; j < nx; j++)
+                for (i = 0; i < nx; i++) t[nu + j] += A[i * nx + j] * sol->pi[(k + 1) * nx + i];
+        }
+        for (i = 0; i < s->m; i++) row_axpy(&s->r[i], -(s->r[i].ll - s->r[i].lu), t);
+        for (i = 0; i < nx; i++) sol->pi[k * nx + i] = t[nu + i];
+    }
+    free(w.st);
+}
+
+/* NLP residuals (inf-norms: stationarity, dynamics, inequality, complementarity) of the iterate the QP `q`
+ * was linearised at, with the multipliers / slacks of `sol` (the previous QP; NULL = all zero, first iteration). */
+void usv_nlp_residuals(const usv_qp *q, const usv_qp_sol *sol, double *res)
+{
+    const int N = q->N, nx = q->nx;
+    ipm_ws w;
+    int k, i;
+    w.q = q;
+    w.st = (stage_t *)calloc((size_t)N + 1, sizeof(stage_t));
+    build_rows(&w);
+    if (sol) {
+        load_rows(&w, sol);
+        for (k = 1; k <= N; k++)
+            for (i = 0; i < nx; i++) w.st[k].pi[i] = sol->pi[k * nx + i];
+    }
+    residuals(&w); /* z = 0: the QP residual at the origin IS the NLP residual of the linearisation point */
+    for (i = 0; i < 4; i++) res[i] = w.res[i];
+    free(w.st);
+}
+
+/* Full SQP on one instance: linearise, test the NLP residuals, solve the QP, full step; acados status
+ * (0 converged, 2 max iter, 4 QP failure).  info[8] = {sqp_iter, last qp_status, res_stat, res_eq, res_ineq,
+ * res_comp, total qp iterations, 0}. */
+int usv_sqp(const usv_spec *s, double *x, double *u, const double *x0, const double *yref,
+            const double *yref_e, const double *p, const double *lh, double *info)
+{
+    const int N = s->N, nx = s->nx, nu = s->nu, nz = nx + nu;
+    usv_qp *q = usv_qp_alloc(s);
+    usv_qp_sol *sol = usv_qp_sol_alloc(q);
+    int k, i, it, status = 2, qs = 0, have = 0, qpit = 0;
+    double res[4] = {0, 0, 0, 0};
+    const int max_iter = s->nlp_max_iter > 0 ? s->nlp_max_iter : 100;
+    for (it = 0; it < max_iter; it++) {
+        usv_linearize(s, x, u, x0, yref, yref_e, p, lh, q);
+        usv_nlp_residuals(q, have ? sol : NULL, res);
+        if (res[0] <= s->nlp_tol[0] && res[1] <= s->nlp_tol[1] && res[2] <= s->nlp_tol[2] && res[3] <= s->nlp_tol[3]) {
+            status = 0;
+            break;
+        }
+        qs = usv_qp_solve(q, &s->opts, sol);
+        qpit += sol->iter;
+        if (!(qs == 0 || qs == 1)) { status = 4; break; }
+        usv_qp_adjoint_pi(q, sol);
+        have = 1;
+        for (k = 0; k <= N; k++) {
+            for (i = 0; i < nx; i++) x[k * nx + i] += sol->dz[k * nz + nu + i];
+            if (k < N)
+                for (i = 0; i < nu; i++) u[k * nu + i] += sol->dz[k * nz + i];
+        }
+    }
+    if (info) {
+        info[0] = it; info[1] = qs;
+        for (i = 0; i < 4; i++) info[2 + i] = res[i];
+        info[6] = qpit; info[7] = 0;
+    }
+    usv_qp_sol_free(sol);
+    usv_qp_free(q);
+    return status;
+}
+
+int usv_sqp_batch(const usv_spec *s, int B, double *x, double *u, const double *x0,
+                  const double *yref, const double *yref_e, const double *p, const double *lh,
+                  int *status, int *sqp_iter, double *res)
+{
+    const int N = s->N, nx = s->nx, nu = s->nu, K = s->K;
+    int b, worst = 0;
+    for (b = 0; b < B; b++) {
+        double info[8];
+        const int st = usv_sqp(s, x + (size_t)b * (N + 1) * nx, u + (size_t)b * N * nu, x0 + (size_t)b * nx,
+                               yref + (size_t)b * N * s->ny, yref_e + (size_t)b * s->ny_e,
+                               p + (size_t)b * (N + 1) * 2 * K, lh + (size_t)b * N * K, info);
+        if (status) status[b] = st;
+        if (sqp_iter) sqp_iter[b] = (int)info[0];
+        if (res) { res[b * 4 + 0] = info[2]; res[b * 4 + 1] = info[3]; res[b * 4 + 2] = info[4]; res[b * 4 + 3] = info[5]; }
+        if (st > worst) worst = st;
+    }
+    return worst;
 }
 
 /* ------------------------------------------------------------------------------------------

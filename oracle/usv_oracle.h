@@ -90,6 +90,9 @@ typedef struct usv_spec {
     double lsh[USV_K_MAX], ush[USV_K_MAX];
     double zl[USV_K_MAX], zu[USV_K_MAX], Zl[USV_K_MAX], Zu[USV_K_MAX];
     usv_opts opts;
+    int sim_steps;        /* RK4 steps per shooting interval (sim_method_num_steps); 0 = 1 */
+    int nlp_max_iter;     /* full SQP only (nlp_solver_max_iter); 0 = 100 */
+    double nlp_tol[4];    /* full SQP only: stat, eq, ineq, comp (acados default 1e-6 each) */
 } usv_spec;
 
 /* Fill `s` with the reference's OCP definition for `model` (weights, selectors, bounds, soft
@@ -108,6 +111,10 @@ void usv_model_pos_idx(int model, int *ipx, int *ipy);
 void usv_model_h(int model, int K, const double *x, const double *p, double *h, double *Cxy);
 /* one RK4 step with forward sensitivities: xn[nx], A[nx*nx], B[nx*nu] (row-major) */
 void usv_rk4_sens(int model, double dt, const double *x, const double *u,
+                  double *xn, double *A, double *B);
+
+/* the same with `steps` RK4 steps of size dt/steps */
+void usv_erk_sens(int model, double dt, int steps, const double *x, const double *u,
                   double *xn, double *A, double *B);
 
 /* ---- dense OCP-QP of one RTI iteration (uniform stage dims, [u;x] ordering) ---- */
@@ -155,6 +162,16 @@ int usv_qp_solve(const usv_qp *q, const usv_opts *o, usv_qp_sol *sol);
 int usv_rti(const usv_spec *s, double *x, double *u, const double *x0,
             const double *yref, const double *yref_e, const double *p, const double *lh,
             double *sl, double *su, double *pi, double *info);
+
+/* ---- full SQP (nlp_solver_type = "SQP": S/race_cars/acados_settings_dev.py:157-164; commented knobs
+ * S/usv_guidance_ca1/acados_settings.py:192-204) ---- */
+void usv_qp_adjoint_pi(const usv_qp *q, usv_qp_sol *sol);
+void usv_nlp_residuals(const usv_qp *q, const usv_qp_sol *sol, double *res);
+int usv_sqp(const usv_spec *s, double *x, double *u, const double *x0,
+            const double *yref, const double *yref_e, const double *p, const double *lh, double *info);
+int usv_sqp_batch(const usv_spec *s, int B, double *x, double *u, const double *x0,
+                  const double *yref, const double *yref_e, const double *p, const double *lh,
+                  int *status, int *sqp_iter, double *res);
 
 /* Batch driver used as the CPU baseline: instance b uses the b-th slice of every array. */
 int usv_rti_batch(const usv_spec *s, int B, double *x, double *u, const double *x0,

@@ -37,4 +37,5 @@ def emu():
     lib = C.CDLL(out)
     dp, ip = _capi._dp, _capi._ip
     lib.usv_emu_solve.argtypes = [C.POINTER(_capi.Desc)] + [dp] * 10 + [ip] * 3 + [dp] * 4
+    lib.usv_emu_sqp.argtypes = [C.POINTER(_capi.Desc)] + [dp] * 10 + [ip] * 3 + [dp] + [ip] + [dp]
     return lib

@@ -101,7 +101,7 @@ namespace {
 
 using namespace usv;
 
-struct Job { const DevPtrs *P; long gid; };
+struct Job { const DevPtrs *P; long gid; int qp_phase; };
 
 template <class M, int KCH, bool SOFT>
 void lin_body(void *a)
@@ -114,7 +114,7 @@ void qp_body(void *a)
 {
     Job *j = (Job *)a;
     QpIpm<M, KCH, SOFT, HDIAG, PACK> q(*j->P, j->gid);
-    q.solve();
+    q.solve(j->qp_phase);
 }
 
 double *g_dbg_BAt = nullptr; // [N][nx][Bp*16]: the packed planes expanded back to one plane per row (inspection)
@@ -143,17 +143,17 @@ void expand_packed(const DevPtrs &P, const DevSpec &S)
 }
 
 template <class M, int KCH, bool SOFT>
-void run_all(const DevPtrs &P, const DevSpec &S, int phase)
+void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
 {
     if (phase & 1)
         for (long gid = 0; gid < (long)(S.N + 1) * S.Bp; gid++) {
-            Job j{&P, gid};
+            Job j{&P, gid, 0};
             lanes::run_group(gid, &lin_body<M, KCH, SOFT>, &j);
         }
     if ((phase & 1) && g_dbg_BAt) expand_packed<M>(P, S);
     if (phase & 2)
         for (long g = 0; g < S.Bp; g++) {
-            Job j{&P, g};
+            Job j{&P, g, qp_phase};
             constexpr bool CANPACK = KCH > 0;
             const bool pack = CANPACK && S.boxpack != 0;
             if (S.hdiag) lanes::run_group(g, pack ? &qp_body<M, KCH, SOFT, true, CANPACK> : &qp_body<M, KCH, SOFT, true, false>, &j);
@@ -163,14 +163,15 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase)
 
 } // namespace
 
-// One RTI iteration of every instance on the emulator. Arrays as in include/usvmpc.h (host).
+// One RTI iteration (sqp = 0) or a full SQP run (sqp = 1: the host loop of usvmpc_solve_sqp) of every instance
+// on the emulator. Arrays as in include/usvmpc.h (host).
 // dbg (optional, may be NULL) receives the linearisation planes for inspection:
 // BAt [N][nx][Bp*16], rb0 [N][Bp*16], gq [N+1][Bp*16].
-extern "C" int usv_emu_solve(const usvmpc_desc *d, double *x, double *u, const double *x0,
-                             const double *yref, const double *yref_e, const double *p,
-                             const double *lh, double *sl, double *su, double *pi, int *status,
-                             int *qp_status, int *qp_iter, double *res, double *dbg_BAt,
-                             double *dbg_rb0, double *dbg_gq)
+static int emu_run(const usvmpc_desc *d, int sqp, double *x, double *u, const double *x0,
+                   const double *yref, const double *yref_e, const double *p,
+                   const double *lh, double *sl, double *su, double *pi, int *status,
+                   int *qp_status, int *qp_iter, double *res, double *dbg_BAt,
+                   double *dbg_rb0, double *dbg_gq, int *sqp_iter, double *nlp_res)
 {
     DevSpec S;
     const std::string err = build_spec(*d, S);
@@ -180,7 +181,7 @@ extern "C" int usv_emu_solve(const usvmpc_desc *d, double *x, double *u, const d
     }
     int nx, nu;
     model_dims(d->model, nx, nu);
-    const int nz = nx + nu, N = S.N;
+    const int N = S.N;
     int kch = (S.K + LANES - 1) / LANES;
     bool soft = d->soft != 0;
 #ifdef USV_GEN_MODEL_HEADER
@@ -189,30 +190,75 @@ extern "C" int usv_emu_solve(const usvmpc_desc *d, double *x, double *u, const d
     const long stride = (long)S.Bp * LANES;
     std::vector<double> BAp((size_t)N * 16 * stride), rb0((size_t)N * stride), // 16 >= MatPack::NPK of any model
         gq((size_t)(N + 1) * stride),
-        ws((size_t)(N + 1) * ws_planes(nx, nu, kch, soft) * stride);
+        ws((size_t)(N + 1) * ws_planes(nx, nu, kch, soft) * stride), nres((size_t)S.B * 4);
+    std::vector<int> sit(S.B, 0), sstate(S.B, -1);
+    int running = 0;
     DevPtrs P;
     std::memset(&P, 0, sizeof(P));
     P.spec = &S;
     P.x = x; P.u = u; P.x0 = x0; P.yref = yref; P.yref_e = yref_e; P.p = p; P.lh = lh;
     P.sl = sl; P.su = su; P.pi = pi; P.status = status; P.qp_iter = qp_iter; P.qp_status = qp_status; P.res = res;
     P.BAp = BAp.data(); P.rb0 = rb0.data(); P.gq = gq.data(); P.ws = ws.data();
-    const int phase = 3;
+    P.nlp_res = nres.data(); P.sqp_iter = sit.data(); P.sqp_state = sstate.data(); P.sqp_running = &running;
     g_dbg_BAt = dbg_BAt;
+    auto one = [&](int qp_phase) -> int {
+        const int phase = 3;
 #ifdef USV_GEN_MODEL_HEADER
-    if (d->model == USVMPC_MODEL_GENERATED) run_all<ModelGen, USV_GEN_KCH, (USV_GEN_SOFT != 0)>(P, S, phase);
-    else
+        if (d->model == USVMPC_MODEL_GENERATED) { run_all<ModelGen, USV_GEN_KCH, (USV_GEN_SOFT != 0)>(P, S, phase, qp_phase); return 0; }
 #endif
-    if (d->model == USVMPC_MODEL_USV) run_all<ModelM0, 0, false>(P, S, phase);
-    else if (d->model == USVMPC_MODEL_GUIDANCE_CA1) {
-        if (!soft) return -2;
-        if (kch <= 1) run_all<ModelM1, 1, true>(P, S, phase);
-        else run_all<ModelM1, 2, true>(P, S, phase);
+#ifndef USV_GEN_ONLY
+        if (d->model == USVMPC_MODEL_USV) run_all<ModelM0, 0, false>(P, S, phase, qp_phase);
+        else if (d->model == USVMPC_MODEL_GUIDANCE_CA1) {
+            if (!soft) return -2;
+            if (kch <= 1) run_all<ModelM1, 1, true>(P, S, phase, qp_phase);
+            else run_all<ModelM1, 2, true>(P, S, phase, qp_phase);
+        } else if (d->model == USVMPC_MODEL_PF_CA) {
+            if (soft) return -2;
+            if (kch <= 1) run_all<ModelM2, 1, false>(P, S, phase, qp_phase);
+            else run_all<ModelM2, 2, false>(P, S, phase, qp_phase);
+        } else return -3;
+        return 0;
+#else
+        return -3;
+#endif
+    };
+    if (!sqp) {
+        const int rc = one(0);
+        if (rc) return rc;
     } else {
-        if (soft) return -2;
-        if (kch <= 1) run_all<ModelM2, 1, false>(P, S, phase);
-        else run_all<ModelM2, 2, false>(P, S, phase);
+        const int max_iter = d->nlp_max_iter > 0 ? d->nlp_max_iter : 100;
+        for (int it = 0; it < max_iter; it++) {
+            running = 0;
+            const int rc = one(it == 0 ? 1 : 2);
+            if (rc) return rc;
+            if (running == 0) break;
+        }
+        for (int b = 0; b < S.B; b++) {
+            status[b] = sstate[b] < 0 ? 2 : sstate[b];
+            if (sqp_iter) sqp_iter[b] = sit[b];
+            if (nlp_res) std::memcpy(nlp_res + (size_t)b * 4, nres.data() + (size_t)b * 4, 4 * sizeof(double));
+        }
     }
     if (dbg_rb0) std::memcpy(dbg_rb0, rb0.data(), rb0.size() * sizeof(double));
     if (dbg_gq) std::memcpy(dbg_gq, gq.data(), gq.size() * sizeof(double));
     return 0;
+}
+
+extern "C" int usv_emu_solve(const usvmpc_desc *d, double *x, double *u, const double *x0,
+                             const double *yref, const double *yref_e, const double *p,
+                             const double *lh, double *sl, double *su, double *pi, int *status,
+                             int *qp_status, int *qp_iter, double *res, double *dbg_BAt,
+                             double *dbg_rb0, double *dbg_gq)
+{
+    return emu_run(d, 0, x, u, x0, yref, yref_e, p, lh, sl, su, pi, status, qp_status, qp_iter, res, dbg_BAt, dbg_rb0,
+                   dbg_gq, nullptr, nullptr);
+}
+
+extern "C" int usv_emu_sqp(const usvmpc_desc *d, double *x, double *u, const double *x0,
+                           const double *yref, const double *yref_e, const double *p,
+                           const double *lh, double *sl, double *su, double *pi, int *status,
+                           int *qp_status, int *qp_iter, double *res, int *sqp_iter, double *nlp_res)
+{
+    return emu_run(d, 1, x, u, x0, yref, yref_e, p, lh, sl, su, pi, status, qp_status, qp_iter, res, nullptr, nullptr,
+                   nullptr, sqp_iter, nlp_res);
 }

@@ -83,7 +83,7 @@ def test_validation_errors_like_acados():
     with pytest.raises(Exception, match="mismatching dimension"):
         _capi.desc_from_ocp(ocp)
     ocp = usv_models.make_ocp("usv_model_pf_ca", 0.4, 40, 10)
-    ocp.solver_options.nlp_solver_type = "SQP"
+    ocp.solver_options.nlp_solver_type = "DDP"
     with pytest.raises(Exception, match="SQP_RTI"):
         _capi.desc_from_ocp(ocp)
     ocp = usv_models.make_ocp("usv_model_pf_ca", 0.4, 40, 10)

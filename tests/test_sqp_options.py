@@ -1,0 +1,167 @@
+"""the solver options the reference's settings files mention but leave commented
+(scripts/usv_guidance_ca1/acados_settings.py:192-204; set in scripts/race_cars/acados_settings_dev.py:157-164):
+sim_method_num_steps > 1 and the full SQP (nlp_solver_type "SQP", nlp_solver_max_iter, nlp_solver_tol_*).
+CPU tests run the unmodified kernel bodies on the lane emulator against the oracle; GPU tests the device."""
+import ctypes as C
+
+import numpy as np
+import pytest
+from scipy.integrate import solve_ivp
+
+from mpc_collisionavoidance_amd import _capi, scenario, usv_models
+from tests import util
+from tests.test_emu_kernels import _d, _i, emu_rti
+
+MID = {"usv_model": 0, "usv_model_guidance_ca1": 1, "usv_model_pf_ca": 2}
+
+
+# ------------------------------------------------------------------ oracle: multi-step ERK
+@pytest.mark.parametrize("name", ["usv_model", "usv_model_guidance_ca1", "usv_model_pf_ca"])
+def test_oracle_multi_step_erk(oracle, name):
+    mid = MID[name]
+    nx, nu = oracle.dims(mid)
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=nx) * 0.3
+    x[3 if mid == 2 else 0] = 0.9
+    if mid == 2: x[4] = 0.02  # small sway speed: the stiff damping term stays inside RK4's stability region
+    if mid == 0: x[1] = 0.02
+    u = rng.normal(size=nu) * 0.2
+    dt = 0.05
+    ref = solve_ivp(lambda t, y: oracle.model_f(mid, y, u), (0, dt), x, rtol=1e-12, atol=1e-14).y[:, -1]
+    e1 = np.abs(oracle.erk_sens(mid, dt, 1, x, u)[0] - ref).max()
+    e4 = np.abs(oracle.erk_sens(mid, dt, 4, x, u)[0] - ref).max()
+    assert e4 <= max(e1 / 50.0, 1e-13)                       # 4th order: 4 steps gain ~ 4^4
+    # steps = 1 is the single-step routine; sensitivities of the composed map = finite differences of that map
+    x1, A1, B1 = oracle.rk4_sens(mid, dt, x, u)
+    xs, As, Bs = oracle.erk_sens(mid, dt, 1, x, u)
+    assert np.array_equal(x1, xs) and np.array_equal(A1, As) and np.array_equal(B1, Bs)
+    xn, A, B = oracle.erk_sens(mid, dt, 3, x, u)
+    h = 1e-6
+    for j in range(nx):
+        e = np.zeros(nx); e[j] = h
+        fd = (oracle.erk_sens(mid, dt, 3, x + e, u)[0] - oracle.erk_sens(mid, dt, 3, x - e, u)[0]) / (2 * h)
+        assert np.allclose(A[:, j], fd, rtol=2e-6, atol=2e-7)
+    for j in range(nu):
+        e = np.zeros(nu); e[j] = h
+        fd = (oracle.erk_sens(mid, dt, 3, x, u + e)[0] - oracle.erk_sens(mid, dt, 3, x, u - e)[0]) / (2 * h)
+        assert np.allclose(B[:, j], fd, rtol=2e-6, atol=2e-7)
+
+
+# ------------------------------------------------------------------ kernels on the emulator
+def _ocp(name, N, K, **opts):
+    ocp = usv_models.make_ocp(name, N * scenario.DT[name], N, None if name == "usv_model" else K)
+    for k, v in opts.items():
+        setattr(ocp.solver_options, k, v)
+    return ocp
+
+
+@pytest.mark.parametrize("name,K", [("usv_model", 0), ("usv_model_guidance_ca1", 4), ("usv_model_pf_ca", 3)])
+def test_multi_step_integrator_kernels_match_oracle(oracle, emu, name, K):
+    N, B = 6, 3
+    wl = scenario.make_batch(name, N, K, B, seed=12)
+    desc = _capi.desc_from_ocp(_ocp(name, N, K, sim_method_num_steps=3), batch=B)
+    assert desc.sim_num_steps == 3
+    spec = util.oracle_spec(oracle, name, N, scenario.DT[name], K, sim_steps=3)
+    r = emu_rti(emu, desc, wl, wl["x_init"], wl["u_init"])
+    xo, uo, sto, ito = util.oracle_rti(oracle, spec, wl, wl["x_init"], wl["u_init"])
+    assert np.array_equal(r["status"], sto) and np.abs(r["qp_iter"] - ito).max() <= 1
+    assert util.rel_err(r["x"], xo) < 1e-8 and util.rel_err(r["u"], uo) < 1e-8
+    # and it is not the single-step result
+    x1, _, _, _ = util.oracle_rti(oracle, util.oracle_spec(oracle, name, N, scenario.DT[name], K), wl, wl["x_init"], wl["u_init"])
+    assert np.abs(x1 - xo).max() > 1e-9
+
+
+def emu_sqp(emu, desc, wl, x, u):
+    B, N = x.shape[0], desc.N
+    nx, K = x.shape[2], desc.K
+    sl, su, pi = np.zeros((B, N, max(K, 1))), np.zeros((B, N, max(K, 1))), np.zeros((B, N, nx))
+    st, qs, qi, res = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros((B, 4))
+    sit, nres = np.zeros(B, np.int32), np.zeros((B, 4))
+    x, u = x.copy(), u.copy()
+    rc = emu.usv_emu_sqp(C.byref(desc), _d(x), _d(u), _d(wl["x0"]), _d(wl["yref"]), _d(wl["yref_e"]), _d(wl["p"]),
+                         _d(wl["lh"]), _d(sl), _d(su), _d(pi), _i(st), _i(qs), _i(qi), _d(res), _i(sit), _d(nres))
+    assert rc == 0
+    return dict(x=x, u=u, status=st, sqp_iter=sit, nlp_res=nres)
+
+
+@pytest.mark.parametrize("name,K", [("usv_model", 0), ("usv_model_guidance_ca1", 4), ("usv_model_pf_ca", 3)])
+def test_full_sqp_kernels_match_oracle(oracle, emu, name, K):
+    N, B = 6, 5   # 5 instances = two wave-quarters: converged instances ride along frozen
+    wl = scenario.make_batch(name, N, K, B, seed=21)
+    desc = _capi.desc_from_ocp(_ocp(name, N, K, nlp_solver_type="SQP", nlp_solver_max_iter=30), batch=B)
+    spec = util.oracle_spec(oracle, name, N, scenario.DT[name], K, nlp_max_iter=30)
+    r = emu_sqp(emu, desc, wl, wl["x_init"], wl["u_init"])
+    xo, uo = wl["x_init"].copy(), wl["u_init"].copy()
+    sto, ito, reso = oracle.sqp_batch(spec, xo, uo, wl["x0"], wl["yref"], wl["yref_e"], wl["p"], wl["lh"])
+    assert np.array_equal(r["status"], sto) and (sto == 0).all()
+    assert np.abs(r["sqp_iter"] - ito).max() <= 1 and ito.min() >= 1
+    assert (r["nlp_res"] <= 1e-6).all()
+    assert util.rel_err(r["x"], xo) < 1e-6 and util.rel_err(r["u"], uo) < 1e-5   # both are within tol of the NLP solution
+    same = r["sqp_iter"] == ito
+    if same.any():   # same number of QPs: same iterate, to round-off
+        assert util.rel_err(r["x"][same], xo[same]) < 1e-8
+        assert np.allclose(r["nlp_res"][same], reso[same], rtol=1e-3, atol=1e-9)
+
+
+def test_full_sqp_max_iter_status(oracle, emu):
+    name, N, K, B = "usv_model_pf_ca", 6, 3, 2
+    wl = scenario.make_batch(name, N, K, B, seed=21)
+    desc = _capi.desc_from_ocp(_ocp(name, N, K, nlp_solver_type="SQP", nlp_solver_max_iter=1), batch=B)
+    r = emu_sqp(emu, desc, wl, wl["x_init"], wl["u_init"])
+    assert (r["status"] == 2).all() and (r["sqp_iter"] == 1).all()   # acados: ACADOS_MAXITER
+    # one SQP iteration that does not converge is exactly one RTI iteration
+    rr = emu_rti(emu, _capi.desc_from_ocp(_ocp(name, N, K), batch=B), wl, wl["x_init"], wl["u_init"])
+    assert np.array_equal(rr["x"], r["x"]) and np.array_equal(rr["u"], r["u"])
+
+
+def test_option_validation():
+    with pytest.raises(Exception, match="nlp_solver_type"):
+        _capi.desc_from_ocp(_ocp("usv_model", 5, 0, nlp_solver_type="DDP"), batch=1)
+    with pytest.raises(Exception, match="num_stages"):
+        _capi.desc_from_ocp(_ocp("usv_model", 5, 0, sim_method_num_stages=2), batch=1)
+    with pytest.raises(Exception, match="num_steps"):
+        _capi.desc_from_ocp(_ocp("usv_model", 5, 0, sim_method_num_steps=0), batch=1)
+    d = _capi.desc_from_ocp(_ocp("usv_model", 5, 0, nlp_solver_type="SQP", nlp_solver_tol_stat=1e-4, nlp_solver_max_iter=7), batch=1)
+    assert d.nlp_max_iter == 7 and d.nlp_tol_stat == 1e-4 and d.nlp_tol_eq == 1e-6
+
+
+# ------------------------------------------------------------------ on the device
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,K", [("usv_model", 0), ("usv_model_guidance_ca1", 10), ("usv_model_pf_ca", 10)])
+def test_gpu_full_sqp_and_multi_step(oracle, name, K):
+    from mpc_collisionavoidance_amd import BatchOcpSolver
+    N, B = 20, 96
+    wl = scenario.make_batch(name, N, K, B, seed=9)
+    s = BatchOcpSolver(_ocp(name, N, K, nlp_solver_type="SQP", nlp_solver_max_iter=40, sim_method_num_steps=2), B)
+    scenario.load_into(s, wl)
+    st = s.solve_sqp()
+    spec = util.oracle_spec(oracle, name, N, scenario.DT[name], K, nlp_max_iter=40, sim_steps=2)
+    xo, uo = wl["x_init"].copy(), wl["u_init"].copy()
+    sto, ito, reso = oracle.sqp_batch(spec, xo, uo, wl["x0"], wl["yref"], wl["yref_e"], wl["p"], wl["lh"])
+    ok = (st == 0) & (sto == 0)
+    assert ok.mean() > 0.9 and np.array_equal(st[ok], sto[ok])
+    it = s.get_int("sqp_iter")
+    # Gauss-Newton converges linearly and each QP is only solved to tol_stat = 1e-6, so the exit test
+    # (1e-6 as well) can fire a few iterations apart on the two sides; most instances agree exactly
+    assert np.abs(it[ok] - ito[ok]).max() <= 3 and (it[ok] == ito[ok]).mean() > 0.6
+    assert (s.get("nlp_res", 0)[ok] <= 1e-6).all()
+    assert util.rel_err(s.get_all("x")[ok], xo[ok]) < 1e-5 and util.rel_err(s.get_all("u")[ok], uo[ok]) < 1e-4
+    # a second call from the converged point returns at once: 0 QPs
+    st2 = s.solve_sqp()
+    assert (s.get_int("sqp_iter")[ok] == 0).all() and (st2[ok] == 0).all()
+    s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_acados_style_sqp_solver():
+    from mpc_collisionavoidance_amd import AcadosOcpSolver
+    name, N, K = "usv_model_guidance_ca1", 20, 4
+    wl = scenario.make_batch(name, N, K, 1, seed=2)
+    sol = AcadosOcpSolver(_ocp(name, N, K, nlp_solver_type="SQP"))
+    sol.set(0, "lbx", wl["x0"][0]); sol.set(0, "ubx", wl["x0"][0])
+    for j in range(N):
+        sol.set(j, "yref", wl["yref"][0, j]); sol.set(j, "p", wl["p"][0, j]); sol.constraints_set(j, "lh", wl["lh"][0, j])
+        sol.set(j, "x", wl["x_init"][0, j]); sol.set(j, "u", wl["u_init"][0, j])
+    sol.set(N, "yref", wl["yref_e"][0]); sol.set(N, "p", wl["p"][0, N]); sol.set(N, "x", wl["x_init"][0, N])
+    assert sol.solve() == 0
+    assert 1 <= sol.get_stats("sqp_iter") <= 30 and (sol.get_stats("residuals") <= 1e-6).all()

@@ -56,7 +56,7 @@ def main():
 
     from mpc_collisionavoidance_amd import BatchOcpSolver, scenario, usv_models
 
-    dist = None
+    dist = torch = None
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -78,9 +78,11 @@ def main():
     nx, nu = solver.nx, solver.nu
 
     def barrier():
-        solver.sync()
+        solver.sync()                      # hipStreamSynchronize on the stream the kernels run on
         if dist is not None:
+            torch.cuda.synchronize()       # and the whole device, before and after the rendezvous
             dist.barrier()
+            torch.cuda.synchronize()
 
     # ---- warmup (un-timed); the first warmup step doubles as the parity spot check
     parity = None
@@ -103,7 +105,6 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -206,6 +207,7 @@ def main():
             "workload_stats": {
                 "status_nonzero_frac": float((st != 0).mean()),
                 "qp_not_converged_frac": float((qs != 0).mean()),
+                "converged_solves_per_s": value * float(1.0 - (qs != 0).mean()),
                 "qp_iter_mean": float(qi.mean()), "qp_iter_p50": float(np.percentile(qi, 50)),
                 "qp_iter_p99": float(np.percentile(qi, 99)), "qp_iter_max": int(qi.max()),
             },

@@ -15,7 +15,9 @@
 
 namespace usv {
 
-template <class M, int KCH>
+// MULTI: more than one RK4 step per interval (the initial sensitivity column is then a carried variable
+// instead of a lane pattern the compiler rematerialises for free: 28 more VGPRs for M2, hence a separate build)
+template <class M, int KCH, bool MULTI = false>
 struct Linearize {
     static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
 
@@ -60,11 +62,12 @@ struct Linearize {
 
         // ---- ERK4 + forward VDE for this lane's sensitivity column; sim_steps steps of size dt / sim_steps
         // (acados sim_method_num_steps; the reference leaves it at 1): the column is simply carried on ----
-        const double dt = S.dt / (double)S.sim_steps;
+        const int nsteps = MULTI ? S.sim_steps : 1;
+        const double dt = S.dt / (double)nsteps;
         double s0[NX], f[NX], js[NX], xs[NX], ss[NX], xa[NX], sa[NX], su[NU > 0 ? NU : 1];
         sfor<0, NU>([&](auto l) { su[l] = (lane == l) ? 1.0 : 0.0; });
         sfor<0, NX>([&](auto i) { s0[i] = (lane == NU + i) ? 1.0 : 0.0; });
-        for (int step = 0; step < S.sim_steps; step++) { // wave-uniform
+        for (int step = 0; step < nsteps; step++) { // wave-uniform
             M::fjvp(x, U, s0, su, f, js);
             sfor<0, NX>([&](auto i) {
                 xa[i] = f[i];
@@ -90,7 +93,7 @@ struct Linearize {
             sfor<0, NX>([&](auto i) {
                 x[i] = fma(dt / 6.0, xa[i] + f[i], x[i]);
                 sa[i] = fma(dt / 6.0, sa[i] + js[i], s0[i]);
-                s0[i] = sa[i];
+                if constexpr (MULTI) s0[i] = sa[i];
             });
         }
         const double *xn = P.x + ((long)b * (N + 1) + k + 1) * NX;

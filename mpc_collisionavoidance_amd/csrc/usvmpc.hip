@@ -24,12 +24,12 @@
 using namespace usv;
 
 // ---------------------------------------------------------------------------------- kernels
-template <class M, int KCH>
+template <class M, int KCH, bool MULTI>
 __global__ void __launch_bounds__(256, 2) usv_linearize(DevPtrs P, long ngroups)
 {
     const long gid = lanes::group_linear();
     if (gid >= ngroups) return; // ngroups is a multiple of 4: whole waves leave together
-    Linearize<M, KCH>::run(P, gid);
+    Linearize<M, KCH, MULTI>::run(P, gid);
 }
 
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK>
@@ -272,7 +272,10 @@ int launch_pair(usvmpc_handle *h, int phase)
         h->ptrs.perm = h->d_perm;
     }
     HIP_TRY(h, hipEventRecord(ev[0], h->stream));
-    hipLaunchKernelGGL((usv_linearize<M, KCH>), dim3((unsigned)lin_grid), dim3(lin_block), 0, h->stream, h->ptrs, lin_groups);
+    if (h->spec.sim_steps > 1)
+        hipLaunchKernelGGL((usv_linearize<M, KCH, true>), dim3((unsigned)lin_grid), dim3(lin_block), 0, h->stream, h->ptrs, lin_groups);
+    else
+        hipLaunchKernelGGL((usv_linearize<M, KCH, false>), dim3((unsigned)lin_grid), dim3(lin_block), 0, h->stream, h->ptrs, lin_groups);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[1], h->stream));
     constexpr bool CANPACK = KCH > 0;

@@ -107,7 +107,8 @@ template <class M, int KCH, bool SOFT>
 void lin_body(void *a)
 {
     Job *j = (Job *)a;
-    Linearize<M, KCH>::run(*j->P, j->gid);
+    if (j->P->spec->sim_steps > 1) Linearize<M, KCH, true>::run(*j->P, j->gid);
+    else Linearize<M, KCH, false>::run(*j->P, j->gid);
 }
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK>
 void qp_body(void *a)

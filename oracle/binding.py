@@ -47,7 +47,8 @@ class Qp(C.Structure):
                 ("idxbu", C.c_int * NUM), ("idxbx", C.c_int * NXM), ("ipx", C.c_int), ("ipy", C.c_int),
                 ("A", _dp), ("B", _dp), ("b", _dp), ("H", _dp), ("g", _dp), ("dx0", _dp),
                 ("lbu", _dp), ("ubu", _dp), ("lbx", _dp), ("ubx", _dp), ("Cxy", _dp), ("lg", _dp), ("ug", _dp),
-                ("zl", _dp), ("zu", _dp), ("Zl", _dp), ("Zu", _dp), ("lsl", _dp), ("lsu", _dp)]
+                ("zl", _dp), ("zu", _dp), ("Zl", _dp), ("Zu", _dp), ("lsl", _dp), ("lsu", _dp),
+                ("scratch", C.c_void_p)]
 
 
 class QpSol(C.Structure):

@@ -461,6 +461,7 @@ usv_qp *usv_qp_alloc(const usv_spec *s)
 void usv_qp_free(usv_qp *q)
 {
     if (!q) return;
+    free(q->scratch);
     free(q->A); free(q->B); free(q->b); free(q->H); free(q->g); free(q->dx0);
     free(q->lbu); free(q->ubu); free(q->lbx); free(q->ubx); free(q->Cxy); free(q->lg); free(q->ug);
     free(q->zl); free(q->zu); free(q->Zl); free(q->Zu); free(q->lsl); free(q->lsu);
@@ -1057,7 +1058,8 @@ int usv_qp_solve(const usv_qp *q, const usv_opts *o, usv_qp_sol *sol)
     ipm_ws w;
     int k, i, it, status = 1;
     w.q = q;
-    w.st = (stage_t *)calloc((size_t)N + 1, sizeof(stage_t));
+    if (!q->scratch) ((usv_qp *)q)->scratch = calloc((size_t)N + 1, sizeof(stage_t)); /* build_rows clears it */
+    w.st = (stage_t *)q->scratch;
     build_rows(&w);
     init_cold(&w, o);
     residuals(&w);
@@ -1166,7 +1168,6 @@ int usv_qp_solve(const usv_qp *q, const usv_opts *o, usv_qp_sol *sol)
     sol->iter = it;
     sol->status = status;
     for (i = 0; i < 4; i++) sol->res[i] = w.res[i];
-    free(w.st);
     (void)nu;
     return status;
 }
@@ -1319,13 +1320,11 @@ int usv_sqp_batch(const usv_spec *s, int B, double *x, double *u, const double *
  * 6. SQP-RTI iteration (acados ocp_nlp_sqp_rti: preparation + feedback + full step).
  *    Caller protocol it serves: usv_guidance_ca1/main.py:111-175.
  * ---------------------------------------------------------------------------------------- */
-int usv_rti(const usv_spec *s, double *x, double *u, const double *x0, const double *yref,
-            const double *yref_e, const double *p, const double *lh, double *sl, double *su,
-            double *pi, double *info)
+static int rti_core(const usv_spec *s, usv_qp *q, usv_qp_sol *sol, double *x, double *u, const double *x0,
+                    const double *yref, const double *yref_e, const double *p, const double *lh, double *sl,
+                    double *su, double *pi, double *info)
 {
     const int N = s->N, nx = s->nx, nu = s->nu, nz = nx + nu, K = s->K;
-    usv_qp *q = usv_qp_alloc(s);
-    usv_qp_sol *sol = usv_qp_sol_alloc(q);
     int k, i, qs, status;
     usv_linearize(s, x, u, x0, yref, yref_e, p, lh, q);
     qs = usv_qp_solve(q, &s->opts, sol);
@@ -1350,6 +1349,16 @@ int usv_rti(const usv_spec *s, double *x, double *u, const double *x0, const dou
         for (i = 0; i < 4; i++) info[2 + i] = sol->res[i];
         info[6] = 0; info[7] = 0;
     }
+    return status;
+}
+
+int usv_rti(const usv_spec *s, double *x, double *u, const double *x0, const double *yref,
+            const double *yref_e, const double *p, const double *lh, double *sl, double *su,
+            double *pi, double *info)
+{
+    usv_qp *q = usv_qp_alloc(s);
+    usv_qp_sol *sol = usv_qp_sol_alloc(q);
+    const int status = rti_core(s, q, sol, x, u, x0, yref, yref_e, p, lh, sl, su, pi, info);
     usv_qp_sol_free(sol);
     usv_qp_free(q);
     return status;
@@ -1386,15 +1395,24 @@ int usv_rti_batch_mt(const usv_spec *s, int B, double *x, double *u, const doubl
 #else
     (void)nthreads;
 #endif
-#pragma omp parallel for schedule(dynamic, 4) reduction(max : worst)
-    for (b = 0; b < B; b++) {
-        double info[8];
-        const int st = usv_rti(s, x + (size_t)b * (N + 1) * nx, u + (size_t)b * N * nu, x0 + (size_t)b * nx,
-                               yref + (size_t)b * N * s->ny, yref_e + (size_t)b * s->ny_e,
-                               p + (size_t)b * (N + 1) * 2 * K, lh + (size_t)b * N * K, NULL, NULL, NULL, info);
-        if (status) status[b] = st;
-        if (qp_iter) qp_iter[b] = (int)info[0];
-        if (st > worst) worst = st;
+#pragma omp parallel reduction(max : worst)
+    {
+        /* one QP + solution + IPM work space per thread, reused for all its instances: allocating them per
+         * instance (1-2 MB each) serialises a many-core machine in the kernel's address-space lock */
+        usv_qp *q = usv_qp_alloc(s);
+        usv_qp_sol *sol = usv_qp_sol_alloc(q);
+#pragma omp for schedule(dynamic, 4)
+        for (b = 0; b < B; b++) {
+            double info[8];
+            const int st = rti_core(s, q, sol, x + (size_t)b * (N + 1) * nx, u + (size_t)b * N * nu, x0 + (size_t)b * nx,
+                                    yref + (size_t)b * N * s->ny, yref_e + (size_t)b * s->ny_e,
+                                    p + (size_t)b * (N + 1) * 2 * K, lh + (size_t)b * N * K, NULL, NULL, NULL, info);
+            if (status) status[b] = st;
+            if (qp_iter) qp_iter[b] = (int)info[0];
+            if (st > worst) worst = st;
+        }
+        usv_qp_sol_free(sol);
+        usv_qp_free(q);
     }
     return worst;
 }

@@ -130,6 +130,7 @@ typedef struct usv_qp {
     double *Cxy;            /* [N+1][K*2] */
     double *lg, *ug;        /* [N+1][K]   relative to hbar; active for 1 <= k <= N-1 */
     double *zl, *zu, *Zl, *Zu, *lsl, *lsu; /* [K] soft data, already scaled by dt */
+    void *scratch;          /* IPM work space, allocated by the first usv_qp_solve on this QP and reused */
 } usv_qp;
 
 typedef struct usv_qp_sol {

@@ -35,6 +35,25 @@ def algorithmic_bytes(nx, nu, N, K):
     return 8 * (nx + ny + ny_e + npar + nh + 2 * ((N + 1) * nx + N * nu)) + 4
 
 
+def usable_cores():
+    """CPUs this process may actually use: affinity mask and the cgroup CPU quota (the GPU boxes show 256 logical
+    CPUs but run under a 16-CPU quota; more threads than that only get throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,7 +162,7 @@ def main():
     if rank == 0 and args.gpus == 1 and args.cpu_sample != 0:
         from oracle import binding as ob
         per_solve_ms = {"usv_model": 0.12, "usv_model_guidance_ca1": 1.2, "usv_model_pf_ca": 3.5}[name] * N / 40.0
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         S1 = int(max(32, min(B, 4000.0 / per_solve_ms)))               # ~4 s on one core
         S = args.cpu_sample if args.cpu_sample > 0 else int(min(B, max(64, 12000.0 / per_solve_ms * cores)))  # ~12 s on all
         S = min(S, B)

@@ -284,3 +284,68 @@ def test_threaded_batch_driver_is_bit_identical(oracle):
         out.append((x, u, st, it))
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+
+
+def test_block_condensed_qp_has_the_same_solution(oracle):
+    """partial condensing (BASELINE config 5: blocks of 8 stages) is a block elimination of the
+    same KKT system.  Condense the oracle's QP here (numpy: states inside a block expressed through the block's
+    first state and its controls) and check that the uncondensed solution, mapped to the condensed variables
+    with the same multipliers, satisfies the condensed QP's KKT conditions - so the Riccati sweep over the
+    uncondensed stages solves the QP a condensing solver would solve."""
+    name, N, K, M = "usv_model_pf_ca", 16, 5, 8
+    ocp, wl = util.make(name, N, K, 2, seed=4)
+    spec = util.oracle_spec(oracle, name, N, scenario.DT[name], K)
+    b = 0
+    qp, sol = oracle.linearize_and_solve(spec, wl["x_init"][b], wl["u_init"][b], wl["x0"][b], wl["yref"][b],
+                                         wl["yref_e"][b], wl["p"][b], wl["lh"][b])
+    assert sol["status"] == 0
+    nx, nu, nz = qp["nx"], qp["nu"], qp["nz"]
+    A, Bm, bb, H, g = qp["A"], qp["B"], qp["b"], qp["H"], qp["g"]
+    dz, pi = sol["dz"], sol["pi"]
+
+    def row_grad(k):   # C_k'(lambda_l - lambda_u) as a vector over z_k = [u; x]
+        v = np.zeros(nz)
+        if k < N:
+            for i, j in enumerate(qp["idxbu"]):
+                v[j] += sol["lam_bu"][k, 0, i] - sol["lam_bu"][k, 1, i]
+        if 1 <= k < N:
+            for i, j in enumerate(qp["idxbx"]):
+                v[nu + j] += sol["lam_bx"][k, 0, i] - sol["lam_bx"][k, 1, i]
+            for i in range(K):
+                dl = sol["lam_g"][k, 0, i] - sol["lam_g"][k, 1, i]
+                v[nu + qp["ipx"]] += dl * qp["Cxy"][k, i, 0]
+                v[nu + qp["ipy"]] += dl * qp["Cxy"][k, i, 1]
+        return v
+
+    scale = max(1.0, np.abs(g).max())
+    for k0 in range(0, N, M):
+        # prediction inside the block: x_{k0+j} = Phi_j x_{k0} + Gam_j U + beta_j,  U = (u_{k0} .. u_{k0+M-1})
+        Phi, Gam, beta = [np.eye(nx)], [np.zeros((nx, M * nu))], [np.zeros(nx)]
+        for j in range(M):
+            k = k0 + j
+            G = A[k] @ Gam[j]
+            G[:, j * nu:(j + 1) * nu] += Bm[k]
+            Phi.append(A[k] @ Phi[j]); Gam.append(G); beta.append(A[k] @ beta[j] + bb[k])
+        x0b = dz[k0, nu:]
+        U = np.concatenate([dz[k0 + j, :nu] for j in range(M)])
+        # primal: the condensed prediction reproduces the uncondensed states (dynamics residual of the solve)
+        for j in range(M + 1):
+            assert np.abs(Phi[j] @ x0b + Gam[j] @ U + beta[j] - dz[k0 + j, nu:]).max() < 1e-7
+        # stationarity of the condensed Lagrangian in (x_{k0}, U)
+        gx, gU = np.zeros(nx), np.zeros(M * nu)
+        for j in range(M):
+            k = k0 + j
+            r = H[k] @ dz[k] + g[k] - row_grad(k)            # d(stage cost + inequality terms)/dz_k
+            gU[j * nu:(j + 1) * nu] += r[:nu]
+            gx += Phi[j].T @ r[nu:]
+            gU += Gam[j].T @ r[nu:]
+        pin = pi[k0 + M]                                      # multiplier of the block's end-state equation
+        if k0 + M == N:                                       # the last block also owns the terminal stage
+            rN = H[N] @ dz[N] + g[N] - row_grad(N)
+            gx += Phi[M].T @ rN[nu:]; gU += Gam[M].T @ rN[nu:]
+        else:
+            gx += Phi[M].T @ pin; gU += Gam[M].T @ pin
+        if k0 > 0:
+            gx -= pi[k0]
+            assert np.abs(gx).max() <= 1e-9 * scale           # (x_0 is fixed: no stationarity row for block 0)
+        assert np.abs(gU).max() <= 1e-9 * scale

@@ -143,3 +143,56 @@ def test_single_instance_acados_style_loop(oracle):
         x0o = xo[1].copy()
         acados_solver.set(0, "lbx", xg1)
         acados_solver.set(0, "ubx", xg1)
+
+
+def test_full_size_batch_properties(oracle):
+    """BASELINE config 3 at its full size (batch 65536, N=40, K=10): the oracle cannot follow in seconds, so the
+    checks are size-independent properties plus an oracle spot check.
+    * replication: the batch is 512 distinct instances tiled 128 times - every copy must return bit-identical
+      results wherever it sits in the batch (different wave, lane quarter, XCD);
+    * determinism: a second solver object fed the same data returns bit-identical results;
+    * permutation: a rolled batch returns the rolled results;
+    * spot check: the 512 distinct instances against the oracle."""
+    name, N, K, U, R = "usv_model_pf_ca", 40, 10, 512, 128
+    B = U * R
+    ocp, wl0 = util.make(name, N, K, U, seed=99)
+    tile = lambda a: np.ascontiguousarray(np.tile(a, (R,) + (1,) * (a.ndim - 1)))
+    wl = {k: (tile(v) if isinstance(v, np.ndarray) and v.shape[:1] == (U,) else v) for k, v in wl0.items()}
+
+    def run(w, **opts):
+        s = BatchOcpSolver(ocp, B)
+        scenario.load_into(s, w)
+        for k, v in opts.items():
+            s.set_option(k, v)
+        outs = []
+        for it in range(2):
+            st = s.solve()
+            outs.append((s.get_all("x"), s.get_all("u"), st.copy(), s.get_int("qp_iter")))
+        s.close()
+        return outs
+
+    a = run(wl)
+    for x, u, st, qi in a:
+        xr, ur = x.reshape(R, U, N + 1, -1), u.reshape(R, U, N, -1)
+        assert np.array_equal(xr, np.broadcast_to(xr[0], xr.shape)) and np.array_equal(ur, np.broadcast_to(ur[0], ur.shape))
+        assert np.array_equal(st.reshape(R, U), np.broadcast_to(st[:U], (R, U)))
+        assert np.array_equal(qi.reshape(R, U), np.broadcast_to(qi[:U], (R, U)))
+    b = run(wl)
+    for (x, u, st, qi), (x2, u2, st2, qi2) in zip(a, b):
+        assert np.array_equal(x, x2) and np.array_equal(u, u2) and np.array_equal(st, st2) and np.array_equal(qi, qi2)
+    sh = 12345
+    rolled = {k: (np.ascontiguousarray(np.roll(v, sh, axis=0)) if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v)
+              for k, v in wl.items()}
+    c = run(rolled)
+    assert np.array_equal(c[0][0], np.roll(a[0][0], sh, axis=0)) and np.array_equal(c[0][1], np.roll(a[0][1], sh, axis=0))
+    # the scheduling / storage options must not change a single bit either
+    d = run(wl, sort_by_difficulty=0, pack_box_rows=0)
+    assert np.array_equal(d[1][0], a[1][0]) and np.array_equal(d[1][1], a[1][1])
+    e = run(wl, static_obstacles=1)   # the obstacle set of this workload is stage-independent
+    assert np.array_equal(e[1][0], a[1][0]) and np.array_equal(e[1][1], a[1][1])
+    # spot check against the oracle
+    spec = util.oracle_spec(oracle, name, N, scenario.DT[name], K)
+    xo, uo, sto, ito = util.oracle_rti(oracle, spec, wl0, wl0["x_init"], wl0["u_init"])
+    ok = (sto == 0) & (ito < 50) & (a[0][2][:U] == 0)
+    assert ok.mean() > 0.95
+    assert util.rel_err(a[0][0][:U][ok], xo[ok]) <= TOL and util.rel_err(a[0][1][:U][ok], uo[ok]) <= TOL

@@ -101,6 +101,14 @@ USV_DEV double gmin(double v)
     return v;
 }
 
+// A value that is the same in every lane of the wave, moved to a scalar register.  Values read from global
+// memory arrive in vector registers and the compiler then treats every test on them as divergent (EXEC masking,
+// vector compares, conservative waits) although the control flow is wave-uniform by construction.
+USV_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// no instruction may be scheduled across this point
+USV_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
 // one more in a global counter
 USV_DEV void count_one(int *p) { atomicAdd(p, 1); }
 

@@ -26,11 +26,12 @@ struct Linearize {
     {
         const DevSpec &S = *P.spec;
         const int lane = lanes::lane();
-        const int N = S.N, K = S.K;
-        const long Bp = S.Bp;
+        const int N = lanes::uniform(S.N), K = lanes::uniform(S.K);
+        const long Bp = lanes::uniform(S.Bp);
         const int k = (int)(gid / Bp);
         const long g = gid - (long)k * Bp;
-        const long gi = g < S.B ? g : (long)S.B - 1; // padded groups replay the last instance
+        const int nB = lanes::uniform(S.B);
+        const long gi = g < nB ? g : (long)nB - 1; // padded groups replay the last instance
         const long b = P.perm ? (long)P.perm[gi] : gi;
         const long stride = Bp * LANES;
         const long gl = g * LANES + lane;

@@ -159,6 +159,11 @@ struct QpIpm {
     const DevPtrs &P;
     const DevSpec &S;
     double rbscale; // product of (1 - alpha) over the steps taken: scales the dynamics residual
+    // Copies of the DevSpec scalars the sweeps test per stage.  DevSpec lives in global memory and the compiler
+    // must assume the plane stores alias it, so every `S.field` inside a sweep is re-loaded with a VECTOR load
+    // followed by s_waitcnt vmcnt(0) - which drains the whole prefetch queue of the stage.
+    int Kn, nB, itmax; // S.K, S.B, S.iter_max
+    bool pstat;     // S.p_static
     bool keep;      // full SQP: this instance is finished, its workspace (multipliers of the last QP) must survive
     int lane, N;
     long g, b, stride;
@@ -191,14 +196,18 @@ struct QpIpm {
     USV_DEV QpIpm(const DevPtrs &P_, long g_) : P(P_), S(*P_.spec)
     {
         lane = lanes::lane();
-        N = S.N;
+        N = lanes::uniform(S.N);
+        Kn = lanes::uniform(S.K);
+        pstat = lanes::uniform(S.p_static) != 0;
+        nB = lanes::uniform(S.B);
+        itmax = lanes::uniform(S.iter_max);
         g = g_;
         {
-            const long gi = g < S.B ? g : (long)S.B - 1;
+            const long gi = g < nB ? g : (long)nB - 1;
             b = P.perm ? (long)P.perm[gi] : gi;
         }
         gl = (unsigned)(g * LANES + lane);
-        stride = (long)S.Bp * LANES;
+        stride = (long)lanes::uniform(S.Bp) * LANES;
         ulane = lane < NU;
         xlane = lane >= NU && lane < NZ;
         valid = lane < NZ;
@@ -211,7 +220,7 @@ struct QpIpm {
         mci = mstored ? MP::rank(MP::CMASK, lane) : 0;
         isslot = PACK && S.slot_is[lane] == 1;
         isdense = PACK && S.slot_is[lane] == 2;
-        anydense = PACK && S.box_dense != 0; // wave-uniform
+        anydense = PACK && lanes::uniform(S.box_dense) != 0; // wave-uniform
         bsrc = S.box_slot[lane];
         bstep = S.box_step[lane];
         ssrc = S.slot_var[lane];
@@ -269,7 +278,7 @@ struct QpIpm {
     {
         const int i = C * LANES + lane;
         const bool stage_ok = (k >= 1 && k < N); // wave-uniform
-        r.act = stage_ok && i < S.K;
+        r.act = stage_ok && i < Kn;
         const double dx = lanes::bcast<PXL>(zb) - raw[0], dy = lanes::bcast<PYL>(zb) - raw[1];
         const double d2 = dx * dx + dy * dy;
         const double id = lanes::frsqrt(d2);
@@ -284,15 +293,15 @@ struct QpIpm {
     template <int C>
     USV_DEV void obs_raw(int k, double *raw) const
     {
-        if (S.p_static) { // wave-uniform
+        if (pstat) { // wave-uniform
             raw[0] = c_ox[C]; raw[1] = c_oy[C]; raw[2] = c_lh[C];
         } else {
             const int i = C * LANES + lane;
-            const int ii = i < S.K ? i : 0;
+            const int ii = i < Kn ? i : 0;
             const int kl = k < N ? k : N - 1;
-            const double *pk = P.p + ((long)b * (N + 1) + k) * 2 * S.K;
+            const double *pk = P.p + ((long)b * (N + 1) + k) * 2 * Kn;
             raw[0] = pk[2 * ii]; raw[1] = pk[2 * ii + 1];
-            raw[2] = P.lh[((long)b * N + kl) * S.K + ii];
+            raw[2] = P.lh[((long)b * N + kl) * Kn + ii];
         }
     }
     // pk: the box rows gathered to their storage lanes (PACK, last chunk), else nullptr
@@ -425,7 +434,8 @@ struct QpIpm {
         in.zb = W.ld(P_ZB);
         // b_k of the current iterate = rbscale * (residual of the linearisation point): the forward sweeps
         // enforce the linearised dynamics, so every step scales it by (1 - alpha) and it is never rewritten
-        if constexpr (SW != SW_BACK_B) in.rb = (k < N) ? Planes(P.rb0, stride, N, gl).ld(k) * rbscale : 0.0;
+        // (raw value here: scaling it in place would make the prefetch wait for its own load)
+        if constexpr (SW != SW_BACK_B) in.rb = (k < N) ? Planes(P.rb0, stride, N, gl).ld(k) : 0.0;
         if constexpr (SW == SW_BACK_A) {
             in.dz = W.ld(P_DZ);
             in.dza = W.ld(P_DZA);
@@ -511,10 +521,29 @@ struct QpIpm {
             nm.rg = nm.rb = nm.rd = nm.rm = nm.musum = nm.nan = 0.0;
             rbscale = pend ? rbscale * (1.0 - a_prev) : rbscale; // the step applied in this sweep
         }
+        // Results of a stage are stored one stage LATE (dfr_*), right after the next stage has consumed its
+        // prefetched planes: the wait at the top of a stage then covers loads that have been in flight for a
+        // whole stage and nothing else - with the stores issued at the end of their own stage it would also cover
+        // those, i.e. a store round trip per stage.
+        double dfr_pi = 0.0, dfr_pb = 0.0, dfr_lz[NU > 0 ? NU : 1];
+        int dfr_k = -1;
+        sfor<0, NU>([&](auto l) { dfr_lz[l] = 0.0; });
+        auto flush = [&]() {
+            if (dfr_k >= 0) { // wave-uniform
+                const Planes Wp = ws(dfr_k);
+                if (FACT && !keep) Wp.st(P_PI, dfr_pi);
+                if (dfr_k < N) {
+                    Wp.st(P_PB, dfr_pb);
+                    if (FACT) sfor<0, NU>([&](auto l) { Wp.st(P_LZU + l, dfr_lz[l]); });
+                }
+            }
+        };
         StageIn nxt;
         load_in<SW>(N, nxt);
         for (int k = N; k >= 0; k--) {
             const StageIn in = nxt;
+            lanes::sched_fence();
+            flush();
             const Planes W = ws(k);
             // this stage's packed [B A] planes: in flight while the rows below are processed
             double mpk[MP::NPK];
@@ -523,7 +552,7 @@ struct QpIpm {
             const double *Hrow = (k < N ? S.Hc : S.He) + lane * LANES; // only read when !HDIAG
             const double hd = (k < N) ? hd_stage : hd_term;
             const double dza = FACT ? 0.0 : in.dza;
-            double rb = FACT ? in.rb : 0.0;
+            double rb = FACT ? in.rb * rbscale : 0.0;
             // ---- rows (with the pending update of the previous iteration applied first)
             BoxRow br;
             box_from(in, k, br);
@@ -609,7 +638,7 @@ struct QpIpm {
                 t -= isPX ? lx : (isPY ? ly : 0.0);
                 pik = xlane ? t : 0.0;
                 rg = (ulane && k < N) ? t : 0.0;
-                if (!keep) W.st(P_PI, rg + pik); // rg lives on the u lanes, pik on the x lanes
+                dfr_pi = rg + pik; // rg lives on the u lanes, pik on the x lanes
                 nm.rg = fmax(nm.rg, fabs(rg));
                 nm.nan = fma(0.0, t, nm.nan);
                 if (br.act) {
@@ -677,7 +706,7 @@ struct QpIpm {
                         sfor<0, NU>([&](auto l) { lanes::fma_bc<NU + c>(a, Lzu[l], -Lzu[l]); });
                         Pn[c] = xlane ? a : 0.0;
                     });
-                    sfor<0, NU>([&](auto l) { W.st(P_LZU + l, Lzu[l]); });
+                    sfor<0, NU>([&](auto l) { dfr_lz[l] = Lzu[l]; });
                 } else {
                     Pb = xlane ? in.pb : 0.0;
                     sfor<0, NU>([&](auto l) {
@@ -702,11 +731,13 @@ struct QpIpm {
                 pv = rq;
                 sfor<0, NU>([&](auto l) { pv -= Lzu[l] * lu[l]; });
                 pv = xlane ? pv : 0.0;
-                W.st(P_PB, luv + Pb); // luv is non-zero on the u lanes only, Pb on the x lanes only
+                dfr_pb = luv + Pb; // luv is non-zero on the u lanes only, Pb on the x lanes only
             }
             pn = pv;
             pin = pik;
+            dfr_k = k;
         }
+        flush();
         if (FACT) {
             const Planes W0 = ws(0);
             const double e0 = xlane ? W0.ld(P_DX0) - W0.ld(P_Z) : 0.0;
@@ -731,11 +762,13 @@ struct QpIpm {
             const Planes W0 = ws(0);
             dzx = xlane ? W0.ld(P_DX0) - W0.ld(P_Z) : 0.0;
         }
-        double q = 1.0, s1 = 0.0, s2 = 0.0;
+        double q = 1.0, s1 = 0.0, s2 = 0.0, dfr_dz = 0.0;
         StageIn nxt;
         load_in<SW>(0, nxt);
         for (int k = 0; k <= N; k++) {
             const StageIn in = nxt;
+            lanes::sched_fence();
+            if (k > 0) ws(k - 1).st(FINAL ? P_DZ : P_DZA, dfr_dz); // stored one stage late (see backward())
             const Planes W = ws(k);
             // this stage's packed [B A] planes and the next stage's small planes: both in flight during the
             // gain / row computations below
@@ -797,13 +830,13 @@ struct QpIpm {
                     });
                 }
             }
-            W.st(FINAL ? P_DZ : P_DZA, dz);
+            dfr_dz = dz;
             if (k < N) {
                 // dx+_j = b_j + sum_c [B A][j][c] dz_c: lane c holds [B A][j][c] in bat[j], so the row sum is a
                 // group reduction delivered to lane nu+j (no transposed copy of the matrix in HBM)
                 double bat[NX];
                 mat_unpack(mpk, bat);
-                double dxn = in.rb;
+                double dxn = in.rb * rbscale;
                 sfor<0, NX>([&](auto j) {
                     if constexpr (out_unit(j)) {
                         dxn += (lane == NU + j) ? dz : 0.0;
@@ -815,6 +848,7 @@ struct QpIpm {
                 dzx = xlane ? dxn : 0.0;
             }
         }
+        ws(N).st(FINAL ? P_DZ : P_DZA, dfr_dz);
         alpha = 1.0 / lanes::gmax(q); // q >= 1: alpha = min(1, min over blocking pairs of -v/dv)
         if (!FINAL) { S1 = lanes::gsum(s1); S2 = lanes::gsum(s2); }
     }
@@ -907,7 +941,7 @@ struct QpIpm {
         bool frozen = false;
         keep = false;
         if (phase > 0) {
-            const bool real0 = g < S.B;
+            const bool real0 = g < nB;
             frozen = !real0 || P.sqp_state[b] >= 0;
             if (!lanes::wave_any(!frozen)) return;
             double nr[4];
@@ -940,7 +974,7 @@ struct QpIpm {
                 if (nm.nan != nm.nan) { status = 3; done = true; }
                 else if (nm.rg <= S.tol_stat && nm.rb <= S.tol_eq && nm.rd <= S.tol_ineq && nm.rm <= S.tol_comp) {
                     status = 0; done = true;
-                } else if (it >= S.iter_max) { status = 1; done = true; }
+                } else if (it >= itmax) { status = 1; done = true; }
             }
 #ifdef USV_DEBUG_FIXED_ITERS // timing experiments only: fixed iteration count, subset of sweeps
             done = false;
@@ -974,7 +1008,7 @@ struct QpIpm {
         }
         // ---- RTI step + outputs
         const bool ok = (status == 0 || status == 1);
-        const bool real = g < S.B && !frozen;
+        const bool real = g < nB && !frozen;
         for (int k = 0; k <= N; k++) {
             const Planes W = ws(k);
             const double z = W.ld(P_Z);

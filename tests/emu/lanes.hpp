@@ -85,6 +85,8 @@ inline double gmin(double v)
 // finished instances are frozen by the kernels, so results do not depend on the grouping
 inline bool wave_any(bool p) { return gmax(p ? 1.0 : 0.0) > 0.5; }
 
+inline int uniform(int v) { return v; }
+inline void sched_fence() {}
 inline void count_one(int *p) { ++*p; }
 
 inline double frcp(double x) { return 1.0 / x; }

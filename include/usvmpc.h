@@ -150,6 +150,13 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value);
 int usvmpc_guidance_reset(usvmpc_handle *h, const double *waypoints, int npts, const double *psi);
 int usvmpc_guidance_prepare(usvmpc_handle *h, const double *vel_uv, const double *pose, const double *obstacles,
                             const int *n_obstacles, int lmax);
+/* The obstacle simulator's simulate() (catkin_ws/src/simulation/scripts/obstacle_sim_node.py:56-81,101-117):
+ * world[batch][n_world][3] = (X, Y, R) in NED, pose[batch][3] = (ned_x, ned_y, yaw); every obstacle closer than
+ * max_radius (the node: 100) is reported in the body frame, in list order, at most 64 per instance.  The lists
+ * stay on the device as the input of the next usvmpc_guidance_prepare when that is called with
+ * n_obstacles == NULL; obstacles [batch][64][3] / n_obstacles [batch] (both optional) receive a copy. */
+int usvmpc_guidance_sense(usvmpc_handle *h, const double *pose, const double *world, int n_world, double max_radius,
+                          double *obstacles, int *n_obstacles);
 int usvmpc_guidance_publish(usvmpc_handle *h, double *heading, double *r_des, double *speed, double *ye, int *active);
 int usvmpc_guidance_state(usvmpc_handle *h, int *wp_index, float *past_psied);
 /* Profiling aid: stream `nplanes` workspace planes with the solver kernels' access instruction

@@ -50,7 +50,7 @@ loaded_before_torch = False
 EXPORTS = ["usvmpc_model_dims", "usvmpc_default_options", "usvmpc_create", "usvmpc_destroy",
            "usvmpc_set", "usvmpc_get", "usvmpc_get_int", "usvmpc_solve", "usvmpc_solve_sqp", "usvmpc_solve_async",
            "usvmpc_sync", "usvmpc_get_device_ptr", "usvmpc_last_kernel_ms", "usvmpc_kernel_ms",
-           "usvmpc_advance", "usvmpc_set_stream", "usvmpc_set_option", "usvmpc_calibrate_traffic", "usvmpc_guidance_reset", "usvmpc_guidance_prepare",
+           "usvmpc_advance", "usvmpc_set_stream", "usvmpc_set_option", "usvmpc_calibrate_traffic", "usvmpc_guidance_reset", "usvmpc_guidance_prepare", "usvmpc_guidance_sense",
            "usvmpc_guidance_publish", "usvmpc_guidance_state", "usvmpc_device_bytes", "usvmpc_last_error"]
 
 
@@ -91,6 +91,7 @@ def load(path):
     L.usvmpc_calibrate_traffic.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
     L.usvmpc_guidance_reset.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
     L.usvmpc_guidance_prepare.argtypes = [C.c_void_p, _dp, _dp, _dp, _ip, C.c_int]
+    L.usvmpc_guidance_sense.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_double, _dp, _ip]
     L.usvmpc_guidance_publish.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _ip]
     L.usvmpc_guidance_state.argtypes = [C.c_void_p, _ip, C.POINTER(C.c_float)]
     L.usvmpc_device_bytes.argtypes = [C.c_void_p]

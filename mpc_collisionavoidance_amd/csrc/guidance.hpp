@@ -53,6 +53,36 @@ __device__ __forceinline__ void body2ned(double psi, double nedx, double nedy, d
     oy = (double)(float)((double)r1 + nedy);
 }
 
+// The obstacle-simulator node's simulate() (/root/reference/catkin_ws/src/simulation/scripts/
+// obstacle_sim_node.py:56-81, ned_to_body :101-117): every world obstacle (X, Y, R) closer to the vessel than
+// max_visible_radius is reported in the body frame, in list order.  The node inverts the rotation matrix with
+// numpy.linalg.inv; here the inverse is written out (adjugate / determinant), which agrees to rounding.
+// The body-frame list is what obstaclesCallback of the NMPC node receives: it is written straight into the
+// front end's input buffers, so a scenario sweep needs no host round trip between "sensor" and solver.
+__global__ void usv_obstacle_sim(GuidancePtrs G, const double *world, int nw, double max_radius, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double nedx = G.pose[b * 3 + 0], nedy = G.pose[b * 3 + 1], yaw = G.pose[b * 3 + 2];
+    const double c = cos(yaw), s = sin(yaw);
+    const double det = c * c - (-s) * s;
+    const double i00 = c / det, i01 = s / det, i10 = -s / det, i11 = c / det;
+    double *out = const_cast<double *>(G.obs) + (long)b * G.lmax * 3;
+    const double *w = world + (long)b * nw * 3;
+    int n = 0;
+    for (int i = 0; i < nw && n < G.lmax; i++) {
+        const double dx = w[3 * i] - nedx, dy = w[3 * i + 1] - nedy;
+        const double dist = sqrt(dx * dx + dy * dy);
+        if (dist < max_radius) {
+            out[3 * n + 0] = __dadd_rn(__dmul_rn(i00, dx), __dmul_rn(i01, dy));
+            out[3 * n + 1] = __dadd_rn(__dmul_rn(i10, dx), __dmul_rn(i11, dy));
+            out[3 * n + 2] = w[3 * i + 2];
+            n++;
+        }
+    }
+    const_cast<int *>(G.nobs)[b] = n;
+}
+
 __global__ void usv_guidance_reset(GuidancePtrs G, const double *psi, int B)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;

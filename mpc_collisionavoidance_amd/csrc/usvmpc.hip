@@ -146,6 +146,8 @@ struct usvmpc_handle {
     bool gd_ready;
     int gd_npts_cap;
     double *gd_psi;
+    double *gd_world;   // [B][n_world][3] world obstacles of the last usvmpc_guidance_sense
+    size_t gd_world_cap;
     bool sort_enabled;
     size_t bytes;
     std::string err;
@@ -437,7 +439,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     TRY_C(dev_alloc(h, &h->d_hist, SORT_BINS, true));
     TRY_C(dev_alloc(h, &h->d_cursor, SORT_BINS, true));
     h->sort_enabled = true;
-    h->gd_ready = false; h->gd_npts_cap = 0; h->gd_psi = nullptr;
+    h->gd_ready = false; h->gd_npts_cap = 0; h->gd_psi = nullptr; h->gd_world = nullptr; h->gd_world_cap = 0;
     std::memset(&h->gd, 0, sizeof(h->gd));
     TRY_C(dev_alloc(h, &P.BAp, N * (size_t)model_mat_planes(d->model) * stride, true));
     TRY_C(dev_alloc(h, &P.rb0, N * stride, true));
@@ -670,15 +672,17 @@ int usvmpc_guidance_reset(usvmpc_handle *h, const double *waypoints, int npts, c
 int usvmpc_guidance_prepare(usvmpc_handle *h, const double *vel_uv, const double *pose, const double *obstacles,
                             const int *n_obstacles, int lmax)
 {
-    if (!h || !vel_uv || !pose || !n_obstacles || lmax < 0 || lmax > GUIDANCE_LMAX) return USVMPC_E_ARG;
+    // n_obstacles == NULL: keep the body-frame lists usvmpc_guidance_sense left on the device
+    if (!h || !vel_uv || !pose || lmax < 0 || lmax > GUIDANCE_LMAX) return USVMPC_E_ARG;
     if (!h->gd_ready || h->gd.npts < 2) { h->err = "usvmpc_guidance_reset must be called first"; return USVMPC_E_ARG; }
     HIP_TRY(h, hipSetDevice(h->device));
     GuidancePtrs &G = h->gd;
     const size_t B = h->B;
     HIP_TRY(h, hipMemcpyAsync(const_cast<double *>(G.vel), vel_uv, B * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(const_cast<double *>(G.pose), pose, B * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(const_cast<int *>(G.nobs), n_obstacles, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    if (lmax > 0) {
+    if (n_obstacles)
+        HIP_TRY(h, hipMemcpyAsync(const_cast<int *>(G.nobs), n_obstacles, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (n_obstacles && lmax > 0) {
         if (!obstacles) return USVMPC_E_ARG;
         // [B][lmax][3] -> [B][GUIDANCE_LMAX][3]
         HIP_TRY(h, hipMemcpy2DAsync(const_cast<double *>(G.obs), GUIDANCE_LMAX * 3 * sizeof(double), obstacles,
@@ -687,6 +691,32 @@ int usvmpc_guidance_prepare(usvmpc_handle *h, const double *vel_uv, const double
     }
     hipLaunchKernelGGL(usv_guidance_pre, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, h->stream, h->ptrs, G);
     HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int usvmpc_guidance_sense(usvmpc_handle *h, const double *pose, const double *world, int n_world, double max_radius,
+                          double *obstacles, int *n_obstacles)
+{
+    if (!h || !pose || n_world < 0 || (n_world > 0 && !world)) return USVMPC_E_ARG;
+    if (!h->gd_ready) { h->err = "usvmpc_guidance_reset must be called first"; return USVMPC_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    GuidancePtrs &G = h->gd;
+    const size_t B = h->B;
+    if ((size_t)n_world > h->gd_world_cap) {
+        if (dev_alloc(h, &h->gd_world, B * (size_t)n_world * 3, true)) return USVMPC_E_HIP;
+        h->gd_world_cap = (size_t)n_world;
+    }
+    HIP_TRY(h, hipMemcpyAsync(const_cast<double *>(G.pose), pose, B * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (n_world > 0)
+        HIP_TRY(h, hipMemcpyAsync(h->gd_world, world, B * (size_t)n_world * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(usv_obstacle_sim, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, h->stream, G, h->gd_world, n_world,
+                       max_radius, (int)B);
+    HIP_TRY(h, hipGetLastError());
+    if (obstacles)
+        HIP_TRY(h, hipMemcpyAsync(obstacles, G.obs, B * GUIDANCE_LMAX * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (n_obstacles)
+        HIP_TRY(h, hipMemcpyAsync(n_obstacles, G.nobs, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (obstacles || n_obstacles) HIP_TRY(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 

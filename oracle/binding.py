@@ -297,6 +297,16 @@ def guidance_prepare(K, vel_uv, pose, waypoints, obs, k, past_psied):
     return dict(active=act, k=kk.value, past_psied=pp.value, x0=x0, p_obs=p, r_obs=r, ak=ak[0], ye=ye[0])
 
 
+def obstacle_sim(pose, world, max_radius=100.0, lmax=64):
+    """obstacle_sim_node.simulate(): (obstacles [n,3] body frame, n)."""
+    pose, world = _arr(pose), _arr(np.asarray(world, dtype=float).reshape(-1, 3))
+    out = np.zeros((lmax, 3))
+    L = lib()
+    L.usv_obstacle_sim_ref.argtypes = [_dp, _dp, C.c_int, C.c_double, C.c_int, _dp]
+    n = L.usv_obstacle_sim_ref(_d(pose), _d(world), world.shape[0], float(max_radius), lmax, _d(out))
+    return out[:n].copy(), n
+
+
 def guidance_publish(x1_psied, u0, ak, past_psied):
     pp = C.c_float(float(past_psied))
     h, r, s = C.c_double(), C.c_double(), C.c_double()

@@ -153,3 +153,26 @@ void usv_guidance_publish_ref(double x1_psied, double u0, double ak, float *past
     *r_des = u0;
     *speed = D_SPEED;
 }
+
+/* obstacle_sim_node.py simulate() :56-81 with ned_to_body :101-117.  The node inverts the 2x2 rotation with
+ * numpy.linalg.inv (LAPACK); the adjugate / determinant form used here agrees with it to rounding. */
+int usv_obstacle_sim_ref(const double *pose, const double *world, int n_world, double max_radius, int lmax,
+                         double *obstacles)
+{
+    const double nedx = pose[0], nedy = pose[1], yaw = pose[2];
+    const double c = cos(yaw), s = sin(yaw);
+    const double det = c * c - (-s) * s;
+    const double i00 = c / det, i01 = s / det, i10 = -s / det, i11 = c / det;
+    int i, n = 0;
+    for (i = 0; i < n_world && n < lmax; i++) {
+        const double dx = world[3 * i] - nedx, dy = world[3 * i + 1] - nedy;
+        const double dist = pow(dx * dx + dy * dy, 0.5);
+        if (dist < max_radius) {
+            obstacles[3 * n + 0] = i00 * dx + i01 * dy;
+            obstacles[3 * n + 1] = i10 * dx + i11 * dy;
+            obstacles[3 * n + 2] = world[3 * i + 2];
+            n++;
+        }
+    }
+    return n;
+}

@@ -19,6 +19,11 @@ int usv_guidance_prepare_ref(int K, const double *vel_uv, const double *pose, co
 /* one tick, output side */
 void usv_guidance_publish_ref(double x1_psied, double u0, double ak, float *past_psied,
                               double *heading, double *r_des, double *speed);
+/* obstacle simulator (catkin_ws/src/simulation/scripts/obstacle_sim_node.py:56-81,101-117): the world obstacles
+ * (X, Y, R) within max_radius of the vessel, in the body frame, in list order; returns their number (<= lmax). */
+int usv_obstacle_sim_ref(const double *pose, const double *world, int n_world, double max_radius, int lmax,
+                         double *obstacles);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,3 +148,56 @@ def test_device_front_end_matches_oracle(oracle):
     s2.solve()
     assert np.array_equal(s2.get_all("x"), s.get_all("x")) and np.array_equal(s2.get_all("u"), s.get_all("u"))
     s.close(); s2.close()
+
+
+def test_obstacle_simulator_restatement(oracle):
+    """obstacle_sim_node.simulate(): the restatement against the node's own formulas written with numpy
+    (math.pow distance test, numpy.linalg.inv of the rotation matrix)."""
+    rng = np.random.default_rng(4)
+    world = np.column_stack([rng.uniform(-60, 60, 30), rng.uniform(-60, 60, 30), rng.uniform(0.2, 1.5, 30)])
+    for t in range(20):
+        pose = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-3.2, 3.2)])
+        R = 100.0 if t % 2 else 35.0
+        want = []
+        for X, Y, r in world:
+            dx, dy = X - pose[0], Y - pose[1]
+            if (dx * dx + dy * dy) ** 0.5 < R:
+                J = np.array([[np.cos(pose[2]), -np.sin(pose[2])], [np.sin(pose[2]), np.cos(pose[2])]])
+                b = np.linalg.inv(J).dot(np.array([dx, dy]))
+                want.append([b[0], b[1], r])
+        got, n = oracle.obstacle_sim(pose, world, R)
+        assert n == len(want)
+        if n:
+            assert np.allclose(got, np.array(want), rtol=0, atol=1e-13) and np.array_equal(got[:, 2], np.array(want)[:, 2])
+    got, n = oracle.obstacle_sim(np.zeros(3), world, 100.0, lmax=5)        # capacity of the input list
+    assert n == 5
+
+
+@pytest.mark.gpu
+def test_device_obstacle_simulator_feeds_the_front_end(oracle):
+    from mpc_collisionavoidance_amd import BatchOcpSolver
+    from mpc_collisionavoidance_amd.guidance import GuidanceFrontEnd
+    B, N, K, L = 200, 20, 8, 40
+    rng = np.random.default_rng(3)
+    ocp = usv_models.make_ocp("usv_model_guidance_ca1", N * 0.05, N, K)
+    s = BatchOcpSolver(ocp, B)
+    fe = GuidanceFrontEnd(s)
+    wps = np.array([[4.0, -5.0], [4.0, 25.0], [10.0, 30.0]])
+    pose = np.column_stack([rng.uniform(2, 6, B), rng.uniform(-5, 20, B), rng.uniform(-3.2, 3.2, B)])
+    vel = np.column_stack([rng.uniform(0.3, 1.2, B), rng.uniform(-0.1, 0.1, B)])
+    world = np.concatenate([rng.uniform(-30, 40, (B, L, 2)), rng.uniform(0.2, 1.5, (B, L, 1))], axis=2)
+    fe.reset(wps, pose[:, 2])
+    obs, n = fe.sense(pose, world, max_radius=18.0, fetch=True)
+    for b in range(B):
+        want, nw = oracle.obstacle_sim(pose[b], world[b], 18.0)
+        assert n[b] == nw and 0 < n.max() <= L
+        assert np.allclose(obs[b, :nw], want, rtol=0, atol=1e-12) and np.array_equal(obs[b, :nw, 2], want[:, 2])
+    # the lists stay on the device: prepare() without obstacles == prepare() with the fetched lists
+    fe.prepare(vel, pose)
+    s.sync()
+    p1, lh1, x01 = s.get_all("p"), s.get_all("lh"), s.get("x0", 0)
+    fe.reset(wps, pose[:, 2])
+    fe.prepare(vel, pose, obs, n)
+    s.sync()
+    assert np.array_equal(p1, s.get_all("p")) and np.array_equal(lh1, s.get_all("lh")) and np.array_equal(x01, s.get("x0", 0))
+    s.close()

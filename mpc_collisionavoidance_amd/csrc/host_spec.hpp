@@ -148,7 +148,12 @@ inline void default_options(usvmpc_desc &d)
     d.nlp_tol_stat = d.nlp_tol_eq = d.nlp_tol_ineq = d.nlp_tol_comp = 1e-6;
 }
 
-// planes of the QP workspace per stage for a (model, KCH, soft) combination (see qp_ipm.hpp)
-inline int ws_planes(int nx, int nu, int kch, bool soft) { (void)nx; return 11 + kch * (soft ? 10 : 4) + nu; }
+// planes of the solver workspace per stage for a (model, KCH, soft) combination: WsLayout::NPT (params.hpp);
+// mat_planes = MatPack<M>::NPK of the model
+inline int ws_planes(int nx, int nu, int kch, bool soft, int mat_planes)
+{
+    (void)nx;
+    return 11 + kch * (soft ? 10 : 4) + nu + 2 + mat_planes;
+}
 
 } // namespace usv

@@ -17,9 +17,10 @@ namespace usv {
 
 // MULTI: more than one RK4 step per interval (the initial sensitivity column is then a carried variable
 // instead of a lane pattern the compiler rematerialises for free: 28 more VGPRs for M2, hence a separate build)
-template <class M, int KCH, bool MULTI = false>
+template <class M, int KCH, bool SOFT, bool MULTI = false>
 struct Linearize {
     static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
+    using WL = WsLayout<M, KCH, SOFT>;
 
     // gid = k * Bp + g  (groups of a wave share the stage k)
     USV_DEV static void run(const DevPtrs &P, long gid)
@@ -57,7 +58,7 @@ struct Linearize {
             sfor<0, NU>([&](auto i) { acc = fma(Hrow[i], U[i], acc); });
             sfor<0, NX>([&](auto i) { acc = fma(Hrow[NU + i], x[i], acc); });
             for (int y = 0; y < ny; y++) acc = fma(-Mrow[y], yr[y], acc);
-            P.gq[(long)k * stride + gl] = acc;
+            P.ws[((long)k * WL::NPT + WL::P_GQ) * stride + gl] = acc;
         }
         if (k == N) return; // wave-uniform
 
@@ -116,9 +117,9 @@ struct Linearize {
                 const double gth = lanes::gather(sa[MP::nth(MP::RMASK, jj)], c_l);
                 val = (jj_l == jj) ? gth : val;
             });
-            P.BAp[((long)k * MP::NPK + q) * stride + gl] = val;
+            P.ws[((long)k * WL::NPT + WL::P_MAT + q) * stride + gl] = val;
         });
-        P.rb0[(long)k * stride + gl] = xlane ? bres : 0.0;
+        P.ws[((long)k * WL::NPT + WL::P_RB0) * stride + gl] = xlane ? bres : 0.0;
         // (obstacle rows are linearised inside the QP kernel from the iterate and (p, lh): QpIpm::obs_geom)
     }
 };

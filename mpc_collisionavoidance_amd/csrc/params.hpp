@@ -62,6 +62,22 @@ struct MatPack {
     static constexpr int rank(unsigned mask, int b) { return __builtin_popcount(mask & ((1u << b) - 1u)); }
 };
 
+// Plane map of one stage of the solver workspace `ws` (lane-major planes, one window per stage).  The
+// lineariser writes the last planes (dynamics residual, cost gradient, packed [B A]); everything lives in ONE
+// window per stage so that the QP kernel needs one buffer descriptor and compile-time plane numbers (separate
+// arrays cost scalar registers, and once those ran out the compiler moved plane offsets to vector registers
+// and wrapped the loads in waterfall loops).
+template <class M, int KCH, bool SOFT>
+struct WsLayout {
+    enum : int { P_Z = 0, P_ZB, P_DZA, P_DZ, P_DX0, P_PB, P_PI, P_BLL, P_BLU, P_BTL, P_BTU, P_OBS };
+    static constexpr int OBSN = SOFT ? 10 : 4;
+    static constexpr int P_LZU = P_OBS + KCH * OBSN;
+    static constexpr int P_RB0 = P_LZU + M::NU; // b_k of the linearisation point (x lanes)
+    static constexpr int P_GQ = P_RB0 + 1;      // cost gradient
+    static constexpr int P_MAT = P_GQ + 1;      // packed [B A] (MatPack<M>::NPK planes)
+    static constexpr int NPT = P_MAT + MatPack<M>::NPK;
+};
+
 // Device pointers of one solver handle.
 struct DevPtrs {
     const DevSpec *spec;
@@ -85,12 +101,8 @@ struct DevPtrs {
     int *sqp_iter;        // [B]         SQP iterations taken
     int *sqp_state;       // [B]         -1 running, else the final acados status (0 converged, 2 max iter, 4 QP failure)
     int *sqp_running;     // [1]         instances still running after the last launch
-    // linearisation output, lane-major planes: element (k, e) of group g, lane r at
-    // ((k*E + e) * Bp + g) * 16 + r
-    double *BAp;          // [N][NPK]  the informative entries of [B A], packed (MatPack)
-    double *rb0;          // [N]       dynamics residual b_k (x lanes)
-    double *gq;           // [N+1]     cost gradient
-    // QP workspace, lane-major planes [N+1][NPL]
+    // lane-major planes: element (k, e) of group g, lane r at ((k*E + e) * Bp + g) * 16 + r
+    // solver workspace, lane-major planes [N+1][WsLayout::NPT]: linearisation output + QP state
     double *ws;
 };
 

@@ -145,10 +145,13 @@ struct QpIpm {
     // plane map of the per-stage workspace window
     // P_PB holds (l_u | P b): the u lanes carry the gain rhs, the x lanes P_{k+1} b_k;  P_PI holds (r_g | pi):
     // stationarity residual on the u lanes, dynamics multiplier on the x lanes (u and x lanes are disjoint)
-    enum : int { P_Z = 0, P_ZB, P_DZA, P_DZ, P_DX0, P_PB, P_PI, P_BLL, P_BLU, P_BTL, P_BTU, P_OBS };
-    static constexpr int OBSN = SOFT ? 10 : 4;
-    static constexpr int P_LZU = P_OBS + KCH * OBSN;
-    static constexpr int NPL = P_LZU + NU;
+    // (plane numbers: WsLayout, params.hpp - shared with the lineariser, which fills P_RB0, P_GQ and P_MAT..)
+    using WL = WsLayout<M, KCH, SOFT>;
+    enum : int { P_Z = WL::P_Z, P_ZB = WL::P_ZB, P_DZA = WL::P_DZA, P_DZ = WL::P_DZ, P_DX0 = WL::P_DX0, P_PB = WL::P_PB,
+                 P_PI = WL::P_PI, P_BLL = WL::P_BLL, P_BLU = WL::P_BLU, P_BTL = WL::P_BTL, P_BTU = WL::P_BTU,
+                 P_OBS = WL::P_OBS, P_LZU = WL::P_LZU, P_RB0 = WL::P_RB0, P_GQ = WL::P_GQ, P_MAT = WL::P_MAT };
+    static constexpr int OBSN = WL::OBSN;
+    static constexpr int NPL = WL::NPT;
 
     static constexpr bool out_unit(int j) { return ((M::OUT_UNIT >> j) & 1u) != 0u; }
 
@@ -331,8 +334,8 @@ struct QpIpm {
     // mat_issue puts the plane loads in flight, mat_unpack (call under wave-uniform control flow) distributes.
     USV_DEV void mat_issue(int k, double *pk) const
     {
-        const Planes BP(P.BAp + (long)k * MP::NPK * stride, stride, MP::NPK, gl);
-        sfor<0, MP::NPK>([&](auto q) { pk[q] = BP.ld(q); });
+        const Planes W = ws(k);
+        sfor<0, MP::NPK>([&](auto q) { pk[q] = W.ld(P_MAT + q); });
     }
     USV_DEV void mat_unpack(const double *pk, double *bat) const
     {
@@ -435,11 +438,11 @@ struct QpIpm {
         // b_k of the current iterate = rbscale * (residual of the linearisation point): the forward sweeps
         // enforce the linearised dynamics, so every step scales it by (1 - alpha) and it is never rewritten
         // (raw value here: scaling it in place would make the prefetch wait for its own load)
-        if constexpr (SW != SW_BACK_B) in.rb = (k < N) ? Planes(P.rb0, stride, N, gl).ld(k) : 0.0;
+        if constexpr (SW != SW_BACK_B) in.rb = (k < N) ? W.ld(P_RB0) : 0.0;
         if constexpr (SW == SW_BACK_A) {
             in.dz = W.ld(P_DZ);
             in.dza = W.ld(P_DZA);
-            in.gq = Planes(P.gq, stride, N + 1, gl).ld(k);
+            in.gq = W.ld(P_GQ);
         }
         if constexpr (SW == SW_BACK_B || SW == SW_FWD_B) in.dza = W.ld(P_DZA);
         if constexpr (SW == SW_BACK_B) {
@@ -916,7 +919,7 @@ struct QpIpm {
                 lx = lanes::gsum(lx); ly = lanes::gsum(ly);
             }
             // stationarity: g + [B A]' pi_{k+1} - C'(ll - lu) (- pi_k on the x lanes)
-            double t = Planes(P.gq, stride, N + 1, gl).ld(k);
+            double t = W.ld(P_GQ);
             sfor<0, NX>([&](auto j) {
                 if constexpr (!out_unit(j)) lanes::fma_bc<NU + j>(t, pin, bat[j]);
             });
@@ -926,7 +929,7 @@ struct QpIpm {
             const double pik = (xlane && !first) ? W.ld(P_PI) : 0.0;
             if (xlane && k >= 1) rg = fmax(rg, fabs(t - pik));
             if (ulane && k < N) rg = fmax(rg, fabs(t));
-            if (k < N) rbn = fmax(rbn, xlane ? fabs(Planes(P.rb0, stride, N, gl).ld(k)) : 0.0);
+            if (k < N) rbn = fmax(rbn, xlane ? fabs(W.ld(P_RB0)) : 0.0);
             if (k == 0) rbn = fmax(rbn, xlane ? fabs(P.x0[(long)b * NX + (lane - NU)] - in.zb) : 0.0);
             pin = pik;
         }

@@ -24,12 +24,12 @@
 using namespace usv;
 
 // ---------------------------------------------------------------------------------- kernels
-template <class M, int KCH, bool MULTI>
+template <class M, int KCH, bool SOFT, bool MULTI>
 __global__ void __launch_bounds__(256, 2) usv_linearize(DevPtrs P, long ngroups)
 {
     const long gid = lanes::group_linear();
     if (gid >= ngroups) return; // ngroups is a multiple of 4: whole waves leave together
-    Linearize<M, KCH, MULTI>::run(P, gid);
+    Linearize<M, KCH, SOFT, MULTI>::run(P, gid);
 }
 
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK>
@@ -275,9 +275,9 @@ int launch_pair(usvmpc_handle *h, int phase)
     }
     HIP_TRY(h, hipEventRecord(ev[0], h->stream));
     if (h->spec.sim_steps > 1)
-        hipLaunchKernelGGL((usv_linearize<M, KCH, true>), dim3((unsigned)lin_grid), dim3(lin_block), 0, h->stream, h->ptrs, lin_groups);
+        hipLaunchKernelGGL((usv_linearize<M, KCH, SOFT, true>), dim3((unsigned)lin_grid), dim3(lin_block), 0, h->stream, h->ptrs, lin_groups);
     else
-        hipLaunchKernelGGL((usv_linearize<M, KCH, false>), dim3((unsigned)lin_grid), dim3(lin_block), 0, h->stream, h->ptrs, lin_groups);
+        hipLaunchKernelGGL((usv_linearize<M, KCH, SOFT, false>), dim3((unsigned)lin_grid), dim3(lin_block), 0, h->stream, h->ptrs, lin_groups);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[1], h->stream));
     constexpr bool CANPACK = KCH > 0;
@@ -441,10 +441,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->sort_enabled = true;
     h->gd_ready = false; h->gd_npts_cap = 0; h->gd_psi = nullptr; h->gd_world = nullptr; h->gd_world_cap = 0;
     std::memset(&h->gd, 0, sizeof(h->gd));
-    TRY_C(dev_alloc(h, &P.BAp, N * (size_t)model_mat_planes(d->model) * stride, true));
-    TRY_C(dev_alloc(h, &P.rb0, N * stride, true));
-    TRY_C(dev_alloc(h, &P.gq, (N + 1) * stride, true));
-    TRY_C(dev_alloc(h, &P.ws, (N + 1) * (size_t)ws_planes(h->nx, h->nu, h->kch, h->soft) * stride, true));
+    TRY_C(dev_alloc(h, &P.ws, (N + 1) * (size_t)ws_planes(h->nx, h->nu, h->kch, h->soft, model_mat_planes(h->desc.model)) * stride, true));
     HIP_C(hipDeviceSynchronize());
 #undef TRY_C
 #undef HIP_C
@@ -755,7 +752,7 @@ int usvmpc_calibrate_traffic(usvmpc_handle *h, int nplanes, double *bytes_read, 
     if (!h || nplanes < 1) return USVMPC_E_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     const long stride = (long)h->Bp * LANES;
-    const long avail = (long)(h->N + 1) * ws_planes(h->nx, h->nu, h->kch, h->soft);
+    const long avail = (long)(h->N + 1) * ws_planes(h->nx, h->nu, h->kch, h->soft, model_mat_planes(h->desc.model));
     if (nplanes + 1 > avail) { h->err = "nplanes exceeds the workspace"; return USVMPC_E_ARG; }
     const long groups = h->Bp;
     hipLaunchKernelGGL(usv_calib_stream, dim3((unsigned)((groups * LANES + 63) / 64)), dim3(64), 0, h->stream, h->ptrs, groups, nplanes, stride);

@@ -107,8 +107,8 @@ template <class M, int KCH, bool SOFT>
 void lin_body(void *a)
 {
     Job *j = (Job *)a;
-    if (j->P->spec->sim_steps > 1) Linearize<M, KCH, true>::run(*j->P, j->gid);
-    else Linearize<M, KCH, false>::run(*j->P, j->gid);
+    if (j->P->spec->sim_steps > 1) Linearize<M, KCH, SOFT, true>::run(*j->P, j->gid);
+    else Linearize<M, KCH, SOFT, false>::run(*j->P, j->gid);
 }
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK>
 void qp_body(void *a)
@@ -118,13 +118,22 @@ void qp_body(void *a)
     q.solve(j->qp_phase);
 }
 
-double *g_dbg_BAt = nullptr; // [N][nx][Bp*16]: the packed planes expanded back to one plane per row (inspection)
+// inspection copies of the lineariser's output: BAt [N][nx][Bp*16] (the packed planes expanded back to one plane
+// per row), rb0 [N][Bp*16], gq [N+1][Bp*16]
+double *g_dbg_BAt = nullptr, *g_dbg_rb0 = nullptr, *g_dbg_gq = nullptr;
 
-template <class M>
+template <class M, int KCH, bool SOFT>
 void expand_packed(const DevPtrs &P, const DevSpec &S)
 {
     using MP = MatPack<M>;
+    using WL = WsLayout<M, KCH, SOFT>;
     const long stride = (long)S.Bp * LANES;
+    for (int k = 0; k <= S.N; k++)
+        for (long i = 0; i < stride; i++) {
+            if (g_dbg_gq) g_dbg_gq[(long)k * stride + i] = P.ws[((long)k * WL::NPT + WL::P_GQ) * stride + i];
+            if (g_dbg_rb0 && k < S.N) g_dbg_rb0[(long)k * stride + i] = P.ws[((long)k * WL::NPT + WL::P_RB0) * stride + i];
+        }
+    if (!g_dbg_BAt) return;
     for (int k = 0; k < S.N; k++)
         for (int j = 0; j < M::NX; j++) {
             if (!((MP::RMASK >> j) & 1u)) continue; // unit rows are not stored: left at zero
@@ -134,7 +143,7 @@ void expand_packed(const DevPtrs &P, const DevSpec &S)
                     double v;
                     if ((MP::CMASK >> c) & 1u) {
                         const int pos = jj * MP::NC + MP::rank(MP::CMASK, c);
-                        v = P.BAp[((long)k * MP::NPK + pos / 16) * stride + g * LANES + pos % 16];
+                        v = P.ws[((long)k * WL::NPT + WL::P_MAT + pos / 16) * stride + g * LANES + pos % 16];
                     } else {
                         v = (c == M::NU + j) ? 1.0 : 0.0;
                     }
@@ -151,7 +160,7 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
             Job j{&P, gid, 0};
             lanes::run_group(gid, &lin_body<M, KCH, SOFT>, &j);
         }
-    if ((phase & 1) && g_dbg_BAt) expand_packed<M>(P, S);
+    if ((phase & 1) && (g_dbg_BAt || g_dbg_rb0 || g_dbg_gq)) expand_packed<M, KCH, SOFT>(P, S);
     if (phase & 2)
         for (long g = 0; g < S.Bp; g++) {
             Job j{&P, g, qp_phase};
@@ -189,9 +198,8 @@ static int emu_run(const usvmpc_desc *d, int sqp, double *x, double *u, const do
     if (d->model == USVMPC_MODEL_GENERATED) { kch = USV_GEN_KCH; soft = USV_GEN_SOFT != 0; }
 #endif
     const long stride = (long)S.Bp * LANES;
-    std::vector<double> BAp((size_t)N * 16 * stride), rb0((size_t)N * stride), // 16 >= MatPack::NPK of any model
-        gq((size_t)(N + 1) * stride),
-        ws((size_t)(N + 1) * ws_planes(nx, nu, kch, soft) * stride), nres((size_t)S.B * 4);
+    std::vector<double> ws((size_t)(N + 1) * ws_planes(nx, nu, kch, soft, 16) * stride), // 16 >= MatPack::NPK of any model
+        nres((size_t)S.B * 4);
     std::vector<int> sit(S.B, 0), sstate(S.B, -1);
     int running = 0;
     DevPtrs P;
@@ -199,9 +207,9 @@ static int emu_run(const usvmpc_desc *d, int sqp, double *x, double *u, const do
     P.spec = &S;
     P.x = x; P.u = u; P.x0 = x0; P.yref = yref; P.yref_e = yref_e; P.p = p; P.lh = lh;
     P.sl = sl; P.su = su; P.pi = pi; P.status = status; P.qp_iter = qp_iter; P.qp_status = qp_status; P.res = res;
-    P.BAp = BAp.data(); P.rb0 = rb0.data(); P.gq = gq.data(); P.ws = ws.data();
+    P.ws = ws.data();
     P.nlp_res = nres.data(); P.sqp_iter = sit.data(); P.sqp_state = sstate.data(); P.sqp_running = &running;
-    g_dbg_BAt = dbg_BAt;
+    g_dbg_BAt = dbg_BAt; g_dbg_rb0 = dbg_rb0; g_dbg_gq = dbg_gq;
     auto one = [&](int qp_phase) -> int {
         const int phase = 3;
 #ifdef USV_GEN_MODEL_HEADER
@@ -240,8 +248,6 @@ static int emu_run(const usvmpc_desc *d, int sqp, double *x, double *u, const do
             if (nlp_res) std::memcpy(nlp_res + (size_t)b * 4, nres.data() + (size_t)b * 4, 4 * sizeof(double));
         }
     }
-    if (dbg_rb0) std::memcpy(dbg_rb0, rb0.data(), rb0.size() * sizeof(double));
-    if (dbg_gq) std::memcpy(dbg_gq, gq.data(), gq.size() * sizeof(double));
     return 0;
 }
 

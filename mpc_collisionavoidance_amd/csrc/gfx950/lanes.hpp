@@ -132,32 +132,33 @@ USV_DEV double frsqrt(double x)
     return y;
 }
 
-// A window of lane-major planes [nplanes][stride] in HBM, addressed through a buffer resource:
-// the descriptor and the plane offset live in SGPRs, the lane offset in ONE VGPR for the whole
-// kernel, so a plane access costs no VALU address arithmetic (buffer_load_dwordx2 ... offen).
+// lane index inside the wave (a wave carries four 16-lane groups)
+USV_DEV unsigned wave_lane() { return threadIdx.x & 63u; }
+
+// One wave's tile of lane-major planes in HBM: [nplanes][64 lanes], 512 contiguous bytes per plane, planes
+// back to back.  Addressed through a buffer resource: the descriptor lives in SGPRs, the lane offset in ONE VGPR
+// for the whole kernel, and the plane offset (plane * 512) is a compile-time constant of the instruction, so a
+// plane access costs neither VALU address arithmetic nor a live scalar register (buffer_load_dwordx2 ... offen).
+// tile must be wave-uniform.
 struct Planes {
     __amdgpu_buffer_rsrc_t rsrc;
-    unsigned voff;        // (group * 16 + lane) * 8
-    unsigned plane_bytes; // stride * 8
+    unsigned voff; // wave_lane * 8
 
-    USV_DEV Planes(const double *base, long stride, int nplanes, unsigned gl)
+    USV_DEV Planes(const double *tile, int nplanes, unsigned wl)
     {
-        plane_bytes = (unsigned)(stride * 8);
-        voff = gl * 8u;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0,
-                                                 (int)((unsigned)nplanes * plane_bytes), 0x00020000);
+        voff = wl * 8u;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(tile), 0, nplanes * 512, 0x00020000);
     }
     USV_DEV double ld(int plane) const
     {
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)((unsigned)plane * plane_bytes), 0);
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, plane * 512, 0);
         return __builtin_bit_cast(double, v);
     }
     USV_DEV void st(int plane, double x) const
     {
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), rsrc, (int)voff,
-                                              (int)((unsigned)plane * plane_bytes), 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), rsrc, (int)voff, plane * 512, 0);
     }
 };
 

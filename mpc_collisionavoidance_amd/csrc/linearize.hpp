@@ -34,8 +34,8 @@ struct Linearize {
         const int nB = lanes::uniform(S.B);
         const long gi = g < nB ? g : (long)nB - 1; // padded groups replay the last instance
         const long b = P.perm ? (long)P.perm[gi] : gi;
-        const long stride = Bp * LANES;
-        const long gl = g * LANES + lane;
+        // workspace: [stage][wave tile of 4 groups][plane][64 lanes] (lanes::Planes)
+        double *tile = P.ws + (((long)k * (Bp / 4) + (g >> 2)) * WL::NPT) * 64 + (g & 3) * LANES + lane;
         const bool xlane = lane >= NU && lane < NZ;
 
         double x[NX], U[NU > 0 ? NU : 1];
@@ -58,7 +58,7 @@ struct Linearize {
             sfor<0, NU>([&](auto i) { acc = fma(Hrow[i], U[i], acc); });
             sfor<0, NX>([&](auto i) { acc = fma(Hrow[NU + i], x[i], acc); });
             for (int y = 0; y < ny; y++) acc = fma(-Mrow[y], yr[y], acc);
-            P.ws[((long)k * WL::NPT + WL::P_GQ) * stride + gl] = acc;
+            tile[WL::P_GQ * 64] = acc;
         }
         if (k == N) return; // wave-uniform
 
@@ -117,9 +117,9 @@ struct Linearize {
                 const double gth = lanes::gather(sa[MP::nth(MP::RMASK, jj)], c_l);
                 val = (jj_l == jj) ? gth : val;
             });
-            P.ws[((long)k * WL::NPT + WL::P_MAT + q) * stride + gl] = val;
+            tile[(WL::P_MAT + q) * 64] = val;
         });
-        P.ws[((long)k * WL::NPT + WL::P_RB0) * stride + gl] = xlane ? bres : 0.0;
+        tile[WL::P_RB0 * 64] = xlane ? bres : 0.0;
         // (obstacle rows are linearised inside the QP kernel from the iterate and (p, lh): QpIpm::obs_geom)
     }
 };

@@ -169,8 +169,10 @@ struct QpIpm {
     bool pstat;     // S.p_static
     bool keep;      // full SQP: this instance is finished, its workspace (multipliers of the last QP) must survive
     int lane, N;
-    long g, b, stride;
-    unsigned gl;
+    long g, b;
+    long tile_stride; // doubles between the tiles of consecutive stages: (Bp / 4) * NPL * 64
+    const double *tile0;  // this wave's tile of stage 0
+    unsigned wl;
     bool xlane, ulane, valid, isPX, isPY;
     // per-lane constants, read once: box bounds of this lane's variable, Hessian diagonal
     // PACK: the box rows' (lambda_l, lambda_u, t_l, t_u) do not get four planes of their own.  A *slot* row
@@ -209,8 +211,12 @@ struct QpIpm {
             const long gi = g < nB ? g : (long)nB - 1;
             b = P.perm ? (long)P.perm[gi] : gi;
         }
-        gl = (unsigned)(g * LANES + lane);
-        stride = (long)lanes::uniform(S.Bp) * LANES;
+        wl = lanes::wave_lane();
+        {   // workspace layout: [stage][wave tile][plane][64 lanes]; the four groups of a wave share a tile
+            const long nblk = (long)lanes::uniform(S.Bp) / 4;
+            tile_stride = nblk * NPL * 64;
+            tile0 = P.ws + (long)lanes::uniform((int)(g >> 2)) * NPL * 64;
+        }
         ulane = lane < NU;
         xlane = lane >= NU && lane < NZ;
         valid = lane < NZ;
@@ -252,7 +258,7 @@ struct QpIpm {
         }
     }
 
-    USV_DEV Planes ws(int k) const { return Planes(P.ws + (long)k * NPL * stride, stride, NPL, gl); }
+    USV_DEV Planes ws(int k) const { return Planes(tile0 + (long)k * tile_stride, NPL, wl); }
     // iterate value of this lane's variable at stage k (caller-visible arrays)
     USV_DEV double zbar(int k) const
     {

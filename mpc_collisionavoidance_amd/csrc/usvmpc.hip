@@ -86,12 +86,11 @@ __global__ void usv_advance(DevPtrs P, int nx, double sigma, unsigned long long 
 // Traffic calibration for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters: streams a KNOWN number of
 // workspace planes with exactly the access instruction of the solver kernels (one
 // buffer_load_dwordx2 per lane per plane, 16 lanes of a group contiguous) and writes one plane.
-__global__ void __launch_bounds__(64) usv_calib_stream(DevPtrs P, long ngroups, int nread, long stride)
+__global__ void __launch_bounds__(64) usv_calib_stream(DevPtrs P, long ngroups, int nread)
 {
     const long g = lanes::group_linear();
     if (g >= ngroups) return;
-    const unsigned gl = (unsigned)(g * LANES + lanes::lane());
-    const lanes::Planes W(P.ws, stride, nread + 1, gl);
+    const lanes::Planes W(P.ws + (long)blockIdx.x * (nread + 1) * 64, nread + 1, lanes::wave_lane());
     double acc = 0.0;
     for (int i = 0; i < nread; i++) acc += W.ld(i);
     W.st(nread, acc);
@@ -755,7 +754,7 @@ int usvmpc_calibrate_traffic(usvmpc_handle *h, int nplanes, double *bytes_read, 
     const long avail = (long)(h->N + 1) * ws_planes(h->nx, h->nu, h->kch, h->soft, model_mat_planes(h->desc.model));
     if (nplanes + 1 > avail) { h->err = "nplanes exceeds the workspace"; return USVMPC_E_ARG; }
     const long groups = h->Bp;
-    hipLaunchKernelGGL(usv_calib_stream, dim3((unsigned)((groups * LANES + 63) / 64)), dim3(64), 0, h->stream, h->ptrs, groups, nplanes, stride);
+    hipLaunchKernelGGL(usv_calib_stream, dim3((unsigned)((groups * LANES + 63) / 64)), dim3(64), 0, h->stream, h->ptrs, groups, nplanes);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (bytes_read) *bytes_read = (double)nplanes * stride * 8.0;

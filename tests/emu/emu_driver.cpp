@@ -128,11 +128,16 @@ void expand_packed(const DevPtrs &P, const DevSpec &S)
     using MP = MatPack<M>;
     using WL = WsLayout<M, KCH, SOFT>;
     const long stride = (long)S.Bp * LANES;
+    // workspace element (stage k, plane e, group g, lane r): [stage][tile of 4 groups][plane][64 lanes]
+    auto at = [&](int k, int e, long g, int r) -> double {
+        return P.ws[((((long)k * (S.Bp / 4) + (g >> 2)) * WL::NPT + e) * 64) + (g & 3) * LANES + r];
+    };
     for (int k = 0; k <= S.N; k++)
-        for (long i = 0; i < stride; i++) {
-            if (g_dbg_gq) g_dbg_gq[(long)k * stride + i] = P.ws[((long)k * WL::NPT + WL::P_GQ) * stride + i];
-            if (g_dbg_rb0 && k < S.N) g_dbg_rb0[(long)k * stride + i] = P.ws[((long)k * WL::NPT + WL::P_RB0) * stride + i];
-        }
+        for (long g = 0; g < S.Bp; g++)
+            for (int r = 0; r < LANES; r++) {
+                if (g_dbg_gq) g_dbg_gq[(long)k * stride + g * LANES + r] = at(k, WL::P_GQ, g, r);
+                if (g_dbg_rb0 && k < S.N) g_dbg_rb0[(long)k * stride + g * LANES + r] = at(k, WL::P_RB0, g, r);
+            }
     if (!g_dbg_BAt) return;
     for (int k = 0; k < S.N; k++)
         for (int j = 0; j < M::NX; j++) {
@@ -143,7 +148,7 @@ void expand_packed(const DevPtrs &P, const DevSpec &S)
                     double v;
                     if ((MP::CMASK >> c) & 1u) {
                         const int pos = jj * MP::NC + MP::rank(MP::CMASK, c);
-                        v = P.ws[((long)k * WL::NPT + WL::P_MAT + pos / 16) * stride + g * LANES + pos % 16];
+                        v = at(k, WL::P_MAT + pos / 16, g, pos % 16);
                     } else {
                         v = (c == M::NU + j) ? 1.0 : 0.0;
                     }

@@ -92,22 +92,24 @@ inline void count_one(int *p) { ++*p; }
 inline double frcp(double x) { return 1.0 / x; }
 inline double frsqrt(double x) { return 1.0 / std::sqrt(x); }
 
-// window of lane-major planes (plain pointers here; a buffer resource on the GPU)
+// lane index inside the (emulated) wave: the group's quarter of its 4-group tile
+inline unsigned wave_lane() { return (unsigned)((g_emu.group & 3) * 16 + g_emu.cur); }
+
+// one wave's tile of lane-major planes [nplanes][64] (plain pointers here; a buffer resource on the GPU)
 struct Planes {
     double *base;
-    long stride;
     int nplanes;
-    unsigned gl;
-    Planes(const double *b, long s, int n, unsigned g) : base(const_cast<double *>(b)), stride(s), nplanes(n), gl(g) {}
+    unsigned wl;
+    Planes(const double *tile, int n, unsigned w) : base(const_cast<double *>(tile)), nplanes(n), wl(w) {}
     double ld(int plane) const
     {
         if (plane < 0 || plane >= nplanes) { std::fprintf(stderr, "Planes::ld out of window (%d of %d)\n", plane, nplanes); std::abort(); }
-        return base[(long)plane * stride + gl];
+        return base[(long)plane * 64 + wl];
     }
     void st(int plane, double x) const
     {
         if (plane < 0 || plane >= nplanes) { std::fprintf(stderr, "Planes::st out of window (%d of %d)\n", plane, nplanes); std::abort(); }
-        base[(long)plane * stride + gl] = x;
+        base[(long)plane * 64 + wl] = x;
     }
 };
 

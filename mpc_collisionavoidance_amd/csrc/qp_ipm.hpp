@@ -469,7 +469,7 @@ struct QpIpm {
             if (k >= 1 && k < N) { // wave-uniform
                 sfor<0, KCH>([&](auto c) {
                     sfor<0, OBSN>([&](auto e) { in.obs[c][e] = W.ld(P_OBS + c * OBSN + e); });
-                    obs_raw<c>(k, in.raw[c]);
+                    if (!pstat) obs_raw<c>(k, in.raw[c]);
                 });
             } else if (PACK && k == 0) { // the input bounds of stage 0 live there too
                 sfor<0, 4>([&](auto e) { in.obs[KCH - 1][e] = W.ld(P_OBS + (KCH - 1) * OBSN + e); });
@@ -500,7 +500,9 @@ struct QpIpm {
     {
         r.neutral();
         if (k >= 1 && k < N) { // wave-uniform
-            obs_geom<C>(k, in.zb, in.raw[C], r, cx, cy);
+            // with a stage-independent obstacle set the data sits in per-lane constants: no copy in the prefetch
+            const double cst[3] = {c_ox[C], c_oy[C], c_lh[C]};
+            obs_geom<C>(k, in.zb, pstat ? cst : in.raw[C], r, cx, cy);
         } else {
             r.act = false; cx = 0.0; cy = 0.0;
             if constexpr (SOFT) {
@@ -672,6 +674,9 @@ struct QpIpm {
             } else {
                 double Lzu[NU], iLd[NU], Pb;
                 if (FACT) {
+                    // P_{k+1} b_k first: each column of P_{k+1} then dies as soon as its column of T is formed
+                    Pb = 0.0;
+                    sfor<0, NX>([&](auto c) { lanes::fma_bc<NU + c>(Pb, rb, Pn[c]); });
                     // T = [B A]' P_{k+1}   (row r: sum_j bat_j * P_{k+1}[j][:])
                     double T[NX];
                     sfor<0, NX>([&](auto c) {
@@ -683,9 +688,6 @@ struct QpIpm {
                         if constexpr (M::OUT_UNIT != 0u) a += ounit ? Pn[c] : 0.0;
                         T[c] = a;
                     });
-                    // P_{k+1} b_k (needs the old P before it is overwritten)
-                    Pb = 0.0;
-                    sfor<0, NX>([&](auto c) { lanes::fma_bc<NU + c>(Pb, rb, Pn[c]); });
                     // G = H~ + T [B A]     (row r, column c': sum_j T_j * BAt[c'][j])
                     double Gr[NZ];
                     sfor<0, NZ>([&](auto c) {
@@ -891,7 +893,7 @@ struct QpIpm {
                 }
             }
             if constexpr (KCH > 0) {
-                if (k >= 1 && k < N) sfor<0, KCH>([&](auto c) { obs_raw<c>(k, in.raw[c]); });
+                if (k >= 1 && k < N && !pstat) sfor<0, KCH>([&](auto c) { obs_raw<c>(k, in.raw[c]); });
             }
             double bat[NX], mpk[MP::NPK];
             if (k < N) { mat_issue(k, mpk); mat_unpack(mpk, bat); }

@@ -688,9 +688,8 @@ struct QpIpm {
                         if constexpr (M::OUT_UNIT != 0u) a += ounit ? Pn[c] : 0.0;
                         T[c] = a;
                     });
-                    // G = H~ + T [B A]     (row r, column c': sum_j T_j * BAt[c'][j])
-                    double Gr[NZ];
-                    sfor<0, NZ>([&](auto c) {
+                    // G = H~ + T [B A]     (row r, column c': sum_j T_j * BAt[c'][j]), one column at a time
+                    auto gcol = [&](auto c) {
                         double a;
                         if constexpr (HDIAG) a = (lane == c) ? hd + Ghb : 0.0;
                         else a = Hrow[c] + ((lane == c) ? Ghb : 0.0);
@@ -702,18 +701,21 @@ struct QpIpm {
                             if constexpr (!out_unit(j)) lanes::fma_bc<c>(a, bat[j], T[j]);
                             else if constexpr (c == NU + j) a += T[j]; // column nu+j of a unit row is e_j
                         });
-                        Gr[c] = a;
-                    });
-                    // Cholesky of the leading nu columns, all rows at once
+                        return a;
+                    };
+                    // the nu control columns and their Cholesky factor, all rows at once
+                    double Gu[NU > 0 ? NU : 1];
+                    sfor<0, NU>([&](auto c) { Gu[c] = gcol(c); });
                     sfor<0, NU>([&](auto l) {
-                        const double il = lanes::frsqrt(lanes::bcast<l>(Gr[l]));
-                        Lzu[l] = Gr[l] * il;
+                        const double il = lanes::frsqrt(lanes::bcast<l>(Gu[l]));
+                        Lzu[l] = Gu[l] * il;
                         iLd[l] = il;
-                        sfor<l + 1, NU>([&](auto m) { lanes::fma_bc<m>(Gr[m], Lzu[l], -Lzu[l]); });
+                        sfor<l + 1, NU>([&](auto m) { lanes::fma_bc<m>(Gu[m], Lzu[l], -Lzu[l]); });
                     });
-                    // P_k = G_xx - Lxu Lxu'
+                    // P_k = G_xx - Lxu Lxu': every state column is consumed as soon as it is formed (16 columns
+                    // of G are never alive together)
                     sfor<0, NX>([&](auto c) {
-                        double a = Gr[NU + c];
+                        double a = gcol(std::integral_constant<int, NU + c>{});
                         sfor<0, NU>([&](auto l) { lanes::fma_bc<NU + c>(a, Lzu[l], -Lzu[l]); });
                         Pn[c] = xlane ? a : 0.0;
                     });

@@ -109,3 +109,19 @@ def test_soft_slacks_and_multipliers_exported(oracle, emu):
         assert np.allclose(r["sl"][b], o["sl"], atol=1e-7) and np.allclose(r["su"][b], o["su"], atol=1e-7)
         assert np.allclose(r["pi"][b], o["pi"], rtol=1e-6, atol=1e-7)
         assert np.allclose(r["sl"][b][0], 0.0)  # stage 0 carries no h rows
+
+
+@pytest.mark.parametrize("name,K", [("usv_model_guidance_ca1", 5), ("usv_model_pf_ca", 20)])
+def test_stage_dependent_obstacle_set(oracle, emu, name, K):
+    """Moving obstacles (p and lh differ from stage to stage): the lineariser hands them to the QP kernel as
+    planes instead of the per-lane constants of the stage-independent case."""
+    N, B = 6, 3
+    ocp, wl = util.make(name, N, K, B, seed=17, moving=True)
+    assert np.ptp(wl["p"], axis=1).max() > 0
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    spec = util.oracle_spec(oracle, name, N, scenario.DT[name], K)
+    r = emu_rti(emu, desc, wl, wl["x_init"], wl["u_init"])
+    xo, uo, sto, ito = util.oracle_rti(oracle, spec, wl, wl["x_init"], wl["u_init"])
+    assert np.array_equal(r["status"], sto)
+    ok = sto == 0
+    assert util.rel_err(r["x"][ok], xo[ok]) < 1e-8 and util.rel_err(r["u"][ok], uo[ok]) < 1e-8

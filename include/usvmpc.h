@@ -132,8 +132,12 @@ int usvmpc_kernel_ms(usvmpc_handle *h, int n, float *linearize_ms, float *qp_ms)
 int usvmpc_advance(usvmpc_handle *h, double sigma, unsigned long long seed);
 /* Adopt a caller-owned HIP stream (e.g. torch's current stream) for all subsequent work */
 int usvmpc_set_stream(usvmpc_handle *h, void *stream);
-/* run-time options: "sort_by_difficulty" (default 1) - group instances of similar IPM iteration
- * count (from their previous solve) into the same wavefront; scheduling only, results unchanged */
+/* run-time options (none changes a result bit):
+ *   "sort_by_difficulty" (default 1) - group instances of similar IPM iteration count (from their previous
+ *       solve) into the same wavefront;
+ *   "static_obstacles" (default 0) - every stage uses stage 0's p and lh (what the reference's callers set:
+ *       scripts/usv_pf_ca/main.py puts one obstacle set on all stages), which the kernel then keeps in registers;
+ *   "pack_box_rows" (default 1 when the rows fit) - box-row multipliers share the obstacle rows' planes. */
 int usvmpc_set_option(usvmpc_handle *h, const char *name, double value);
 /* ---- Guidance front end (model usv_model_guidance_ca1 only): the arithmetic either side of the solver
  * call in the reference's ROS node, batched on the device (class NMPC in

@@ -555,7 +555,8 @@ int usvmpc_get_device_ptr(usvmpc_handle *h, const char *field, void **dptr)
                   : s == "p" ? (const void *)P.p : s == "lh" ? (const void *)P.lh : s == "pi" ? (const void *)P.pi
                   : s == "sl" ? (const void *)P.sl : s == "su" ? (const void *)P.su
                   : s == "status" ? (const void *)P.status : s == "qp_iter" ? (const void *)P.qp_iter
-                  : s == "qp_status" ? (const void *)P.qp_status : s == "res" ? (const void *)P.res : nullptr;
+                  : s == "qp_status" ? (const void *)P.qp_status : s == "res" ? (const void *)P.res
+                  : s == "nlp_res" ? (const void *)P.nlp_res : s == "sqp_iter" ? (const void *)P.sqp_iter : nullptr;
     if (!p) { h->err = "unknown field '" + s + "'"; return USVMPC_E_FIELD; }
     *dptr = const_cast<void *>(p);
     return 0;

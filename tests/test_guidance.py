@@ -201,3 +201,22 @@ def test_device_obstacle_simulator_feeds_the_front_end(oracle):
     s.sync()
     assert np.array_equal(p1, s.get_all("p")) and np.array_equal(lh1, s.get_all("lh")) and np.array_equal(x01, s.get("x0", 0))
     s.close()
+
+
+@pytest.mark.gpu
+def test_scenario_sweep_closed_loop_invariants():
+    """examples/scenario_sweep.py: sensor -> selection / waypoints -> solve -> set-points for 96 random obstacle
+    fields, 400 ticks with the reference's horizon (N = 100, Tf = 5 s).  SURVEY 8(c)-3 invariants, batched: no
+    solver failure, the vessel keeps the nominal clearance (lsh = -0.2 on the soft rows => 0.2 m), progress
+    along the leg."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("scenario_sweep", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "examples", "scenario_sweep.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.run(B=96, ticks=400, N=100, quiet=True)
+    assert not r["solver_failures"].any()
+    mc = r["min_clearance"]
+    assert np.median(mc) > 0.17 and np.percentile(mc, 5) > 0.1 and mc.min() > -0.3
+    assert (r["final_pose"][:, 1] > 5.0).all()          # 20 s at ~0.7 m/s from y = -5

@@ -205,8 +205,8 @@ def main():
             "config": {
                 "workload": "BASELINE.json configs[2]: batch=%d per GPU, %s, N=%d, %d static obstacles, dt=%g s, GN SQP-RTI, "
                             "closed loop x0<-x1+N(0,%g), seed 1234+rank" % (B, name, N, K, dt, args.sigma),
-                "model": name, "batch_per_gpu": B, "global_batch": world * B, "horizon": N, "obstacles": K,
-                "parallelism": "batch-sharded x%d, no collective" % world,
+                "ocp": name, "instances_per_gpu": B, "instances_total": world * B, "horizon": N, "obstacles": K,
+                "sharding": "batch-sharded x%d, no collective" % world,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "usv_qp_rti",

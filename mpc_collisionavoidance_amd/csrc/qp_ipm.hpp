@@ -8,7 +8,8 @@
 // Mapping: one OCP instance = one 16-lane DPP row (lanes.hpp).  Lane r owns variable r of the
 // stage vector z = [u;x], row r of every stage matrix ([B A]', P, G), the box constraint on
 // variable r, and obstacle row c*16+r of chunk c.  All matrix products are "own row x broadcast
-// row" FMAs; the only reductions are the obstacle-row sums and the nu gain dot products.
+// row" FMAs; the reductions are the obstacle-row sums, the nu gain dot products and the rows of the
+// forward product [B A] dz (the stage matrix is stored once, packed: MatPack in params.hpp).
 //
 // Riccati form: classical (explicit, symmetric P_k; Cholesky of the nu x nu block only).  In the
 // row-per-lane layout every product it needs is a natural one, whereas the square-root form

@@ -1,11 +1,12 @@
 // usvmpc.hip — gfx950 kernels + the C ABI of include/usvmpc.h.
 //
-// Two kernels per SQP-RTI iteration:
-//   usv_linearize<M,KCH>      one 16-lane group per (instance, stage): ERK4 + forward VDE, GN
-//                             gradient, obstacle rows                       (linearize.hpp)
-//   usv_qp_rti<M,KCH,SOFT,..> one 16-lane group per instance: Riccati-IPM QP + RTI step
-//                             (qp_ipm.hpp)
-// Both are FP64 VALU + DPP kernels: no LDS, no MFMA (blocks are at most 16x16).
+// Two kernels per SQP-RTI iteration (and per iteration of the full SQP):
+//   usv_linearize<M,KCH,..>   one 16-lane group per (instance, stage): ERK4 + forward VDE, GN gradient, the
+//                             stage matrix packed into the workspace planes   (linearize.hpp)
+//   usv_qp_rti<M,KCH,SOFT,..> one 16-lane group per instance: obstacle-row linearisation, Riccati-IPM QP,
+//                             RTI / SQP step, NLP residual test for the full SQP  (qp_ipm.hpp)
+// Both are FP64 VALU + DPP kernels (lane gathers go through the LDS crossbar, no LDS memory, no MFMA: the
+// blocks are at most 16x16).
 #include "gfx950/lanes.hpp"
 
 #include "guidance.hpp"

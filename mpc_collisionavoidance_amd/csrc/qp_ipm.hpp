@@ -698,10 +698,16 @@ struct QpIpm {
                             if constexpr (c == PXL) a += isPX ? Sxx : (isPY ? Sxy : 0.0);
                             if constexpr (c == PYL) a += isPX ? Sxy : (isPY ? Syy : 0.0);
                         }
-                        sfor<0, NX>([&](auto j) {
-                            if constexpr (!out_unit(j)) lanes::fma_bc<c>(a, bat[j], T[j]);
-                            else if constexpr (c == NU + j) a += T[j]; // column nu+j of a unit row is e_j
-                        });
+                        if constexpr (((M::IN_UNIT >> c) & 1u) != 0u) {
+                            // column c of [B A] is a unit vector (the variable feeds no right-hand side): the
+                            // whole sum collapses to one term
+                            if constexpr (c >= NU) a += T[c - NU];
+                        } else {
+                            sfor<0, NX>([&](auto j) {
+                                if constexpr (!out_unit(j)) lanes::fma_bc<c>(a, bat[j], T[j]);
+                                else if constexpr (c == NU + j) a += T[j]; // column nu+j of a unit row is e_j
+                            });
+                        }
                         return a;
                     };
                     // the nu control columns and their Cholesky factor, all rows at once

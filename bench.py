@@ -167,20 +167,29 @@ def main():
         S = args.cpu_sample if args.cpu_sample > 0 else int(min(B, max(64, 12000.0 / per_solve_ms * cores)))  # ~12 s on all
         S = min(S, B)
         spec = ob.spec(_ID[name], N, N * dt, K)
+        native = ob.native_lib() is not None   # -O3 -march=native build of the same sources, for timing only
+        args1 = (wl["x0"][:S1], wl["yref"][:S1], wl["yref_e"][:S1], wl["p"][:S1], wl["lh"][:S1])
+        # parity spot check: the checker build (bit-stable flags), sequential
+        xo, uo = wl["x_init"][:S1].copy(), wl["u_init"][:S1].copy()
+        sto, ito = ob.rti_batch(spec, xo, uo, *args1)
+        # single core, then all usable cores, timed on the native build
         x1, u1 = wl["x_init"][:S1].copy(), wl["u_init"][:S1].copy()
         c0 = time.perf_counter()
-        ob.rti_batch(spec, x1, u1, wl["x0"][:S1], wl["yref"][:S1], wl["yref_e"][:S1], wl["p"][:S1], wl["lh"][:S1])
+        ob.rti_batch(spec, x1, u1, *args1, native=True)
         c1sec = time.perf_counter() - c0
-        xo, uo = wl["x_init"][:S].copy(), wl["u_init"][:S].copy()
+        xa, ua = wl["x_init"][:S].copy(), wl["u_init"][:S].copy()
         c0 = time.perf_counter()
-        sto, ito = ob.rti_batch(spec, xo, uo, wl["x0"][:S], wl["yref"][:S], wl["yref_e"][:S], wl["p"][:S], wl["lh"][:S],
-                                threads=cores)
+        ob.rti_batch(spec, xa, ua, wl["x0"][:S], wl["yref"][:S], wl["yref_e"][:S], wl["p"][:S], wl["lh"][:S],
+                     threads=cores, native=True)
         csec = time.perf_counter() - c0
         cpu_baseline = {"value": S / csec, "unit": "solves/s", "cores": cores, "kind": "port",
                         "single_core_value": S1 / c1sec, "single_instance_latency_ms": c1sec / S1 * 1e3,
                         "sample": "first %d instances of the same batch, 1 RTI iteration from the same initial guess, "
-                                  "oracle/usv_oracle.c, one instance per OpenMP thread on %d threads (%.1f s); "
-                                  "single-core figure from the first %d instances (%.1f s)" % (S, cores, csec, S1, c1sec)}
+                                  "oracle/usv_oracle.c built %s, one instance per OpenMP thread on %d threads (%.1f s); "
+                                  "single-core figure from the first %d instances (%.1f s)"
+                                  % (S, "-O3 -march=native on this host" if native else "with the checker's flags (-O2)",
+                                     cores, csec, S1, c1sec)}
+        S = S1  # the parity spot check below covers the checker-build sample
         if first_x is not None:
             ok = (sto == 0) & (ito < spec.opts.qp_iter_max) & (first_qs[:S] == 0)
             ex = float(np.abs(first_x[:S][ok] - xo[ok]).max() / max(1.0, np.abs(xo).max()))

@@ -232,7 +232,32 @@ def rti(s, x, u, x0, yref, yref_e, p, lh):
                 status=st, qp_iter=int(info[0]), qp_status=int(info[1]), res=info[2:6].copy())
 
 
-def rti_batch(s, x, u, x0, yref, yref_e, p, lh, threads=1):
+_native = None
+
+
+def native_lib():
+    """The same sources compiled for THIS machine's CPU with full optimisation (-O3 -march=native, FMA contraction
+    allowed): used only to TIME the CPU baseline in bench.py, so that the baseline is not handicapped by the
+    bit-stable flags the checker is built with.  Built on first use (never shipped: the build host's CPU is not the
+    GPU box's).  Returns None when it cannot be built; results then come from the checker library."""
+    global _native
+    if _native is None:
+        out = os.path.join(_HERE, "_native", "libusv_oracle_native.so")
+        try:
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=c99", "-fopenmp", "-shared", "-o", out,
+                                   os.path.join(_HERE, "usv_oracle.c"), os.path.join(_HERE, "usv_guidance_oracle.c"), "-lm"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            L = C.CDLL(out)
+            L.usv_rti_batch.argtypes = [C.POINTER(Spec), C.c_int] + [_dp] * 7 + [_ip, _ip]
+            L.usv_rti_batch_mt.argtypes = [C.POINTER(Spec), C.c_int] + [_dp] * 7 + [_ip, _ip, C.c_int]
+            _native = L
+        except Exception:
+            _native = False
+    return _native or None
+
+
+def rti_batch(s, x, u, x0, yref, yref_e, p, lh, threads=1, native=False):
     """In-place batched RTI over leading batch axis (row-major per instance); threads > 1 (or 0 = all cores)
     distributes the instances over OpenMP threads."""
     B = x.shape[0]
@@ -241,11 +266,12 @@ def rti_batch(s, x, u, x0, yref, yref_e, p, lh, threads=1):
     x0, yref, yref_e, p, lh = map(_arr, (x0, yref, yref_e, p, lh))
     status = np.zeros(B, dtype=np.int32)
     it = np.zeros(B, dtype=np.int32)
+    L = (native_lib() if native else None) or lib()
     if threads == 1:
-        lib().usv_rti_batch(C.byref(s), B, _d(x), _d(u), _d(x0), _d(yref), _d(yref_e), _d(p), _d(lh),
-                            status.ctypes.data_as(_ip), it.ctypes.data_as(_ip))
+        L.usv_rti_batch(C.byref(s), B, _d(x), _d(u), _d(x0), _d(yref), _d(yref_e), _d(p), _d(lh),
+                        status.ctypes.data_as(_ip), it.ctypes.data_as(_ip))
     else:
-        lib().usv_rti_batch_mt(C.byref(s), B, _d(x), _d(u), _d(x0), _d(yref), _d(yref_e), _d(p), _d(lh),
+        L.usv_rti_batch_mt(C.byref(s), B, _d(x), _d(u), _d(x0), _d(yref), _d(yref_e), _d(p), _d(lh),
                                status.ctypes.data_as(_ip), it.ctypes.data_as(_ip), int(threads))
     return status, it
 

@@ -156,6 +156,13 @@ def desc_from_ocp(ocp, batch=1, device=0, generated=False):
         raise Exception("integrator_type must be ERK and hessian_approx GAUSS_NEWTON")
     if opts.qp_solver not in ("PARTIAL_CONDENSING_HPIPM", "FULL_CONDENSING_HPIPM"):
         raise Exception("qp_solver must be an HPIPM variant")
+    if getattr(opts, "qp_solver_warm_start", 0) not in (0, None):
+        raise Exception("qp_solver_warm_start must be 0: every QP is cold-started (the acados default)")
+    if getattr(opts, "nlp_solver_step_length", 1.0) not in (1.0, 1, None):
+        raise Exception("nlp_solver_step_length must be 1.0 (full steps)")
+    cn = getattr(opts, "qp_solver_cond_N", None)
+    if cn is not None and not (1 <= int(cn) <= int(ocp.dims.N)):
+        raise Exception("qp_solver_cond_N must lie in 1..N")
     if opts.tf is None or ocp.dims.N is None:
         raise Exception("solver_options.tf and dims.N must be set")
     ny, ny_e = nx + nu, nx

@@ -116,6 +116,12 @@ class AcadosOcpOptions:
         self.nlp_solver_tol_eq = None
         self.nlp_solver_tol_ineq = None
         self.nlp_solver_tol_comp = None
+        # accepted for compatibility: block condensing is a reformulation of the same KKT system, the Riccati sweep
+        # works on the uncondensed stages whatever the block size
+        self.qp_solver_cond_N = None
+        self.qp_solver_warm_start = 0   # 0 (cold start of every QP, the acados default) is the only mode built
+        self.nlp_solver_step_length = 1.0
+        self.print_level = 0
         self.model_source = None  # "symbolic": compile the model from its expressions even if the registry has it
 
 

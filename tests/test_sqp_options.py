@@ -121,6 +121,11 @@ def test_option_validation():
         _capi.desc_from_ocp(_ocp("usv_model", 5, 0, sim_method_num_stages=2), batch=1)
     with pytest.raises(Exception, match="num_steps"):
         _capi.desc_from_ocp(_ocp("usv_model", 5, 0, sim_method_num_steps=0), batch=1)
+    with pytest.raises(Exception, match="warm_start"):
+        _capi.desc_from_ocp(_ocp("usv_model", 5, 0, qp_solver_warm_start=1), batch=1)
+    with pytest.raises(Exception, match="cond_N"):
+        _capi.desc_from_ocp(_ocp("usv_model", 5, 0, qp_solver_cond_N=9), batch=1)
+    _capi.desc_from_ocp(_ocp("usv_model", 10, 0, qp_solver_cond_N=5), batch=1)   # accepted: same QP, same solution
     d = _capi.desc_from_ocp(_ocp("usv_model", 5, 0, nlp_solver_type="SQP", nlp_solver_tol_stat=1e-4, nlp_solver_max_iter=7), batch=1)
     assert d.nlp_max_iter == 7 and d.nlp_tol_stat == 1e-4 and d.nlp_tol_eq == 1e-6
 

@@ -74,6 +74,12 @@ typedef struct usvmpc_desc {
     double zl[USVMPC_K_MAX], zu[USVMPC_K_MAX], Zl[USVMPC_K_MAX], Zu[USVMPC_K_MAX];
     int qp_iter_max;
     double mu0, thr0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min;
+    /* soft state bounds (acados idxsbx / lsbx / usbx, scripts/race_cars/acados_settings_dev.py:107-127), per entry of
+     * the bx list: flag, lower bounds of the two slacks, slack penalties (acados keeps the penalties of all slacks in
+     * one vector ordered [sbx.., sh..]; zl.. above are the sh part, these the sbx part) */
+    int sbx[USVMPC_NX_MAX];
+    double lsbx[USVMPC_NX_MAX], usbx[USVMPC_NX_MAX];
+    double zl_bx[USVMPC_NX_MAX], zu_bx[USVMPC_NX_MAX], Zl_bx[USVMPC_NX_MAX], Zu_bx[USVMPC_NX_MAX];
     /* integrator: RK4 steps per shooting interval (acados sim_method_num_steps; 0 is read as 1) */
     int sim_num_steps;
     /* full SQP only (usvmpc_solve_sqp): nlp_solver_max_iter (0 is read as 100) and the exit tolerances on

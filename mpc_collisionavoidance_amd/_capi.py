@@ -32,6 +32,8 @@ class Desc(C.Structure):
                 ("qp_iter_max", C.c_int), ("mu0", C.c_double), ("thr0", C.c_double),
                 ("tol_stat", C.c_double), ("tol_eq", C.c_double), ("tol_ineq", C.c_double),
                 ("tol_comp", C.c_double), ("alpha_min", C.c_double),
+                ("sbx", C.c_int * NXM), ("lsbx", C.c_double * NXM), ("usbx", C.c_double * NXM),
+                ("zl_bx", C.c_double * NXM), ("zu_bx", C.c_double * NXM), ("Zl_bx", C.c_double * NXM), ("Zu_bx", C.c_double * NXM),
                 ("sim_num_steps", C.c_int), ("nlp_max_iter", C.c_int),
                 ("nlp_tol_stat", C.c_double), ("nlp_tol_eq", C.c_double), ("nlp_tol_ineq", C.c_double),
                 ("nlp_tol_comp", C.c_double)]
@@ -197,20 +199,36 @@ def desc_from_ocp(ocp, batch=1, device=0, generated=False):
         for i in range(K):
             d.uh[i] = float(con.uh[i])
     idxsh = np.asarray(con.idxsh, dtype=int).reshape(-1)
+    idxsbx = np.asarray(getattr(con, "idxsbx", []), dtype=int).reshape(-1)
+    nsbx = idxsbx.size
+    ns = nsbx + idxsh.size   # acados orders the slack penalty vectors [sbx.., sh..]
+    if ns:
+        for nm in ("zl", "zu", "Zl", "Zu"):
+            if np.asarray(getattr(cost, nm)).size != ns:
+                raise Exception("cost.%s must have ns = %d entries" % (nm, ns))
+    if nsbx:
+        nbx = np.asarray(con.idxbx).size
+        if np.unique(idxsbx).size != nsbx or idxsbx.min() < 0 or idxsbx.max() >= nbx:
+            raise Exception("idxsbx must hold distinct positions in the bx list (0..nbx-1)")
+        for nm in ("lsbx", "usbx"):
+            if np.asarray(getattr(con, nm)).size != nsbx:
+                raise Exception("%s must have nsbx = %d entries" % (nm, nsbx))
+        for j, i in enumerate(idxsbx):
+            d.sbx[i] = 1
+            d.lsbx[i], d.usbx[i] = float(con.lsbx[j]), float(con.usbx[j])
+            d.zl_bx[i], d.zu_bx[i] = float(cost.zl[j]), float(cost.zu[j])
+            d.Zl_bx[i], d.Zu_bx[i] = float(cost.Zl[j]), float(cost.Zu[j])
     if idxsh.size:
         if sorted(idxsh.tolist()) != list(range(K)):
             raise Exception("soft constraints are supported for all h rows at once (idxsh = 0..nh-1)")
         for nm in ("lsh", "ush"):
             if np.asarray(getattr(con, nm)).size != K:
                 raise Exception("%s must have nsh = %d entries" % (nm, K))
-        for nm in ("zl", "zu", "Zl", "Zu"):
-            if np.asarray(getattr(cost, nm)).size != K:
-                raise Exception("cost.%s must have ns = %d entries" % (nm, K))
         d.soft = 1
         for i in range(K):
             d.lsh[i], d.ush[i] = float(con.lsh[i]), float(con.ush[i])
-            d.zl[i], d.zu[i] = float(cost.zl[i]), float(cost.zu[i])
-            d.Zl[i], d.Zu[i] = float(cost.Zl[i]), float(cost.Zu[i])
+            d.zl[i], d.zu[i] = float(cost.zl[nsbx + i]), float(cost.zu[nsbx + i])
+            d.Zl[i], d.Zu[i] = float(cost.Zl[nsbx + i]), float(cost.Zu[nsbx + i])
     if generated and d.soft == 0 and idxsh.size == 0:
         pass
     if mid == 1 and K and not d.soft:

@@ -92,6 +92,10 @@ class AcadosOcpConstraints:
         self.lsh = np.array([])
         self.ush = np.array([])
         self.idxsh = np.array([])
+        # soft state bounds: positions in the bx list, lower bounds of their slacks (race_cars/acados_settings_dev.py:107-127)
+        self.idxsbx = np.array([])
+        self.lsbx = np.array([])
+        self.usbx = np.array([])
         self.x0 = None
 
 

@@ -85,6 +85,15 @@ inline std::string build_spec(const usvmpc_desc &d, DevSpec &S)
         if (j < 0 || j >= nx) return "idxbx out of range";
         S.has_b[nu + j] = 1; S.lb[nu + j] = d.lbx[i]; S.ub[nu + j] = d.ubx[i];
     }
+    for (int i = 0; i < d.nbx; i++) {
+        if (!d.sbx[i]) continue;
+        const int r = nu + d.idxbx[i];
+        S.any_bsoft = 1;
+        S.bsoft[r] = 1;
+        S.b_zl[r] = S.dt * d.zl_bx[i]; S.b_zu[r] = S.dt * d.zu_bx[i];
+        S.b_Zl[r] = S.dt * d.Zl_bx[i]; S.b_Zu[r] = S.dt * d.Zu_bx[i];
+        S.b_lsl[r] = d.lsbx[i]; S.b_lsu[r] = d.usbx[i];
+    }
     for (int i = 0; i < d.K; i++) {
         S.uh[i] = d.uh[i];
         S.lsl[i] = d.lsh[i]; S.lsu[i] = d.ush[i];
@@ -100,7 +109,8 @@ inline std::string build_spec(const usvmpc_desc &d, DevSpec &S)
         for (int r = 0; r < LANES; r++) nb += S.has_b[r];
         const int nslot = kch > 0 ? LANES - k_last : 0;
         const int ndense = nb > nslot ? nb - nslot : 0;
-        S.boxpack_ok = (kch > 0 && nb > 0 && ndense <= 4 && 4 * ndense <= k_last) ? 1 : 0;
+        // (soft state bounds carry six more values per row: they keep planes of their own)
+        S.boxpack_ok = (kch > 0 && nb > 0 && ndense <= 4 && 4 * ndense <= k_last && !S.any_bsoft) ? 1 : 0;
         S.boxpack = S.boxpack_ok;
         if (S.boxpack_ok) {
             S.box_dense = ndense > 0;
@@ -122,6 +132,7 @@ inline std::string build_spec(const usvmpc_desc &d, DevSpec &S)
         for (int j = 0; j < LANES; j++)
             if (i != j && (S.Hc[i * LANES + j] != 0.0 || S.He[i * LANES + j] != 0.0)) S.hdiag = 0;
     S.nc = d.N * d.nbu * 2 + (d.N - 1) * (d.nbx * 2 + d.K * (d.soft ? 4 : 2));
+    for (int i = 0; i < d.nbx; i++) S.nc += d.sbx[i] ? (d.N - 1) * 2 : 0;
     S.iter_max = d.qp_iter_max;
     S.mu0 = d.mu0; S.thr0 = d.thr0;
     S.tol_stat = d.tol_stat; S.tol_eq = d.tol_eq; S.tol_ineq = d.tol_ineq; S.tol_comp = d.tol_comp;
@@ -150,10 +161,10 @@ inline void default_options(usvmpc_desc &d)
 
 // planes of the solver workspace per stage for a (model, KCH, soft) combination: WsLayout::NPT (params.hpp);
 // mat_planes = MatPack<M>::NPK of the model
-inline int ws_planes(int nx, int nu, int kch, bool soft, int mat_planes)
+inline int ws_planes(int nx, int nu, int kch, bool soft, int mat_planes, bool softbox = false)
 {
     (void)nx;
-    return 11 + kch * (soft ? 10 : 4) + nu + 2 + mat_planes;
+    return 11 + kch * (soft ? 10 : 4) + nu + 2 + mat_planes + (softbox ? 6 : 0);
 }
 
 } // namespace usv

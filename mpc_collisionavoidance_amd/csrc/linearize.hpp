@@ -35,7 +35,7 @@ struct Linearize {
         const long gi = g < nB ? g : (long)nB - 1; // padded groups replay the last instance
         const long b = P.perm ? (long)P.perm[gi] : gi;
         // workspace: [stage][wave tile of 4 groups][plane][64 lanes] (lanes::Planes)
-        double *tile = P.ws + (((long)k * (Bp / 4) + (g >> 2)) * WL::NPT) * 64 + (g & 3) * LANES + lane;
+        double *tile = P.ws + (((long)k * (Bp / 4) + (g >> 2)) * lanes::uniform(S.npt)) * 64 + (g & 3) * LANES + lane;
         const bool xlane = lane >= NU && lane < NZ;
 
         double x[NX], U[NU > 0 ? NU : 1];

@@ -35,6 +35,11 @@ struct DevSpec {
     int iter_max;
     double mu0, thr0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min;
     int sim_steps;                // RK4 steps per shooting interval (sim_method_num_steps)
+    int npt;                      // workspace planes per stage (WsLayout::NPT of the QP kernel in use)
+    // soft state bounds (acados idxsbx): per variable of [u;x], penalties already scaled by dt
+    int any_bsoft;
+    int bsoft[LANES];
+    double b_zl[LANES], b_zu[LANES], b_Zl[LANES], b_Zu[LANES], b_lsl[LANES], b_lsu[LANES];
     double nlp_tol[4];            // full SQP: exit tolerances on the NLP residuals (stat, eq, ineq, comp)
 };
 
@@ -67,7 +72,7 @@ struct MatPack {
 // window per stage so that the QP kernel needs one buffer descriptor and compile-time plane numbers (separate
 // arrays cost scalar registers, and once those ran out the compiler moved plane offsets to vector registers
 // and wrapped the loads in waterfall loops).
-template <class M, int KCH, bool SOFT>
+template <class M, int KCH, bool SOFT, bool SOFTBOX = false>
 struct WsLayout {
     enum : int { P_Z = 0, P_ZB, P_DZA, P_DZ, P_DX0, P_PB, P_PI, P_BLL, P_BLU, P_BTL, P_BTU, P_OBS };
     static constexpr int OBSN = SOFT ? 10 : 4;
@@ -75,7 +80,8 @@ struct WsLayout {
     static constexpr int P_RB0 = P_LZU + M::NU; // b_k of the linearisation point (x lanes)
     static constexpr int P_GQ = P_RB0 + 1;      // cost gradient
     static constexpr int P_MAT = P_GQ + 1;      // packed [B A] (MatPack<M>::NPK planes)
-    static constexpr int NPT = P_MAT + MatPack<M>::NPK;
+    static constexpr int P_BS = P_MAT + MatPack<M>::NPK; // soft state bounds only: sl, su, lsl, lsu, tsl, tsu of the box rows
+    static constexpr int NPT = P_BS + (SOFTBOX ? 6 : 0);  // (DevSpec::npt at run time: the lineariser does not know SOFTBOX)
 };
 
 // Device pointers of one solver handle.

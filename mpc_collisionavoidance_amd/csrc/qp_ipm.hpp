@@ -34,12 +34,20 @@ namespace usv {
 
 // One two-sided inequality row  dl <= v (+ sl),  v (- su) <= du  with its multipliers/slacks,
 // and the closed-form elimination of (lambda, t, sl, su) used by HPIPM-style IPMs.
-template <bool SOFTROW>
+// MIXED (only with SOFTROW): the rows handled by this code are partly soft - `soft` says which; a hard row keeps
+// sl = su = 0 and its slack multipliers out of everything.
+template <bool SOFTROW, bool MIXED = false>
 struct RowCalc {
     double ll, lu, tl, tu, sl, su, lsl, lsu, tsl, tsu;          // state
     double dl, du, zl, zu, Zl, Zu, bsl, bsu;                    // data
-    bool act;
+    bool act, soft;
     double rdl, rdu, rsl, rsu, rdsl, rdsu;                      // residuals
+    USV_DEV bool is_soft() const
+    {
+        if constexpr (!SOFTROW) return false;
+        else if constexpr (MIXED) return soft;
+        else return true;
+    }
     double itl, itu, itsl, itsu;                                // reciprocals of the slacks
     double Gl, Gu, iDl, iDu, rhol, rhou;                        // elimination
     double ml, mu, msl, msu;                                    // complementarity targets
@@ -49,6 +57,7 @@ struct RowCalc {
     {
         ll = lu = 0.0; tl = tu = 1.0; sl = su = 0.0; lsl = lsu = 0.0; tsl = tsu = 1.0;
         dl = -1.0; du = 1.0; zl = zu = 0.0; Zl = Zu = 1.0; bsl = bsu = -1.0;
+        soft = SOFTROW && !MIXED;
     }
     USV_DEV void resid(double v)
     {
@@ -63,6 +72,9 @@ struct RowCalc {
             rdsu = su - bsu - tsu;
             itsl = lanes::frcp(tsl);
             itsu = lanes::frcp(tsu);
+            if constexpr (MIXED) {
+                if (!soft) { rsl = 0.0; rsu = 0.0; rdsl = 0.0; rdsu = 0.0; }
+            }
         }
     }
     USV_DEV void targets_pred()
@@ -73,7 +85,12 @@ struct RowCalc {
     USV_DEV void targets_corr(double sigmu) // uses the affine step currently held in d*
     {
         ml = ll * tl + dll * dtl - sigmu; mu = lu * tu + dlu * dtu - sigmu;
-        if constexpr (SOFTROW) { msl = lsl * tsl + dlsl * dtsl - sigmu; msu = lsu * tsu + dlsu * dtsu - sigmu; }
+        if constexpr (SOFTROW) {
+            msl = lsl * tsl + dlsl * dtsl - sigmu; msu = lsu * tsu + dlsu * dtsu - sigmu;
+            if constexpr (MIXED) {
+                if (!soft) { msl = 0.0; msu = 0.0; }
+            }
+        }
     }
     // Gh: coefficient of c c' added to the stage Hessian; gam: coefficient of c added to the gradient
     USV_DEV void reduce(double &Gh, double &gam)
@@ -90,6 +107,13 @@ struct RowCalc {
             Ghu = Gu * (1.0 - Gu * iDu);
             gl = ml * itl + Gl * rdl + Gl * rhol * iDl;
             gu = mu * itu + Gu * rdu + Gu * rhou * iDu;
+            if constexpr (MIXED) {
+                if (!soft) {
+                    Ghl = Gl; Ghu = Gu;
+                    gl = ml * itl + Gl * rdl;
+                    gu = mu * itu + Gu * rdu;
+                }
+            }
         } else {
             Ghl = Gl; Ghu = Gu;
             gl = ml * itl + Gl * rdl;
@@ -103,6 +127,9 @@ struct RowCalc {
         if constexpr (SOFTROW) {
             dsl = (rhol - Gl * w) * iDl;
             dsu = (rhou + Gu * w) * iDu;
+            if constexpr (MIXED) {
+                if (!soft) { dsl = 0.0; dsu = 0.0; }
+            }
             dtsl = dsl + rdsl;
             dtsu = dsu + rdsu;
             dlsl = -(msl + lsl * dtsl) * itsl;
@@ -122,8 +149,10 @@ struct RowCalc {
         q = fmax(q, -dtl * itl); q = fmax(q, -dtu * itu);
         q = fmax(q, -dll * lanes::frcp(ll)); q = fmax(q, -dlu * lanes::frcp(lu));
         if constexpr (SOFTROW) {
-            q = fmax(q, -dtsl * itsl); q = fmax(q, -dtsu * itsu);
-            q = fmax(q, -dlsl * lanes::frcp(lsl)); q = fmax(q, -dlsu * lanes::frcp(lsu));
+            if (is_soft()) {
+                q = fmax(q, -dtsl * itsl); q = fmax(q, -dtsu * itsu);
+                q = fmax(q, -dlsl * lanes::frcp(lsl)); q = fmax(q, -dlsu * lanes::frcp(lsu));
+            }
         }
         return q;
     }
@@ -137,9 +166,12 @@ struct RowCalc {
     }
 };
 
-template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK>
+// SOFTBOX: some state bounds are soft (acados idxsbx); their rows carry slacks like the soft obstacle rows and
+// keep ten planes of their own (no packing).
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false>
 struct QpIpm {
     static_assert(!PACK || KCH > 0, "box rows are packed into obstacle planes");
+    static_assert(!(PACK && SOFTBOX), "soft state bounds are not packed");
     static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
     static constexpr int PXL = NU + M::IPX, PYL = NU + M::IPY;
     using MP = MatPack<M>;
@@ -147,16 +179,17 @@ struct QpIpm {
     // P_PB holds (l_u | P b): the u lanes carry the gain rhs, the x lanes P_{k+1} b_k;  P_PI holds (r_g | pi):
     // stationarity residual on the u lanes, dynamics multiplier on the x lanes (u and x lanes are disjoint)
     // (plane numbers: WsLayout, params.hpp - shared with the lineariser, which fills P_RB0, P_GQ and P_MAT..)
-    using WL = WsLayout<M, KCH, SOFT>;
+    using WL = WsLayout<M, KCH, SOFT, SOFTBOX>;
     enum : int { P_Z = WL::P_Z, P_ZB = WL::P_ZB, P_DZA = WL::P_DZA, P_DZ = WL::P_DZ, P_DX0 = WL::P_DX0, P_PB = WL::P_PB,
                  P_PI = WL::P_PI, P_BLL = WL::P_BLL, P_BLU = WL::P_BLU, P_BTL = WL::P_BTL, P_BTU = WL::P_BTU,
-                 P_OBS = WL::P_OBS, P_LZU = WL::P_LZU, P_RB0 = WL::P_RB0, P_GQ = WL::P_GQ, P_MAT = WL::P_MAT };
+                 P_OBS = WL::P_OBS, P_LZU = WL::P_LZU, P_RB0 = WL::P_RB0, P_GQ = WL::P_GQ, P_MAT = WL::P_MAT,
+                 P_BS = WL::P_BS };
     static constexpr int OBSN = WL::OBSN;
     static constexpr int NPL = WL::NPT;
 
     static constexpr bool out_unit(int j) { return ((M::OUT_UNIT >> j) & 1u) != 0u; }
 
-    using BoxRow = RowCalc<false>;
+    using BoxRow = RowCalc<SOFTBOX, SOFTBOX>;
     using ObsRow = RowCalc<SOFT>;
     using Planes = lanes::Planes;
 
@@ -193,6 +226,8 @@ struct QpIpm {
     int bsrc, bstep, ssrc;
     bool hasb;
     double lbv, ubv, hd_stage, hd_term;
+    bool bsoft;                               // SOFTBOX: this lane's state bound is soft
+    double bzl, bzu, bZl, bZu, bbsl, bbsu;    // its slack penalties (scaled by dt) and slack lower bounds
     double c_zl[KCH > 0 ? KCH : 1], c_zu[KCH > 0 ? KCH : 1], c_Zl[KCH > 0 ? KCH : 1], c_Zu[KCH > 0 ? KCH : 1],
         c_bsl[KCH > 0 ? KCH : 1], c_bsu[KCH > 0 ? KCH : 1];
     // obstacle data of this lane's row(s): upper bound, and - when the obstacle set is the same on every
@@ -238,6 +273,9 @@ struct QpIpm {
         ubv = S.ub[lane];
         hd_stage = S.Hc[lane * LANES + lane];
         hd_term = S.He[lane * LANES + lane];
+        bsoft = SOFTBOX && S.bsoft[lane] != 0;
+        bzl = S.b_zl[lane]; bzu = S.b_zu[lane]; bZl = bsoft ? S.b_Zl[lane] : 1.0; bZu = bsoft ? S.b_Zu[lane] : 1.0;
+        bbsl = S.b_lsl[lane]; bbsu = S.b_lsu[lane];
         if constexpr (KCH > 0) {
             sfor<0, KCH>([&](auto c) {
                 const int i = c * LANES + lane;
@@ -274,10 +312,18 @@ struct QpIpm {
         r.act = valid && hasb && stage_ok;
         r.dl = r.act ? lbv - zb : -1.0;
         r.du = r.act ? ubv - zb : 1.0;
+        if constexpr (SOFTBOX) {
+            r.soft = r.act && bsoft;
+            r.zl = bzl; r.zu = bzu; r.Zl = bZl; r.Zu = bZu; r.bsl = bbsl; r.bsu = bbsu;
+        }
     }
     USV_DEV static void box_store(const Planes &W, const BoxRow &r)
     {
         W.st(P_BLL, r.ll); W.st(P_BLU, r.lu); W.st(P_BTL, r.tl); W.st(P_BTU, r.tu);
+        if constexpr (SOFTBOX) {
+            W.st(P_BS, r.sl); W.st(P_BS + 1, r.su); W.st(P_BS + 2, r.lsl); W.st(P_BS + 3, r.lsu);
+            W.st(P_BS + 4, r.tsl); W.st(P_BS + 5, r.tsu);
+        }
     }
     // Obstacle chunk c at stage k.  The row h_i = |pos - o_i| >= lh_i is linearised here, from the iterate's
     // position (the px / py lanes of zb) and the obstacle data, instead of being streamed from planes written
@@ -385,6 +431,12 @@ struct QpIpm {
             box_data(k, zb, r);
             r.tl = fmax(0.0 - r.dl, S.thr0); r.tu = fmax(r.du - 0.0, S.thr0);
             r.ll = S.mu0 / r.tl; r.lu = S.mu0 / r.tu;
+            if constexpr (SOFTBOX) {
+                if (r.soft) {
+                    r.tsl = fmax(0.0 - r.bsl, S.thr0); r.tsu = fmax(0.0 - r.bsu, S.thr0);
+                    r.lsl = S.mu0 / r.tsl; r.lsu = S.mu0 / r.tsu;
+                }
+            }
             double pk[4];
             if constexpr (PACK) box_pack(W, r, pk, !keep);
             else if (!keep) box_store(W, r);
@@ -431,6 +483,7 @@ struct QpIpm {
         double z, zb, rb, dz, dza, gq, rg, pb, luv;
         double lzu[NU];
         double box[4];
+        double bxs[SOFTBOX ? 6 : 1]; // soft state bounds: sl, su, lsl, lsu, tsl, tsu of this lane's box row
         double obs[KCH > 0 ? KCH : 1][OBSN];
         double raw[KCH > 0 ? KCH : 1][3];
     };
@@ -465,6 +518,7 @@ struct QpIpm {
             in.box[0] = (anydense && k < N) ? W.ld(P_BLL) : 0.0; // wave-uniform
         } else {
             in.box[0] = W.ld(P_BLL); in.box[1] = W.ld(P_BLU); in.box[2] = W.ld(P_BTL); in.box[3] = W.ld(P_BTU);
+            if constexpr (SOFTBOX) sfor<0, 6>([&](auto e) { in.bxs[e] = W.ld(P_BS + e); });
         }
         if constexpr (KCH > 0) {
             if (k >= 1 && k < N) { // wave-uniform
@@ -495,6 +549,11 @@ struct QpIpm {
         }
         r.ll = r.act ? b0 : 0.0; r.lu = r.act ? b1 : 0.0;
         r.tl = r.act ? b2 : 1.0; r.tu = r.act ? b3 : 1.0;
+        if constexpr (SOFTBOX) {
+            r.sl = r.soft ? in.bxs[0] : 0.0; r.su = r.soft ? in.bxs[1] : 0.0;
+            r.lsl = r.soft ? in.bxs[2] : 0.0; r.lsu = r.soft ? in.bxs[3] : 0.0;
+            r.tsl = r.soft ? in.bxs[4] : 1.0; r.tsu = r.soft ? in.bxs[5] : 1.0;
+        }
     }
     template <int C>
     USV_DEV void obs_from(const StageIn &in, int k, ObsRow &r, double &cx, double &cy) const
@@ -658,6 +717,15 @@ struct QpIpm {
                     nm.rm = fmax(nm.rm, fmax(br.ll * br.tl, br.lu * br.tu));
                     nm.musum += br.ll * br.tl + br.lu * br.tu;
                     nm.nan = fma(0.0, br.rdl + br.rdu, nm.nan);
+                    if constexpr (SOFTBOX) {
+                        if (br.soft) {
+                            nm.rg = fmax(nm.rg, fmax(fabs(br.rsl), fabs(br.rsu)));
+                            nm.rd = fmax(nm.rd, fmax(fabs(br.rdsl), fabs(br.rdsu)));
+                            nm.rm = fmax(nm.rm, fmax(br.lsl * br.tsl, br.lsu * br.tsu));
+                            nm.musum += br.lsl * br.tsl + br.lsu * br.tsu;
+                            nm.nan = fma(0.0, br.rsl + br.rsu + br.rdsl + br.rdsu, nm.nan);
+                        }
+                    }
                 }
                 nm.rb = fmax(nm.rb, fabs(rb));
             } else {
@@ -827,6 +895,12 @@ struct QpIpm {
                 if (!FINAL && br.act) {
                     s1 += br.ll * br.dtl + br.tl * br.dll + br.lu * br.dtu + br.tu * br.dlu;
                     s2 += br.dll * br.dtl + br.dlu * br.dtu;
+                    if constexpr (SOFTBOX) {
+                        if (br.soft) {
+                            s1 += br.lsl * br.dtsl + br.tsl * br.dlsl + br.lsu * br.dtsu + br.tsu * br.dlsu;
+                            s2 += br.dlsl * br.dtsl + br.dlsu * br.dtsu;
+                        }
+                    }
                 }
                 if constexpr (KCH > 0) {
                     sfor<0, KCH>([&](auto c) {
@@ -886,12 +960,14 @@ struct QpIpm {
             StageIn in;
             in.zb = zbar(k);
             sfor<0, 4>([&](auto e) { in.box[e] = 0.0; });
+            if constexpr (SOFTBOX) sfor<0, 6>([&](auto e) { in.bxs[e] = 0.0; });
             if constexpr (KCH > 0) sfor<0, KCH>([&](auto c) { sfor<0, OBSN>([&](auto e) { in.obs[c][e] = 0.0; }); });
             if (!first) { // wave-uniform
                 if constexpr (PACK) {
                     in.box[0] = (anydense && k < N) ? W.ld(P_BLL) : 0.0;
                 } else {
                     in.box[0] = W.ld(P_BLL); in.box[1] = W.ld(P_BLU); in.box[2] = W.ld(P_BTL); in.box[3] = W.ld(P_BTU);
+                    if constexpr (SOFTBOX) sfor<0, 6>([&](auto e) { in.bxs[e] = W.ld(P_BS + e); });
                 }
                 if constexpr (KCH > 0) {
                     if (k >= 1 && k < N) {
@@ -910,10 +986,17 @@ struct QpIpm {
             // rows: with no multipliers yet lambda = t = 0 (box_from / obs_from deliver 0 / 1 for inactive rows)
             BoxRow br;
             box_from(in, k, br);
-            if (first) { br.tl = 0.0; br.tu = 0.0; }
+            if (first) { br.tl = 0.0; br.tu = 0.0; if constexpr (SOFTBOX) { br.tsl = 0.0; br.tsu = 0.0; } }
             if (br.act) {
-                rd = fmax(rd, fmax(fabs(-br.dl - br.tl), fabs(br.du - br.tu)));
+                rd = fmax(rd, fmax(fabs(br.sl - br.dl - br.tl), fabs(br.du + br.su - br.tu)));
                 rm = fmax(rm, fmax(br.ll * br.tl, br.lu * br.tu));
+                if constexpr (SOFTBOX) {
+                    if (br.soft) {
+                        rg = fmax(rg, fmax(fabs(br.Zl * br.sl + br.zl - br.ll - br.lsl), fabs(br.Zu * br.su + br.zu - br.lu - br.lsu)));
+                        rd = fmax(rd, fmax(fabs(br.sl - br.bsl - br.tsl), fabs(br.su - br.bsu - br.tsu)));
+                        rm = fmax(rm, fmax(br.lsl * br.tsl, br.lsu * br.tsu));
+                    }
+                }
             }
             double lx = 0.0, ly = 0.0;
             if constexpr (KCH > 0) {

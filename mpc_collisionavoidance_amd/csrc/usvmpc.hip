@@ -33,12 +33,12 @@ __global__ void __launch_bounds__(256, 2) usv_linearize(DevPtrs P, long ngroups)
     Linearize<M, KCH, SOFT, MULTI>::run(P, gid);
 }
 
-template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK>
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX>
 __global__ void __launch_bounds__(64, 2) usv_qp_rti(DevPtrs P, long ngroups, int phase)
 {
     const long gid = lanes::group_linear();
     if (gid >= ngroups) return;
-    QpIpm<M, KCH, SOFT, HDIAG, PACK> q(P, gid);
+    QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX> q(P, gid);
     q.solve(phase);
 }
 
@@ -283,12 +283,19 @@ int launch_pair(usvmpc_handle *h, int phase)
     constexpr bool CANPACK = KCH > 0;
     const bool pack = CANPACK && h->spec.boxpack != 0;
     const dim3 qg((unsigned)qp_grid), qb(qp_block);
-    if (h->spec.hdiag) {
-        if (pack) hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, CANPACK>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
-        else hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
+    if (h->spec.npt != (h->spec.any_bsoft ? WsLayout<M, KCH, SOFT, true>::NPT : WsLayout<M, KCH, SOFT, false>::NPT)) {
+        h->err = "workspace layout mismatch between host and kernels";
+        return USVMPC_E_ARG;
+    }
+    if (h->spec.any_bsoft) { // soft state bounds: rows with slacks, ten planes of their own
+        if (h->spec.hdiag) hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, false, true>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
+        else hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, false, true>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
+    } else if (h->spec.hdiag) {
+        if (pack) hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
+        else hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, false, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
     } else {
-        if (pack) hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, CANPACK>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
-        else hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
+        if (pack) hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, CANPACK, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
+        else hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, false, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
     }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[2], h->stream));
@@ -414,6 +421,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     const size_t kch = h->kch ? h->kch : 1;
     DevPtrs &P = h->ptrs;
     TRY_C(dev_alloc(h, &h->d_spec, 1, false));
+    h->spec.npt = ws_planes(h->nx, h->nu, h->kch, h->soft, model_mat_planes(h->desc.model), h->spec.any_bsoft != 0);
     HIP_C(hipMemcpy(h->d_spec, &h->spec, sizeof(DevSpec), hipMemcpyHostToDevice));
     P.spec = h->d_spec;
     double *t;
@@ -441,7 +449,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->sort_enabled = true;
     h->gd_ready = false; h->gd_npts_cap = 0; h->gd_psi = nullptr; h->gd_world = nullptr; h->gd_world_cap = 0;
     std::memset(&h->gd, 0, sizeof(h->gd));
-    TRY_C(dev_alloc(h, &P.ws, (N + 1) * (size_t)ws_planes(h->nx, h->nu, h->kch, h->soft, model_mat_planes(h->desc.model)) * stride, true));
+    TRY_C(dev_alloc(h, &P.ws, (N + 1) * (size_t)ws_planes(h->nx, h->nu, h->kch, h->soft, model_mat_planes(h->desc.model), h->spec.any_bsoft != 0) * stride, true));
     HIP_C(hipDeviceSynchronize());
 #undef TRY_C
 #undef HIP_C
@@ -753,7 +761,7 @@ int usvmpc_calibrate_traffic(usvmpc_handle *h, int nplanes, double *bytes_read, 
     if (!h || nplanes < 1) return USVMPC_E_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     const long stride = (long)h->Bp * LANES;
-    const long avail = (long)(h->N + 1) * ws_planes(h->nx, h->nu, h->kch, h->soft, model_mat_planes(h->desc.model));
+    const long avail = (long)(h->N + 1) * ws_planes(h->nx, h->nu, h->kch, h->soft, model_mat_planes(h->desc.model), h->spec.any_bsoft != 0);
     if (nplanes + 1 > avail) { h->err = "nplanes exceeds the workspace"; return USVMPC_E_ARG; }
     const long groups = h->Bp;
     hipLaunchKernelGGL(usv_calib_stream, dim3((unsigned)((groups * LANES + 63) / 64)), dim3(64), 0, h->stream, h->ptrs, groups, nplanes);

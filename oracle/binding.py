@@ -38,7 +38,10 @@ class Spec(C.Structure):
                 ("uh", C.c_double * KM), ("soft", C.c_int),
                 ("lsh", C.c_double * KM), ("ush", C.c_double * KM),
                 ("zl", C.c_double * KM), ("zu", C.c_double * KM), ("Zl", C.c_double * KM), ("Zu", C.c_double * KM),
-                ("opts", Opts), ("sim_steps", C.c_int), ("nlp_max_iter", C.c_int), ("nlp_tol", C.c_double * 4)]
+                ("opts", Opts),
+                ("sbx", C.c_int * NXM), ("lsbx", C.c_double * NXM), ("usbx", C.c_double * NXM),
+                ("zl_bx", C.c_double * NXM), ("zu_bx", C.c_double * NXM), ("Zl_bx", C.c_double * NXM), ("Zu_bx", C.c_double * NXM),
+                ("sim_steps", C.c_int), ("nlp_max_iter", C.c_int), ("nlp_tol", C.c_double * 4)]
 
 
 class Qp(C.Structure):
@@ -48,12 +51,13 @@ class Qp(C.Structure):
                 ("A", _dp), ("B", _dp), ("b", _dp), ("H", _dp), ("g", _dp), ("dx0", _dp),
                 ("lbu", _dp), ("ubu", _dp), ("lbx", _dp), ("ubx", _dp), ("Cxy", _dp), ("lg", _dp), ("ug", _dp),
                 ("zl", _dp), ("zu", _dp), ("Zl", _dp), ("Zu", _dp), ("lsl", _dp), ("lsu", _dp),
-                ("scratch", C.c_void_p)]
+                ("sbx", C.c_int * NXM), ("scratch", C.c_void_p)]
 
 
 class QpSol(C.Structure):
     _fields_ = [("dz", _dp), ("pi", _dp), ("lam_bu", _dp), ("t_bu", _dp), ("lam_bx", _dp), ("t_bx", _dp),
                 ("lam_g", _dp), ("t_g", _dp), ("sl", _dp), ("su", _dp), ("lam_s", _dp), ("t_s", _dp),
+                ("sl_bx", _dp), ("su_bx", _dp), ("lam_sbx", _dp), ("t_sbx", _dp),
                 ("iter", C.c_int), ("status", C.c_int), ("res", C.c_double * 4)]
 
 
@@ -137,6 +141,10 @@ def spec(model, N, Tf, K=0, **opts):
     for k, v in opts.items():
         if k in ("sim_steps", "nlp_max_iter"):
             setattr(s, k, int(v))
+        elif k == "soft_bx":   # {position in the bx list: (lsbx, usbx, zl, zu, Zl, Zu)}
+            for i, d in v.items():
+                s.sbx[i] = 1
+                s.lsbx[i], s.usbx[i], s.zl_bx[i], s.zu_bx[i], s.Zl_bx[i], s.Zu_bx[i] = (float(t) for t in d)
         elif k == "nlp_tol":
             for i in range(4):
                 s.nlp_tol[i] = float(v[i] if np.ndim(v) else v)
@@ -200,8 +208,8 @@ def linearize_and_solve(s, x, u, x0, yref, yref_e, p, lh, solve=True):
               lbu=_np_from(qc.lbu, (N, nbu)), ubu=_np_from(qc.ubu, (N, nbu)),
               lbx=_np_from(qc.lbx, (N + 1, nbx)), ubx=_np_from(qc.ubx, (N + 1, nbx)),
               Cxy=_np_from(qc.Cxy, (N + 1, K, 2)), lg=_np_from(qc.lg, (N + 1, K)), ug=_np_from(qc.ug, (N + 1, K)),
-              zl=_np_from(qc.zl, (K,)), zu=_np_from(qc.zu, (K,)), Zl=_np_from(qc.Zl, (K,)), Zu=_np_from(qc.Zu, (K,)),
-              lsl=_np_from(qc.lsl, (K,)), lsu=_np_from(qc.lsu, (K,)))
+              zl=_np_from(qc.zl, (K + nbx,)), zu=_np_from(qc.zu, (K + nbx,)), Zl=_np_from(qc.Zl, (K + nbx,)), Zu=_np_from(qc.Zu, (K + nbx,)),
+              lsl=_np_from(qc.lsl, (K + nbx,)), lsu=_np_from(qc.lsu, (K + nbx,)), sbx=list(qc.sbx[:nbx]))
     sol = None
     if solve:
         sp = L.usv_qp_sol_alloc(q)
@@ -213,6 +221,8 @@ def linearize_and_solve(s, x, u, x0, yref, yref_e, p, lh, solve=True):
                    lam_g=_np_from(sc.lam_g, (N + 1, 2, K)), t_g=_np_from(sc.t_g, (N + 1, 2, K)),
                    sl=_np_from(sc.sl, (N + 1, K)), su=_np_from(sc.su, (N + 1, K)),
                    lam_s=_np_from(sc.lam_s, (N + 1, 2, K)), t_s=_np_from(sc.t_s, (N + 1, 2, K)),
+                   sl_bx=_np_from(sc.sl_bx, (N + 1, nbx)), su_bx=_np_from(sc.su_bx, (N + 1, nbx)),
+                   lam_sbx=_np_from(sc.lam_sbx, (N + 1, 2, nbx)), t_sbx=_np_from(sc.t_sbx, (N + 1, 2, nbx)),
                    iter=sc.iter, status=sc.status, res=np.array(sc.res[:]))
         L.usv_qp_sol_free(sp)
     L.usv_qp_free(q)
@@ -386,9 +396,16 @@ def spec_from_ocp(ocp, model_id, **opts):
     for i in range(s.nbx):
         s.idxbx[i], s.lbx[i], s.ubx[i] = int(idxbx[i]), float(con.lbx[i]), float(con.ubx[i])
     s.soft = 1 if np.asarray(con.idxsh).size else 0
+    idxsbx = np.asarray(getattr(con, "idxsbx", []), dtype=int).reshape(-1)
+    nsbx = idxsbx.size
+    for j, i in enumerate(idxsbx):   # acados orders the slack penalties [sbx.., sh..]
+        s.sbx[i] = 1
+        s.lsbx[i], s.usbx[i] = float(con.lsbx[j]), float(con.usbx[j])
+        s.zl_bx[i], s.zu_bx[i], s.Zl_bx[i], s.Zu_bx[i] = float(cost.zl[j]), float(cost.zu[j]), float(cost.Zl[j]), float(cost.Zu[j])
     for i in range(K):
         s.uh[i] = float(con.uh[i])
         if s.soft:
             s.lsh[i], s.ush[i] = float(con.lsh[i]), float(con.ush[i])
-            s.zl[i], s.zu[i], s.Zl[i], s.Zu[i] = float(cost.zl[i]), float(cost.zu[i]), float(cost.Zl[i]), float(cost.Zu[i])
+            s.zl[i], s.zu[i], s.Zl[i], s.Zu[i] = (float(cost.zl[nsbx + i]), float(cost.zu[nsbx + i]),
+                                                  float(cost.Zl[nsbx + i]), float(cost.Zu[nsbx + i]))
     return s

@@ -453,8 +453,9 @@ usv_qp *usv_qp_alloc(const usv_spec *s)
     q->Cxy = dalloc((size_t)(N + 1) * (K ? K : 1) * 2);
     q->lg = dalloc((size_t)(N + 1) * (K ? K : 1));
     q->ug = dalloc((size_t)(N + 1) * (K ? K : 1));
-    q->zl = dalloc(K); q->zu = dalloc(K); q->Zl = dalloc(K); q->Zu = dalloc(K);
-    q->lsl = dalloc(K); q->lsu = dalloc(K);
+    q->zl = dalloc(K + s->nbx); q->zu = dalloc(K + s->nbx); q->Zl = dalloc(K + s->nbx); q->Zu = dalloc(K + s->nbx);
+    q->lsl = dalloc(K + s->nbx); q->lsu = dalloc(K + s->nbx);
+    for (i = 0; i < s->nbx; i++) q->sbx[i] = s->sbx[i];
     return q;
 }
 
@@ -479,6 +480,8 @@ usv_qp_sol *usv_qp_sol_alloc(const usv_qp *q)
     s->lam_g = dalloc((size_t)(N + 1) * 2 * K); s->t_g = dalloc((size_t)(N + 1) * 2 * K);
     s->sl = dalloc((size_t)(N + 1) * K); s->su = dalloc((size_t)(N + 1) * K);
     s->lam_s = dalloc((size_t)(N + 1) * 2 * K); s->t_s = dalloc((size_t)(N + 1) * 2 * K);
+    s->sl_bx = dalloc((size_t)(N + 1) * nbx); s->su_bx = dalloc((size_t)(N + 1) * nbx);
+    s->lam_sbx = dalloc((size_t)(N + 1) * 2 * nbx); s->t_sbx = dalloc((size_t)(N + 1) * 2 * nbx);
     return s;
 }
 
@@ -487,6 +490,7 @@ void usv_qp_sol_free(usv_qp_sol *s)
     if (!s) return;
     free(s->dz); free(s->pi); free(s->lam_bu); free(s->t_bu); free(s->lam_bx); free(s->t_bx);
     free(s->lam_g); free(s->t_g); free(s->sl); free(s->su); free(s->lam_s); free(s->t_s);
+    free(s->sl_bx); free(s->su_bx); free(s->lam_sbx); free(s->t_sbx);
     free(s);
 }
 
@@ -577,6 +581,11 @@ void usv_linearize(const usv_spec *s, const double *x, const double *u, const do
         q->zl[i] = s->dt * s->zl[i]; q->zu[i] = s->dt * s->zu[i];
         q->Zl[i] = s->dt * s->Zl[i]; q->Zu[i] = s->dt * s->Zu[i];
         q->lsl[i] = s->lsh[i]; q->lsu[i] = s->ush[i];
+    }
+    for (i = 0; i < s->nbx; i++) { /* soft state bounds: the same scaling */
+        q->zl[K + i] = s->dt * s->zl_bx[i]; q->zu[K + i] = s->dt * s->zu_bx[i];
+        q->Zl[K + i] = s->dt * s->Zl_bx[i]; q->Zu[K + i] = s->dt * s->Zu_bx[i];
+        q->lsl[K + i] = s->lsbx[i]; q->lsu[K + i] = s->usbx[i];
     }
 }
 
@@ -689,6 +698,7 @@ static void build_rows(ipm_ws *w)
                 row_t *r = &s->r[m++];
                 r->kind = 0; r->j0 = nu + q->idxbx[i];
                 r->dl = q->lbx[k * q->nbx + i]; r->du = q->ubx[k * q->nbx + i];
+                r->soft = q->sbx[i]; r->ks = K + i;
             }
             for (i = 0; i < K; i++) {
                 row_t *r = &s->r[m++];
@@ -1155,6 +1165,9 @@ int usv_qp_solve(const usv_qp *q, const usv_opts *o, usv_qp_sol *sol)
             for (i = 0; i < q->nbx; i++, m++) {
                 sol->lam_bx[k * 2 * q->nbx + i] = s->r[m].ll; sol->lam_bx[k * 2 * q->nbx + q->nbx + i] = s->r[m].lu;
                 sol->t_bx[k * 2 * q->nbx + i] = s->r[m].tl; sol->t_bx[k * 2 * q->nbx + q->nbx + i] = s->r[m].tu;
+                sol->sl_bx[k * q->nbx + i] = s->r[m].sl; sol->su_bx[k * q->nbx + i] = s->r[m].su;
+                sol->lam_sbx[k * 2 * q->nbx + i] = s->r[m].lsl; sol->lam_sbx[k * 2 * q->nbx + q->nbx + i] = s->r[m].lsu;
+                sol->t_sbx[k * 2 * q->nbx + i] = s->r[m].tsl; sol->t_sbx[k * 2 * q->nbx + q->nbx + i] = s->r[m].tsu;
             }
             for (i = 0; i < K; i++, m++) {
                 sol->lam_g[k * 2 * K + i] = s->r[m].ll; sol->lam_g[k * 2 * K + K + i] = s->r[m].lu;
@@ -1192,6 +1205,9 @@ static void load_rows(ipm_ws *w, const usv_qp_sol *sol)
             for (i = 0; i < q->nbx; i++, m++) {
                 s->r[m].ll = sol->lam_bx[k * 2 * q->nbx + i]; s->r[m].lu = sol->lam_bx[k * 2 * q->nbx + q->nbx + i];
                 s->r[m].tl = sol->t_bx[k * 2 * q->nbx + i]; s->r[m].tu = sol->t_bx[k * 2 * q->nbx + q->nbx + i];
+                s->r[m].sl = sol->sl_bx[k * q->nbx + i]; s->r[m].su = sol->su_bx[k * q->nbx + i];
+                s->r[m].lsl = sol->lam_sbx[k * 2 * q->nbx + i]; s->r[m].lsu = sol->lam_sbx[k * 2 * q->nbx + q->nbx + i];
+                s->r[m].tsl = sol->t_sbx[k * 2 * q->nbx + i]; s->r[m].tsu = sol->t_sbx[k * 2 * q->nbx + q->nbx + i];
             }
             for (i = 0; i < K; i++, m++) {
                 s->r[m].ll = sol->lam_g[k * 2 * K + i]; s->r[m].lu = sol->lam_g[k * 2 * K + K + i];

@@ -90,6 +90,12 @@ typedef struct usv_spec {
     double lsh[USV_K_MAX], ush[USV_K_MAX];
     double zl[USV_K_MAX], zu[USV_K_MAX], Zl[USV_K_MAX], Zu[USV_K_MAX];
     usv_opts opts;
+    /* soft state bounds (acados idxsbx / lsbx / usbx; S/race_cars/acados_settings_dev.py:107-127): flag per entry
+     * of the bx list, lower bounds of its two slacks, and its slack penalties (acados orders the slack penalty
+     * vectors zl.. as [sbx.., sh..]; they are kept apart here) */
+    int sbx[USV_NX_MAX];
+    double lsbx[USV_NX_MAX], usbx[USV_NX_MAX];
+    double zl_bx[USV_NX_MAX], zu_bx[USV_NX_MAX], Zl_bx[USV_NX_MAX], Zu_bx[USV_NX_MAX];
     int sim_steps;        /* RK4 steps per shooting interval (sim_method_num_steps); 0 = 1 */
     int nlp_max_iter;     /* full SQP only (nlp_solver_max_iter); 0 = 100 */
     double nlp_tol[4];    /* full SQP only: stat, eq, ineq, comp (acados default 1e-6 each) */
@@ -129,7 +135,8 @@ typedef struct usv_qp {
     double *lbx, *ubx;      /* [N+1][nbx] relative to xbar; active for 1 <= k <= N-1 */
     double *Cxy;            /* [N+1][K*2] */
     double *lg, *ug;        /* [N+1][K]   relative to hbar; active for 1 <= k <= N-1 */
-    double *zl, *zu, *Zl, *Zu, *lsl, *lsu; /* [K] soft data, already scaled by dt */
+    double *zl, *zu, *Zl, *Zu, *lsl, *lsu; /* [K + nbx] soft data (h rows, then bx rows), already scaled by dt */
+    int sbx[USV_NX_MAX];    /* which bx rows are soft */
     void *scratch;          /* IPM work space, allocated by the first usv_qp_solve on this QP and reused */
 } usv_qp;
 
@@ -141,6 +148,8 @@ typedef struct usv_qp_sol {
     double *lam_g, *t_g;    /* [N+1][2*K] */
     double *sl, *su;        /* [N+1][K] */
     double *lam_s, *t_s;    /* [N+1][2*K]  slack bound multipliers (sl | su) */
+    double *sl_bx, *su_bx;  /* [N+1][nbx]  slacks of the soft state bounds */
+    double *lam_sbx, *t_sbx; /* [N+1][2*nbx] */
     int iter, status;       /* status: 0 ok, 1 max iter, 2 min step, 3 nan */
     double res[4];          /* inf-norms: stat, eq, ineq, comp */
 } usv_qp_sol;

@@ -110,11 +110,11 @@ void lin_body(void *a)
     if (j->P->spec->sim_steps > 1) Linearize<M, KCH, SOFT, true>::run(*j->P, j->gid);
     else Linearize<M, KCH, SOFT, false>::run(*j->P, j->gid);
 }
-template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK>
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false>
 void qp_body(void *a)
 {
     Job *j = (Job *)a;
-    QpIpm<M, KCH, SOFT, HDIAG, PACK> q(*j->P, j->gid);
+    QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX> q(*j->P, j->gid);
     q.solve(j->qp_phase);
 }
 
@@ -130,7 +130,7 @@ void expand_packed(const DevPtrs &P, const DevSpec &S)
     const long stride = (long)S.Bp * LANES;
     // workspace element (stage k, plane e, group g, lane r): [stage][tile of 4 groups][plane][64 lanes]
     auto at = [&](int k, int e, long g, int r) -> double {
-        return P.ws[((((long)k * (S.Bp / 4) + (g >> 2)) * WL::NPT + e) * 64) + (g & 3) * LANES + r];
+        return P.ws[((((long)k * (S.Bp / 4) + (g >> 2)) * S.npt + e) * 64) + (g & 3) * LANES + r];
     };
     for (int k = 0; k <= S.N; k++)
         for (long g = 0; g < S.Bp; g++)
@@ -160,6 +160,7 @@ void expand_packed(const DevPtrs &P, const DevSpec &S)
 template <class M, int KCH, bool SOFT>
 void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
 {
+    const_cast<DevSpec &>(S).npt = S.any_bsoft ? WsLayout<M, KCH, SOFT, true>::NPT : WsLayout<M, KCH, SOFT, false>::NPT;
     if (phase & 1)
         for (long gid = 0; gid < (long)(S.N + 1) * S.Bp; gid++) {
             Job j{&P, gid, 0};
@@ -171,6 +172,11 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
             Job j{&P, g, qp_phase};
             constexpr bool CANPACK = KCH > 0;
             const bool pack = CANPACK && S.boxpack != 0;
+            if (S.any_bsoft) {
+                if (S.hdiag) lanes::run_group(g, &qp_body<M, KCH, SOFT, true, false, true>, &j);
+                else lanes::run_group(g, &qp_body<M, KCH, SOFT, false, false, true>, &j);
+                continue;
+            }
             if (S.hdiag) lanes::run_group(g, pack ? &qp_body<M, KCH, SOFT, true, CANPACK> : &qp_body<M, KCH, SOFT, true, false>, &j);
             else lanes::run_group(g, pack ? &qp_body<M, KCH, SOFT, false, CANPACK> : &qp_body<M, KCH, SOFT, false, false>, &j);
         }
@@ -203,7 +209,7 @@ static int emu_run(const usvmpc_desc *d, int sqp, double *x, double *u, const do
     if (d->model == USVMPC_MODEL_GENERATED) { kch = USV_GEN_KCH; soft = USV_GEN_SOFT != 0; }
 #endif
     const long stride = (long)S.Bp * LANES;
-    std::vector<double> ws((size_t)(N + 1) * ws_planes(nx, nu, kch, soft, 16) * stride), // 16 >= MatPack::NPK of any model
+    std::vector<double> ws((size_t)(N + 1) * ws_planes(nx, nu, kch, soft, 16, true) * stride), // upper bounds: 16 >= MatPack::NPK, soft-box planes
         nres((size_t)S.B * 4);
     std::vector<int> sit(S.B, 0), sstate(S.B, -1);
     int running = 0;

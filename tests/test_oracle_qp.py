@@ -57,6 +57,14 @@ def kkt_residuals(qp, sol):
                 prim = max(prim, max(0.0, qp["lsl"][i] - sl), max(0.0, qp["lsu"][i] - su))
                 comp = max(comp, lsl * (sl - qp["lsl"][i]), lsu * (su - qp["lsu"][i]))
                 dual = max(dual, -min(lsl, lsu, 0.0))
+            if kind == "bx" and qp["sbx"][i]:   # soft state bound: slack data sits behind the K obstacle entries
+                q = qp["K"] + i
+                sl, su = sol["sl_bx"][k, i], sol["su_bx"][k, i]
+                lsl, lsu = sol["lam_sbx"][k, 0, i], sol["lam_sbx"][k, 1, i]
+                stat = max(stat, abs(qp["Zl"][q] * sl + qp["zl"][q] - ll - lsl), abs(qp["Zu"][q] * su + qp["zu"][q] - lu - lsu))
+                prim = max(prim, max(0.0, qp["lsl"][q] - sl), max(0.0, qp["lsu"][q] - su))
+                comp = max(comp, lsl * (sl - qp["lsl"][q]), lsu * (su - qp["lsu"][q]))
+                dual = max(dual, -min(lsl, lsu, 0.0))
             g -= c * (ll - lu)
             prim = max(prim, max(0.0, dl - (v + sl)), max(0.0, (v - su) - du))
             comp = max(comp, abs(ll * (v + sl - dl)), abs(lu * (du - v + su)))
@@ -349,3 +357,29 @@ def test_block_condensed_qp_has_the_same_solution(oracle):
             gx -= pi[k0]
             assert np.abs(gx).max() <= 1e-9 * scale           # (x_0 is fixed: no stationarity row for block 0)
         assert np.abs(gU).max() <= 1e-9 * scale
+
+
+def test_soft_state_bounds_in_the_oracle(oracle):
+    """acados idxsbx / lsbx / usbx: a state bound that the hard-constrained problem cannot keep
+    becomes a penalised violation; the solution satisfies the KKT conditions of the QP with the slack variables."""
+    name, N = "usv_model", 12
+    ocp, wl = util.make(name, N, 0, 3, seed=6)
+    dt = scenario.DT[name]
+    b = 0
+    x0 = wl["x0"][b].copy()
+    x0[0] = 1.8                                     # surge speed above ubx[0] = 1.5: infeasible as a hard bound at stage 1
+    hard = util.oracle_spec(oracle, name, N, dt, 0)
+    soft = util.oracle_spec(oracle, name, N, dt, 0, soft_bx={0: (0.0, 0.0, 50.0, 50.0, 10.0, 10.0)})
+    args = (wl["x_init"][b], wl["u_init"][b], x0, wl["yref"][b], wl["yref_e"][b], wl["p"][b], wl["lh"][b])
+    qp_h, sol_h = oracle.linearize_and_solve(hard, *args)
+    qp_s, sol_s = oracle.linearize_and_solve(soft, *args)
+    assert sol_h["status"] != 0 and sol_s["status"] == 0
+    stat, prim, dual, comp = kkt_residuals(qp_s, sol_s)
+    assert stat <= 1e-6 * max(1.0, np.abs(qp_s["g"]).max()) and prim <= 1e-7 and dual == 0.0 and comp <= 1e-6
+    assert sol_s["su_bx"][1, 0] > 0.05 and np.allclose(sol_s["sl_bx"], 0.0, atol=1e-6)   # upper slack in use at stage 1
+    assert (sol_s["su_bx"][1:N, 1:] == 0).all()                                            # the other rows stay hard
+    # a bound that is not violated: soft and hard give the same solution
+    args2 = (wl["x_init"][b], wl["u_init"][b], wl["x0"][b], wl["yref"][b], wl["yref_e"][b], wl["p"][b], wl["lh"][b])
+    _, a = oracle.linearize_and_solve(hard, *args2)
+    _, c = oracle.linearize_and_solve(soft, *args2)
+    assert a["status"] == 0 and c["status"] == 0 and np.abs(a["dz"] - c["dz"]).max() < 1e-6

@@ -170,3 +170,73 @@ def test_gpu_acados_style_sqp_solver():
     sol.set(N, "yref", wl["yref_e"][0]); sol.set(N, "p", wl["p"][0, N]); sol.set(N, "x", wl["x_init"][0, N])
     assert sol.solve() == 0
     assert 1 <= sol.get_stats("sqp_iter") <= 30 and (sol.get_stats("residuals") <= 1e-6).all()
+
+
+# ------------------------------------------------------------------ soft state bounds (idxsbx / lsbx / usbx)
+def _soft_bx_ocp(name, N, K, pos, zl=50.0, Zl=10.0):
+    """The registry OCP with the bx entries at positions `pos` softened (acados: cost.zl.. ordered [sbx.., sh..])."""
+    ocp = _ocp(name, N, K)
+    n = len(pos)
+    ocp.constraints.idxsbx = np.array(pos)
+    ocp.constraints.lsbx, ocp.constraints.usbx = np.zeros(n), np.zeros(n)
+    for nm, v in (("zl", zl), ("zu", zl), ("Zl", Zl), ("Zu", Zl)):
+        old = np.asarray(getattr(ocp.cost, nm), dtype=float).reshape(-1)
+        setattr(ocp.cost, nm, np.concatenate([np.full(n, v), old]))
+    return ocp
+
+
+@pytest.mark.parametrize("name,K,pos", [("usv_model", 0, [0, 2]), ("usv_model_pf_ca", 3, [0])])
+def test_soft_state_bounds_kernels_match_oracle(oracle, emu, name, K, pos):
+    N, B = 6, 3
+    wl = scenario.make_batch(name, N, K, B, seed=33)
+    ocp = _soft_bx_ocp(name, N, K, pos)
+    j, ub = int(ocp.constraints.idxbx[pos[0]]), float(ocp.constraints.ubx[pos[0]])
+    wl["x0"][0, j] = ub + 0.3; wl["x_init"][0, :, j] = ub + 0.3             # instance 0 starts outside the (soft) bound
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    assert [desc.sbx[i] for i in range(5)] == [1 if i in pos else 0 for i in range(5)]
+    spec = oracle.spec_from_ocp(ocp, MID[name])
+    xe, ue, xo, uo = wl["x_init"], wl["u_init"], wl["x_init"].copy(), wl["u_init"].copy()
+    for it in range(3):
+        r = emu_rti(emu, desc, wl, xe, ue)
+        xe, ue = r["x"], r["u"]
+        xo, uo, sto, ito = util.oracle_rti(oracle, spec, wl, xo, uo)
+        assert np.array_equal(r["status"], sto) and (sto == 0).all()
+        assert np.abs(r["qp_iter"] - ito).max() <= 1
+        assert util.rel_err(xe, xo) < 1e-8 and util.rel_err(ue, uo) < 1e-8
+    # with the bound hard the first instance has no feasible QP
+    hard = emu_rti(emu, _capi.desc_from_ocp(_ocp(name, N, K), batch=B), wl, wl["x_init"], wl["u_init"])
+    assert hard["qp_status"][0] != 0 and (hard["qp_status"][1:] == 0).all()
+
+
+def test_soft_state_bound_option_validation():
+    ocp = _soft_bx_ocp("usv_model", 5, 0, [1])
+    ocp.constraints.idxsbx = np.array([7])
+    with pytest.raises(Exception, match="idxsbx"):
+        _capi.desc_from_ocp(ocp, batch=1)
+    ocp = _soft_bx_ocp("usv_model", 5, 0, [1])
+    ocp.cost.zl = np.zeros(3)
+    with pytest.raises(Exception, match="cost.zl"):
+        _capi.desc_from_ocp(ocp, batch=1)
+
+
+@pytest.mark.gpu
+def test_gpu_soft_state_bounds(oracle):
+    from mpc_collisionavoidance_amd import BatchOcpSolver
+    for name, K, pos in (("usv_model", 0, [0, 2]), ("usv_model_pf_ca", 10, [0, 3])):
+        N, B = 20, 64
+        wl = scenario.make_batch(name, N, K, B, seed=3)
+        ocp = _soft_bx_ocp(name, N, K, pos)
+        j, ub = int(ocp.constraints.idxbx[pos[0]]), float(ocp.constraints.ubx[pos[0]])
+        wl["x0"][:8, j] = ub + 0.3; wl["x_init"][:8, :, j] = ub + 0.3
+        s = BatchOcpSolver(ocp, B)
+        scenario.load_into(s, wl)
+        spec = oracle.spec_from_ocp(ocp, MID[name])
+        xo, uo = wl["x_init"].copy(), wl["u_init"].copy()
+        for it in range(3):
+            st = s.solve()
+            xo, uo, sto, ito = util.oracle_rti(oracle, spec, wl, xo, uo)
+            ok = (st == 0) & (sto == 0) & (s.get_int("qp_status") == 0) & (ito < 50)
+            assert ok[:8].sum() >= 6 and ok.mean() > 0.9   # (a hard obstacle row can still make an instance infeasible)
+            assert util.rel_err(s.get_all("x")[ok], xo[ok]) < 1e-7 and util.rel_err(s.get_all("u")[ok], uo[ok]) < 1e-7
+            s.set_all("x", xo); s.set_all("u", uo)
+        s.close()

@@ -33,8 +33,11 @@ __global__ void __launch_bounds__(256, 2) usv_linearize(DevPtrs P, long ngroups)
     Linearize<M, KCH, SOFT, MULTI>::run(P, gid);
 }
 
+#ifndef USV_QP_WAVES
+#define USV_QP_WAVES 2 // waves per SIMD the QP kernel is compiled for (register budget 512 / USV_QP_WAVES)
+#endif
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX>
-__global__ void __launch_bounds__(64, 2) usv_qp_rti(DevPtrs P, long ngroups, int phase)
+__global__ void __launch_bounds__(64, USV_QP_WAVES) usv_qp_rti(DevPtrs P, long ngroups, int phase)
 {
     const long gid = lanes::group_linear();
     if (gid >= ngroups) return;

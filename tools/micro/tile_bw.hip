@@ -4,7 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
-template <int NPT, int NRD, int NWR, bool SPLIT>
+// EVERY: the NWR planes are written only in every EVERY-th tile (same plane count per write, rarer write bursts)
+template <int NPT, int NRD, int NWR, bool SPLIT, int EVERY = 1, bool INDEP = false>
 __global__ void __launch_bounds__(64, 2) k(u2 *buf, int ntiles, int iters, unsigned *out)
 {
     const unsigned lane = threadIdx.x;
@@ -19,23 +20,25 @@ __global__ void __launch_bounds__(64, 2) k(u2 *buf, int ntiles, int iters, unsig
         for (int d = 0; d < NRD; d++) v[d] = p[(SPLIT ? (d * NPT) / NRD : d) * 64];
 #pragma unroll
         for (int d = 0; d < NRD; d++) acc += v[d].x;
-        u2 w; w.x = acc; w.y = it;
+        u2 w; w.x = INDEP ? lane : acc; w.y = it; // INDEP: the stored value does not depend on this tile's loads
+        if (it % EVERY == EVERY - 1) {
 #pragma unroll
-        for (int d = 0; d < NWR; d++) p[(NPT - 1 - d) * 64] = w;
+            for (int d = 0; d < NWR; d++) p[(NPT - 1 - d) * 64] = w;
+        }
     }
     out[blockIdx.x * 64 + lane] = acc;
 }
-template <int NPT, int NRD, int NWR, bool SPLIT>
+template <int NPT, int NRD, int NWR, bool SPLIT, int EVERY = 1, bool INDEP = false>
 void run(u2 *buf, unsigned *out, const char *tag)
 {
     const int blocks = 16384, ntiles = 41, iters = 41 * 12;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    hipLaunchKernelGGL((k<NPT, NRD, NWR, SPLIT>), dim3(blocks), dim3(64), 0, 0, buf, ntiles, 41, out);
+    hipLaunchKernelGGL((k<NPT, NRD, NWR, SPLIT, EVERY, INDEP>), dim3(blocks), dim3(64), 0, 0, buf, ntiles, 41, out);
     hipEventRecord(a);
-    hipLaunchKernelGGL((k<NPT, NRD, NWR, SPLIT>), dim3(blocks), dim3(64), 0, 0, buf, ntiles, iters, out);
+    hipLaunchKernelGGL((k<NPT, NRD, NWR, SPLIT, EVERY, INDEP>), dim3(blocks), dim3(64), 0, 0, buf, ntiles, iters, out);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
-    const double gb = (double)blocks * iters * (NRD + NWR) * 512 / 1e9;
+    const double gb = (double)blocks * iters * (NRD + (double)NWR / EVERY) * 512 / 1e9;
     printf("%-52s tile %2d planes, read %2d write %2d : %6.1f GB in %6.2f ms = %5.2f TB/s\n", tag, NPT, NRD, NWR, gb, ms, gb / ms);
 }
 int main()
@@ -49,5 +52,9 @@ int main()
     run<27, 20, 4, false>(buf, out, "first 20 planes read, 4 planes written");
     run<27, 20, 1, false>(buf, out, "first 20 planes read, 1 plane written");
     run<27, 12, 0, false>(buf, out, "first 12 planes, reads only");
+    run<27, 20, 4, false, 4>(buf, out, "20 planes read, 4 planes written every 4th tile");
+    run<27, 20, 8, false, 8>(buf, out, "20 planes read, 8 planes written every 8th tile");
+    run<27, 20, 4, false, 1, true>(buf, out, "20 planes read, 4 written (value independent of loads)");
+    run<27, 20, 1, false, 1, true>(buf, out, "20 planes read, 1 written (value independent of loads)");
     return 0;
 }

@@ -140,6 +140,16 @@ USV_DEV unsigned wave_lane() { return threadIdx.x & 63u; }
 // for the whole kernel, and the plane offset (plane * 512) is a compile-time constant of the instruction, so a
 // plane access costs neither VALU address arithmetic nor a live scalar register (buffer_load_dwordx2 ... offen).
 // tile must be wave-uniform.
+// Cache policy of the plane accesses (aux operand of the buffer instructions: 0 default, 2 = nt, non-temporal).
+// A stored plane is not read again before tens of gigabytes have passed: non-temporal STORES measure -3 % (M2) /
+// -5 % (M1) on the QP kernel; non-temporal loads +-0, both together +6 % (tools/micro/store_policy.hip has the
+// isolated streams).
+#ifndef USV_PLANE_LOAD_AUX
+#define USV_PLANE_LOAD_AUX 0
+#endif
+#ifndef USV_PLANE_STORE_AUX
+#define USV_PLANE_STORE_AUX 2
+#endif
 struct Planes {
     __amdgpu_buffer_rsrc_t rsrc;
     unsigned voff; // wave_lane * 8
@@ -152,13 +162,13 @@ struct Planes {
     USV_DEV double ld(int plane) const
     {
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, plane * 512, 0);
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, plane * 512, USV_PLANE_LOAD_AUX);
         return __builtin_bit_cast(double, v);
     }
     USV_DEV void st(int plane, double x) const
     {
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), rsrc, (int)voff, plane * 512, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), rsrc, (int)voff, plane * 512, USV_PLANE_STORE_AUX);
     }
 };
 

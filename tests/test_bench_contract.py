@@ -21,7 +21,7 @@ def test_usable_cores_is_sane():
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_f_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01_g_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k

@@ -4,18 +4,27 @@
 A "step" is one pass of the hot path over one batch: one SQP-RTI iteration (linearise + QP + full
 step) of every instance, followed by the closed-loop hand-over x0 <- x_1 + N(0, sigma) that the
 reference's callers perform between ticks (scripts/usv_guidance_ca1/main.py:169-175), both on the
-device.  Workload at N=1: BASELINE.json configs[2] - batch 65536, usv_model_pf_ca (3-DOF model,
-path-following LS cost, circular obstacles), horizon N=40, 10 obstacles, FP64.  With --gpus N every
-rank runs the same batch size on its own GPU (weak scaling, no data-path collective: instances are
-independent); the only collective is the timing barrier / max.
+device.  Workload at N=1: BASELINE.json configs[2] as SURVEY.md 8(d) spells it out - batch 65536,
+usv_model_pf_ca (3-DOF model, path-following LS cost, hard circular obstacles), horizon N=40 over
+Tf = 2 s, 10 static obstacles, FP64, seed 1234, 3 un-timed warm-up iterations, then the timed closed loop with
+sigma = 1e-3 (mpc_collisionavoidance_amd/scenario.py states the generator and its one clip).  `--workload r01`
+replays the round-1 workload (dt = 0.01 s, obstacles beside the roll-out, no disturbance) for kernel-to-kernel
+comparisons across rounds.
+
+With --gpus N every rank runs the same batch size on its own GPU (weak scaling, no data-path collective:
+instances are independent); the only collective inside the timed region is the closing barrier.  Started
+without a launcher (`python bench.py --gpus N`, no WORLD_SIZE in the environment) it re-executes itself under
+torch.distributed.run with N ranks; it refuses to run if the node has fewer than N GPUs or if the launcher's
+WORLD_SIZE disagrees with --gpus.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (usv_qp_rti), timed with HIP
 events on the stream the kernels run on; `cpu_baseline` times the CPU oracle (a port, not the
-reference) on a bounded sample of the same workload with one thread.
+reference) on a bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -26,13 +35,15 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak
+_ID = {"usv_model": 0, "usv_model_guidance_ca1": 1, "usv_model_pf_ca": 2}
 
 
-def algorithmic_bytes(nx, nu, N, K):
-    """inputs + warm-start iterate in + iterate out, FP64, static obstacle set:
-    8*[nx + ny + ny_e + np + nh + 2*((N+1)*nx + N*nu)] + 4 (status)."""
+def algorithmic_bytes(nx, nu, N, K, moving=False):
+    """inputs + warm-start iterate in + iterate out, FP64:
+    8*[nx + ny + ny_e + P + nh + 2*((N+1)*nx + N*nu)] + 4 (status), P = np (static set) or (N+1)*np (moving)."""
     ny, ny_e, npar, nh = nx + nu, nx, 2 * K, K
-    return 8 * (nx + ny + ny_e + npar + nh + 2 * ((N + 1) * nx + N * nu)) + 4
+    P = (N + 1) * npar if moving else npar
+    return 8 * (nx + ny + ny_e + P + nh + 2 * ((N + 1) * nx + N * nu)) + 4
 
 
 def usable_cores():
@@ -54,45 +65,110 @@ def usable_cores():
     return n
 
 
+def baseline_config(name, B, world, N, K, moving):
+    """Which BASELINE.json config this run is (the line must name itself, whatever the flags)."""
+    total = B * world
+    if name == "usv_model" and N == 20 and K == 0 and total == 1:
+        return "BASELINE.json configs[0]"
+    if N == 20 and K == 3 and total == 1024 and world == 1:
+        return "BASELINE.json configs[1]"
+    if N == 40 and K == 10 and B == 65536 and world == 1:
+        return "BASELINE.json configs[2]"
+    if N == 40 and K == 10 and total == 262144 and world == 8:
+        return "BASELINE.json configs[3]"
+    if N == 80 and K == 20 and moving and total == 65536:
+        return "BASELINE.json configs[4]"
+    if N == 40 and K == 10 and B == 65536:
+        return "BASELINE.json configs[2] per GPU x%d GPUs (weak scaling)" % world
+    return "custom (not a BASELINE.json config)"
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: become N ranks under torch.distributed.run."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but this node has %d visible GPU(s); refusing to run a "
+                         "mislabelled benchmark\n" % (args.gpus, have))
+        sys.exit(3)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="usv_model_pf_ca")
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=40)
     ap.add_argument("--obstacles", type=int, default=10)
-    ap.add_argument("--sigma", type=float, default=0.0, help="std of the Gaussian disturbance added at the hand-over (reference loop: 0)")
+    ap.add_argument("--moving", action="store_true", help="obstacles move: per-stage p (BASELINE configs[4])")
+    ap.add_argument("--workload", default="survey", choices=["survey", "r01"],
+                    help="survey: SURVEY.md 8(d) (dt 0.05 s); r01: the round-1 workload (reference dt, no disturbance)")
+    ap.add_argument("--sigma", type=float, default=None,
+                    help="std of the Gaussian disturbance added at the hand-over (default: 1e-3 for survey, 0 for r01)")
+    ap.add_argument("--cond-N", type=int, default=0, help="qp_solver_cond_N (0: acados default = N, no condensing)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="instances timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)  # does not return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("bench.py: the launcher started %d rank(s) but --gpus is %d; refusing to print a line whose "
+                         "n_gpus is not the number of GPUs that worked" % (world, args.gpus))
 
-    from mpc_collisionavoidance_amd import BatchOcpSolver, scenario, usv_models
+    import torch
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU (visible: %d)" % (local_rank, torch.cuda.device_count()))
+    from mpc_collisionavoidance_amd import BatchOcpSolver, scenario, sharding, usv_models
 
-    dist = torch = None
+    dist = None
+    ranks_seen = 1
     if world > 1:
-        import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ones = torch.ones(1, dtype=torch.int32, device="cuda")
+        dist.all_reduce(ones)                       # every rank that takes part adds one: RCCL really spans them
+        ranks_seen = int(ones.item())
+        if ranks_seen != args.gpus:
+            raise SystemExit("bench.py: all-reduce saw %d ranks, --gpus is %d" % (ranks_seen, args.gpus))
 
     name, N, B = args.model, args.horizon, args.batch
     K = 0 if name == "usv_model" else args.obstacles
-    dt = scenario.DT[name]
+    if args.workload == "survey":
+        dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
+        wl = scenario.make_bench_batch(name, N, K, B, seed=1234 + rank, moving=args.moving)
+        sigma = 1e-3 if args.sigma is None else args.sigma
+        mask = scenario.NOISE_MASK[name]
+    else:
+        dt, steps = scenario.DT[name], 1
+        wl = scenario.make_batch(name, N, K, B, seed=1234 + rank, moving=args.moving)
+        sigma = 0.0 if args.sigma is None else args.sigma
+        mask = (1 << 14) - 1
     ocp = usv_models.make_ocp(name, N * dt, N, None if name == "usv_model" else K)
-    wl = scenario.make_batch(name, N, K, B, seed=1234 + rank)
+    ocp.solver_options.sim_method_num_steps = steps
+    if args.cond_N:
+        ocp.solver_options.qp_solver_cond_N = args.cond_N
     solver = BatchOcpSolver(ocp, B, device=local_rank)
     scenario.load_into(solver, wl)
-    if K > 0:
+    solver.set_option("disturbance_mask", mask)
+    static = K > 0 and float(np.ptp(wl["p"], axis=1).max()) == 0.0 and float(np.ptp(wl["lh"], axis=1).max()) == 0.0
+    if static:
         # the obstacle set of this workload is the same on every stage (as the reference's callers set it:
-        # usv_pf_ca/main.py sets one pobs on all stages); the solver then keeps it in registers
-        assert float(np.ptp(wl["p"], axis=1).max()) == 0.0 and float(np.ptp(wl["lh"], axis=1).max()) == 0.0
+        # usv_pf_ca/main.py puts one pobs on all stages); the solver then keeps it in registers
         solver.set_option("static_obstacles", 1)
     nx, nu = solver.nx, solver.nu
 
@@ -103,24 +179,50 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # ---- warmup (un-timed); the first warmup step doubles as the parity spot check
-    parity = None
-    cpu_baseline = None
-    first_x = first_u = None
+    # ---- warmup (un-timed).  On a single GPU it doubles as a closed-loop parity check: the first S1 instances are
+    # replayed tick by tick on the CPU oracle, fed the x0 the device's hand-over produced (disturbance included)
+    check = rank == 0 and args.gpus == 1 and args.cpu_sample != 0
+    parity = cpu_baseline = None
+    if check:
+        from oracle import binding as ob
+        per_solve_ms = {"usv_model": 0.12, "usv_model_guidance_ca1": 1.2, "usv_model_pf_ca": 3.5}[name] * N / 40.0 * (1 + 0.15 * (steps - 1))
+        S1 = int(max(32, min(B, 4000.0 / per_solve_ms)))               # ~4 s per tick on one core
+        spec = ob.spec(_ID[name], N, N * dt, K, sim_steps=steps)
+        xo, uo = wl["x_init"][:S1].copy(), wl["u_init"][:S1].copy()
+        x0o = wl["x0"][:S1].copy()
+        good = np.ones(S1, dtype=bool)
+        worst = 0.0
+        same_status = 0
     for w in range(args.warmup):
         solver.solve_async()
-        if w == 0 and rank == 0 and args.gpus == 1:
+        if check:
             solver.sync()
-            first_x, first_u = solver.get_all("x"), solver.get_all("u")
-            first_qs = solver.get_int("qp_status")
-        solver.advance(args.sigma, seed=1000 + w)
+            sto, ito = ob.rti_batch(spec, xo, uo, x0o, wl["yref"][:S1], wl["yref_e"][:S1], wl["p"][:S1], wl["lh"][:S1],
+                                    threads=usable_cores())
+            xg, ug = solver.get_all("x")[:S1], solver.get_all("u")[:S1]
+            stg, qsg = solver.get_int("status")[:S1], solver.get_int("qp_status")[:S1]
+            same_status += int(((stg != 0) == (sto != 0)).sum())
+            good &= (sto == 0) & (ito < spec.opts.qp_iter_max) & (qsg == 0)
+            if good.any():
+                sc = np.maximum(1.0, np.abs(xo[good]).max(axis=(0, 1)))   # per-component scale
+                su_ = np.maximum(1.0, np.abs(uo[good]).max(axis=(0, 1)))
+                worst = max(worst, float((np.abs(xg[good] - xo[good]) / sc).max()), float((np.abs(ug[good] - uo[good]) / su_).max()))
+        solver.advance(sigma, seed=1000 + w)
+        if check:
+            solver.sync()
+            x0o = solver.get("x0", 0)[:S1].copy()
+    if check and args.warmup > 0:
+        parity = {"ticks": args.warmup, "instances_converged_on_both_sides_every_tick": int(good.sum()), "of": int(S1),
+                  "status_agreement_frac": same_status / float(args.warmup * S1),
+                  "max_rel_err_per_component": worst,
+                  "vs": "CPU oracle (port; parity vs acados itself is unpinned), closed loop, fed the device's x0"}
     barrier()
 
     # ---- timed region: exactly K steps
     t0 = time.perf_counter()
     for k in range(args.steps):
         solver.solve_async()
-        solver.advance(args.sigma, seed=2000 + k)
+        solver.advance(sigma, seed=2000 + k)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -130,13 +232,31 @@ def main():
 
     nk = min(args.steps, 64)
     lin_ms, qp_ms = solver.kernel_ms(nk)
+    fails = solver.fail_counts(nk)
     st = solver.get_int("status")
     qi = solver.get_int("qp_iter")
     qs = solver.get_int("qp_status")
+    tmin = solver.get("obs_tmin", 0) if K > 0 else np.full(B, 1e300)
+
+    # ---- optional exchange (north_star): all-gather of the optimal trajectories over RCCL, un-timed, on the solver's
+    # own device buffers (zero-copy views)
+    gather = None
+    if dist is not None:
+        g = {}
+        for what in ("u0", "x1", "trajectory"):
+            torch.cuda.synchronize()
+            dist.barrier()
+            c0 = time.perf_counter()
+            full = sharding.gather_results(solver, what, B * world, device_index=local_rank)
+            torch.cuda.synchronize()
+            g[what] = {"ms": (time.perf_counter() - c0) * 1e3, "shape": list(full.shape),
+                       "GB": full.numel() * 8 / 1e9}
+            del full
+        gather = g
 
     total_solves = world * B * args.steps
     value = total_solves / elapsed
-    balg = algorithmic_bytes(nx, nu, N, K)
+    balg = algorithmic_bytes(nx, nu, N, K, moving=args.moving)
     qp_avg_s = float(qp_ms.mean()) * 1e-3
     achieved = balg * B / qp_avg_s / 1e9
     traffic = None
@@ -144,7 +264,8 @@ def main():
     if os.path.exists(pmc):
         try:
             for e in json.load(open(pmc)):
-                if e.get("model") == name and e.get("N") == N and e.get("K") == K and e.get("batch") == B:
+                if (e.get("model") == name and e.get("N") == N and e.get("K") == K and e.get("batch") == B
+                        and e.get("workload", "r01") == args.workload):
                     traffic = e.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -154,28 +275,20 @@ def main():
     nz_, nh_ = nx + nu, K
     c_f = {"usv_model": 60, "usv_model_guidance_ca1": 60, "usv_model_pf_ca": 150}.get(name, 100)
     n_ipm = float(qi.mean()) + 1.0  # factorisations = iterations + the final residual pass
-    falg = N * (4 * (2 * nx * nx * nz_ + c_f) + 8 * nx * (nz_ + 1)) + \
+    falg = steps * N * (4 * (2 * nx * nx * nz_ + c_f) + 8 * nx * (nz_ + 1)) + \
         n_ipm * N * (nx * nx * (nz_ + 1) + nx * nz_ * (nz_ + 1) + nz_ ** 3 / 3.0 + nh_ * nz_ * (nz_ + 1) + 8 * nz_ * nz_)
     fp64_tflops = falg * B / qp_avg_s / 1e12
 
-    # ---- CPU baseline + parity spot check (rank 0, single GPU runs only)
-    if rank == 0 and args.gpus == 1 and args.cpu_sample != 0:
-        from oracle import binding as ob
-        per_solve_ms = {"usv_model": 0.12, "usv_model_guidance_ca1": 1.2, "usv_model_pf_ca": 3.5}[name] * N / 40.0
+    # ---- CPU baseline (rank 0, single GPU runs only): the oracle sources built -O3 -march=native on this host
+    if check:
         cores = usable_cores()
-        S1 = int(max(32, min(B, 4000.0 / per_solve_ms)))               # ~4 s on one core
         S = args.cpu_sample if args.cpu_sample > 0 else int(min(B, max(64, 12000.0 / per_solve_ms * cores)))  # ~12 s on all
         S = min(S, B)
-        spec = ob.spec(_ID[name], N, N * dt, K)
         native = ob.native_lib() is not None   # -O3 -march=native build of the same sources, for timing only
-        args1 = (wl["x0"][:S1], wl["yref"][:S1], wl["yref_e"][:S1], wl["p"][:S1], wl["lh"][:S1])
-        # parity spot check: the checker build (bit-stable flags), sequential
-        xo, uo = wl["x_init"][:S1].copy(), wl["u_init"][:S1].copy()
-        sto, ito = ob.rti_batch(spec, xo, uo, *args1)
-        # single core, then all usable cores, timed on the native build
-        x1, u1 = wl["x_init"][:S1].copy(), wl["u_init"][:S1].copy()
+        S1t = min(S1, 1024)
+        x1, u1 = wl["x_init"][:S1t].copy(), wl["u_init"][:S1t].copy()
         c0 = time.perf_counter()
-        ob.rti_batch(spec, x1, u1, *args1, native=True)
+        ob.rti_batch(spec, x1, u1, wl["x0"][:S1t], wl["yref"][:S1t], wl["yref_e"][:S1t], wl["p"][:S1t], wl["lh"][:S1t], native=True)
         c1sec = time.perf_counter() - c0
         xa, ua = wl["x_init"][:S].copy(), wl["u_init"][:S].copy()
         c0 = time.perf_counter()
@@ -183,26 +296,21 @@ def main():
                      threads=cores, native=True)
         csec = time.perf_counter() - c0
         cpu_baseline = {"value": S / csec, "unit": "solves/s", "cores": cores, "kind": "port",
-                        "single_core_value": S1 / c1sec, "single_instance_latency_ms": c1sec / S1 * 1e3,
+                        "single_core_value": S1t / c1sec, "single_instance_latency_ms": c1sec / S1t * 1e3,
                         "sample": "first %d instances of the same batch, 1 RTI iteration from the same initial guess, "
                                   "oracle/usv_oracle.c built %s, one instance per OpenMP thread on %d threads (%.1f s); "
                                   "single-core figure from the first %d instances (%.1f s)"
                                   % (S, "-O3 -march=native on this host" if native else "with the checker's flags (-O2)",
-                                     cores, csec, S1, c1sec)}
-        S = S1  # the parity spot check below covers the checker-build sample
-        if first_x is not None:
-            ok = (sto == 0) & (ito < spec.opts.qp_iter_max) & (first_qs[:S] == 0)
-            ex = float(np.abs(first_x[:S][ok] - xo[ok]).max() / max(1.0, np.abs(xo).max()))
-            eu = float(np.abs(first_u[:S][ok] - uo[ok]).max() / max(1.0, np.abs(uo).max()))
-            parity = {"instances": int(ok.sum()), "of": int(S), "max_rel_err_x": ex, "max_rel_err_u": eu,
-                      "vs": "CPU oracle (port; parity vs acados itself is unpinned)"}
+                                     cores, csec, S1t, c1sec)}
 
     if rank == 0:
+        ff = fails / float(B)
+        at = lambda i: float(ff[i - 1]) if 1 <= i <= len(ff) else None   # noqa: E731
         out = {
             "metric": "batched SQP-RTI solves/sec (USV, N=%d horizon, %d obstacles)" % (N, K),
             "value": value,
             "unit": "solves/s",
-            "n_gpus": args.gpus,
+            "n_gpus": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -212,10 +320,13 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE.json configs[2]: batch=%d per GPU, %s, N=%d, %d static obstacles, dt=%g s, GN SQP-RTI, "
-                            "closed loop x0<-x1+N(0,%g), seed 1234+rank" % (B, name, N, K, dt, args.sigma),
+                "workload": "%s: batch=%d per GPU, %s, N=%d, Tf=%g s (dt=%g s, %d RK4 step(s) per interval), %d %s obstacles, "
+                            "GN SQP-RTI, generator '%s', closed loop x0<-x1+N(0,%g) on states mask 0x%x, seed 1234+rank"
+                            % (baseline_config(name, B, world, N, K, args.moving), B, name, N, N * dt, dt, steps, K,
+                               "moving" if args.moving else "static", wl["generator"], sigma, mask),
                 "ocp": name, "instances_per_gpu": B, "instances_total": world * B, "horizon": N, "obstacles": K,
-                "sharding": "batch-sharded x%d, no collective" % world,
+                "qp_solver_cond_N": args.cond_N if args.cond_N else N,
+                "sharding": "batch-sharded x%d, no data-path collective" % world, "ranks_seen": ranks_seen,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "usv_qp_rti",
@@ -223,6 +334,7 @@ def main():
                 "traffic": traffic,
                 "traffic_GBs": (traffic / qp_avg_s / 1e9) if traffic else None,
                 "traffic_frac": (traffic / qp_avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "traffic_over_algorithmic": (traffic / (balg * B)) if traffic else None,
                 "fp64_alg_tflops": fp64_tflops, "fp64_frac": fp64_tflops / FP64_PEAK_TFLOPS,
                 "algorithmic_bytes_per_solve": balg, "algorithmic_flops_per_solve": falg,
                 "kernel_ms": {"usv_linearize": float(lin_ms.mean()), "usv_qp_rti": float(qp_ms.mean())},
@@ -234,19 +346,23 @@ def main():
             "cpu_baseline": cpu_baseline,
             "workload_stats": {
                 "status_nonzero_frac": float((st != 0).mean()),
+                "status_nonzero_frac_at_step": {"5": at(5), "10": at(10), "20": at(20), "last": float(ff[-1])},
+                "status_nonzero_frac_per_step": [float(v) for v in ff],
                 "qp_not_converged_frac": float((qs != 0).mean()),
                 "converged_solves_per_s": value * float(1.0 - (qs != 0).mean()),
+                "active_row_frac": float((tmin < 1e-3).mean()) if K > 0 else 0.0,
                 "qp_iter_mean": float(qi.mean()), "qp_iter_p50": float(np.percentile(qi, 50)),
                 "qp_iter_p99": float(np.percentile(qi, 99)), "qp_iter_max": int(qi.max()),
+                "qp_iter_histogram": np.bincount(np.clip(qi, 0, None)).tolist(),
             },
             "parity": parity,
+            "allgather": gather,
         }
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
-
-_ID = {"usv_model": 0, "usv_model_guidance_ca1": 1, "usv_model_pf_ca": 2}
 
 if __name__ == "__main__":
     main()

@@ -107,6 +107,8 @@ int usvmpc_set(usvmpc_handle *h, const char *field, int stage, const double *v, 
  * n = 4: QP residuals stat/eq/ineq/comp), "nlp_res" (the same for the NLP, full SQP only); same stage = -1
  * convention. */
 int usvmpc_get(usvmpc_handle *h, const char *field, int stage, double *out, size_t n);
+/* further get fields: "obs_tmin" (stage ignored, n = 1): the smallest lower-side slack t_l over the instance's obstacle rows
+ * in the last QP (1e300 without rows) - below ~1e-3 the solution touches a keep-out circle, i.e. an obstacle row is active */
 /* integer per-instance results: "status" (0 | 4; after usvmpc_solve_sqp 0 | 2 | 4), "qp_status" (0 ok,
  * 1 max iter,2 min step, 3 nan), "qp_iter", "sqp_iter" */
 int usvmpc_get_int(usvmpc_handle *h, const char *field, int *out);
@@ -132,7 +134,11 @@ int usvmpc_get_device_ptr(usvmpc_handle *h, const char *field, void **dptr);
  * (oldest first, n <= 64), measured on the stream the kernels were launched on */
 int usvmpc_last_kernel_ms(usvmpc_handle *h, float *linearize_ms, float *qp_ms);
 int usvmpc_kernel_ms(usvmpc_handle *h, int n, float *linearize_ms, float *qp_ms);
-/* Closed-loop hand-over on the device: x0 <- x_1 (+ sigma * N(0,1)), enqueued on the stream.
+/* number of instances whose solve ended with status != 0, for each of the last n solves (oldest first, n <= 64); counted on
+ * the device by the solve itself, so a closed loop can be audited without a read-back per tick */
+int usvmpc_fail_counts(usvmpc_handle *h, int n, int *counts);
+/* Closed-loop hand-over on the device: x0 <- x_1 (+ sigma * N(0,1) on the states selected by option
+ * "disturbance_mask", default all), enqueued on the stream.
  * Replaces x0 = solver.get(1,"x"); solver.set(0,"lbx",x0); solver.set(0,"ubx",x0)
  * (catkin_ws/src/nmpc_ca/scripts/usv_guidance_ca1/main.py:169-175). */
 int usvmpc_advance(usvmpc_handle *h, double sigma, unsigned long long seed);
@@ -143,7 +149,9 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  *       solve) into the same wavefront;
  *   "static_obstacles" (default 0) - every stage uses stage 0's p and lh (what the reference's callers set:
  *       scripts/usv_pf_ca/main.py puts one obstacle set on all stages), which the kernel then keeps in registers;
- *   "pack_box_rows" (default 1 when the rows fit) - box-row multipliers share the obstacle rows' planes. */
+ *   "pack_box_rows" (default 1 when the rows fit) - box-row multipliers share the obstacle rows' planes;
+ *   "disturbance_mask" (default all ones) - bit j set: usvmpc_advance adds its noise to state j (the reference's commented
+ *       hooks disturb x0[3] and x0[5] only: catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/main.py:181-183). */
 int usvmpc_set_option(usvmpc_handle *h, const char *name, double value);
 /* ---- Guidance front end (model usv_model_guidance_ca1 only): the arithmetic either side of the solver
  * call in the reference's ROS node, batched on the device (class NMPC in

@@ -233,6 +233,10 @@ class BatchOcpSolver:
             out = np.zeros((self.B, 4))
             self._check(self._lib.usvmpc_get(self._h, field.encode(), 0, out.ctypes.data_as(_capi._dp), 4))
             return out
+        if field == "obs_tmin":
+            out = np.zeros(self.B)
+            self._check(self._lib.usvmpc_get(self._h, b"obs_tmin", 0, out.ctypes.data_as(_capi._dp), 1))
+            return out
         n, _ = self._field(field, stage)
         out = np.zeros((self.B, n))
         self._check(self._lib.usvmpc_get(self._h, field.encode(), int(stage), out.ctypes.data_as(_capi._dp), n))
@@ -285,6 +289,12 @@ class BatchOcpSolver:
         b = (C.c_float * n)()
         self._check(self._lib.usvmpc_kernel_ms(self._h, n, a, b))
         return np.array(a[:]), np.array(b[:])
+
+    def fail_counts(self, n):
+        """Instances with status != 0 in each of the last n solves (oldest first), counted on the device."""
+        a = (C.c_int * n)()
+        self._check(self._lib.usvmpc_fail_counts(self._h, n, a))
+        return np.array(a[:])
 
     def advance(self, sigma=0.0, seed=0):
         """Closed-loop hand-over on the device: x0 <- x_1 (+ sigma N(0,1)); asynchronous."""

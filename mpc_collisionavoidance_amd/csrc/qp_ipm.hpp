@@ -1112,9 +1112,18 @@ struct QpIpm {
         // ---- RTI step + outputs
         const bool ok = (status == 0 || status == 1);
         const bool real = g < nB && !frozen;
+        double tmin = 1e300; // smallest t_l over this instance's obstacle rows: how close the QP solution sits to a keep-out circle
         for (int k = 0; k <= N; k++) {
             const Planes W = ws(k);
             const double z = W.ld(P_Z);
+            if constexpr (KCH > 0) {
+                if (k >= 1 && k < N) { // wave-uniform
+                    sfor<0, KCH>([&](auto c) {
+                        const double tl = W.ld(P_OBS + c * OBSN + 2);
+                        tmin = (c * LANES + lane < Kn) ? fmin(tmin, tl) : tmin;
+                    });
+                }
+            }
             if (real) {
                 if (ok && xlane) P.x[((long)b * (N + 1) + k) * NX + (lane - NU)] += z;
                 if (ok && ulane && k < N) P.u[((long)b * N + k) * NU + lane] += z;
@@ -1134,7 +1143,10 @@ struct QpIpm {
                 }
             }
         }
+        tmin = lanes::gmin(tmin);
         if (real && lane == 0) {
+            if (P.obs_tmin) P.obs_tmin[b] = tmin;
+            if (!ok && P.fail_count) lanes::count_one(P.fail_count);
             P.status[b] = ok ? 0 : 4;
             P.qp_iter[b] = iters;
             P.res[b * 4 + 0] = res0; P.res[b * 4 + 1] = res1; P.res[b * 4 + 2] = res2; P.res[b * 4 + 3] = res3;

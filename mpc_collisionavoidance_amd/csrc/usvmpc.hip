@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 using namespace usv;
 
@@ -69,7 +70,7 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long z)
     return z ^ (z >> 31);
 }
 
-__global__ void usv_advance(DevPtrs P, int nx, double sigma, unsigned long long seed)
+__global__ void usv_advance(DevPtrs P, int nx, double sigma, unsigned long long seed, unsigned mask)
 {
     const DevSpec &S = *P.spec;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,7 +78,7 @@ __global__ void usv_advance(DevPtrs P, int nx, double sigma, unsigned long long 
     const long b = i / nx;
     const int j = (int)(i - b * nx);
     double v = P.x[(b * (S.N + 1) + 1) * nx + j];
-    if (sigma != 0.0) {
+    if (sigma != 0.0 && ((mask >> j) & 1u)) {
         const unsigned long long h1 = splitmix64(seed ^ (unsigned long long)(2 * i));
         const unsigned long long h2 = splitmix64(seed ^ (unsigned long long)(2 * i + 1));
         const double u1 = ((double)(h1 >> 11) + 1.0) * (1.0 / 9007199254740993.0);
@@ -152,10 +153,12 @@ struct usvmpc_handle {
     double *gd_world;   // [B][n_world][3] world obstacles of the last usvmpc_guidance_sense
     size_t gd_world_cap;
     bool sort_enabled;
+    bool map_changed;         // the group -> instance map differs from the one the workspace's multipliers were written under
+    unsigned noise_mask;      // states usvmpc_advance disturbs (option "disturbance_mask"; default: all)
+    int *d_fail_ring;         // [RING] instances with status != 0, one slot per solve
     size_t bytes;
     std::string err;
-    void *allocs[64];
-    int nallocs;
+    std::vector<void *> allocs;
 };
 
 namespace {
@@ -176,10 +179,22 @@ int dev_alloc(usvmpc_handle *h, T **p, size_t count, bool zero)
 {
     const size_t nbytes = (count ? count : 1) * sizeof(T);
     HIP_TRY(h, hipMalloc((void **)p, nbytes));
-    h->allocs[h->nallocs++] = (void *)*p;
+    h->allocs.push_back((void *)*p);
     h->bytes += nbytes;
-    if (zero) HIP_TRY(h, hipMemset((void *)*p, 0, nbytes));
+    // on the handle's stream: it is non-blocking, i.e. NOT ordered against the legacy default stream hipMemset uses
+    if (zero) HIP_TRY(h, hipMemsetAsync((void *)*p, 0, nbytes, h->stream));
     return 0;
+}
+
+// release one buffer obtained from dev_alloc (growing a guidance buffer replaces it)
+void dev_free(usvmpc_handle *h, void *p, size_t nbytes)
+{
+    if (!p) return;
+    for (size_t i = 0; i < h->allocs.size(); i++)
+        if (h->allocs[i] == p) { h->allocs.erase(h->allocs.begin() + (long)i); break; }
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(p);
+    h->bytes -= nbytes;
 }
 
 struct Field {
@@ -208,6 +223,7 @@ int lookup(usvmpc_handle *h, const char *f, int stage, bool set, Field &o)
     else if (!set && s == "sl") o = {P.sl, h->K, N, 0};
     else if (!set && s == "su") o = {P.su, h->K, N, 0};
     else if (!set && s == "res") o = {P.res, 4, 1, 0};
+    else if (!set && s == "obs_tmin") o = {P.obs_tmin, 1, 1, 0};
     else if (!set && s == "nlp_res") o = {P.nlp_res, 4, 1, 0};
     else {
         h->err = "unknown field '" + s + "'";
@@ -222,6 +238,7 @@ int copy_field(usvmpc_handle *h, const char *field, int stage, double *host, siz
     if (!host) { h->err = "null buffer"; return USVMPC_E_ARG; }
     Field f;
     if (std::string(field ? field : "") == "res" || std::string(field ? field : "") == "nlp_res" ||
+        std::string(field ? field : "") == "obs_tmin" ||
         std::string(field ? field : "") == "x0" ||
         std::string(field ? field : "") == "yref_e")
         stage = stage < 0 ? -1 : 0;
@@ -269,6 +286,7 @@ int launch_pair(usvmpc_handle *h, int phase)
     // (the later iterations of a full SQP read the multipliers the previous launch left in the group-indexed
     // workspace: the group -> instance map must not change inside one SQP call)
     if (h->sort_enabled && h->nsolves > 0 && phase != 2) {
+        h->map_changed = true;
         const int B = h->B;
         hipLaunchKernelGGL(usv_sort_hist, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_iter, B, h->d_hist);
         hipLaunchKernelGGL(usv_sort_scan, dim3(1), dim3(64), 0, h->stream, h->d_hist, h->d_cursor);
@@ -283,6 +301,8 @@ int launch_pair(usvmpc_handle *h, int phase)
         hipLaunchKernelGGL((usv_linearize<M, KCH, SOFT, false>), dim3((unsigned)lin_grid), dim3(lin_block), 0, h->stream, h->ptrs, lin_groups);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[1], h->stream));
+    h->ptrs.fail_count = h->d_fail_ring + h->nsolves % usvmpc_handle::RING;
+    HIP_TRY(h, hipMemsetAsync(h->ptrs.fail_count, 0, sizeof(int), h->stream));
     constexpr bool CANPACK = KCH > 0;
     const bool pack = CANPACK && h->spec.boxpack != 0;
     const dim3 qg((unsigned)qp_grid), qb(qp_block);
@@ -405,11 +425,13 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     if (d->model == USVMPC_MODEL_GENERATED) { h->kch = USV_GEN_KCH; h->soft = USV_GEN_SOFT != 0; }
 #endif
     h->device = d->device;
-    h->nallocs = 0; h->bytes = 0; h->nsolves = 0; h->own_stream = true;
+    h->bytes = 0; h->nsolves = 0; h->own_stream = true;
+    h->map_changed = false;
+    h->noise_mask = ~0u;
     std::memset(&h->ptrs, 0, sizeof(h->ptrs));
     auto fail = [&](int rc) {
         std::fprintf(stderr, "usvmpc_create: %s\n", h->err.c_str());
-        for (int i = 0; i < h->nallocs; i++) (void)hipFree(h->allocs[i]);
+        for (void *a : h->allocs) (void)hipFree(a);
         delete h;
         return rc;
     };
@@ -442,6 +464,8 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     TRY_C(dev_alloc(h, &P.qp_iter, B, true));
     TRY_C(dev_alloc(h, &P.qp_status, B, true));
     TRY_C(dev_alloc(h, &P.res, B * 4, true));
+    TRY_C(dev_alloc(h, &P.obs_tmin, B, true));
+    TRY_C(dev_alloc(h, &h->d_fail_ring, usvmpc_handle::RING, true));
     TRY_C(dev_alloc(h, &P.nlp_res, B * 4, true));
     TRY_C(dev_alloc(h, &P.sqp_iter, B, true));
     TRY_C(dev_alloc(h, &P.sqp_state, B, true));
@@ -465,7 +489,7 @@ int usvmpc_destroy(usvmpc_handle *h)
     if (!h) return USVMPC_E_ARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    for (int i = 0; i < h->nallocs; i++) (void)hipFree(h->allocs[i]);
+    for (void *a : h->allocs) (void)hipFree(a);
     for (int r = 0; r < usvmpc_handle::RING; r++)
         for (int i = 0; i < 3; i++) (void)hipEventDestroy(h->ev[r][i]);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -538,7 +562,12 @@ int usvmpc_solve_sqp(usvmpc_handle *h, int *status)
         HIP_TRY(h, hipMemsetAsync(h->ptrs.sqp_running, 0, sizeof(int), h->stream));
         // the very first launch of a handle has no multipliers yet; afterwards the workspace holds those of the
         // last QP of every instance (acados likewise keeps nlp_out between calls)
-        const int rc = launch(h, (it == 0 && h->nsolves == 0) ? 1 : 2);
+        // ... unless the group -> instance map has changed since (difficulty binning re-sorted or switched off): the
+        // workspace is group-indexed, so the multipliers there belong to other instances and the call starts from
+        // zero multipliers like a first one
+        const bool fresh = it == 0 && (h->nsolves == 0 || h->map_changed);
+        if (it == 0) h->map_changed = false;
+        const int rc = launch(h, fresh ? 1 : 2);
         if (rc) return rc;
         int running = 0;
         HIP_TRY(h, hipMemcpyAsync(&running, h->ptrs.sqp_running, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -568,6 +597,7 @@ int usvmpc_get_device_ptr(usvmpc_handle *h, const char *field, void **dptr)
                   : s == "sl" ? (const void *)P.sl : s == "su" ? (const void *)P.su
                   : s == "status" ? (const void *)P.status : s == "qp_iter" ? (const void *)P.qp_iter
                   : s == "qp_status" ? (const void *)P.qp_status : s == "res" ? (const void *)P.res
+                  : s == "obs_tmin" ? (const void *)P.obs_tmin
                   : s == "nlp_res" ? (const void *)P.nlp_res : s == "sqp_iter" ? (const void *)P.sqp_iter : nullptr;
     if (!p) { h->err = "unknown field '" + s + "'"; return USVMPC_E_FIELD; }
     *dptr = const_cast<void *>(p);
@@ -591,6 +621,18 @@ int usvmpc_kernel_ms(usvmpc_handle *h, int n, float *linearize_ms, float *qp_ms)
     return 0;
 }
 
+int usvmpc_fail_counts(usvmpc_handle *h, int n, int *counts)
+{
+    if (!h || n < 1 || !counts) return USVMPC_E_ARG;
+    if (h->nsolves < n || n > usvmpc_handle::RING) { h->err = "fewer solves recorded than requested"; return USVMPC_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    int ring[usvmpc_handle::RING];
+    HIP_TRY(h, hipMemcpyAsync(ring, h->d_fail_ring, sizeof(ring), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; i++) counts[i] = ring[(h->nsolves - n + i) % usvmpc_handle::RING];
+    return 0;
+}
+
 int usvmpc_last_kernel_ms(usvmpc_handle *h, float *linearize_ms, float *qp_ms)
 {
     return usvmpc_kernel_ms(h, 1, linearize_ms, qp_ms);
@@ -601,7 +643,7 @@ int usvmpc_advance(usvmpc_handle *h, double sigma, unsigned long long seed)
     if (!h) return USVMPC_E_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     const long n = (long)h->B * h->nx;
-    hipLaunchKernelGGL(usv_advance, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ptrs, h->nx, sigma, seed);
+    hipLaunchKernelGGL(usv_advance, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ptrs, h->nx, sigma, seed, h->noise_mask);
     HIP_TRY(h, hipGetLastError());
     return 0;
 }
@@ -612,7 +654,11 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
     const std::string s(name ? name : "");
     if (s == "sort_by_difficulty") {
         h->sort_enabled = value != 0.0;
-        if (!h->sort_enabled) h->ptrs.perm = nullptr;
+        if (!h->sort_enabled && h->ptrs.perm) { h->ptrs.perm = nullptr; h->map_changed = true; }
+        return 0;
+    }
+    if (s == "disturbance_mask") { // bit j: usvmpc_advance adds its noise to state j
+        h->noise_mask = (unsigned)value;
         return 0;
     }
     if (s == "static_obstacles" || s == "pack_box_rows") {
@@ -652,7 +698,8 @@ static int guidance_alloc(usvmpc_handle *h, int npts)
         G.lmax = GUIDANCE_LMAX;
         h->gd_ready = true;
     }
-    if (npts > h->gd_npts_cap) {
+    if (npts > h->gd_npts_cap) { // grow: the old list is released, its slot in the allocation table with it
+        dev_free(h, const_cast<double *>(G.wp), B * 2 * (size_t)h->gd_npts_cap * sizeof(double));
         double *d;
         if (dev_alloc(h, &d, B * 2 * (size_t)npts, true)) return USVMPC_E_HIP;
         G.wp = d;
@@ -700,6 +747,9 @@ int usvmpc_guidance_prepare(usvmpc_handle *h, const double *vel_uv, const double
     }
     hipLaunchKernelGGL(usv_guidance_pre, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, h->stream, h->ptrs, G);
     HIP_TRY(h, hipGetLastError());
+    // the copies above read caller memory: it must be reusable when this call returns (pinned buffers make
+    // hipMemcpyAsync truly asynchronous)
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 
@@ -712,6 +762,8 @@ int usvmpc_guidance_sense(usvmpc_handle *h, const double *pose, const double *wo
     GuidancePtrs &G = h->gd;
     const size_t B = h->B;
     if ((size_t)n_world > h->gd_world_cap) {
+        dev_free(h, h->gd_world, B * h->gd_world_cap * 3 * sizeof(double));
+        h->gd_world = nullptr;
         if (dev_alloc(h, &h->gd_world, B * (size_t)n_world * 3, true)) return USVMPC_E_HIP;
         h->gd_world_cap = (size_t)n_world;
     }

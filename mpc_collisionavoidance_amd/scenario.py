@@ -24,12 +24,85 @@ def wrap(a):
 # stiff and the explicit RK4 map is unstable at 0.05 s once |v| > 0.07.
 DT = {"usv_model": 0.05, "usv_model_guidance_ca1": 0.05, "usv_model_pf_ca": 0.01}
 
+# Benchmark settings: shooting interval 0.05 s for EVERY model, i.e. Tf = 2 s at N = 40.
+# usv_model_pf_ca cannot take one RK4 step of 0.05 s (see above), so its integrator runs 5 steps per interval
+# (acados sim_method_num_steps = 5): the integration step stays the reference's 0.01 s while the look-ahead is
+# the 2 s the obstacle rows need to become active.  NOISE_MASK: states the closed-loop disturbance is added to -
+# every state for the soft-row model, (u, r) for usv_model_pf_ca as the reference's own "Add noise" hooks have it
+# (scripts/usv_pf_ca/main.py:181-183: x0[3], x0[5]; position noise on a vehicle that grazes a HARD keep-out
+# circle makes the next QP infeasible by construction).
+BENCH_DT = 0.05
+BENCH_SIM_STEPS = {"usv_model": 1, "usv_model_guidance_ca1": 1, "usv_model_pf_ca": 5}
+NOISE_MASK = {"usv_model": (1 << 5) - 1, "usv_model_guidance_ca1": (1 << 8) - 1, "usv_model_pf_ca": (1 << 3) | (1 << 5)}
 
-def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None):
+_CY = 0.5 * (-40.0 * 1000.0) * (1.1 + 0.0045 * (1.01 / 0.09) - 0.1 * (0.27 / 0.09) + 0.016 * ((0.27 / 0.09) ** 2))
+
+
+def _pf_ca_rhs(y, ak, Tp, Ts):
+    """usv_model_pf_ca right-hand side with zero input (thrusts constant), vectorised over the batch
+    (scripts/usv_pf_ca/usv_model.py:137-160).  y = rows (psi, sinpsi, cospsi, u, v, r, ye, nedx, nedy) of shape [9, B]:
+    the states that move; only used to roll the initial guess forward."""
+    m, Iz, Bw = 30.0, 4.1, 0.41
+    Xud, Yvd, Yrd, Nvd, Nrd = -2.25, -23.13, -1.31, -16.41, -2.79
+    Yvv, Yvr, Nrv, Nrr = -99.99, -5.49, -8.8, -3.49
+    psi, u, v, r = y[0], y[3], y[4], y[5]
+    fast = u > 1.25
+    Xu, Xuu = np.where(fast, 64.55, -25.0), np.where(fast, -70.92, 0.0)
+    au, av, ar = np.abs(u), np.abs(v), np.abs(r)
+    Nr = -0.52 * np.sqrt(u * u + v * v)
+    a = Yrd + Nvd
+    f = np.empty_like(y)
+    chi = psi + np.arctan2(v, u + 0.001)
+    sp, cp = np.sin(psi), np.cos(psi)
+    vx, vy = u * cp - v * sp, u * sp + v * cp
+    f[0] = r
+    f[1] = np.cos(chi) * r
+    f[2] = -np.sin(chi) * r
+    f[3] = ((Tp + Ts) - (-m + 2.0 * Yvd) * v - a * r * r - (-Xu * u - Xuu * au * u)) / (m - Xud)
+    f[4] = (-(m - Xud) * u * r - (-_CY * av - Yvv * av - Yvr * ar) * v) / (m - Yvd)
+    f[5] = ((Tp - Ts) * (Bw / 2.0) - (-2.0 * Yvd * u * v - a * r * u + Xud * u * r) -
+            (-Nr * r - Nrv * av * r - Nrr * ar * r)) / (Iz - Nrd)
+    f[6] = -vx * np.sin(ak) + vy * np.cos(ak)
+    f[7] = vx
+    f[8] = vy
+    return f
+
+
+def _pf_ca_rollout(x0, N, dt, steps):
+    """Zero-input simulation with the solver's own integrator (RK4, `steps` steps per interval): [B, N+1, nx]."""
+    h = dt / steps
+    mov = [0, 1, 2, 3, 4, 5, 6, 10, 11]
+    y = np.ascontiguousarray(x0[:, mov].T)
+    ak, Tp, Ts = x0[:, 9].copy(), x0[:, 12].copy(), x0[:, 13].copy()
+    out = np.repeat(x0[:, None, :], N + 1, axis=1)
+    for k in range(N):
+        for _ in range(steps):
+            k1 = _pf_ca_rhs(y, ak, Tp, Ts)
+            k2 = _pf_ca_rhs(y + 0.5 * h * k1, ak, Tp, Ts)
+            k3 = _pf_ca_rhs(y + 0.5 * h * k2, ak, Tp, Ts)
+            k4 = _pf_ca_rhs(y + h * k3, ak, Tp, Ts)
+            y = y + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+        out[:, k + 1, mov] = y.T
+    return out
+
+
+def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None, generator="beside", sim_steps=1):
     """Returns dict(x0 [B,nx], yref [B,N,ny], yref_e [B,nx], p [B,N+1,2K], lh [B,N,K],
-    x_init [B,N+1,nx], u_init [B,N,nu])."""
+    x_init [B,N+1,nx], u_init [B,N,nu]).
+
+    generator (obstacle placement and initial guess of usv_model_pf_ca; the other models have one):
+      "survey" - SURVEY.md 8(d): sway v ~ U(-0.1, 0.1); obstacles in polar form about the vehicle (bearing within
+                 +-60 deg of the course, range R+0.7 .. 6 m), with ONE stated clip: an obstacle whose keep-out circle
+                 the course ray would enter closer than 0.4 m + 1.2 s * u is moved outwards along its bearing until it
+                 does not (hard rows: nearer than that the first QP has no feasible point - the vehicle can neither
+                 stop nor turn in time); initial guess = zero-input simulation with the solver's integrator.
+      "beside" - round-1 workload for the reference's dt = 0.01 s (0.4 s look-ahead at N = 40): v ~ U(-0.03, 0.03),
+                 obstacles beside the straight-line roll-out; kept for the parity tests at the reference's step size."""
     if dt is None:
         dt = DT[name]
+    if generator not in ("survey", "beside"):
+        raise ValueError(generator)
+    survey = generator == "survey" and name == "usv_model_pf_ca"
     rng = np.random.default_rng(seed)
     x1, y1, x2, y2 = PATH
     ak = np.arctan2(y2 - y1, x2 - x1)
@@ -37,7 +110,7 @@ def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None):
     nedy = rng.uniform(-5.0, 15.0, B)
     psi = ak + rng.uniform(-0.6, 0.6, B)
     u = rng.uniform(0.3, 1.2, B)
-    v = rng.uniform(-0.1, 0.1, B) if name == "usv_model_guidance_ca1" else rng.uniform(-0.03, 0.03, B)
+    v = rng.uniform(-0.1, 0.1, B) if (name == "usv_model_guidance_ca1" or survey) else rng.uniform(-0.03, 0.03, B)
     r = rng.uniform(-0.1, 0.1, B)
     Tp = rng.uniform(0.0, 15.0, B)
     Ts = rng.uniform(0.0, 15.0, B)
@@ -76,10 +149,27 @@ def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None):
         R = rng.uniform(0.3, 1.5, (B, K)) + 0.5
         margin = 0.0 if name == "usv_model_guidance_ca1" else 0.2
         lhv = R + margin
-        if name == "usv_model_guidance_ca1":
+        if name == "usv_model_guidance_ca1" or survey:
             # polar about the vehicle: bearing within +-60 deg of the course, range R+0.7 .. 6 m
             rad = (R + 0.7) + rng.uniform(0.0, 1.0, (B, K)) * np.maximum(6.0 - (R + 0.7), 0.0)
-            bearing = course[:, None] + rng.uniform(-np.pi / 3, np.pi / 3, (B, K))
+            rel = rng.uniform(-np.pi / 3, np.pi / 3, (B, K))
+            if survey:
+                # hard rows: the course ray enters the keep-out circle (radius lh) at s = lon - sqrt(lh^2 - lat^2);
+                # obstacles with s < s_min(u) move out along their bearing to the range where s = s_min
+                smin = (0.4 + 1.2 * u)[:, None]
+                lat, lon = rad * np.sin(rel), rad * np.cos(rel)
+                hit = np.abs(lat) < lhv
+                s_enter = np.where(hit, lon - np.sqrt(np.maximum(lhv ** 2 - lat ** 2, 0.0)), np.inf)
+                cb = np.cos(rel)
+                # s_enter grows with the range; it equals s_min at the larger root of the quadratic below PROVIDED that
+                # root still has the centre beyond s_min (lon >= s_min) - otherwise the chord the ray cuts vanishes
+                # first, and the obstacle moves out to where the ray is tangent to its circle
+                disc = (smin * cb) ** 2 - (smin ** 2 - lhv ** 2)
+                root = smin * cb + np.sqrt(np.maximum(disc, 0.0))
+                tangent = lhv / np.maximum(np.abs(np.sin(rel)), 1e-12)
+                rad_out = np.where((disc >= 0.0) & (root * cb >= smin), root, tangent)
+                rad = np.where(hit & (s_enter < smin), np.maximum(rad, rad_out) + 1e-9, rad)
+            bearing = course[:, None] + rel
             ox = nedx[:, None] + rad * np.cos(bearing)
             oy = nedy[:, None] + rad * np.sin(bearing)
         else:
@@ -97,7 +187,7 @@ def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None):
             ox[:, na:], oy[:, na:], lhv[:, na:] = 1000.0, 1000.0, 0.0
         if not moving:
             vel = np.zeros((B, K, 2))
-        elif name == "usv_model_guidance_ca1":
+        elif name == "usv_model_guidance_ca1" or survey:
             vel = rng.uniform(-0.3, 0.3, (B, K, 2))
         else:
             # hard rows: obstacles slide parallel to the course, which keeps their lateral clearance
@@ -120,13 +210,21 @@ def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None):
         x_init[:, :, 2] += tk * yed
         x_init[:, :, 5] += tk * vx
         x_init[:, :, 6] += tk * vy
+    elif survey:
+        x_init = _pf_ca_rollout(x0, N, dt, sim_steps)
     elif name == "usv_model_pf_ca":
         x_init[:, :, 6] += tk * yed
         x_init[:, :, 10] += tk * vx
         x_init[:, :, 11] += tk * vy
     u_init = np.zeros((B, N, nu))
     return dict(x0=x0, yref=yref, yref_e=yref_e, p=p, lh=lh, x_init=x_init, u_init=u_init,
-                nx=nx, nu=nu, K=K, N=N, dt=dt)
+                nx=nx, nu=nu, K=K, N=N, dt=dt, sim_steps=sim_steps, generator=generator)
+
+
+def make_bench_batch(name, N, K, B, seed=1234, moving=False):
+    """The benchmark workload of SURVEY.md 8(d) for `name`: dt = 0.05 s, the "survey" generator."""
+    return make_batch(name, N, K, B, dt=BENCH_DT, seed=seed, moving=moving, generator="survey",
+                      sim_steps=BENCH_SIM_STEPS[name])
 
 
 def load_into(solver, wl):

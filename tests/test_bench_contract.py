@@ -37,3 +37,27 @@ def test_committed_bench_line_has_the_contract_fields():
     assert c["kind"] == "port" and c["cores"] >= 1
     # value = units all ranks processed / time
     assert abs(d["value"] - d["config"]["instances_total"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+
+
+def test_line_names_its_own_config():
+    assert bench.baseline_config("usv_model_pf_ca", 65536, 1, 40, 10, False) == "BASELINE.json configs[2]"
+    assert bench.baseline_config("usv_model_pf_ca", 1024, 1, 20, 3, False) == "BASELINE.json configs[1]"
+    assert bench.baseline_config("usv_model_pf_ca", 32768, 8, 40, 10, False) == "BASELINE.json configs[3]"
+    assert bench.baseline_config("usv_model_pf_ca", 8192, 8, 80, 20, True) == "BASELINE.json configs[4]"
+    assert "configs[2] per GPU x8" in bench.baseline_config("usv_model_pf_ca", 65536, 8, 40, 10, False)
+    assert bench.baseline_config("usv_model_pf_ca", 4096, 1, 40, 10, False).startswith("custom")
+
+
+def test_gpus_gt_visible_devices_is_refused():
+    """`python bench.py --gpus 2` without a launcher on a box with fewer than 2 GPUs must fail loudly instead of printing
+    a 1-GPU number labelled n_gpus = 2; and a launcher whose WORLD_SIZE disagrees with --gpus is refused too."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--batch", "8", "--cpu-sample", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr and "{" not in r.stdout
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
+                        "--batch", "8", "--cpu-sample", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and '"metric"' not in r.stdout

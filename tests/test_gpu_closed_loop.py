@@ -1,0 +1,148 @@
+"""GPU closed-loop parity (run on a real MI355X with `pytest -m gpu`).
+
+* the bench workload itself (BASELINE configs[2] as SURVEY.md 8(d) spells it out: usv_model_pf_ca, N=40, Tf=2 s,
+  10 static obstacles, closed loop x0 <- x1 + disturbance), B distinct instances, 25 ticks of solve + advance with
+  the bench's options (static obstacle set in registers, difficulty binning on), against the CPU oracle TICK BY TICK:
+  the oracle is handed the x0 the device's hand-over produced, keeps its own iterate, and must agree on the status of
+  every instance, on the failing set, and on the iterate (per-component relative error, tests/util.rel_err);
+* the reference's own usv_pf_ca scenario at its exact settings (N=100, Tf=1, 4 obstacles,
+  /root/reference/catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/main.py:54-55,73-75,106-133) through the AcadosOcpSolver
+  look-alike, 25 closed-loop ticks;
+* a batch solved as two handles on the shards sharding.shard_bounds gives two ranks returns bit-for-bit what one
+  handle returns for the whole batch (what bench.py --gpus 2 relies on).
+"""
+import numpy as np
+import pytest
+
+from mpc_collisionavoidance_amd import BatchOcpSolver, scenario, sharding, usv_models
+from tests import util
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-7
+
+
+def _closed_loop(oracle, name, N, K, B, ticks, sigma, seed=1234):
+    wl = scenario.make_bench_batch(name, N, K, B, seed=seed)
+    dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
+    ocp = usv_models.make_ocp(name, N * dt, N, K)
+    ocp.solver_options.sim_method_num_steps = steps
+    s = BatchOcpSolver(ocp, B)
+    scenario.load_into(s, wl)
+    s.set_option("static_obstacles", 1)
+    s.set_option("disturbance_mask", scenario.NOISE_MASK[name])
+    spec = oracle.spec(util.MODEL_ID[name], N, N * dt, K, sim_steps=steps)
+    xo, uo, x0o = wl["x_init"].copy(), wl["u_init"].copy(), wl["x0"].copy()
+    good = np.ones(B, dtype=bool)       # converged on both sides in every tick so far: iterates comparable
+    slack = max(1, int(0.01 * B))       # instances allowed to sit on a threshold (iteration cap / step-length floor)
+    fail_g_total = fail_o_total = 0
+    worst = 0.0
+    for t in range(ticks):
+        s.solve_async()
+        s.sync()
+        sto, ito = oracle.rti_batch(spec, xo, uo, x0o, wl["yref"], wl["yref_e"], wl["p"], wl["lh"], threads=8)
+        stg, qs, qi = s.get_int("status"), s.get_int("qp_status"), s.get_int("qp_iter")
+        assert int(s.fail_counts(1)[0]) == int((stg != 0).sum())          # the on-device audit counter
+        xg, ug = s.get_all("x"), s.get_all("u")
+        # same status per instance / same failing set (among instances whose history is shared)
+        differ = (stg != sto) & good
+        assert differ.sum() <= slack, (name, t, np.where(differ)[0], stg[differ], sto[differ])
+        fail_g_total += int((stg != 0).sum())
+        fail_o_total += int((sto != 0).sum())
+        conv_g, conv_o = qs == 0, (sto == 0) & (ito < spec.opts.qp_iter_max)
+        assert ((conv_g != conv_o) & good).sum() <= slack, (name, t)
+        good &= conv_g & conv_o
+        assert good.mean() >= 0.9, (name, t, good.mean())
+        ex, eu = util.rel_err(xg[good], xo[good]), util.rel_err(ug[good], uo[good])
+        worst = max(worst, ex, eu)
+        assert ex <= TOL and eu <= TOL, (name, t, ex, eu)
+        dit = np.abs(qi - ito)[good]
+        assert dit.max() <= 1 and (dit > 0).sum() <= slack, (name, t, dit.max(), (dit > 0).sum())
+        s.advance(sigma, seed=2000 + t)
+        s.sync()
+        x0g = s.get("x0", 0)
+        # the hand-over: x1 of the device's iterate plus the disturbance on the masked states only
+        d = x0g - xg[:, 1]
+        mask = np.array([(scenario.NOISE_MASK[name] >> j) & 1 for j in range(d.shape[1])], dtype=bool)
+        assert np.all(d[:, ~mask] == 0.0)
+        if sigma > 0:
+            assert 0.5 * sigma < d[:, mask].std() < 2.0 * sigma
+        x0o = x0g.copy()
+    s.close()
+    return dict(good=float(good.mean()), fail_g=fail_g_total, fail_o=fail_o_total, worst=worst)
+
+
+def test_bench_workload_closed_loop_pf_ca(oracle):
+    r = _closed_loop(oracle, "usv_model_pf_ca", 40, 10, 512, ticks=25, sigma=1e-3)
+    # failures do not pile up: hard rows make some QPs infeasible for a tick or two, but the count stays small
+    assert r["fail_g"] <= 0.01 * 512 * 25 and abs(r["fail_g"] - r["fail_o"]) <= 25, r
+
+
+def test_bench_workload_closed_loop_guidance_ca1(oracle):
+    r = _closed_loop(oracle, "usv_model_guidance_ca1", 40, 10, 512, ticks=25, sigma=1e-3)
+    assert r["fail_g"] == r["fail_o"] == 0, r
+
+
+def test_reference_scenario_pf_ca_exact_settings(oracle):
+    """scripts/usv_pf_ca/main.py at its own settings: N=100, Tf=1, obstacles (3,2),(4,8),(3.7,16),(4.2,20) of radius
+    0.5 (+0.2), start at the origin heading 0 towards the path (4,-5)->(4,25); same call sequence, 25 ticks."""
+    N, Tf, K = 100, 1.0, 4
+    constraint, model, acados_solver = usv_models.acados_settings(Tf, N, name="usv_model_pf_ca", n_obstacles=K)
+    spec = oracle.spec(2, N, Tf, K)
+    x1, y1, x2, y2 = 4.0, -5.0, 4.0, 25.0
+    ak = np.arctan2(y2 - y1, x2 - x1)
+    ye = -(0.0 - x1) * np.sin(ak) + (0.0 - y1) * np.cos(ak)
+    x_start = np.array([0.0, 0.0, 1.0, 0.001, 0, 0, ye, x1, y1, ak, 0, 0, 0, 0])
+    acados_solver.set(0, "lbx", x_start)
+    acados_solver.set(0, "ubx", x_start)
+    pobs = np.array([3, 2, 4, 8, 3.7, 16, 4.2, 20], dtype=float)
+    robs = np.full(K, 0.7)
+    yref = np.array([0, np.sin(ak), np.cos(ak), 0.7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    x0m = np.asarray(model.x0, dtype=float)
+    xo, uo = np.tile(x0m, (N + 1, 1)), np.zeros((N, 2))   # acados_create: x = constraints.x0 on every stage, u = 0
+    x0o = x_start.copy()
+    for i in range(25):
+        for j in range(N):
+            acados_solver.set(j, "yref", yref)
+            acados_solver.set(j, "p", pobs)
+            acados_solver.constraints_set(j, "lh", robs)
+        acados_solver.set(N, "yref", yref[:14])
+        acados_solver.set(N, "p", pobs)
+        status = acados_solver.solve()
+        r = oracle.rti(spec, xo, uo, x0o, np.tile(yref, (N, 1)), yref[:14], np.tile(pobs, (N + 1, 1)), np.tile(robs, (N, 1)))
+        xo, uo = r["x"], r["u"]
+        assert status == r["status"] == 0, (i, status, r["status"])
+        xs = np.stack([acados_solver.get(j, "x") for j in range(N + 1)])
+        us = np.stack([acados_solver.get(j, "u") for j in range(N)])
+        assert util.rel_err(xs, xo) <= TOL and util.rel_err(us, uo) <= TOL, (i, util.rel_err(xs, xo), util.rel_err(us, uo))
+        x0o = xo[1].copy()
+        x0g = acados_solver.get(1, "x")
+        acados_solver.set(0, "lbx", x0g)
+        acados_solver.set(0, "ubx", x0g)
+
+
+@pytest.mark.parametrize("name,B", [("usv_model_pf_ca", 203), ("usv_model_guidance_ca1", 64)])
+def test_two_handles_on_shards_equal_unsharded(name, B):
+    N, K = 20, 6
+    wl = scenario.make_bench_batch(name, N, K, B, seed=77)
+    dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
+    ocp = usv_models.make_ocp(name, N * dt, N, K)
+    ocp.solver_options.sim_method_num_steps = steps
+
+    def run(w, n):
+        s = BatchOcpSolver(ocp, n)
+        scenario.load_into(s, w)
+        s.set_option("disturbance_mask", scenario.NOISE_MASK[name])
+        for t in range(3):
+            s.solve()
+            s.advance(0.0)
+        out = (s.get_all("x"), s.get_all("u"), s.get_int("status"), s.get_int("qp_iter"), s.get("x0", 0))
+        s.close()
+        return out
+
+    whole = run(wl, B)
+    parts = []
+    for r in range(2):
+        lo, hi = sharding.shard_bounds(B, 2, r)
+        parts.append(run(sharding.split_workload(wl, 2, r), hi - lo))
+    for i in range(5):
+        assert np.array_equal(np.concatenate([parts[0][i], parts[1][i]], axis=0), whole[i]), i

@@ -188,12 +188,13 @@ def main():
         per_solve_ms = {"usv_model": 0.12, "usv_model_guidance_ca1": 1.2, "usv_model_pf_ca": 3.5}[name] * N / 40.0 * (1 + 0.15 * (steps - 1))
         S1 = int(max(32, min(B, 4000.0 / per_solve_ms)))               # ~4 s per tick on one core
         spec = ob.spec(_ID[name], N, N * dt, K, sim_steps=steps)
-        xo, uo = wl["x_init"][:S1].copy(), wl["u_init"][:S1].copy()
         x0o = wl["x0"][:S1].copy()
-        good = np.ones(S1, dtype=bool)
-        worst = 0.0
-        same_status = 0
+        errs = []
+        same_status = n_ok = 0
     for w in range(args.warmup):
+        if check:   # the oracle starts every tick from the iterate and x0 the device starts it from ("same inputs")
+            solver.sync()
+            xo, uo = solver.get_all("x")[:S1].copy(), solver.get_all("u")[:S1].copy()
         solver.solve_async()
         if check:
             solver.sync()
@@ -201,21 +202,27 @@ def main():
                                     threads=usable_cores())
             xg, ug = solver.get_all("x")[:S1], solver.get_all("u")[:S1]
             stg, qsg = solver.get_int("status")[:S1], solver.get_int("qp_status")[:S1]
-            same_status += int(((stg != 0) == (sto != 0)).sum())
-            good &= (sto == 0) & (ito < spec.opts.qp_iter_max) & (qsg == 0)
-            if good.any():
-                sc = np.maximum(1.0, np.abs(xo[good]).max(axis=(0, 1)))   # per-component scale
-                su_ = np.maximum(1.0, np.abs(uo[good]).max(axis=(0, 1)))
-                worst = max(worst, float((np.abs(xg[good] - xo[good]) / sc).max()), float((np.abs(ug[good] - uo[good]) / su_).max()))
+            same_status += int((stg == sto).sum())
+            ok = (sto == 0) & (ito < spec.opts.qp_iter_max) & (qsg == 0)
+            n_ok += int(ok.sum())
+            if ok.any():
+                sc = np.maximum(1e-2, np.abs(xo[ok]).max(axis=(0, 1)))   # per-component scale
+                su_ = np.maximum(1e-2, np.abs(uo[ok]).max(axis=(0, 1)))
+                errs.append(np.maximum((np.abs(xg[ok] - xo[ok]) / sc).reshape(int(ok.sum()), -1).max(axis=1),
+                                       (np.abs(ug[ok] - uo[ok]) / su_).reshape(int(ok.sum()), -1).max(axis=1)))
         solver.advance(sigma, seed=1000 + w)
         if check:
             solver.sync()
             x0o = solver.get("x0", 0)[:S1].copy()
     if check and args.warmup > 0:
-        parity = {"ticks": args.warmup, "instances_converged_on_both_sides_every_tick": int(good.sum()), "of": int(S1),
+        parity = {"ticks": args.warmup, "instances": int(S1), "converged_on_both_sides_frac": n_ok / float(args.warmup * S1),
                   "status_agreement_frac": same_status / float(args.warmup * S1),
-                  "max_rel_err_per_component": worst,
-                  "vs": "CPU oracle (port; parity vs acados itself is unpinned), closed loop, fed the device's x0"}
+                  "rel_err_per_instance": {"p50": float(np.percentile(np.concatenate(errs), 50)),
+                                           "p99": float(np.percentile(np.concatenate(errs), 99)),
+                                           "max": float(np.concatenate(errs).max())} if errs else None,
+                  "vs": "CPU oracle (port; parity vs acados itself is unpinned); closed loop, every tick from the iterate "
+                        "and x0 the device starts it from; error of an instance = max over (x, u) components of |dev - oracle| / "
+                        "(that component's max |oracle| over the sample)"}
     barrier()
 
     # ---- timed region: exactly K steps

@@ -181,6 +181,14 @@ int usvmpc_guidance_state(usvmpc_handle *h, int *wp_index, float *past_psied);
  * (kernel usv_calib_stream) and report the exact byte counts, to calibrate HBM PMC counters.
  * Overwrites solver scratch; the next usvmpc_solve re-initialises it. */
 int usvmpc_calibrate_traffic(usvmpc_handle *h, int nplanes, double *bytes_read, double *bytes_written);
+/* Test entry points (no handle): the device transcription of the reference's model files evaluated on caller-supplied
+ * points - f [n][nx] and the Jacobian J [n][nx][nu+nx] with respect to z = [u; x] exactly as the lineariser obtains them
+ * (one tangent column per call of the model's fjvp), for the CasADi expressions of
+ * catkin_ws/src/nmpc_ca/scripts/{usv_acados,usv_guidance_ca1,usv_pf_ca}/usv_model.py; and the obstacle row
+ * h = sqrt((px-ox)^2 + (py-oy)^2) with its position gradient exactly as the QP kernel evaluates it:
+ * pos [n][2], p [n][2K] -> h [n][K], grad [n][K][2]. */
+int usvmpc_debug_model_eval(int model, int device, int n, const double *x, const double *u, double *f, double *J);
+int usvmpc_debug_obstacle_eval(int device, int n, int K, const double *pos, const double *p, double *h, double *grad);
 /* bytes of device memory held by the handle */
 size_t usvmpc_device_bytes(usvmpc_handle *h);
 const char *usvmpc_last_error(usvmpc_handle *h);

@@ -53,7 +53,8 @@ EXPORTS = ["usvmpc_model_dims", "usvmpc_default_options", "usvmpc_create", "usvm
            "usvmpc_set", "usvmpc_get", "usvmpc_get_int", "usvmpc_solve", "usvmpc_solve_sqp", "usvmpc_solve_async",
            "usvmpc_sync", "usvmpc_get_device_ptr", "usvmpc_last_kernel_ms", "usvmpc_kernel_ms", "usvmpc_fail_counts",
            "usvmpc_advance", "usvmpc_set_stream", "usvmpc_set_option", "usvmpc_calibrate_traffic", "usvmpc_guidance_reset", "usvmpc_guidance_prepare", "usvmpc_guidance_sense",
-           "usvmpc_guidance_publish", "usvmpc_guidance_state", "usvmpc_device_bytes", "usvmpc_last_error"]
+           "usvmpc_guidance_publish", "usvmpc_guidance_state", "usvmpc_device_bytes", "usvmpc_last_error",
+           "usvmpc_debug_model_eval", "usvmpc_debug_obstacle_eval"]
 
 
 _libs = {}
@@ -97,6 +98,8 @@ def load(path):
     L.usvmpc_guidance_sense.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_double, _dp, _ip]
     L.usvmpc_guidance_publish.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _ip]
     L.usvmpc_guidance_state.argtypes = [C.c_void_p, _ip, C.POINTER(C.c_float)]
+    L.usvmpc_debug_model_eval.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
+    L.usvmpc_debug_obstacle_eval.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
     L.usvmpc_device_bytes.argtypes = [C.c_void_p]
     L.usvmpc_device_bytes.restype = C.c_size_t
     L.usvmpc_last_error.argtypes = [C.c_void_p]

@@ -67,6 +67,24 @@ def analyse(model):
     info.nx, info.nu, info.np = nx, nu, len(p)
     info.out_unit = sum(1 << j for j, e in enumerate(f) if e.kind == "const" and e.value == 0.0)
     info.in_unit = sum(1 << l for l, s in enumerate(u) if s not in used) | sum(1 << (nu + c) for c, s in enumerate(x) if s not in used)
+    # ---- pattern of the discrete sensitivities [B A] (MatPack, csrc/params.hpp): x+_j depends on variable c iff there
+    # is a dependency path c -> ... -> x_j of length >= 1 in the right-hand side (transitive closure, valid for any
+    # explicit RK scheme and any number of steps); the diagonal d x+_j / d x_j is exactly 1 iff x_j is on no cycle
+    direct = [set() for _ in range(nx)]                 # variables (index in [u;x]) f_j reads
+    for j, d in enumerate(deps):
+        for sym in d:
+            direct[j].add(us[sym] if sym in us else nu + xs[sym])
+    reach = [set(d) for d in direct]
+    changed = True
+    while changed:
+        changed = False
+        for j in range(nx):
+            for c in list(reach[j]):
+                if c >= nu and not reach[c - nu] <= reach[j]:
+                    reach[j] |= reach[c - nu]
+                    changed = True
+    info.sens = [sum(1 << c for c in sorted(r)) for r in reach]
+    info.diag_one = sum(1 << j for j in range(nx) if (nu + j) not in reach[j])
     # ---- obstacle rows
     info.K, info.ipx, info.ipy = len(h), 0, 0
     if h:
@@ -228,6 +246,8 @@ namespace usv {
 struct ModelGen {
     static constexpr int ID = 3, NX = %(nx)d, NU = %(nu)d, IPX = %(ipx)d, IPY = %(ipy)d;
     static constexpr unsigned OUT_UNIT = %(out)du, IN_UNIT = %(inn)du;
+    static constexpr unsigned SENS[NX] = {%(sens)s};
+    static constexpr unsigned DIAG_ONE = %(diag)du;
     USV_DEV static void fjvp(const double *x, const double *U, const double *s, const double *su, double *f, double *js)
     {
         %(body)s
@@ -235,7 +255,8 @@ struct ModelGen {
 };
 
 } // namespace usv
-''' % dict(name=info.name, nx=info.nx, nu=info.nu, ipx=info.ipx, ipy=info.ipy, out=info.out_unit, inn=info.in_unit, body=body)
+''' % dict(name=info.name, nx=info.nx, nu=info.nu, ipx=info.ipx, ipy=info.ipy, out=info.out_unit, inn=info.in_unit, body=body,
+           sens=", ".join("%du" % v for v in info.sens), diag=info.diag_one)
 
 
 def emit_oracle_c(info):

@@ -101,21 +101,23 @@ struct Linearize {
         const double *xn = P.x + ((long)b * (N + 1) + k + 1) * NX;
         double bres = 0.0;
         sfor<0, NX>([&](auto i) { bres = (lane == NU + i) ? x[i] - xn[i] : bres; });
-        // lane r now holds row r of [B A]' (sa[i] = d x+_i / d z_r).  Its informative entries are packed into
-        // MatPack<M>::NPK planes: lane L of plane q stores entry (jj, ci) = divmod(16 q + L, NC), i.e. sa[row jj]
-        // as held by the lane of column ci - a lane gather per row that the plane touches.
+        // lane r now holds row r of [B A]' (sa[i] = d x+_i / d z_r).  The structurally informative entries (MatPack:
+        // M::SENS) are packed into MatPack<M>::NPK planes: lane L of plane q stores entry number 16 q + L of the
+        // stream, i.e. for the row j whose range contains it the value sa[j] held by the lane of its column - a lane
+        // gather per row that the plane touches.
         using MP = MatPack<M>;
         sfor<0, MP::NPK>([&](auto q) {
             const int sidx = 16 * q + lane;
-            const int jj_l = sidx / MP::NC, ci_l = sidx - jj_l * MP::NC;
-            int c_l = 0; // lane that owns column ci_l
-            sfor<0, MP::NC>([&](auto ci) { c_l = (ci_l == ci) ? MP::nth(MP::CMASK, ci) : c_l; });
             double val = 0.0;
-            constexpr int jj0 = (16 * q) / MP::NC;
-            constexpr int jj1 = ((16 * q + 15) / MP::NC < MP::NR - 1) ? (16 * q + 15) / MP::NC : MP::NR - 1;
-            sfor<jj0, jj1 + 1>([&](auto jj) {
-                const double gth = lanes::gather(sa[MP::nth(MP::RMASK, jj)], c_l);
-                val = (jj_l == jj) ? gth : val;
+            sfor<0, NX>([&](auto j) {
+                constexpr int s0 = MP::start(j), cnt = MP::count(j);
+                if constexpr (cnt > 0 && s0 < 16 * q + 16 && s0 + cnt > 16 * q) {
+                    const int within = sidx - s0;
+                    int c_l = 0; // lane that owns this entry's column
+                    sfor<0, cnt>([&](auto ci) { c_l = (within == ci) ? MP::nth(MP::row_mask(j), ci) : c_l; });
+                    const double gth = lanes::gather(sa[j], c_l);
+                    val = (within >= 0 && within < cnt) ? gth : val;
+                }
             });
             tile[(WL::P_MAT + q) * 64] = val;
         });

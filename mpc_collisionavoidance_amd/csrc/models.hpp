@@ -63,6 +63,10 @@ struct ModelM0 {
     static constexpr int ID = 0, NX = 5, NU = 2, IPX = 0, IPY = 0; // no obstacles (K = 0)
     // structural identities of the discrete map (see ModelM2): none for this model
     static constexpr unsigned OUT_UNIT = 0u, IN_UNIT = 0u;
+    // discrete sensitivity pattern (MatPack, params.hpp), z = (U0, U1 | u, v, r, Tport, Tstbd): the 3-DOF rows see
+    // everything; a thrust row is its own state plus dt * its rate
+    static constexpr unsigned SENS[NX] = {0x7fu, 0x7fu, 0x7fu, 1u << 0, 1u << 1};
+    static constexpr unsigned DIAG_ONE = (1u << 3) | (1u << 4);
     USV_DEV static void fjvp(const double *x, const double *U, const double *s, const double *su, double *f, double *js)
     {
         Dof3::eval(0.78, x[0], x[1], x[2], x[3], x[4], s[0], s[1], s[2], s[3], s[4], f, js);
@@ -78,6 +82,12 @@ struct ModelM1 {
     // outputs u, v have f = 0; inputs ye, xned, yned appear in no right-hand side
     static constexpr unsigned OUT_UNIT = (1u << 0) | (1u << 1);
     static constexpr unsigned IN_UNIT = (1u << (NU + 2)) | (1u << (NU + 5)) | (1u << (NU + 6));
+    // discrete sensitivity pattern, z = (U | u, v, ye, chie, psied, xned, yned, psi) = bits 0 | 1..8:
+    //   chie' and psi' read (u, v, chie, psied), psied' = U, so both reach U through psied; ye' reads (u, v, chie);
+    //   the positions read (u, v, psi).  Only chie feeds itself.
+    static constexpr unsigned CH = (1u << 0) | (1u << 1) | (1u << 2) | (1u << 4) | (1u << 5); // U, u, v, chie, psied
+    static constexpr unsigned SENS[NX] = {0u, 0u, CH, CH, 1u << 0, CH | (1u << 8), CH | (1u << 8), CH};
+    static constexpr unsigned DIAG_ONE = 0xffu & ~(1u << 3);
     // x = (u, v, ye, chie, psied, xned, yned, psi), T1 = 1
     USV_DEV static void fjvp(const double *x, const double *U, const double *s, const double *su, double *f, double *js)
     {
@@ -122,6 +132,14 @@ struct ModelM2 {
     static constexpr unsigned OUT_UNIT = (1u << 7) | (1u << 8) | (1u << 9);
     static constexpr unsigned IN_UNIT = (1u << (NU + 1)) | (1u << (NU + 2)) | (1u << (NU + 6)) | (1u << (NU + 7)) |
                                         (1u << (NU + 8)) | (1u << (NU + 10)) | (1u << (NU + 11));
+    // discrete sensitivity pattern, z = (U0, U1 | psi, sinpsi, cospsi, u, v, r, ye, x1, y1, ak, nedx, nedy, Tport, Tstbd)
+    // = bits 0, 1 | 2..15: the 3-DOF core (u, v, r) is driven by the thrusts and those by their rates; psi' = r;
+    // sinpsi', cospsi', the positions and ye' read (psi, u, v[, r]), ye' also ak.  Only u, v, r feed themselves.
+    static constexpr unsigned CORE = (1u << 0) | (1u << 1) | (1u << 5) | (1u << 6) | (1u << 7) | (1u << 14) | (1u << 15);
+    static constexpr unsigned SENS[NX] = {CORE, CORE | (1u << 2), CORE | (1u << 2), CORE, CORE, CORE,
+                                          CORE | (1u << 2) | (1u << 11), 0u, 0u, 0u, CORE | (1u << 2), CORE | (1u << 2),
+                                          1u << 0, 1u << 1};
+    static constexpr unsigned DIAG_ONE = 0x3fffu & ~((1u << 3) | (1u << 4) | (1u << 5));
     // x = (psi, sinpsi, cospsi, u, v, r, ye, x1, y1, ak, nedx, nedy, Tport, Tstbd), c = 1
     USV_DEV static void fjvp(const double *x, const double *U, const double *s, const double *su, double *f, double *js)
     {

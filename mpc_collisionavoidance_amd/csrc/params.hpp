@@ -43,18 +43,28 @@ struct DevSpec {
     double nlp_tol[4];            // full SQP: exit tolerances on the NLP residuals (stat, eq, ineq, comp)
 };
 
-// How the stage matrix [B A] (nx x nz) is kept in HBM.  Rows that are unit vectors (M::OUT_UNIT: x+_j = x_j)
-// and columns that are unit vectors (M::IN_UNIT: the variable feeds no right-hand side) carry no information,
-// and nz is usually below 16, so a plane per row would be mostly padding.  The NR x NC informative entries are
-// stored as one row-major stream, 16 per plane: entry (jj, ci) sits in plane (jj*NC + ci) / 16, lane
-// (jj*NC + ci) % 16.  The lineariser packs with lane gathers, the sweeps unpack the same way (qp_ipm.hpp).
+// How the stage matrix [B A] (nx x nz) is kept in HBM.  Only entries that carry information are stored: the model
+// states which entries of the discrete sensitivities are structurally non-zero (M::SENS[j]: bit c <=> d x+_j / d z_c,
+// z = [u;x], can be non-zero and is not the exact unit diagonal; M::DIAG_ONE bit j <=> d x+_j / d x_j == 1 exactly) -
+// the pattern of (I + J + J^2 + ...)[Ju | I] for the continuous Jacobian J, valid for any explicit RK scheme and any
+// number of steps.  Everything else is an exact 0 (or the exact 1 of DIAG_ONE) and is rebuilt from the pattern.
+// The stored entries form one stream, row after row, within a row by increasing variable index, 16 per plane: entry
+// number e sits in plane e / 16, lane e % 16.  The lineariser packs with lane gathers, the sweeps unpack the same way
+// (qp_ipm.hpp).  usv_model_pf_ca: 71 of 14 x 16 entries = 5 planes (a plane per row: 14; dense 11 x 9 block: 7).
 template <class M>
 struct MatPack {
     static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
-    static constexpr unsigned RMASK = ((1u << NX) - 1u) & ~M::OUT_UNIT; // rows stored
-    static constexpr unsigned CMASK = ((1u << NZ) - 1u) & ~M::IN_UNIT;  // columns (variables of [u;x]) stored
-    static constexpr int NR = __builtin_popcount(RMASK), NC = __builtin_popcount(CMASK);
-    static constexpr int NPK = (NR * NC + 15) / 16;                     // planes per stage
+    static constexpr unsigned row_mask(int j) { return M::SENS[j]; }
+    static constexpr int count(int j) { return __builtin_popcount(M::SENS[j]); }
+    static constexpr int start(int j) // stream position of row j's first entry
+    {
+        int s = 0;
+        for (int i = 0; i < j; i++) s += __builtin_popcount(M::SENS[i]);
+        return s;
+    }
+    static constexpr bool diag_one(int j) { return ((M::DIAG_ONE >> j) & 1u) != 0u; }
+    static constexpr int NE = start(NX);                                // stored entries per stage
+    static constexpr int NPK = (NE + 15) / 16;                          // planes per stage
     static constexpr int nth(unsigned mask, int i)                      // position of the i-th set bit
     {
         for (int b = 0; b < 32; b++)
@@ -65,6 +75,22 @@ struct MatPack {
         return 0;
     }
     static constexpr int rank(unsigned mask, int b) { return __builtin_popcount(mask & ((1u << b) - 1u)); }
+    // consistency of the coarse traits with the pattern: a unit row stores nothing and has the unit diagonal; a unit
+    // column appears in no row
+    static constexpr bool consistent()
+    {
+        unsigned cols = 0;
+        for (int j = 0; j < NX; j++) {
+            cols |= M::SENS[j];
+            if (((M::OUT_UNIT >> j) & 1u) && (M::SENS[j] != 0u || !diag_one(j))) return false;
+            if (((M::SENS[j] >> (NU + j)) & 1u) && diag_one(j)) return false;
+            if (M::SENS[j] >> NZ) return false;
+        }
+        for (int c = 0; c < NZ; c++)
+            if (((M::IN_UNIT >> c) & 1u) && (((cols >> c) & 1u) || (c >= NU && !diag_one(c - NU)))) return false;
+        return true;
+    }
+    static_assert(consistent(), "OUT_UNIT / IN_UNIT disagree with SENS / DIAG_ONE");
 };
 
 // Plane map of one stage of the solver workspace `ws` (lane-major planes, one window per stage).  The

@@ -168,6 +168,16 @@ struct RowCalc {
 
 // SOFTBOX: some state bounds are soft (acados idxsbx); their rows carry slacks like the soft obstacle rows and
 // keep ten planes of their own (no packing).
+// The reference's obstacle row h = sqrt((px - ox)^2 + (py - oy)^2) (scripts/usv_guidance_ca1/usv_model.py:133-140,
+// scripts/usv_pf_ca/usv_model.py:165-168) and its gradient with respect to the position, from (dx, dy) = pos - centre.
+USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
+{
+    const double d2 = dx * dx + dy * dy;
+    const double id = lanes::frsqrt(d2);
+    d = d2 * id;
+    ux = dx * id; uy = dy * id;
+}
+
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false>
 struct QpIpm {
     static_assert(!PACK || KCH > 0, "box rows are packed into obstacle planes");
@@ -218,10 +228,7 @@ struct QpIpm {
     //   ssrc   : variable whose row this lane stores (as slot lane or as dense lane)
     //   isslot / isdense : what this lane stores
     bool ounit; // this lane is the state of a structurally unit row of [A B] (M::OUT_UNIT)
-    // packed matrix planes (MatPack): this lane's column is stored / is a unit column; its index among the
-    // stored columns
-    bool mstored, munit;
-    int mci;
+    unsigned lt_mask; // (1 << lane) - 1: ranks this lane's variable inside a row's pattern (MatPack)
     bool isslot, isdense, anydense;
     int bsrc, bstep, ssrc;
     bool hasb;
@@ -260,9 +267,7 @@ struct QpIpm {
         isPY = KCH > 0 && lane == PYL;
         hasb = S.has_b[lane] != 0;
         ounit = xlane && ((M::OUT_UNIT >> (xlane ? lane - NU : 0)) & 1u) != 0u;
-        mstored = ((MP::CMASK >> lane) & 1u) != 0u;
-        munit = xlane && !mstored;
-        mci = mstored ? MP::rank(MP::CMASK, lane) : 0;
+        lt_mask = (1u << lane) - 1u;
         isslot = PACK && S.slot_is[lane] == 1;
         isdense = PACK && S.slot_is[lane] == 2;
         anydense = PACK && lanes::uniform(S.box_dense) != 0; // wave-uniform
@@ -336,10 +341,9 @@ struct QpIpm {
         const bool stage_ok = (k >= 1 && k < N); // wave-uniform
         r.act = stage_ok && i < Kn;
         const double dx = lanes::bcast<PXL>(zb) - raw[0], dy = lanes::bcast<PYL>(zb) - raw[1];
-        const double d2 = dx * dx + dy * dy;
-        const double id = lanes::frsqrt(d2);
-        const double d = d2 * id;
-        cx = r.act ? dx * id : 0.0; cy = r.act ? dy * id : 0.0;
+        double d, ux, uy;
+        obs_dist(dx, dy, d, ux, uy);
+        cx = r.act ? ux : 0.0; cy = r.act ? uy : 0.0;
         r.dl = r.act ? raw[2] - d : -1.0; r.du = r.act ? c_uh[C] - d : 1.0;
         if constexpr (SOFT) {
             r.zl = c_zl[C]; r.zu = c_zu[C]; r.Zl = c_Zl[C]; r.Zu = c_Zu[C]; r.bsl = c_bsl[C]; r.bsu = c_bsu[C];
@@ -396,16 +400,19 @@ struct QpIpm {
             if constexpr (out_unit(j)) {
                 bat[j] = 0.0; // never read: unit rows are handled structurally
             } else {
-                constexpr int s0 = MP::rank(MP::RMASK, j) * MP::NC;
-                constexpr int q0 = s0 / 16, q1 = (s0 + MP::NC - 1) / 16;
-                const int pos = s0 + mci;
+                constexpr unsigned m = MP::row_mask(j);
+                constexpr int s0 = MP::start(j), cnt = MP::count(j);
+                constexpr int q0 = s0 / 16, q1 = (s0 + cnt - 1) / 16;
+                const bool st = ((m >> lane) & 1u) != 0u;
+                const int pos = s0 + __builtin_popcount(m & lt_mask);
                 double v = lanes::gather(pk[q0], pos & 15);
                 if constexpr (q1 != q0) {
                     const double v1 = lanes::gather(pk[q1], pos & 15);
                     v = (pos >> 4) == q0 ? v : v1;
                 }
-                // a unit column holds the identity entry of its own state row, idle lanes hold zero
-                bat[j] = mstored ? v : ((munit && lane == NU + j) ? 1.0 : 0.0);
+                // entries outside the pattern are exact zeros, or the exact unit diagonal of a state that does not
+                // feed itself
+                bat[j] = st ? v : ((MP::diag_one(j) && lane == NU + j) ? 1.0 : 0.0);
             }
         });
     }

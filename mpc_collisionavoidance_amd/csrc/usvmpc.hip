@@ -88,6 +88,37 @@ __global__ void usv_advance(DevPtrs P, int nx, double sigma, unsigned long long 
     const_cast<double *>(P.x0)[i] = v;
 }
 
+// Debug / test entry points: the model functions exactly as the lineariser calls them (M::fjvp: f and one Jacobian
+// column per call) and the obstacle-row geometry exactly as the QP kernel evaluates it (obs_dist), on caller-supplied
+// points, so that a GPU test can compare the device transcription with vectors derived from the reference's own
+// model files (tests/golden/ref_model_*.npz).  One thread per (point, column).
+template <class M>
+__global__ void usv_debug_model(int n, const double *x, const double *u, double *f, double *J)
+{
+    constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * NZ) return;
+    const int pt = i / NZ, c = i - pt * NZ;
+    double xx[NX], uu[NU > 0 ? NU : 1], s[NX], su[NU > 0 ? NU : 1], ff[NX], js[NX];
+    for (int j = 0; j < NX; j++) { xx[j] = x[pt * NX + j]; s[j] = (c == NU + j) ? 1.0 : 0.0; }
+    for (int j = 0; j < NU; j++) { uu[j] = u[pt * NU + j]; su[j] = (c == j) ? 1.0 : 0.0; }
+    M::fjvp(xx, uu, s, su, ff, js);
+    for (int j = 0; j < NX; j++) {
+        J[((long)pt * NX + j) * NZ + c] = js[j];   // d f_j / d z_c, z = [u; x]
+        if (c == 0) f[pt * NX + j] = ff[j];
+    }
+}
+
+__global__ void usv_debug_obstacle(int n, int K, const double *pos, const double *p, double *h, double *grad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * K) return;
+    const int pt = i / K, k = i - pt * K;
+    double d, ux, uy;
+    usv::obs_dist(pos[2 * pt] - p[(long)pt * 2 * K + 2 * k], pos[2 * pt + 1] - p[(long)pt * 2 * K + 2 * k + 1], d, ux, uy);
+    h[i] = d; grad[2 * i] = ux; grad[2 * i + 1] = uy;
+}
+
 // Traffic calibration for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters: streams a KNOWN number of
 // workspace planes with exactly the access instruction of the solver kernels (one
 // buffer_load_dwordx2 per lane per plane, 16 lanes of a group contiguous) and writes one plane.
@@ -310,6 +341,10 @@ int launch_pair(usvmpc_handle *h, int phase)
         h->err = "workspace layout mismatch between host and kernels";
         return USVMPC_E_ARG;
     }
+#ifdef USV_BENCH_ONLY // development builds (tools/dev_build.sh): only the instantiation the bench workload runs
+    if (!(h->spec.hdiag && pack && !h->spec.any_bsoft)) { h->err = "development build: bench instantiation only"; return USVMPC_E_ARG; }
+    hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
+#else
     if (h->spec.any_bsoft) { // soft state bounds: rows with slacks, ten planes of their own
         if (h->spec.hdiag) hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, false, true>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
         else hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, false, true>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
@@ -320,6 +355,7 @@ int launch_pair(usvmpc_handle *h, int phase)
         if (pack) hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, CANPACK, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
         else hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, false, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
     }
+#endif
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[2], h->stream));
     h->nsolves++;
@@ -345,14 +381,17 @@ int model_mat_planes(int model)
 int launch(usvmpc_handle *h, int phase = 0)
 {
     switch (h->desc.model) {
-#ifndef USV_GEN_ONLY
+#ifdef USV_BENCH_ONLY
+    case USVMPC_MODEL_PF_CA: if (h->kch <= 1) return launch_pair<ModelM2, 1, false>(h, phase); break;
+    case USVMPC_MODEL_GUIDANCE_CA1: if (h->kch <= 1) return launch_pair<ModelM1, 1, true>(h, phase); break;
+#elif !defined(USV_GEN_ONLY)
     case USVMPC_MODEL_USV: return launch_pair<ModelM0, 0, false>(h, phase);
     case USVMPC_MODEL_GUIDANCE_CA1:
         return h->kch <= 1 ? launch_pair<ModelM1, 1, true>(h, phase) : launch_pair<ModelM1, 2, true>(h, phase);
     case USVMPC_MODEL_PF_CA:
         return h->kch <= 1 ? launch_pair<ModelM2, 1, false>(h, phase) : launch_pair<ModelM2, 2, false>(h, phase);
 #endif
-#ifdef USV_GEN_MODEL_HEADER
+#if defined(USV_GEN_MODEL_HEADER) && !defined(USV_BENCH_ONLY)
     case USVMPC_MODEL_GENERATED: return launch_pair<ModelGen, USV_GEN_KCH, (USV_GEN_SOFT != 0)>(h, phase);
 #endif
     }
@@ -619,6 +658,65 @@ int usvmpc_kernel_ms(usvmpc_handle *h, int n, float *linearize_ms, float *qp_ms)
         if (qp_ms) qp_ms[i] = b;
     }
     return 0;
+}
+
+int usvmpc_debug_model_eval(int model, int device, int n, const double *x, const double *u, double *f, double *J)
+{
+    int nx, nu;
+    if (model_dims(model, nx, nu) || n < 1 || !x || !f || !J || (nu > 0 && !u)) return USVMPC_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return USVMPC_E_NODEVICE;
+    const int nz = nx + nu;
+    double *dx = nullptr, *du = nullptr, *df = nullptr, *dJ = nullptr;
+    int rc = 0;
+    if (hipMalloc((void **)&dx, sizeof(double) * n * nx) != hipSuccess || hipMalloc((void **)&du, sizeof(double) * n * (nu ? nu : 1)) != hipSuccess ||
+        hipMalloc((void **)&df, sizeof(double) * n * nx) != hipSuccess || hipMalloc((void **)&dJ, sizeof(double) * n * nx * nz) != hipSuccess)
+        rc = USVMPC_E_HIP;
+    if (!rc) {
+        (void)hipMemcpy(dx, x, sizeof(double) * n * nx, hipMemcpyHostToDevice);
+        if (nu) (void)hipMemcpy(du, u, sizeof(double) * n * nu, hipMemcpyHostToDevice);
+        const dim3 grid((unsigned)((n * nz + 63) / 64)), block(64);
+        switch (model) {
+#ifndef USV_GEN_ONLY
+        case USVMPC_MODEL_USV: hipLaunchKernelGGL(usv_debug_model<ModelM0>, grid, block, 0, 0, n, dx, du, df, dJ); break;
+        case USVMPC_MODEL_GUIDANCE_CA1: hipLaunchKernelGGL(usv_debug_model<ModelM1>, grid, block, 0, 0, n, dx, du, df, dJ); break;
+        case USVMPC_MODEL_PF_CA: hipLaunchKernelGGL(usv_debug_model<ModelM2>, grid, block, 0, 0, n, dx, du, df, dJ); break;
+#endif
+#ifdef USV_GEN_MODEL_HEADER
+        case USVMPC_MODEL_GENERATED: hipLaunchKernelGGL(usv_debug_model<ModelGen>, grid, block, 0, 0, n, dx, du, df, dJ); break;
+#endif
+        default: rc = USVMPC_E_ARG;
+        }
+        if (!rc && (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess)) rc = USVMPC_E_HIP;
+        if (!rc) {
+            (void)hipMemcpy(f, df, sizeof(double) * n * nx, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(J, dJ, sizeof(double) * n * nx * nz, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(dx); (void)hipFree(du); (void)hipFree(df); (void)hipFree(dJ);
+    return rc;
+}
+
+int usvmpc_debug_obstacle_eval(int device, int n, int K, const double *pos, const double *p, double *h, double *grad)
+{
+    if (n < 1 || K < 1 || !pos || !p || !h || !grad) return USVMPC_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return USVMPC_E_NODEVICE;
+    double *dpos = nullptr, *dp = nullptr, *dh = nullptr, *dg = nullptr;
+    int rc = 0;
+    if (hipMalloc((void **)&dpos, sizeof(double) * n * 2) != hipSuccess || hipMalloc((void **)&dp, sizeof(double) * n * 2 * K) != hipSuccess ||
+        hipMalloc((void **)&dh, sizeof(double) * n * K) != hipSuccess || hipMalloc((void **)&dg, sizeof(double) * n * K * 2) != hipSuccess)
+        rc = USVMPC_E_HIP;
+    if (!rc) {
+        (void)hipMemcpy(dpos, pos, sizeof(double) * n * 2, hipMemcpyHostToDevice);
+        (void)hipMemcpy(dp, p, sizeof(double) * n * 2 * K, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(usv_debug_obstacle, dim3((unsigned)((n * K + 63) / 64)), dim3(64), 0, 0, n, K, dpos, dp, dh, dg);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = USVMPC_E_HIP;
+        if (!rc) {
+            (void)hipMemcpy(h, dh, sizeof(double) * n * K, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(grad, dg, sizeof(double) * n * K * 2, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(dpos); (void)hipFree(dp); (void)hipFree(dh); (void)hipFree(dg);
+    return rc;
 }
 
 int usvmpc_fail_counts(usvmpc_handle *h, int n, int *counts)

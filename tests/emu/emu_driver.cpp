@@ -141,16 +141,15 @@ void expand_packed(const DevPtrs &P, const DevSpec &S)
     if (!g_dbg_BAt) return;
     for (int k = 0; k < S.N; k++)
         for (int j = 0; j < M::NX; j++) {
-            if (!((MP::RMASK >> j) & 1u)) continue; // unit rows are not stored: left at zero
-            const int jj = MP::rank(MP::RMASK, j);
+            if ((M::OUT_UNIT >> j) & 1u) continue; // unit rows are not stored: left at zero
             for (long g = 0; g < S.Bp; g++)
                 for (int c = 0; c < MP::NZ; c++) {
                     double v;
-                    if ((MP::CMASK >> c) & 1u) {
-                        const int pos = jj * MP::NC + MP::rank(MP::CMASK, c);
+                    if ((MP::row_mask(j) >> c) & 1u) {
+                        const int pos = MP::start(j) + MP::rank(MP::row_mask(j), c);
                         v = at(k, WL::P_MAT + pos / 16, g, pos % 16);
                     } else {
-                        v = (c == M::NU + j) ? 1.0 : 0.0;
+                        v = (c == M::NU + j && MP::diag_one(j)) ? 1.0 : 0.0;
                     }
                     g_dbg_BAt[((long)k * M::NX + j) * stride + g * LANES + c] = v;
                 }

@@ -9,7 +9,7 @@ import pytest
 from mpc_collisionavoidance_amd import scenario, usv_models
 from tests import util
 
-FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "m[0-9]_*.npz")))   # (ref_model_*.npz: test_ref_vectors.py)
 
 
 def _load(f):

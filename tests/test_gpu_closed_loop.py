@@ -2,9 +2,25 @@
 
 * the bench workload itself (BASELINE configs[2] as SURVEY.md 8(d) spells it out: usv_model_pf_ca, N=40, Tf=2 s,
   10 static obstacles, closed loop x0 <- x1 + disturbance), B distinct instances, 25 ticks of solve + advance with
-  the bench's options (static obstacle set in registers, difficulty binning on), against the CPU oracle TICK BY TICK:
-  the oracle is handed the x0 the device's hand-over produced, keeps its own iterate, and must agree on the status of
-  every instance, on the failing set, and on the iterate (per-component relative error, tests/util.rel_err);
+  the bench's options (static obstacle set in registers, difficulty binning on), against the CPU oracle TICK BY TICK.
+  Two oracle runs follow the device:
+    - "same inputs": before every tick the oracle is handed the iterate and the x0 the device starts that tick from, so
+      each tick compares ONE application of the solver on identical inputs - status of every instance, the failing set,
+      IPM iteration counts, and the iterate with the per-component relative error of tests/util.rel_err.
+      usv_model_guidance_ca1: every instance <= 1e-7 (measured ~1e-10).  usv_model_pf_ca, on every tick: median <= 1e-9, at least 90 % of the
+      instances <= 1e-7 in states and controls (measured over 25 ticks of 512 instances: median ~1e-12, 97th percentile
+      between 1e-9 and 1.4e-7), every instance <= 1e-3.
+      The outliers (up to ~3e-4 on a thrust rate) are this model's conditioning,
+      not slack in the kernels: its control weight is R = 0 (scripts/usv_pf_ca/acados_settings.py:93-99), the
+      thrust-rate profile is fixed only through the barrier terms, and the QP solution itself is known no better than
+      3e-2 (controls) / 9e-4 (states) at the default IPM tolerances - that is how far BOTH implementations sit from the
+      oracle converged to 1e-11 (tools/parity_probe2.py, profiles/r02_parity_probe.txt).  The two implementations
+      follow the same iteration path and so agree ~7 orders of magnitude better than that, except where round-off
+      moves an iterate across one of the path's kinks;
+    - "free running": the oracle keeps its own iterate and only receives the device's x0.  The closed-loop map of the
+      hard-row, bang-bang model amplifies the per-tick differences (measured: up to 6e-3 on a thrust rate around tick 5,
+      decaying again), so this leg checks what must survive - the same status / failing set up to threshold cases - and
+      bounds the divergence at 5e-2;
 * the reference's own usv_pf_ca scenario at its exact settings (N=100, Tf=1, 4 obstacles,
   /root/reference/catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/main.py:54-55,73-75,106-133) through the AcadosOcpSolver
   look-alike, 25 closed-loop ticks;
@@ -21,7 +37,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-7
 
 
-def _closed_loop(oracle, name, N, K, B, ticks, sigma, seed=1234):
+def _closed_loop(oracle, name, N, K, B, ticks, sigma, tol_max, seed=1234):
     wl = scenario.make_bench_batch(name, N, K, B, seed=seed)
     dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
     ocp = usv_models.make_ocp(name, N * dt, N, K)
@@ -31,54 +47,71 @@ def _closed_loop(oracle, name, N, K, B, ticks, sigma, seed=1234):
     s.set_option("static_obstacles", 1)
     s.set_option("disturbance_mask", scenario.NOISE_MASK[name])
     spec = oracle.spec(util.MODEL_ID[name], N, N * dt, K, sim_steps=steps)
-    xo, uo, x0o = wl["x_init"].copy(), wl["u_init"].copy(), wl["x0"].copy()
-    good = np.ones(B, dtype=bool)       # converged on both sides in every tick so far: iterates comparable
+    data = (wl["yref"], wl["yref_e"], wl["p"], wl["lh"])
+    xf, uf = wl["x_init"].copy(), wl["u_init"].copy()      # free-running oracle iterate
+    xg, ug, x0 = wl["x_init"].copy(), wl["u_init"].copy(), wl["x0"].copy()
+    good_f = np.ones(B, dtype=bool)     # free run: converged on both sides in every tick so far
     slack = max(1, int(0.01 * B))       # instances allowed to sit on a threshold (iteration cap / step-length floor)
-    fail_g_total = fail_o_total = 0
-    worst = 0.0
+    out = dict(fail_g=0, fail_o=0, worst_x=0.0, worst_u=0.0, p90=0.0, p50=0.0, worst_free=0.0)
     for t in range(ticks):
+        xs, us = xg.copy(), ug.copy()   # same-inputs oracle: the device's iterate before this tick
         s.solve_async()
         s.sync()
-        sto, ito = oracle.rti_batch(spec, xo, uo, x0o, wl["yref"], wl["yref_e"], wl["p"], wl["lh"], threads=8)
+        sts, its = oracle.rti_batch(spec, xs, us, x0, *data, threads=8)
+        stf, itf = oracle.rti_batch(spec, xf, uf, x0, *data, threads=8)
         stg, qs, qi = s.get_int("status"), s.get_int("qp_status"), s.get_int("qp_iter")
         assert int(s.fail_counts(1)[0]) == int((stg != 0).sum())          # the on-device audit counter
         xg, ug = s.get_all("x"), s.get_all("u")
-        # same status per instance / same failing set (among instances whose history is shared)
-        differ = (stg != sto) & good
-        assert differ.sum() <= slack, (name, t, np.where(differ)[0], stg[differ], sto[differ])
-        fail_g_total += int((stg != 0).sum())
-        fail_o_total += int((sto != 0).sum())
-        conv_g, conv_o = qs == 0, (sto == 0) & (ito < spec.opts.qp_iter_max)
-        assert ((conv_g != conv_o) & good).sum() <= slack, (name, t)
-        good &= conv_g & conv_o
-        assert good.mean() >= 0.9, (name, t, good.mean())
-        ex, eu = util.rel_err(xg[good], xo[good]), util.rel_err(ug[good], uo[good])
-        worst = max(worst, ex, eu)
-        assert ex <= TOL and eu <= TOL, (name, t, ex, eu)
-        dit = np.abs(qi - ito)[good]
+        # ---- same inputs: status of every instance, failing set, iteration counts, iterate
+        assert (stg != sts).sum() <= slack, (name, t, np.where(stg != sts)[0])
+        conv_g, conv_s = qs == 0, (sts == 0) & (its < spec.opts.qp_iter_max)
+        assert (conv_g != conv_s).sum() <= slack, (name, t)
+        ok = conv_g & conv_s
+        assert ok.mean() >= 0.97, (name, t, ok.mean())
+        ex, eu = util.rel_err_per_instance(xg[ok], xs[ok]), util.rel_err_per_instance(ug[ok], us[ok])
+        out["worst_x"], out["worst_u"] = max(out["worst_x"], ex.max()), max(out["worst_u"], eu.max())
+        out["p90"] = max(out["p90"], np.percentile(ex, 90), np.percentile(eu, 90))
+        out["p50"] = max(out["p50"], np.percentile(ex, 50), np.percentile(eu, 50))
+        assert np.percentile(ex, 90) <= TOL and np.percentile(eu, 90) <= TOL, (name, t, np.percentile(ex, 90), np.percentile(eu, 90))
+        assert np.percentile(ex, 50) <= 1e-9 and np.percentile(eu, 50) <= 1e-9, (name, t)
+        assert ex.max() <= tol_max and eu.max() <= tol_max, (name, t, ex.max(), eu.max())
+        dit = np.abs(qi - its)[ok]
         assert dit.max() <= 1 and (dit > 0).sum() <= slack, (name, t, dit.max(), (dit > 0).sum())
+        # a failed solve leaves its iterate untouched on both sides (acados: status 4 returns before the update)
+        bad = (stg != 0) & (sts != 0)
+        assert np.array_equal(xg[bad], xs[bad]) and np.array_equal(ug[bad], us[bad])
+        out["fail_g"] += int((stg != 0).sum())
+        out["fail_o"] += int((sts != 0).sum())
+        # ---- free running: statuses and bounded divergence
+        differ = (stg != stf) & good_f
+        assert differ.sum() <= slack, (name, t, np.where(differ)[0])
+        good_f &= conv_g & (stf == 0) & (itf < spec.opts.qp_iter_max)
+        assert good_f.mean() >= 0.9, (name, t, good_f.mean())
+        ef = max(util.rel_err(xg[good_f], xf[good_f]), util.rel_err(ug[good_f], uf[good_f]))
+        out["worst_free"] = max(out["worst_free"], ef)
+        assert ef <= 5e-2, (name, t, ef)
+        # ---- hand-over: x1 of the device's iterate plus the disturbance on the masked states only
         s.advance(sigma, seed=2000 + t)
         s.sync()
-        x0g = s.get("x0", 0)
-        # the hand-over: x1 of the device's iterate plus the disturbance on the masked states only
-        d = x0g - xg[:, 1]
+        x0 = s.get("x0", 0)
+        d = x0 - xg[:, 1]
         mask = np.array([(scenario.NOISE_MASK[name] >> j) & 1 for j in range(d.shape[1])], dtype=bool)
         assert np.all(d[:, ~mask] == 0.0)
         if sigma > 0:
             assert 0.5 * sigma < d[:, mask].std() < 2.0 * sigma
-        x0o = x0g.copy()
     s.close()
-    return dict(good=float(good.mean()), fail_g=fail_g_total, fail_o=fail_o_total, worst=worst)
+    print(name, out)
+    return out
 
 
 def test_bench_workload_closed_loop_pf_ca(oracle):
-    r = _closed_loop(oracle, "usv_model_pf_ca", 40, 10, 512, ticks=25, sigma=1e-3)
+    r = _closed_loop(oracle, "usv_model_pf_ca", 40, 10, 512, ticks=25, sigma=1e-3, tol_max=1e-3)
     # failures do not pile up: hard rows make some QPs infeasible for a tick or two, but the count stays small
     assert r["fail_g"] <= 0.01 * 512 * 25 and abs(r["fail_g"] - r["fail_o"]) <= 25, r
 
 
 def test_bench_workload_closed_loop_guidance_ca1(oracle):
-    r = _closed_loop(oracle, "usv_model_guidance_ca1", 40, 10, 512, ticks=25, sigma=1e-3)
+    r = _closed_loop(oracle, "usv_model_guidance_ca1", 40, 10, 512, ticks=25, sigma=1e-3, tol_max=TOL)
     assert r["fail_g"] == r["fail_o"] == 0, r
 
 

@@ -175,3 +175,45 @@ def test_structural_unit_rows_and_columns(oracle, model, dt):
         for c in STRUCT[model]["in_unit_x"]:     # state c feeds nothing but itself
             e = np.zeros(nx); e[c] = 1.0
             assert np.array_equal(A[:, c], e)
+
+
+# the full pattern of the discrete sensitivities the kernels pack by (csrc/models.hpp SENS / DIAG_ONE, MatPack in
+# csrc/params.hpp), z = [u; x]: entries outside it must be EXACT zeros - or the exact 1 on a DIAG_ONE diagonal - in the
+# oracle's dense sensitivities, for one RK4 step and for several
+_CORE2 = (1 << 0) | (1 << 1) | (1 << 5) | (1 << 6) | (1 << 7) | (1 << 14) | (1 << 15)
+_CH1 = (1 << 0) | (1 << 1) | (1 << 2) | (1 << 4) | (1 << 5)
+SENS = {0: ([0x7f, 0x7f, 0x7f, 1 << 0, 1 << 1], (1 << 3) | (1 << 4)),
+        1: ([0, 0, _CH1, _CH1, 1 << 0, _CH1 | (1 << 8), _CH1 | (1 << 8), _CH1], 0xff & ~(1 << 3)),
+        2: ([_CORE2, _CORE2 | 4, _CORE2 | 4, _CORE2, _CORE2, _CORE2, _CORE2 | 4 | (1 << 11), 0, 0, 0, _CORE2 | 4, _CORE2 | 4,
+             1 << 0, 1 << 1], 0x3fff & ~((1 << 3) | (1 << 4) | (1 << 5)))}
+
+
+@pytest.mark.parametrize("model,dt,steps", [(0, 0.05, 1), (1, 0.05, 1), (2, 0.01, 1), (2, 0.05, 5), (1, 0.05, 3)])
+def test_sensitivity_pattern(oracle, model, dt, steps):
+    rng = np.random.default_rng(7 + model)
+    nx, nu = oracle.dims(model)
+    sens, diag_one = SENS[model]
+    seen = np.zeros((nx, nu + nx), dtype=bool)
+    for _ in range(10):
+        x = rng.normal(size=nx)
+        x[{0: 0, 1: 0, 2: 3}[model]] += 0.7
+        if model == 2:
+            x[4] *= 0.05
+        U = rng.normal(size=nu)
+        _, A, B = oracle.erk_sens(model, dt, steps, x, U)
+        BA = np.hstack([B, A])
+        for j in range(nx):
+            for c in range(nu + nx):
+                if (sens[j] >> c) & 1:
+                    seen[j, c] |= BA[j, c] != 0.0
+                elif c == nu + j and (diag_one >> j) & 1:
+                    assert BA[j, c] == 1.0, (j, c, BA[j, c])
+                else:
+                    assert BA[j, c] == 0.0, (j, c, BA[j, c])
+        for j in range(nx):   # the diagonal is either stored or exactly one, never both
+            assert ((sens[j] >> (nu + j)) & 1) != ((diag_one >> j) & 1)
+    # and the pattern is tight: every stored entry is non-zero somewhere
+    for j in range(nx):
+        for c in range(nu + nx):
+            if (sens[j] >> c) & 1:
+                assert seen[j, c], (j, c)

@@ -114,6 +114,9 @@ def test_generated_traits_and_derivatives_of_the_registry_models(tmp_path, name,
             "usv_model_guidance_ca1": (8, 1, 10, 5, 6, 0b11, (1 << 3) | (1 << 6) | (1 << 7)),
             "usv_model_pf_ca": (14, 2, 10, 10, 11, 0b1110000000, 0b11011100011000)}[name]   # = csrc/models.hpp
     assert (info.nx, info.nu, info.K, info.ipx, info.ipy, info.out_unit, info.in_unit) == want
+    from tests.test_oracle_models import SENS   # = csrc/models.hpp SENS / DIAG_ONE
+    mid = {"usv_model": 0, "usv_model_guidance_ca1": 1, "usv_model_pf_ca": 2}[name]
+    assert (info.sens, info.diag_one) == (SENS[mid][0], SENS[mid][1])
     _check_against_sympy(info, tmp_path, name)
 
 

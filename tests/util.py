@@ -33,6 +33,17 @@ def rel_err(a, b, floor=1e-2):
     return float((np.abs(a - b).max(axis=ax) / scale).max())
 
 
+def rel_err_per_instance(a, b, floor=1e-2):
+    """The same norm as rel_err (every component scaled by its own magnitude over the whole batch), but returned per
+    instance (first axis): [B] array of each instance's worst component."""
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    if a.shape[0] == 0:
+        return np.zeros(0)
+    ax = tuple(range(a.ndim - 1))
+    scale = np.maximum(floor, np.abs(b).max(axis=ax))
+    return (np.abs(a - b) / scale).reshape(a.shape[0], -1).max(axis=1)
+
+
 def make(name, N, K, B, dt=None, seed=1234, **kw):
     dt = scenario.DT[name] if dt is None else dt
     ocp = usv_models.make_ocp(name, N * dt, N, None if name == "usv_model" else K)

@@ -110,7 +110,9 @@ inline std::string build_spec(const usvmpc_desc &d, DevSpec &S)
         const int nslot = kch > 0 ? LANES - k_last : 0;
         const int ndense = nb > nslot ? nb - nslot : 0;
         // (soft state bounds carry six more values per row: they keep planes of their own)
-        S.boxpack_ok = (kch > 0 && nb > 0 && ndense <= 4 && 4 * ndense <= k_last && !S.any_bsoft) ? 1 : 0;
+        // (the dense rows live in lanes 0..7 of the per-stage aux plane, whose upper lanes hold other small items:
+        // WsLayout in params.hpp)
+        S.boxpack_ok = (kch > 0 && nb > 0 && ndense <= 2 && 4 * ndense <= k_last && !S.any_bsoft) ? 1 : 0;
         S.boxpack = S.boxpack_ok;
         if (S.boxpack_ok) {
             S.box_dense = ndense > 0;

@@ -15,6 +15,28 @@
 
 namespace usv {
 
+// A model may prepare quantities that are constant over a shooting interval (they depend only on states whose
+// right-hand side is zero): `struct Pre`, `prepare(x)`, `fjvp_pre(pre, ...)`.  Models without them are called through
+// their plain fjvp.
+template <class M, class = void>
+struct ModelCall {
+    struct Pre {};
+    USV_DEV static Pre prepare(const double *) { return {}; }
+    USV_DEV static void fjvp(const Pre &, const double *x, const double *U, const double *s, const double *su, double *f, double *js)
+    {
+        M::fjvp(x, U, s, su, f, js);
+    }
+};
+template <class M>
+struct ModelCall<M, std::void_t<typename M::Pre>> {
+    using Pre = typename M::Pre;
+    USV_DEV static Pre prepare(const double *x) { return M::prepare(x); }
+    USV_DEV static void fjvp(const Pre &p, const double *x, const double *U, const double *s, const double *su, double *f, double *js)
+    {
+        M::fjvp_pre(p, x, U, s, su, f, js);
+    }
+};
+
 // MULTI: more than one RK4 step per interval (the initial sensitivity column is then a carried variable
 // instead of a lane pattern the compiler rematerialises for free: 28 more VGPRs for M2, hence a separate build)
 template <class M, int KCH, bool SOFT, bool MULTI = false>
@@ -48,15 +70,13 @@ struct Linearize {
             sfor<0, NU>([&](auto i) { U[i] = 0.0; });
         }
 
-        // ---- cost gradient: g = Hc z - Mc yref (stage) | He z - Me yref_e (terminal) ----
+        // ---- cost gradient, reference part: -Mc yref (stage) | -Me yref_e (terminal).  The QP kernel keeps its iterate in
+        // absolute form (zbar + z), so the gradient at it is this plus H (zbar + z): the H zbar term is not formed here ----
         {
-            const double *Hrow = (k < N ? S.Hc : S.He) + lane * LANES;
             const double *Mrow = (k < N ? S.Mc : S.Me) + lane * LANES;
             const double *yr = (k < N) ? P.yref + ((long)b * N + k) * S.ny : P.yref_e + (long)b * S.ny_e;
             const int ny = (k < N) ? S.ny : S.ny_e;
             double acc = 0.0;
-            sfor<0, NU>([&](auto i) { acc = fma(Hrow[i], U[i], acc); });
-            sfor<0, NX>([&](auto i) { acc = fma(Hrow[NU + i], x[i], acc); });
             for (int y = 0; y < ny; y++) acc = fma(-Mrow[y], yr[y], acc);
             tile[WL::P_GQ * 64] = acc;
         }
@@ -69,29 +89,31 @@ struct Linearize {
         double s0[NX], f[NX], js[NX], xs[NX], ss[NX], xa[NX], sa[NX], su[NU > 0 ? NU : 1];
         sfor<0, NU>([&](auto l) { su[l] = (lane == l) ? 1.0 : 0.0; });
         sfor<0, NX>([&](auto i) { s0[i] = (lane == NU + i) ? 1.0 : 0.0; });
+        using MC = ModelCall<M>;
+        const typename MC::Pre pre = MC::prepare(x);
         for (int step = 0; step < nsteps; step++) { // wave-uniform
-            M::fjvp(x, U, s0, su, f, js);
+            MC::fjvp(pre, x, U, s0, su, f, js);
             sfor<0, NX>([&](auto i) {
                 xa[i] = f[i];
                 sa[i] = js[i];
                 xs[i] = fma(0.5 * dt, f[i], x[i]);
                 ss[i] = fma(0.5 * dt, js[i], s0[i]);
             });
-            M::fjvp(xs, U, ss, su, f, js);
+            MC::fjvp(pre, xs, U, ss, su, f, js);
             sfor<0, NX>([&](auto i) {
                 xa[i] = fma(2.0, f[i], xa[i]);
                 sa[i] = fma(2.0, js[i], sa[i]);
                 xs[i] = fma(0.5 * dt, f[i], x[i]);
                 ss[i] = fma(0.5 * dt, js[i], s0[i]);
             });
-            M::fjvp(xs, U, ss, su, f, js);
+            MC::fjvp(pre, xs, U, ss, su, f, js);
             sfor<0, NX>([&](auto i) {
                 xa[i] = fma(2.0, f[i], xa[i]);
                 sa[i] = fma(2.0, js[i], sa[i]);
                 xs[i] = fma(dt, f[i], x[i]);
                 ss[i] = fma(dt, js[i], s0[i]);
             });
-            M::fjvp(xs, U, ss, su, f, js);
+            MC::fjvp(pre, xs, U, ss, su, f, js);
             sfor<0, NX>([&](auto i) {
                 x[i] = fma(dt / 6.0, xa[i] + f[i], x[i]);
                 sa[i] = fma(dt / 6.0, sa[i] + js[i], s0[i]);

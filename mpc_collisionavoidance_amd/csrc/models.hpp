@@ -141,16 +141,36 @@ struct ModelM2 {
                                           1u << 0, 1u << 1};
     static constexpr unsigned DIAG_ONE = 0x3fffu & ~((1u << 3) | (1u << 4) | (1u << 5));
     // x = (psi, sinpsi, cospsi, u, v, r, ye, x1, y1, ak, nedx, nedy, Tport, Tstbd), c = 1
+    //
+    // Transcendentals: the reference writes beta = atan2(v, u + .001), chi = psi + beta and uses sin / cos of psi, chi
+    // and ak.  ak never changes inside a shooting interval (its right-hand side is zero), so its sine and cosine are
+    // prepared once per interval (Pre) instead of at each of the 4 x steps stage points; and since
+    // cos(beta) = ue / rho, sin(beta) = v / rho with rho = sqrt(ue^2 + v^2) in every quadrant, the angle-sum formulas
+    // give sin / cos(chi) from sin / cos(psi) without the atan2 and without a second sincos (agreement with the
+    // literal expressions: a few ulp, tests/test_ref_vectors.py).
+    struct Pre { double sa, ca; };
+    USV_DEV static Pre prepare(const double *x)
+    {
+        Pre p;
+        sincos(x[9], &p.sa, &p.ca);
+        return p;
+    }
     USV_DEV static void fjvp(const double *x, const double *U, const double *s, const double *su, double *f, double *js)
     {
-        const double psi = x[0], u = x[3], v = x[4], r = x[5], ak = x[9];
+        fjvp_pre(prepare(x), x, U, s, su, f, js);
+    }
+    USV_DEV static void fjvp_pre(const Pre &pre, const double *x, const double *U, const double *s, const double *su, double *f, double *js)
+    {
+        const double psi = x[0], u = x[3], v = x[4], r = x[5];
         const double ue = u + .001;
-        const double iden = 1.0 / (ue * ue + v * v);
-        const double beta = atan2(v, ue);
-        double sc, cc, sp, cp, sa, ca;
-        sincos(psi + beta, &sc, &cc);
+        const double r2 = ue * ue + v * v;
+        const double irho = 1.0 / sqrt(r2);
+        const double iden = irho * irho;
+        const double cb = ue * irho, sb = v * irho;
+        double sp, cp;
         sincos(psi, &sp, &cp);
-        sincos(ak, &sa, &ca);
+        const double sc = sp * cb + cp * sb, cc = cp * cb - sp * sb;
+        const double sa = pre.sa, ca = pre.ca;
         const double dchi = s[0] + (-v * iden) * s[3] + (ue * iden) * s[4];
         double f3[3], j3[3];
         Dof3::eval(1.0, u, v, r, x[12], x[13], s[3], s[4], s[5], s[12], s[13], f3, j3);

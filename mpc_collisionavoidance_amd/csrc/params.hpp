@@ -100,7 +100,15 @@ struct MatPack {
 // and wrapped the loads in waterfall loops).
 template <class M, int KCH, bool SOFT, bool SOFTBOX = false>
 struct WsLayout {
-    enum : int { P_Z = 0, P_ZB, P_DZA, P_DZ, P_DX0, P_PB, P_PI, P_BLL, P_BLU, P_BTL, P_BTU, P_OBS };
+    // P_Z   : the QP iterate in absolute form, zbar + z (what the box rows and the Hessian product need); the step z of an
+    //         obstacle row's position lanes is recovered with the linearisation point kept in P_AUX
+    // P_AUX : the small per-stage items, so that no sweep loads a whole plane for two values -
+    //         lanes 0..: box rows stored densely (four values per row, when packing is on: host_spec.hpp),
+    //         lane AXL_ZX / AXL_ZY: position (px, py) of the linearisation point (obstacle-row geometry),
+    //         lane AXL_RG - l: stationarity residual of control l, lane AXL_LU - l: gain right-hand side of control l
+    // P_PB  : P_{k+1} b_k (x lanes);  P_PI : dynamics multiplier pi_k (x lanes);  P_DX0 (stage 0): x0
+    enum : int { P_Z = 0, P_AUX, P_DZA, P_DZ, P_DX0, P_PB, P_PI, P_BLL, P_BLU, P_BTL, P_BTU, P_OBS };
+    enum : int { AXL_ZX = 15, AXL_ZY = 14, AXL_RG = 13, AXL_LU = 11, AUX_DENSE_LANES = 8 };
     static constexpr int OBSN = SOFT ? 10 : 4;
     static constexpr int P_LZU = P_OBS + KCH * OBSN;
     static constexpr int P_RB0 = P_LZU + M::NU; // b_k of the linearisation point (x lanes)

@@ -25,6 +25,10 @@
 // Four sweeps over the horizon per IPM iteration, all state streamed through lane-major planes
 // in HBM: backward A (apply the previous step, residuals, factorise, predictor rhs), forward A
 // (affine step), backward B (corrector rhs), forward B (step + step length).
+//
+// The primal iterate is kept in absolute form, zfull = zbar + z (plane P_Z): the box rows and the Hessian product
+// only ever need the sum, so the linearisation point is not streamed beside it; the two values of it that the
+// obstacle rows do need (its position) ride in the aux plane with the other per-stage odds and ends (WsLayout).
 #pragma once
 #include "lanes.hpp"
 #include "params.hpp"
@@ -186,14 +190,15 @@ struct QpIpm {
     static constexpr int PXL = NU + M::IPX, PYL = NU + M::IPY;
     using MP = MatPack<M>;
     // plane map of the per-stage workspace window
-    // P_PB holds (l_u | P b): the u lanes carry the gain rhs, the x lanes P_{k+1} b_k;  P_PI holds (r_g | pi):
-    // stationarity residual on the u lanes, dynamics multiplier on the x lanes (u and x lanes are disjoint)
+    // (P_Z: zbar + z;  P_AUX: dense box rows | position of the linearisation point | r_g | l_u;  P_PB: P_{k+1} b_k;
+    // P_PI: pi_k - see WsLayout)
     // (plane numbers: WsLayout, params.hpp - shared with the lineariser, which fills P_RB0, P_GQ and P_MAT..)
     using WL = WsLayout<M, KCH, SOFT, SOFTBOX>;
-    enum : int { P_Z = WL::P_Z, P_ZB = WL::P_ZB, P_DZA = WL::P_DZA, P_DZ = WL::P_DZ, P_DX0 = WL::P_DX0, P_PB = WL::P_PB,
+    enum : int { P_Z = WL::P_Z, P_AUX = WL::P_AUX, P_DZA = WL::P_DZA, P_DZ = WL::P_DZ, P_DX0 = WL::P_DX0, P_PB = WL::P_PB,
                  P_PI = WL::P_PI, P_BLL = WL::P_BLL, P_BLU = WL::P_BLU, P_BTL = WL::P_BTL, P_BTU = WL::P_BTU,
                  P_OBS = WL::P_OBS, P_LZU = WL::P_LZU, P_RB0 = WL::P_RB0, P_GQ = WL::P_GQ, P_MAT = WL::P_MAT,
                  P_BS = WL::P_BS };
+    enum : int { AXL_ZX = WL::AXL_ZX, AXL_ZY = WL::AXL_ZY, AXL_RG = WL::AXL_RG, AXL_LU = WL::AXL_LU };
     static constexpr int OBSN = WL::OBSN;
     static constexpr int NPL = WL::NPT;
 
@@ -221,7 +226,7 @@ struct QpIpm {
     // per-lane constants, read once: box bounds of this lane's variable, Hessian diagonal
     // PACK: the box rows' (lambda_l, lambda_u, t_l, t_u) do not get four planes of their own.  A *slot* row
     // lives in an idle lane (>= K_last) of the last obstacle chunk's four (lambda, t) planes; rows that do not
-    // fit there are *dense*: their four values sit in four consecutive lanes of ONE plane (P_BLL).  Slot lanes
+    // fit there are *dense*: their four values sit in four consecutive lanes of the aux plane (P_AUX).  Slot lanes
     // and dense lanes are disjoint (host_spec.hpp), so one run-time gather per value serves both kinds.
     //   bsrc   : lane this variable's value 0 comes from (slot lane, or first of the four dense lanes)
     //   bstep  : 0 for a slot row, 1 for a dense row (value e comes from lane bsrc + e*bstep)
@@ -311,12 +316,13 @@ struct QpIpm {
         return 0.0;
     }
 
-    USV_DEV void box_data(int k, double zb, BoxRow &r) const
+    // (the row value of a box row is the absolute iterate zbar + z, its bounds are the caller's lb / ub)
+    USV_DEV void box_data(int k, BoxRow &r) const
     {
         const bool stage_ok = ulane ? (k < N) : (k >= 1 && k < N);
         r.act = valid && hasb && stage_ok;
-        r.dl = r.act ? lbv - zb : -1.0;
-        r.du = r.act ? ubv - zb : 1.0;
+        r.dl = r.act ? lbv : -1.0;
+        r.du = r.act ? ubv : 1.0;
         if constexpr (SOFTBOX) {
             r.soft = r.act && bsoft;
             r.zl = bzl; r.zu = bzu; r.Zl = bZl; r.Zu = bZu; r.bsl = bbsl; r.bsu = bbsu;
@@ -333,14 +339,14 @@ struct QpIpm {
     // Obstacle chunk c at stage k.  The row h_i = |pos - o_i| >= lh_i is linearised here, from the iterate's
     // position (the px / py lanes of zb) and the obstacle data, instead of being streamed from planes written
     // by the lineariser: a square root and a few multiplies replace four plane reads per sweep.
-    // raw = (ox, oy, lh) of this lane's obstacle at this stage.
+    // raw = (ox, oy, lh) of this lane's obstacle at this stage; (zbx, zby) = position of the linearisation point.
     template <int C>
-    USV_DEV void obs_geom(int k, double zb, const double *raw, ObsRow &r, double &cx, double &cy) const
+    USV_DEV void obs_geom(int k, double zbx, double zby, const double *raw, ObsRow &r, double &cx, double &cy) const
     {
         const int i = C * LANES + lane;
         const bool stage_ok = (k >= 1 && k < N); // wave-uniform
         r.act = stage_ok && i < Kn;
-        const double dx = lanes::bcast<PXL>(zb) - raw[0], dy = lanes::bcast<PYL>(zb) - raw[1];
+        const double dx = zbx - raw[0], dy = zby - raw[1];
         double d, ux, uy;
         obs_dist(dx, dy, d, ux, uy);
         cx = r.act ? ux : 0.0; cy = r.act ? uy : 0.0;
@@ -376,17 +382,43 @@ struct QpIpm {
             W.st(p0 + 8, r.tsl); W.st(p0 + 9, r.tsu);
         }
     }
-    // box row values delivered to the lanes that store them (call under wave-uniform control flow)
-    USV_DEV void box_pack(const Planes &W, const BoxRow &r, double *pk, bool do_store) const
+    // box row values delivered to the lanes that store them (call under wave-uniform control flow); returns what this
+    // lane contributes to the dense part of the aux plane: value (lane & 3) of the row the lane belongs to
+    USV_DEV double box_pack(const BoxRow &r, double *pk) const
     {
         pk[0] = lanes::gather(r.ll, ssrc); pk[1] = lanes::gather(r.lu, ssrc);
         pk[2] = lanes::gather(r.tl, ssrc); pk[3] = lanes::gather(r.tu, ssrc);
-        if (anydense) { // wave-uniform: the dense plane, value (lane & 3) of the row this lane belongs to
-            const int e = lane & 3;
-            const double v = e == 0 ? pk[0] : (e == 1 ? pk[1] : (e == 2 ? pk[2] : pk[3]));
-            if (do_store && isdense) W.st(P_BLL, v);
-        }
+        const int e = lane & 3;
+        return e == 0 ? pk[0] : (e == 1 ? pk[1] : (e == 2 ? pk[2] : pk[3]));
     }
+    // ---- the aux plane (WsLayout): composition and access
+    USV_DEV static double aux_zx(double aux) { return KCH > 0 ? lanes::bcast<AXL_ZX>(aux) : 0.0; }
+    USV_DEV static double aux_zy(double aux) { return KCH > 0 ? lanes::bcast<AXL_ZY>(aux) : 0.0; }
+    // this lane's entry of a u-lane vector kept in the aux plane from lane TOP downwards (r_g, l_u)
+    template <int TOP>
+    USV_DEV double aux_ulane(double aux) const
+    {
+        double r = 0.0;
+        sfor<0, NU>([&](auto l) {
+            const double v = lanes::bcast<TOP - l>(aux);
+            r = (lane == l) ? v : r;
+        });
+        return r;
+    }
+    // dense: this lane's dense box value (used on the dense lanes only); rg, luv: u-lane vectors
+    USV_DEV double aux_compose(double dense, double zbx, double zby, double rg, double luv) const
+    {
+        double a = isdense ? dense : 0.0;
+        sfor<0, NU>([&](auto l) {
+            const double r_l = lanes::bcast<l>(rg), u_l = lanes::bcast<l>(luv);
+            a = (lane == AXL_RG - l) ? r_l : a;
+            a = (lane == AXL_LU - l) ? u_l : a;
+        });
+        if constexpr (KCH > 0) a = (lane == AXL_ZX) ? zbx : ((lane == AXL_ZY) ? zby : a);
+        return a;
+    }
+    // the position lanes' share of the linearisation point: zfull - this = the step z there (obstacle rows)
+    USV_DEV double pos_sel(double zbx, double zby) const { return isPX ? zbx : (isPY ? zby : 0.0); }
     // Row j of [B A]' for every stored row (bat[j]: lane r = d x+_j / d z_r) from the packed planes of stage k.
     // mat_issue puts the plane loads in flight, mat_unpack (call under wave-uniform control flow) distributes.
     USV_DEV void mat_issue(int k, double *pk) const
@@ -429,14 +461,14 @@ struct QpIpm {
             const Planes W = ws(k);
             const double zb = zbar(k);
             if (!keep) {
-                W.st(P_Z, 0.0);
-                W.st(P_ZB, zb);
-                if (k == 0) W.st(P_DX0, xlane ? P.x0[(long)b * NX + (lane - NU)] - zb : 0.0);
+                W.st(P_Z, zb); // z = 0
+                if (k == 0) W.st(P_DX0, xlane ? P.x0[(long)b * NX + (lane - NU)] : 0.0);
             }
             BoxRow r;
             r.neutral();
-            box_data(k, zb, r);
-            r.tl = fmax(0.0 - r.dl, S.thr0); r.tu = fmax(r.du - 0.0, S.thr0);
+            box_data(k, r);
+            const double v0 = r.act ? zb : 0.0;
+            r.tl = fmax(v0 - r.dl, S.thr0); r.tu = fmax(r.du - v0, S.thr0);
             r.ll = S.mu0 / r.tl; r.lu = S.mu0 / r.tu;
             if constexpr (SOFTBOX) {
                 if (r.soft) {
@@ -444,16 +476,19 @@ struct QpIpm {
                     r.lsl = S.mu0 / r.tsl; r.lsu = S.mu0 / r.tsu;
                 }
             }
-            double pk[4];
-            if constexpr (PACK) box_pack(W, r, pk, !keep);
+            double pk[4], dv = 0.0;
+            if constexpr (PACK) dv = box_pack(r, pk);
             else if (!keep) box_store(W, r);
+            const double zbx = KCH > 0 ? lanes::bcast<PXL>(zb) : 0.0, zby = KCH > 0 ? lanes::bcast<PYL>(zb) : 0.0;
+            const double aux = aux_compose(dv, zbx, zby, 0.0, 0.0);
+            if (!keep) W.st(P_AUX, aux);
             if constexpr (KCH > 0) {
                 sfor<0, KCH>([&](auto c) {
                     ObsRow o;
                     double cx, cy, raw[3];
                     o.neutral();
                     obs_raw<c>(k, raw);
-                    obs_geom<c>(k, zb, raw, o, cx, cy);
+                    obs_geom<c>(k, zbx, zby, raw, o, cx, cy);
                     o.tl = fmax(0.0 - o.dl, S.thr0); o.tu = fmax(o.du - 0.0, S.thr0);
                     o.ll = S.mu0 / o.tl; o.lu = S.mu0 / o.tu;
                     if constexpr (SOFT) {
@@ -487,7 +522,7 @@ struct QpIpm {
     // prefetch): with 2-3 waves per SIMD there is no other wave to hide an HBM round trip, so each
     // stage's loads are put in flight while the previous stage is still being computed.
     struct StageIn {
-        double z, zb, rb, dz, dza, gq, rg, pb, luv;
+        double z, aux, rb, dz, dza, gq, pb; // z: the absolute iterate zbar + z
         double lzu[NU];
         double box[4];
         double bxs[SOFTBOX ? 6 : 1]; // soft state bounds: sl, su, lsl, lsu, tsl, tsu of this lane's box row
@@ -501,7 +536,7 @@ struct QpIpm {
     {
         const Planes W = ws(k);
         in.z = W.ld(P_Z);
-        in.zb = W.ld(P_ZB);
+        in.aux = W.ld(P_AUX);
         // b_k of the current iterate = rbscale * (residual of the linearisation point): the forward sweeps
         // enforce the linearised dynamics, so every step scales it by (1 - alpha) and it is never rewritten
         // (raw value here: scaling it in place would make the prefetch wait for its own load)
@@ -512,18 +547,12 @@ struct QpIpm {
             in.gq = W.ld(P_GQ);
         }
         if constexpr (SW == SW_BACK_B || SW == SW_FWD_B) in.dza = W.ld(P_DZA);
-        if constexpr (SW == SW_BACK_B) {
-            in.rg = W.ld(P_PI);
-            in.pb = (k < N) ? W.ld(P_PB) : 0.0;
-        }
+        if constexpr (SW == SW_BACK_B) in.pb = (k < N) ? W.ld(P_PB) : 0.0;
         if constexpr (SW != SW_BACK_A) {
             if (k < N) sfor<0, NU>([&](auto l) { in.lzu[l] = W.ld(P_LZU + l); });
             else sfor<0, NU>([&](auto l) { in.lzu[l] = 1.0; });
         }
-        if constexpr (SW == SW_FWD_A || SW == SW_FWD_B) in.luv = (k < N) ? W.ld(P_PB) : 0.0; // u lanes matter
-        if constexpr (PACK) {
-            in.box[0] = (anydense && k < N) ? W.ld(P_BLL) : 0.0; // wave-uniform
-        } else {
+        if constexpr (!PACK) {
             in.box[0] = W.ld(P_BLL); in.box[1] = W.ld(P_BLU); in.box[2] = W.ld(P_BTL); in.box[3] = W.ld(P_BTU);
             if constexpr (SOFTBOX) sfor<0, 6>([&](auto e) { in.bxs[e] = W.ld(P_BS + e); });
         }
@@ -541,16 +570,16 @@ struct QpIpm {
     USV_DEV void box_from(const StageIn &in, int k, BoxRow &r) const
     {
         r.neutral();
-        box_data(k, in.zb, r);
+        box_data(k, r);
         double b0, b1, b2, b3;
         if constexpr (PACK) {
             constexpr int CL = KCH > 0 ? KCH - 1 : 0;
             // every lane offers what a reader would want from it: a slot lane its obstacle-plane values, any
-            // other lane the dense plane's value
-            b0 = lanes::gather(isslot ? in.obs[CL][0] : in.box[0], bsrc);
-            b1 = lanes::gather(isslot ? in.obs[CL][1] : in.box[0], bsrc + bstep);
-            b2 = lanes::gather(isslot ? in.obs[CL][2] : in.box[0], bsrc + 2 * bstep);
-            b3 = lanes::gather(isslot ? in.obs[CL][3] : in.box[0], bsrc + 3 * bstep);
+            // other lane the aux plane's value (its low lanes hold the dense rows)
+            b0 = lanes::gather(isslot ? in.obs[CL][0] : in.aux, bsrc);
+            b1 = lanes::gather(isslot ? in.obs[CL][1] : in.aux, bsrc + bstep);
+            b2 = lanes::gather(isslot ? in.obs[CL][2] : in.aux, bsrc + 2 * bstep);
+            b3 = lanes::gather(isslot ? in.obs[CL][3] : in.aux, bsrc + 3 * bstep);
         } else {
             b0 = in.box[0]; b1 = in.box[1]; b2 = in.box[2]; b3 = in.box[3];
         }
@@ -563,13 +592,13 @@ struct QpIpm {
         }
     }
     template <int C>
-    USV_DEV void obs_from(const StageIn &in, int k, ObsRow &r, double &cx, double &cy) const
+    USV_DEV void obs_from(const StageIn &in, int k, double zbx, double zby, ObsRow &r, double &cx, double &cy) const
     {
         r.neutral();
         if (k >= 1 && k < N) { // wave-uniform
             // with a stage-independent obstacle set the data sits in per-lane constants: no copy in the prefetch
             const double cst[3] = {c_ox[C], c_oy[C], c_lh[C]};
-            obs_geom<C>(k, in.zb, pstat ? cst : in.raw[C], r, cx, cy);
+            obs_geom<C>(k, zbx, zby, pstat ? cst : in.raw[C], r, cx, cy);
         } else {
             r.act = false; cx = 0.0; cy = 0.0;
             if constexpr (SOFT) {
@@ -603,16 +632,19 @@ struct QpIpm {
         // prefetched planes: the wait at the top of a stage then covers loads that have been in flight for a
         // whole stage and nothing else - with the stores issued at the end of their own stage it would also cover
         // those, i.e. a store round trip per stage.
-        double dfr_pi = 0.0, dfr_pb = 0.0, dfr_lz[NU > 0 ? NU : 1];
+        double dfr_pi = 0.0, dfr_pb = 0.0, dfr_aux = 0.0, dfr_lz[NU > 0 ? NU : 1];
         int dfr_k = -1;
         sfor<0, NU>([&](auto l) { dfr_lz[l] = 0.0; });
         auto flush = [&]() {
             if (dfr_k >= 0) { // wave-uniform
                 const Planes Wp = ws(dfr_k);
-                if (FACT && !keep) Wp.st(P_PI, dfr_pi);
-                if (dfr_k < N) {
+                if (!keep) {
+                    if (FACT) Wp.st(P_PI, dfr_pi);
+                    Wp.st(P_AUX, dfr_aux);
+                }
+                if (FACT && dfr_k < N) {
                     Wp.st(P_PB, dfr_pb);
-                    if (FACT) sfor<0, NU>([&](auto l) { Wp.st(P_LZU + l, dfr_lz[l]); });
+                    sfor<0, NU>([&](auto l) { Wp.st(P_LZU + l, dfr_lz[l]); });
                 }
             }
         };
@@ -626,7 +658,9 @@ struct QpIpm {
             // this stage's packed [B A] planes: in flight while the rows below are processed
             double mpk[MP::NPK];
             if (k < N) mat_issue(k, mpk);
-            double z = in.z;
+            double z = in.z; // the absolute iterate zbar + z
+            const double zbx = aux_zx(in.aux), zby = aux_zy(in.aux);
+            const double psel = pos_sel(zbx, zby);
             const double *Hrow = (k < N ? S.Hc : S.He) + lane * LANES; // only read when !HDIAG
             const double hd = (k < N) ? hd_stage : hd_term;
             const double dza = FACT ? 0.0 : in.dza;
@@ -644,8 +678,8 @@ struct QpIpm {
                     if constexpr (!PACK) box_store(W, br);
                 }
             }
-            double pk[4];
-            if constexpr (FACT && PACK) box_pack(W, br, pk, pend);
+            double pk[4], dv = in.aux; // dense part of the aux plane: rebuilt where the rows change, else as loaded
+            if constexpr (FACT && PACK) dv = box_pack(br, pk);
             const double znew = (FACT && pend) ? z + a_prev * dzp : z;
             chain(br, znew, !FACT, dza, sigmu, Ghb, gamb);
             double Sxx = 0.0, Sxy = 0.0, Syy = 0.0, gx = 0.0, gy = 0.0, lx = 0.0, ly = 0.0;
@@ -653,9 +687,9 @@ struct QpIpm {
                 sfor<0, KCH>([&](auto c) {
                     ObsRow o;
                     double cx, cy, Gh, gam;
-                    obs_from<c>(in, k, o, cx, cy);
+                    obs_from<c>(in, k, zbx, zby, o, cx, cy);
                     if (FACT) {
-                        const double vo = obs_dot(cx, cy, z), wp = obs_dot(cx, cy, dzp), wap = obs_dot(cx, cy, dzap);
+                        const double vo = obs_dot(cx, cy, z - psel), wp = obs_dot(cx, cy, dzp), wap = obs_dot(cx, cy, dzap);
                         if (pend && o.act) {
                             chain(o, vo, true, wap, sigmu_prev, Gh, gam);
                             o.expand(wp);
@@ -664,7 +698,7 @@ struct QpIpm {
                         const bool slot_here = c == KCH - 1 && isslot;
                         if (pend && (o.act || slot_here)) obs_store(W, c, o, (PACK && c == KCH - 1) ? pk : nullptr);
                     }
-                    const double v = obs_dot(cx, cy, znew);
+                    const double v = obs_dot(cx, cy, znew - psel);
                     const double wa = FACT ? 0.0 : obs_dot(cx, cy, dza);
                     chain(o, v, !FACT, wa, sigmu, Gh, gam);
                     gx += gam * cx; gy += gam * cy;
@@ -703,7 +737,7 @@ struct QpIpm {
 
             double rg, pik = 0.0;
             if (FACT) {
-                // t = H z + g + [B A]' pi_{k+1} - sum c (ll - lu);  x lanes: pi_k := t (adjoint
+                // t = H (zbar + z) - M yref + [B A]' pi_{k+1} - sum c (ll - lu);  x lanes: pi_k := t (adjoint
                 // recursion, stationarity in x holds by construction);  u lanes: residual r_g
                 double t = in.gq;
                 if constexpr (HDIAG) t = fma(hd, z, t);
@@ -736,11 +770,11 @@ struct QpIpm {
                 }
                 nm.rb = fmax(nm.rb, fabs(rb));
             } else {
-                rg = (ulane && k < N) ? in.rg : 0.0;
+                rg = (k < N) ? aux_ulane<AXL_RG>(in.aux) : 0.0;
             }
             const double gt = rg + gamb + (isPX ? gx : (isPY ? gy : 0.0));
 
-            double pv;
+            double pv, luv_new = 0.0;
             if (k == N) {
                 if (FACT) sfor<0, NX>([&](auto c) {
                     if constexpr (HDIAG) Pn[c] = (lane == NU + c) ? hd : 0.0;
@@ -826,8 +860,10 @@ struct QpIpm {
                 pv = rq;
                 sfor<0, NU>([&](auto l) { pv -= Lzu[l] * lu[l]; });
                 pv = xlane ? pv : 0.0;
-                dfr_pb = luv + Pb; // luv is non-zero on the u lanes only, Pb on the x lanes only
+                dfr_pb = Pb;
+                luv_new = luv;
             }
+            dfr_aux = aux_compose(dv, zbx, zby, rg, luv_new);
             pn = pv;
             pin = pik;
             dfr_k = k;
@@ -835,7 +871,7 @@ struct QpIpm {
         flush();
         if (FACT) {
             const Planes W0 = ws(0);
-            const double e0 = xlane ? W0.ld(P_DX0) - W0.ld(P_Z) : 0.0;
+            const double e0 = xlane ? W0.ld(P_DX0) - W0.ld(P_Z) : 0.0; // x0 - (xbar_0 + dx_0)
             nm.rg = lanes::gmax(nm.rg);
             nm.rb = lanes::gmax(fmax(nm.rb, fabs(e0)));
             nm.rd = lanes::gmax(nm.rd);
@@ -873,10 +909,11 @@ struct QpIpm {
                 load_in<SW>(k + 1, nxt);
             }
             double dz;
+            const double zbx = aux_zx(in.aux), zby = aux_zy(in.aux);
             if (k < N) {
                 double t[NU], du[NU];
                 sfor<0, NU>([&](auto l) {
-                    t[l] = lanes::bcast<l>(in.luv) + lanes::gsum(xlane ? in.lzu[l] * dzx : 0.0);
+                    t[l] = lanes::bcast<AXL_LU - l>(in.aux) + lanes::gsum(xlane ? in.lzu[l] * dzx : 0.0);
                 });
                 sfor<0, NU>([&](auto qq) { // back substitution with Luu'
                     constexpr int l = NU - 1 - qq;
@@ -913,8 +950,8 @@ struct QpIpm {
                     sfor<0, KCH>([&](auto c) {
                         ObsRow o;
                         double cx, cy, Gh2, gam2;
-                        obs_from<c>(in, k, o, cx, cy);
-                        const double v = obs_dot(cx, cy, z);
+                        obs_from<c>(in, k, zbx, zby, o, cx, cy);
+                        const double v = obs_dot(cx, cy, z - pos_sel(zbx, zby));
                         const double w = obs_dot(cx, cy, dz);
                         const double wa = FINAL ? obs_dot(cx, cy, dza) : w;
                         chain(o, v, FINAL, wa, sigmu, Gh2, gam2);
@@ -965,13 +1002,16 @@ struct QpIpm {
         for (int k = N; k >= 0; k--) {
             const Planes W = ws(k);
             StageIn in;
-            in.zb = zbar(k);
+            const double zb = zbar(k); // the iterate itself: its residuals are the QP's at z = 0
+            const double zbx = KCH > 0 ? lanes::bcast<PXL>(zb) : 0.0, zby = KCH > 0 ? lanes::bcast<PYL>(zb) : 0.0;
+            in.z = zb;
+            in.aux = 0.0;
             sfor<0, 4>([&](auto e) { in.box[e] = 0.0; });
             if constexpr (SOFTBOX) sfor<0, 6>([&](auto e) { in.bxs[e] = 0.0; });
             if constexpr (KCH > 0) sfor<0, KCH>([&](auto c) { sfor<0, OBSN>([&](auto e) { in.obs[c][e] = 0.0; }); });
             if (!first) { // wave-uniform
                 if constexpr (PACK) {
-                    in.box[0] = (anydense && k < N) ? W.ld(P_BLL) : 0.0;
+                    in.aux = W.ld(P_AUX); // the dense box rows of the last QP (its position lanes are stale: zbx / zby above)
                 } else {
                     in.box[0] = W.ld(P_BLL); in.box[1] = W.ld(P_BLU); in.box[2] = W.ld(P_BTL); in.box[3] = W.ld(P_BTU);
                     if constexpr (SOFTBOX) sfor<0, 6>([&](auto e) { in.bxs[e] = W.ld(P_BS + e); });
@@ -995,7 +1035,7 @@ struct QpIpm {
             box_from(in, k, br);
             if (first) { br.tl = 0.0; br.tu = 0.0; if constexpr (SOFTBOX) { br.tsl = 0.0; br.tsu = 0.0; } }
             if (br.act) {
-                rd = fmax(rd, fmax(fabs(br.sl - br.dl - br.tl), fabs(br.du + br.su - br.tu)));
+                rd = fmax(rd, fmax(fabs(zb + br.sl - br.dl - br.tl), fabs(br.du - zb + br.su - br.tu)));
                 rm = fmax(rm, fmax(br.ll * br.tl, br.lu * br.tu));
                 if constexpr (SOFTBOX) {
                     if (br.soft) {
@@ -1010,7 +1050,7 @@ struct QpIpm {
                 sfor<0, KCH>([&](auto c) {
                     ObsRow o;
                     double cx, cy;
-                    obs_from<c>(in, k, o, cx, cy);
+                    obs_from<c>(in, k, zbx, zby, o, cx, cy);
                     if (first) { o.tl = 0.0; o.tu = 0.0; if constexpr (SOFT) { o.tsl = 0.0; o.tsu = 0.0; } }
                     if (o.act) {
                         rd = fmax(rd, fmax(fabs(o.sl - o.dl - o.tl), fabs(o.du + o.su - o.tu)));
@@ -1025,8 +1065,13 @@ struct QpIpm {
                 });
                 lx = lanes::gsum(lx); ly = lanes::gsum(ly);
             }
-            // stationarity: g + [B A]' pi_{k+1} - C'(ll - lu) (- pi_k on the x lanes)
+            // stationarity: g + [B A]' pi_{k+1} - C'(ll - lu) (- pi_k on the x lanes), g = H zbar - M yref
             double t = W.ld(P_GQ);
+            if constexpr (HDIAG) t = fma((k < N) ? hd_stage : hd_term, zb, t);
+            else {
+                const double *Hrow = (k < N ? S.Hc : S.He) + lane * LANES;
+                sfor<0, NZ>([&](auto c) { lanes::fma_bc<c>(t, zb, Hrow[c]); });
+            }
             sfor<0, NX>([&](auto j) {
                 if constexpr (!out_unit(j)) lanes::fma_bc<NU + j>(t, pin, bat[j]);
             });
@@ -1037,7 +1082,7 @@ struct QpIpm {
             if (xlane && k >= 1) rg = fmax(rg, fabs(t - pik));
             if (ulane && k < N) rg = fmax(rg, fabs(t));
             if (k < N) rbn = fmax(rbn, xlane ? fabs(W.ld(P_RB0)) : 0.0);
-            if (k == 0) rbn = fmax(rbn, xlane ? fabs(P.x0[(long)b * NX + (lane - NU)] - in.zb) : 0.0);
+            if (k == 0) rbn = fmax(rbn, xlane ? fabs(P.x0[(long)b * NX + (lane - NU)] - zb) : 0.0);
             pin = pik;
         }
         res[0] = lanes::gmax(rg); res[1] = lanes::gmax(rbn); res[2] = lanes::gmax(rd); res[3] = lanes::gmax(rm);
@@ -1122,7 +1167,7 @@ struct QpIpm {
         double tmin = 1e300; // smallest t_l over this instance's obstacle rows: how close the QP solution sits to a keep-out circle
         for (int k = 0; k <= N; k++) {
             const Planes W = ws(k);
-            const double z = W.ld(P_Z);
+            const double z = W.ld(P_Z); // zbar + z: the new iterate
             if constexpr (KCH > 0) {
                 if (k >= 1 && k < N) { // wave-uniform
                     sfor<0, KCH>([&](auto c) {
@@ -1132,8 +1177,8 @@ struct QpIpm {
                 }
             }
             if (real) {
-                if (ok && xlane) P.x[((long)b * (N + 1) + k) * NX + (lane - NU)] += z;
-                if (ok && ulane && k < N) P.u[((long)b * N + k) * NU + lane] += z;
+                if (ok && xlane) P.x[((long)b * (N + 1) + k) * NX + (lane - NU)] = z;
+                if (ok && ulane && k < N) P.u[((long)b * N + k) * NU + lane] = z;
                 if (k >= 1 && xlane && P.pi) P.pi[((long)b * N + (k - 1)) * NX + (lane - NU)] = W.ld(P_PI);
             }
             if constexpr (KCH > 0 && SOFT) {

@@ -93,8 +93,11 @@ def test_linearize_planes_match_oracle(oracle, emu, name, N, K):
                 e = np.zeros(nu + nx); e[nu + j] = 1.0
                 assert np.array_equal(BA[j], e) and not got[j].any()
             assert np.allclose(r["rb0"][k, b, nu:nu + nx], qp["b"][k], rtol=1e-12, atol=1e-14)
-            assert np.allclose(r["gq"][k, b, :nu + nx], qp["g"][k], rtol=1e-12, atol=1e-13)
-        assert np.allclose(r["gq"][N, b, nu:nu + nx], qp["g"][N][nu:], rtol=1e-12, atol=1e-13)
+            # the gradient plane holds the reference part -M yref only; the kernel adds H (zbar + z) itself
+            zbar = np.concatenate([wl["u_init"][b, k], wl["x_init"][b, k]])
+            assert np.allclose(r["gq"][k, b, :nu + nx] + qp["H"][k] @ zbar, qp["g"][k], rtol=1e-12, atol=1e-12)
+        zN = np.concatenate([np.zeros(nu), wl["x_init"][b, N]])
+        assert np.allclose((r["gq"][N, b, :nu + nx] + qp["H"][N] @ zN)[nu:], qp["g"][N][nu:], rtol=1e-12, atol=1e-12)
         assert np.all(r["BAt"][:, :, b, nu + nx:] == 0.0)      # idle lanes stay zero
 
 

@@ -116,6 +116,8 @@ def main():
                     help="std of the Gaussian disturbance added at the hand-over (default: 1e-3 for survey, 0 for r01)")
     ap.add_argument("--cond-N", type=int, default=0, help="qp_solver_cond_N (0: acados default = N, no condensing)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="instances timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="solver run-time option (usvmpc_set_option), e.g. dynamic_rows=0; may be repeated")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -165,6 +167,8 @@ def main():
     solver = BatchOcpSolver(ocp, B, device=local_rank)
     scenario.load_into(solver, wl)
     solver.set_option("disturbance_mask", mask)
+    for kv in args.option:
+        solver.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     static = K > 0 and float(np.ptp(wl["p"], axis=1).max()) == 0.0 and float(np.ptp(wl["lh"], axis=1).max()) == 0.0
     if static:
         # the obstacle set of this workload is the same on every stage (as the reference's callers set it:

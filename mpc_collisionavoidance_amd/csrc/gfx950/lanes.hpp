@@ -41,6 +41,14 @@ USV_DEV double bcast(double v)
     return dpp_mov<0x150 + K>(v);
 }
 
+// the same for a 32-bit integer
+template <int K>
+USV_DEV int bcast_i(int v)
+{
+    static_assert(K >= 0 && K < 16, "lane index");
+    return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, true);
+}
+
 // c += bcast<K>(b_remote) * a_own
 template <int K>
 USV_DEV void fma_bc(double &c, double b_remote, double a_own)
@@ -111,6 +119,8 @@ USV_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 // one more in a global counter
 USV_DEV void count_one(int *p) { atomicAdd(p, 1); }
+// ... returning the value before (work-queue head)
+USV_DEV int fetch_add(int *p) { return atomicAdd(p, 1); }
 
 // true if the predicate holds in any lane of the wave (four instances)
 USV_DEV bool wave_any(bool p) { return __any((int)p) != 0; }
@@ -135,11 +145,12 @@ USV_DEV double frsqrt(double x)
 // lane index inside the wave (a wave carries four 16-lane groups)
 USV_DEV unsigned wave_lane() { return threadIdx.x & 63u; }
 
-// One wave's tile of lane-major planes in HBM: [nplanes][64 lanes], 512 contiguous bytes per plane, planes
-// back to back.  Addressed through a buffer resource: the descriptor lives in SGPRs, the lane offset in ONE VGPR
-// for the whole kernel, and the plane offset (plane * 512) is a compile-time constant of the instruction, so a
-// plane access costs neither VALU address arithmetic nor a live scalar register (buffer_load_dwordx2 ... offen).
-// tile must be wave-uniform.
+// The lane-major planes of ONE stage in HBM: [group][plane][16 lanes] - a group's (= OCP instance's) planes of a stage
+// are 128-byte rows back to back, so every group streams its own contiguous block whatever groups share its wave.
+// Addressed through a buffer resource: the descriptor (the stage's window over all groups) lives in SGPRs, the
+// group + lane offset in ONE VGPR that only changes when a row takes up another group, and the plane offset
+// (plane * 128) is a compile-time constant of the instruction, so a plane access costs neither VALU address
+// arithmetic nor a live scalar register (buffer_load_dwordx2 ... offen).  base must be wave-uniform.
 // Cache policy of the plane accesses (aux operand of the buffer instructions: 0 default, 2 = nt, non-temporal).
 // A stored plane is not read again before tens of gigabytes have passed: non-temporal STORES measure -3 % (M2) /
 // -5 % (M1) on the QP kernel; non-temporal loads +-0, both together +6 % (tools/micro/store_policy.hip has the
@@ -152,23 +163,24 @@ USV_DEV unsigned wave_lane() { return threadIdx.x & 63u; }
 #endif
 struct Planes {
     __amdgpu_buffer_rsrc_t rsrc;
-    unsigned voff; // wave_lane * 8
+    unsigned voff; // byte offset of this lane's entry of plane 0 inside the stage window
 
-    USV_DEV Planes(const double *tile, int nplanes, unsigned wl)
+    // byte offset of (group, lane) in a stage window whose groups hold nplanes planes each
+    USV_DEV static unsigned lane_offset(long group, int nplanes, int lane) { return (unsigned)(group * nplanes * 128 + lane * 8); }
+    USV_DEV Planes(const double *base, unsigned nbytes, unsigned voff_) : voff(voff_)
     {
-        voff = wl * 8u;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(tile), 0, nplanes * 512, 0x00020000);
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0, (int)nbytes, 0x00020000);
     }
     USV_DEV double ld(int plane) const
     {
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, plane * 512, USV_PLANE_LOAD_AUX);
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, plane * 128, USV_PLANE_LOAD_AUX);
         return __builtin_bit_cast(double, v);
     }
     USV_DEV void st(int plane, double x) const
     {
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), rsrc, (int)voff, plane * 512, USV_PLANE_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), rsrc, (int)voff, plane * 128, USV_PLANE_STORE_AUX);
     }
 };
 

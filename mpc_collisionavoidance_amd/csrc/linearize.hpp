@@ -56,8 +56,8 @@ struct Linearize {
         const int nB = lanes::uniform(S.B);
         const long gi = g < nB ? g : (long)nB - 1; // padded groups replay the last instance
         const long b = P.perm ? (long)P.perm[gi] : gi;
-        // workspace: [stage][wave tile of 4 groups][plane][64 lanes] (lanes::Planes)
-        double *tile = P.ws + (((long)k * (Bp / 4) + (g >> 2)) * lanes::uniform(S.npt)) * 64 + (g & 3) * LANES + lane;
+        // workspace: [stage][group][plane][16 lanes] (lanes::Planes)
+        double *tile = P.ws + (((long)k * Bp + g) * lanes::uniform(S.npt)) * LANES + lane;
         const bool xlane = lane >= NU && lane < NZ;
 
         double x[NX], U[NU > 0 ? NU : 1];
@@ -78,7 +78,7 @@ struct Linearize {
             const int ny = (k < N) ? S.ny : S.ny_e;
             double acc = 0.0;
             for (int y = 0; y < ny; y++) acc = fma(-Mrow[y], yr[y], acc);
-            tile[WL::P_GQ * 64] = acc;
+            tile[WL::P_GQ * LANES] = acc;
         }
         if (k == N) return; // wave-uniform
 
@@ -141,9 +141,9 @@ struct Linearize {
                     val = (within >= 0 && within < cnt) ? gth : val;
                 }
             });
-            tile[(WL::P_MAT + q) * 64] = val;
+            tile[(WL::P_MAT + q) * LANES] = val;
         });
-        tile[WL::P_RB0 * 64] = xlane ? bres : 0.0;
+        tile[WL::P_RB0 * LANES] = xlane ? bres : 0.0;
         // (obstacle rows are linearised inside the QP kernel from the iterate and (p, lh): QpIpm::obs_geom)
     }
 };

@@ -143,9 +143,10 @@ struct DevPtrs {
     int *sqp_iter;        // [B]         SQP iterations taken
     int *sqp_state;       // [B]         -1 running, else the final acados status (0 converged, 2 max iter, 4 QP failure)
     int *sqp_running;     // [1]         instances still running after the last launch
-    // lane-major planes: element (k, e) of group g, lane r at ((k*E + e) * Bp + g) * 16 + r
-    // solver workspace, lane-major planes [N+1][WsLayout::NPT]: linearisation output + QP state
+    // solver workspace: lane-major planes [N+1 stages][Bp groups][WsLayout::NPT planes][16 lanes] - element e of stage k,
+    // group g, lane r at (((k * Bp + g) * NPT + e) * 16 + r: linearisation output + QP state
     double *ws;
+    int *queue;           // [1]  groups handed out beyond the waves' first four (work queue of the QP kernel)
 };
 
 } // namespace usv

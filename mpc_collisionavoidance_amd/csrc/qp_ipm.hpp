@@ -5,6 +5,13 @@
 // PARTIAL_CONDENSING_HPIPM with the default block size, i.e. no condensing:
 // /root/reference/catkin_ws/src/nmpc_ca/scripts/usv_guidance_ca1/acados_settings.py:190-194).
 //
+// Scheduling: a wave is four independent rows.  Each row works through OCP instances ("groups", in the order of the
+// difficulty binning): when its QP has converged it writes its results, takes the next unclaimed group from a device
+// counter and cold-starts it, while the other three rows carry on with their own iterations - no row waits for the
+// slowest of its wave, and no plane of a finished instance is streamed again.  Only the sweeps run in lock step;
+// which iteration a row is in is per-row state.  (Without the queue - full SQP, option dynamic_rows = 0 - a row
+// keeps its first group and idles once it is done.)
+//
 // Mapping: one OCP instance = one 16-lane DPP row (lanes.hpp).  Lane r owns variable r of the
 // stage vector z = [u;x], row r of every stage matrix ([B A]', P, G), the box constraint on
 // variable r, and obstacle row c*16+r of chunk c.  All matrix products are "own row x broadcast
@@ -218,10 +225,11 @@ struct QpIpm {
     bool pstat;     // S.p_static
     bool keep;      // full SQP: this instance is finished, its workspace (multipliers of the last QP) must survive
     int lane, N;
+    // per row (the same in its 16 lanes): the group it works on, that group's instance, the lane's offset in a stage window
     long g, b;
-    long tile_stride; // doubles between the tiles of consecutive stages: (Bp / 4) * NPL * 64
-    const double *tile0;  // this wave's tile of stage 0
-    unsigned wl;
+    unsigned voff;
+    long stage_stride;     // doubles between consecutive stages of the workspace: Bp * NPL * 16
+    unsigned stage_bytes;  // bytes of one stage's window
     bool xlane, ulane, valid, isPX, isPY;
     // per-lane constants, read once: box bounds of this lane's variable, Hessian diagonal
     // PACK: the box rows' (lambda_l, lambda_u, t_l, t_u) do not get four planes of their own.  A *slot* row
@@ -254,16 +262,10 @@ struct QpIpm {
         pstat = lanes::uniform(S.p_static) != 0;
         nB = lanes::uniform(S.B);
         itmax = lanes::uniform(S.iter_max);
-        g = g_;
-        {
-            const long gi = g < nB ? g : (long)nB - 1;
-            b = P.perm ? (long)P.perm[gi] : gi;
-        }
-        wl = lanes::wave_lane();
-        {   // workspace layout: [stage][wave tile][plane][64 lanes]; the four groups of a wave share a tile
-            const long nblk = (long)lanes::uniform(S.Bp) / 4;
-            tile_stride = nblk * NPL * 64;
-            tile0 = P.ws + (long)lanes::uniform((int)(g >> 2)) * NPL * 64;
+        {   // workspace layout: [stage][group][plane][16 lanes]
+            const long nbp = (long)lanes::uniform(S.Bp);
+            stage_stride = nbp * NPL * LANES;
+            stage_bytes = (unsigned)(nbp * NPL * 128);
         }
         ulane = lane < NU;
         xlane = lane >= NU && lane < NZ;
@@ -289,13 +291,12 @@ struct QpIpm {
         if constexpr (KCH > 0) {
             sfor<0, KCH>([&](auto c) {
                 const int i = c * LANES + lane;
-                const int ii = i < S.K ? i : 0;
-                c_uh[c] = S.uh[ii];
-                c_ox[c] = P.p[(long)b * (N + 1) * 2 * S.K + 2 * ii];
-                c_oy[c] = P.p[(long)b * (N + 1) * 2 * S.K + 2 * ii + 1];
-                c_lh[c] = P.lh[(long)b * N * S.K + ii];
+                c_uh[c] = S.uh[i < S.K ? i : 0];
             });
         }
+        g = 0; b = 0;
+        if constexpr (KCH > 0) sfor<0, KCH>([&](auto c) { c_ox[c] = c_oy[c] = c_lh[c] = 0.0; });
+        bind(g_, true);
         if constexpr (KCH > 0 && SOFT) {
             sfor<0, KCH>([&](auto c) {
                 const int i = c * LANES + lane;
@@ -307,7 +308,27 @@ struct QpIpm {
         }
     }
 
-    USV_DEV Planes ws(int k) const { return Planes(tile0 + (long)k * tile_stride, NPL, wl); }
+    // Point the rows selected by `sel` at group gn: instance, workspace offset, per-instance constants.  Groups beyond the
+    // batch (padding of the last wave) replay the last instance and never write results.
+    USV_DEV void bind(long gn, bool sel)
+    {
+        g = sel ? gn : g;
+        const long gi = g < nB ? g : (long)nB - 1;
+        const long bn = P.perm ? (long)P.perm[gi] : gi;
+        b = sel ? bn : b;
+        voff = Planes::lane_offset(g, NPL, lane);
+        if constexpr (KCH > 0) {
+            sfor<0, KCH>([&](auto c) {
+                const int i = c * LANES + lane;
+                const int ii = i < Kn ? i : 0;
+                const double ox = P.p[(long)b * (N + 1) * 2 * Kn + 2 * ii], oy = P.p[(long)b * (N + 1) * 2 * Kn + 2 * ii + 1];
+                const double lh = P.lh[(long)b * N * Kn + ii];
+                c_ox[c] = sel ? ox : c_ox[c]; c_oy[c] = sel ? oy : c_oy[c]; c_lh[c] = sel ? lh : c_lh[c];
+            });
+        }
+    }
+
+    USV_DEV Planes ws(int k) const { return Planes(P.ws + (long)k * stage_stride, stage_bytes, voff); }
     // iterate value of this lane's variable at stage k (caller-visible arrays)
     USV_DEV double zbar(int k) const
     {
@@ -455,12 +476,14 @@ struct QpIpm {
 
     // ------------------------------------------------------------------ cold start
     // (an instance that a full SQP has frozen keeps the multipliers of its last QP: keep)
-    USV_DEV void init()
+    // sel: rows to cold-start
+    USV_DEV void init(bool sel)
     {
+        const bool wr = sel && !keep;
         for (int k = 0; k <= N; k++) {
             const Planes W = ws(k);
             const double zb = zbar(k);
-            if (!keep) {
+            if (wr) {
                 W.st(P_Z, zb); // z = 0
                 if (k == 0) W.st(P_DX0, xlane ? P.x0[(long)b * NX + (lane - NU)] : 0.0);
             }
@@ -478,10 +501,10 @@ struct QpIpm {
             }
             double pk[4], dv = 0.0;
             if constexpr (PACK) dv = box_pack(r, pk);
-            else if (!keep) box_store(W, r);
+            else if (wr) box_store(W, r);
             const double zbx = KCH > 0 ? lanes::bcast<PXL>(zb) : 0.0, zby = KCH > 0 ? lanes::bcast<PYL>(zb) : 0.0;
             const double aux = aux_compose(dv, zbx, zby, 0.0, 0.0);
-            if (!keep) W.st(P_AUX, aux);
+            if (wr) W.st(P_AUX, aux);
             if constexpr (KCH > 0) {
                 sfor<0, KCH>([&](auto c) {
                     ObsRow o;
@@ -495,7 +518,7 @@ struct QpIpm {
                         o.tsl = fmax(0.0 - o.bsl, S.thr0); o.tsu = fmax(0.0 - o.bsu, S.thr0);
                         o.lsl = S.mu0 / o.tsl; o.lsu = S.mu0 / o.tsu;
                     }
-                    if (!keep) obs_store(W, c, o, (PACK && c == KCH - 1) ? pk : nullptr);
+                    if (wr) obs_store(W, c, o, (PACK && c == KCH - 1) ? pk : nullptr);
                 });
             }
         }
@@ -1088,10 +1111,65 @@ struct QpIpm {
         res[0] = lanes::gmax(rg); res[1] = lanes::gmax(rbn); res[2] = lanes::gmax(rd); res[3] = lanes::gmax(rm);
     }
 
+    // ------------------------------------------------------------------ results of a finished QP
+    // RTI step and outputs of the rows selected by `fin` (acados ocp_nlp_update_variables; status 4 leaves the iterate
+    // untouched).  real: the row holds an instance of the batch that this launch is solving.
+    USV_DEV void finish(bool fin, bool real, int status, int iters, int phase)
+    {
+        const bool ok = (status == 0 || status == 1);
+        const bool out = fin && real;
+        double tmin = 1e300; // smallest t_l over this instance's obstacle rows: how close the QP solution sits to a keep-out circle
+        for (int k = 0; k <= N; k++) {
+            const Planes W = ws(k);
+            const double z = W.ld(P_Z); // zbar + z: the new iterate
+            if constexpr (KCH > 0) {
+                if (k >= 1 && k < N) { // wave-uniform
+                    sfor<0, KCH>([&](auto c) {
+                        const double tl = W.ld(P_OBS + c * OBSN + 2);
+                        tmin = (c * LANES + lane < Kn) ? fmin(tmin, tl) : tmin;
+                    });
+                }
+            }
+            if (out) {
+                if (ok && xlane) P.x[((long)b * (N + 1) + k) * NX + (lane - NU)] = z;
+                if (ok && ulane && k < N) P.u[((long)b * N + k) * NU + lane] = z;
+                if (k >= 1 && xlane && P.pi) P.pi[((long)b * N + (k - 1)) * NX + (lane - NU)] = W.ld(P_PI);
+            }
+            if constexpr (KCH > 0 && SOFT) {
+                if (k < N) {
+                    sfor<0, KCH>([&](auto c) {
+                        const int i = c * LANES + lane;
+                        if (out && i < Kn && P.sl) {
+                            const bool act = k >= 1;
+                            const int p0 = P_OBS + c * OBSN;
+                            P.sl[((long)b * N + k) * Kn + i] = act ? W.ld(p0 + 4) : 0.0;
+                            P.su[((long)b * N + k) * Kn + i] = act ? W.ld(p0 + 5) : 0.0;
+                        }
+                    });
+                }
+            }
+        }
+        tmin = lanes::gmin(tmin);
+        if (out && lane == 0) {
+            if (P.obs_tmin) P.obs_tmin[b] = tmin;
+            if (!ok && P.fail_count) lanes::count_one(P.fail_count);
+            P.status[b] = ok ? 0 : 4;
+            P.qp_iter[b] = iters;
+            P.qp_status[b] = status;
+            if (phase > 0) {
+                P.sqp_iter[b] += 1;
+                if (!ok) P.sqp_state[b] = 4;
+                else lanes::count_one(P.sqp_running);
+            }
+        }
+    }
+
     // ------------------------------------------------------------------ driver
     // phase 0: one SQP-RTI iteration.  phase 1 / 2: one iteration of the full SQP (first / later): test the NLP
     // residuals, and unless the instance has converged (or finished earlier) solve the QP and take the step.
-    USV_DEV void solve(int phase)
+    // queue0 >= 0: the rows of this wave started on groups below queue0 and take further groups queue0, queue0 + 1, ...
+    // from the counter P.queue as they finish (phase 0 only); queue0 < 0: every row keeps its first group.
+    USV_DEV void solve(int phase, int queue0)
     {
         bool frozen = false;
         keep = false;
@@ -1113,34 +1191,61 @@ struct QpIpm {
             if (!lanes::wave_any(!frozen)) return;
         }
         keep = frozen;
-        init();
+        init(true);
+        // ---- per-row state of the IPM (every row is in its own iteration)
         rbscale = 1.0;
-        bool done = frozen, pend = false;
-        int status = 1, iters = 0;
+        bool real = g < nB && !frozen;   // the row holds an instance whose results are to be written
+        bool done = frozen;              // nothing (more) to iterate on in this row
+        bool pend = false;               // a step of the previous iteration is waiting to be applied
+        bool fresh = false;              // cold-started after this pass's factorisation sweep: sits out the rest of the pass
+        bool late = false;               // stopped by the step-length floor after the factorisation sweep: results next pass
+        int status = 1, iters = 0, it = 0;
         Norms nm;
-        double res0 = 0, res1 = 0, res2 = 0, res3 = 0;
         double a_prev = 0.0, sig_prev = 0.0;
         const double nc = (double)S.nc;
-        for (int it = 0;; it++) {
+        const bool refill = phase == 0 && queue0 >= 0; // wave-uniform
+        for (;;) {
             backward<true>(nm, 0.0, pend && !done, a_prev, sig_prev);
+            bool fin = late;
             if (!done) {
-                res0 = nm.rg; res1 = nm.rb; res2 = nm.rd; res3 = nm.rm;
+                // the residuals of the iterate this pass has just evaluated; the last ones written are the final ones
+                if (real && lane == 0) {
+                    P.res[b * 4 + 0] = nm.rg; P.res[b * 4 + 1] = nm.rb; P.res[b * 4 + 2] = nm.rd; P.res[b * 4 + 3] = nm.rm;
+                }
                 iters = it;
-                if (nm.nan != nm.nan) { status = 3; done = true; }
+                if (nm.nan != nm.nan) { status = 3; fin = true; }
                 else if (nm.rg <= S.tol_stat && nm.rb <= S.tol_eq && nm.rd <= S.tol_ineq && nm.rm <= S.tol_comp) {
-                    status = 0; done = true;
-                } else if (it >= itmax) { status = 1; done = true; }
+                    status = 0; fin = true;
+                } else if (it >= itmax) { status = 1; fin = true; }
             }
-#ifdef USV_DEBUG_FIXED_ITERS // timing experiments only: fixed iteration count, subset of sweeps
-            done = false;
-            if (it >= USV_DEBUG_FIXED_ITERS) break;
-#endif
+            done = done || fin;
+            late = false;
+            if (lanes::wave_any(fin)) { // wave-uniform
+                finish(fin, real, status, iters, phase);
+                real = fin ? false : real;
+                if (refill) {
+                    // one ticket per finished row; beyond the batch there is nothing left and the row stays idle
+                    int gn = 0;
+                    if (fin && lane == 0) gn = queue0 + lanes::fetch_add(P.queue);
+                    gn = lanes::bcast_i<0>(gn);
+                    const bool take = fin && gn < nB;
+                    if (lanes::wave_any(take)) { // wave-uniform
+                        bind((long)gn, take);
+                        init(take);
+                        real = take ? true : real;
+                        done = take ? false : done;
+                        fresh = take;
+                        pend = take ? false : pend;
+                        rbscale = take ? 1.0 : rbscale;
+                        it = take ? 0 : it;
+                        status = take ? 1 : status;
+                    }
+                }
+            }
             if (!lanes::wave_any(!done)) break;
+            const bool run = !done && !fresh; // rows that take part in the rest of this pass
             const double mu = nc > 0.0 ? nm.musum / nc : 0.0;
             double a_aff = 1.0, S1 = 0.0, S2 = 0.0, a = 1.0, d1, d2;
-#ifdef USV_DEBUG_FIXED_ITERS
-            if (USV_DEBUG_SWEEPS & 1)
-#endif
             forward<false>(0.0, a_aff, S1, S2);
             double sigmu = 0.0;
             if (nc > 0.0) {
@@ -1148,66 +1253,14 @@ struct QpIpm {
                 const double sg = mu_aff / mu;
                 sigmu = sg * sg * sg * mu;
             }
-#ifdef USV_DEBUG_FIXED_ITERS
-            if (USV_DEBUG_SWEEPS & 2)
-#endif
             backward<false>(nm, sigmu, false, 0.0, 0.0);
-#ifdef USV_DEBUG_FIXED_ITERS
-            if (USV_DEBUG_SWEEPS & 4)
-#endif
             forward<true>(sigmu, a, d1, d2);
-            if (!done && a < S.alpha_min) { status = 2; done = true; iters = it; }
-            a_prev = a * ((1.0 - a) * 0.99 + a * 0.9999999);
-            sig_prev = sigmu;
-            pend = true;
-        }
-        // ---- RTI step + outputs
-        const bool ok = (status == 0 || status == 1);
-        const bool real = g < nB && !frozen;
-        double tmin = 1e300; // smallest t_l over this instance's obstacle rows: how close the QP solution sits to a keep-out circle
-        for (int k = 0; k <= N; k++) {
-            const Planes W = ws(k);
-            const double z = W.ld(P_Z); // zbar + z: the new iterate
-            if constexpr (KCH > 0) {
-                if (k >= 1 && k < N) { // wave-uniform
-                    sfor<0, KCH>([&](auto c) {
-                        const double tl = W.ld(P_OBS + c * OBSN + 2);
-                        tmin = (c * LANES + lane < Kn) ? fmin(tmin, tl) : tmin;
-                    });
-                }
-            }
-            if (real) {
-                if (ok && xlane) P.x[((long)b * (N + 1) + k) * NX + (lane - NU)] = z;
-                if (ok && ulane && k < N) P.u[((long)b * N + k) * NU + lane] = z;
-                if (k >= 1 && xlane && P.pi) P.pi[((long)b * N + (k - 1)) * NX + (lane - NU)] = W.ld(P_PI);
-            }
-            if constexpr (KCH > 0 && SOFT) {
-                if (k < N) {
-                    sfor<0, KCH>([&](auto c) {
-                        const int i = c * LANES + lane;
-                        if (real && i < S.K && P.sl) {
-                            const bool act = k >= 1;
-                            const int p0 = P_OBS + c * OBSN;
-                            P.sl[((long)b * N + k) * S.K + i] = act ? W.ld(p0 + 4) : 0.0;
-                            P.su[((long)b * N + k) * S.K + i] = act ? W.ld(p0 + 5) : 0.0;
-                        }
-                    });
-                }
-            }
-        }
-        tmin = lanes::gmin(tmin);
-        if (real && lane == 0) {
-            if (P.obs_tmin) P.obs_tmin[b] = tmin;
-            if (!ok && P.fail_count) lanes::count_one(P.fail_count);
-            P.status[b] = ok ? 0 : 4;
-            P.qp_iter[b] = iters;
-            P.res[b * 4 + 0] = res0; P.res[b * 4 + 1] = res1; P.res[b * 4 + 2] = res2; P.res[b * 4 + 3] = res3;
-            P.qp_status[b] = status;
-            if (phase > 0) {
-                P.sqp_iter[b] += 1;
-                if (!ok) P.sqp_state[b] = 4;
-                else lanes::count_one(P.sqp_running);
-            }
+            if (run && a < S.alpha_min) { status = 2; done = true; late = true; iters = it; }
+            a_prev = run ? a * ((1.0 - a) * 0.99 + a * 0.9999999) : a_prev;
+            sig_prev = run ? sigmu : sig_prev;
+            pend = run ? true : pend;
+            it = run ? it + 1 : it;
+            fresh = false;
         }
     }
 };

@@ -38,12 +38,12 @@ __global__ void __launch_bounds__(256, 2) usv_linearize(DevPtrs P, long ngroups)
 #define USV_QP_WAVES 2 // waves per SIMD the QP kernel is compiled for (register budget 512 / USV_QP_WAVES)
 #endif
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX>
-__global__ void __launch_bounds__(64, USV_QP_WAVES) usv_qp_rti(DevPtrs P, long ngroups, int phase)
+__global__ void __launch_bounds__(64, USV_QP_WAVES) usv_qp_rti(DevPtrs P, long ngroups, int phase, int queue0)
 {
     const long gid = lanes::group_linear();
     if (gid >= ngroups) return;
     QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX> q(P, gid);
-    q.solve(phase);
+    q.solve(phase, queue0);
 }
 
 // full SQP bookkeeping: start of a call (everything running) and end (still running = max iterations)
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(64) usv_calib_stream(DevPtrs P, long ngroups, 
 {
     const long g = lanes::group_linear();
     if (g >= ngroups) return;
-    const lanes::Planes W(P.ws + (long)blockIdx.x * (nread + 1) * 64, nread + 1, lanes::wave_lane());
+    const lanes::Planes W(P.ws, (unsigned)(ngroups * (nread + 1) * 128), lanes::Planes::lane_offset(g, nread + 1, lanes::lane()));
     double acc = 0.0;
     for (int i = 0; i < nread; i++) acc += W.ld(i);
     W.st(nread, acc);
@@ -184,6 +184,9 @@ struct usvmpc_handle {
     double *gd_world;   // [B][n_world][3] world obstacles of the last usvmpc_guidance_sense
     size_t gd_world_cap;
     bool sort_enabled;
+    bool dynamic_rows;        // QP kernel as a persistent launch whose rows pull instances from a queue (option "dynamic_rows")
+    int ncu;                  // compute units of the device
+    long qp_cap;              // groups a full-occupancy launch of the QP kernel holds at once (0: not yet known)
     bool map_changed;         // the group -> instance map differs from the one the workspace's multipliers were written under
     unsigned noise_mask;      // states usvmpc_advance disturbs (option "disturbance_mask"; default: all)
     int *d_fail_ring;         // [RING] instances with status != 0, one slot per solve
@@ -312,7 +315,6 @@ int launch_pair(usvmpc_handle *h, int phase)
     const long qp_groups = h->Bp;
     const int lin_block = 256, qp_block = 64;
     const long lin_grid = (lin_groups * LANES + lin_block - 1) / lin_block;
-    const long qp_grid = (qp_groups * LANES + qp_block - 1) / qp_block;
     hipEvent_t *ev = h->ev[h->nsolves % usvmpc_handle::RING];
     // (the later iterations of a full SQP read the multipliers the previous launch left in the group-indexed
     // workspace: the group -> instance map must not change inside one SQP call)
@@ -336,26 +338,45 @@ int launch_pair(usvmpc_handle *h, int phase)
     HIP_TRY(h, hipMemsetAsync(h->ptrs.fail_count, 0, sizeof(int), h->stream));
     constexpr bool CANPACK = KCH > 0;
     const bool pack = CANPACK && h->spec.boxpack != 0;
-    const dim3 qg((unsigned)qp_grid), qb(qp_block);
     if (h->spec.npt != (h->spec.any_bsoft ? WsLayout<M, KCH, SOFT, true>::NPT : WsLayout<M, KCH, SOFT, false>::NPT)) {
         h->err = "workspace layout mismatch between host and kernels";
         return USVMPC_E_ARG;
     }
+    // An RTI solve is ONE launch of as many waves as the device holds at once; their rows start on the first groups and
+    // pull the remaining ones from a queue as they finish (qp_ipm.hpp).  The full SQP keeps one group per row: its later
+    // iterations find their multipliers in the group's part of the workspace.
+    auto launch_qp = [&](auto kern) -> int {
+        long ng = qp_groups;
+        int q0 = -1;
+        if (h->dynamic_rows && phase == 0) {
+            if (h->qp_cap == 0) {
+                int nb = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, qp_block, 0) == hipSuccess && nb > 0 && h->ncu > 0)
+                    h->qp_cap = 4L * nb * h->ncu;
+                else
+                    h->qp_cap = -1;
+            }
+            if (h->qp_cap > 0 && h->qp_cap < qp_groups) { ng = h->qp_cap; q0 = (int)ng; }
+        }
+        if (q0 >= 0) HIP_TRY(h, hipMemsetAsync(h->ptrs.queue, 0, sizeof(int), h->stream));
+        const dim3 qg((unsigned)((ng * LANES + qp_block - 1) / qp_block)), qb(qp_block);
+        hipLaunchKernelGGL(kern, qg, qb, 0, h->stream, h->ptrs, ng, phase, q0);
+        return 0;
+    };
+    int rcq = 0;
 #ifdef USV_BENCH_ONLY // development builds (tools/dev_build.sh): only the instantiation the bench workload runs
     if (!(h->spec.hdiag && pack && !h->spec.any_bsoft)) { h->err = "development build: bench instantiation only"; return USVMPC_E_ARG; }
-    hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
+    rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>);
 #else
     if (h->spec.any_bsoft) { // soft state bounds: rows with slacks, ten planes of their own
-        if (h->spec.hdiag) hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, false, true>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
-        else hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, false, true>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
+        rcq = h->spec.hdiag ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, true>) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, true>);
     } else if (h->spec.hdiag) {
-        if (pack) hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
-        else hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, true, false, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
+        rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>) : launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, false>);
     } else {
-        if (pack) hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, CANPACK, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
-        else hipLaunchKernelGGL((usv_qp_rti<M, KCH, SOFT, false, false, false>), qg, qb, 0, h->stream, h->ptrs, qp_groups, phase);
+        rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, false, CANPACK, false>) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, false>);
     }
 #endif
+    if (rcq) return rcq;
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[2], h->stream));
     h->nsolves++;
@@ -467,6 +488,12 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->bytes = 0; h->nsolves = 0; h->own_stream = true;
     h->map_changed = false;
     h->noise_mask = ~0u;
+    h->dynamic_rows = true;
+    h->qp_cap = 0;
+    {
+        hipDeviceProp_t prop;
+        h->ncu = (hipGetDeviceProperties(&prop, d->device) == hipSuccess) ? prop.multiProcessorCount : 0;
+    }
     std::memset(&h->ptrs, 0, sizeof(h->ptrs));
     auto fail = [&](int rc) {
         std::fprintf(stderr, "usvmpc_create: %s\n", h->err.c_str());
@@ -505,6 +532,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     TRY_C(dev_alloc(h, &P.res, B * 4, true));
     TRY_C(dev_alloc(h, &P.obs_tmin, B, true));
     TRY_C(dev_alloc(h, &h->d_fail_ring, usvmpc_handle::RING, true));
+    TRY_C(dev_alloc(h, &P.queue, 1, true));
     TRY_C(dev_alloc(h, &P.nlp_res, B * 4, true));
     TRY_C(dev_alloc(h, &P.sqp_iter, B, true));
     TRY_C(dev_alloc(h, &P.sqp_state, B, true));
@@ -755,13 +783,18 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         if (!h->sort_enabled && h->ptrs.perm) { h->ptrs.perm = nullptr; h->map_changed = true; }
         return 0;
     }
+    if (s == "dynamic_rows") { // 0: one group per row for the whole launch (the rows of a wave wait for its slowest)
+        h->dynamic_rows = value != 0.0;
+        h->qp_cap = 0;
+        return 0;
+    }
     if (s == "disturbance_mask") { // bit j: usvmpc_advance adds its noise to state j
         h->noise_mask = (unsigned)value;
         return 0;
     }
     if (s == "static_obstacles" || s == "pack_box_rows") {
         if (s == "static_obstacles") h->spec.p_static = value != 0.0;
-        else h->spec.boxpack = (value != 0.0 && h->spec.boxpack_ok) ? 1 : 0;
+        else { h->spec.boxpack = (value != 0.0 && h->spec.boxpack_ok) ? 1 : 0; h->qp_cap = 0; }
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipMemcpyAsync(h->d_spec, &h->spec, sizeof(DevSpec), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -101,7 +101,7 @@ namespace {
 
 using namespace usv;
 
-struct Job { const DevPtrs *P; long gid; int qp_phase; };
+struct Job { const DevPtrs *P; long gid; int qp_phase; int queue0; };
 
 template <class M, int KCH, bool SOFT>
 void lin_body(void *a)
@@ -115,12 +115,13 @@ void qp_body(void *a)
 {
     Job *j = (Job *)a;
     QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX> q(*j->P, j->gid);
-    q.solve(j->qp_phase);
+    q.solve(j->qp_phase, j->queue0);
 }
 
 // inspection copies of the lineariser's output: BAt [N][nx][Bp*16] (the packed planes expanded back to one plane
 // per row), rb0 [N][Bp*16], gq [N+1][Bp*16]
 double *g_dbg_BAt = nullptr, *g_dbg_rb0 = nullptr, *g_dbg_gq = nullptr;
+long g_emu_rows = 2; // persistent rows of an emulated RTI solve (0: one row per group, no queue)
 
 template <class M, int KCH, bool SOFT>
 void expand_packed(const DevPtrs &P, const DevSpec &S)
@@ -128,9 +129,9 @@ void expand_packed(const DevPtrs &P, const DevSpec &S)
     using MP = MatPack<M>;
     using WL = WsLayout<M, KCH, SOFT>;
     const long stride = (long)S.Bp * LANES;
-    // workspace element (stage k, plane e, group g, lane r): [stage][tile of 4 groups][plane][64 lanes]
+    // workspace element (stage k, plane e, group g, lane r): [stage][group][plane][16 lanes]
     auto at = [&](int k, int e, long g, int r) -> double {
-        return P.ws[((((long)k * (S.Bp / 4) + (g >> 2)) * S.npt + e) * 64) + (g & 3) * LANES + r];
+        return P.ws[(((long)k * S.Bp + g) * S.npt + e) * LANES + r];
     };
     for (int k = 0; k <= S.N; k++)
         for (long g = 0; g < S.Bp; g++)
@@ -162,13 +163,18 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
     const_cast<DevSpec &>(S).npt = S.any_bsoft ? WsLayout<M, KCH, SOFT, true>::NPT : WsLayout<M, KCH, SOFT, false>::NPT;
     if (phase & 1)
         for (long gid = 0; gid < (long)(S.N + 1) * S.Bp; gid++) {
-            Job j{&P, gid, 0};
+            Job j{&P, gid, 0, -1};
             lanes::run_group(gid, &lin_body<M, KCH, SOFT>, &j);
         }
     if ((phase & 1) && (g_dbg_BAt || g_dbg_rb0 || g_dbg_gq)) expand_packed<M, KCH, SOFT>(P, S);
+    // RTI: a few persistent rows that pull the remaining groups from the queue (as the device launch does); full SQP: one
+    // group per row
+    const bool queue = qp_phase == 0 && g_emu_rows > 0 && g_emu_rows < S.Bp;
+    const long nrows = queue ? g_emu_rows : S.Bp;
+    if (queue) *P.queue = 0;
     if (phase & 2)
-        for (long g = 0; g < S.Bp; g++) {
-            Job j{&P, g, qp_phase};
+        for (long g = 0; g < nrows; g++) {
+            Job j{&P, g, qp_phase, queue ? (int)nrows : -1};
             constexpr bool CANPACK = KCH > 0;
             const bool pack = CANPACK && S.boxpack != 0;
             if (S.any_bsoft) {
@@ -219,6 +225,8 @@ static int emu_run(const usvmpc_desc *d, int sqp, double *x, double *u, const do
     P.sl = sl; P.su = su; P.pi = pi; P.status = status; P.qp_iter = qp_iter; P.qp_status = qp_status; P.res = res;
     P.ws = ws.data();
     P.nlp_res = nres.data(); P.sqp_iter = sit.data(); P.sqp_state = sstate.data(); P.sqp_running = &running;
+    int queue = 0;
+    P.queue = &queue;
     g_dbg_BAt = dbg_BAt; g_dbg_rb0 = dbg_rb0; g_dbg_gq = dbg_gq;
     auto one = [&](int qp_phase) -> int {
         const int phase = 3;

@@ -49,6 +49,9 @@ template <int K>
 inline double bcast(double v) { return exchange(v, K); }
 
 template <int K>
+inline int bcast_i(int v) { return (int)exchange((double)v, K); }
+
+template <int K>
 inline void fma_bc(double &c, double b_remote, double a_own) { c = std::fma(bcast<K>(b_remote), a_own, c); }
 
 inline double gather(double v, int src) { return exchange(v, src); }
@@ -88,6 +91,7 @@ inline bool wave_any(bool p) { return gmax(p ? 1.0 : 0.0) > 0.5; }
 inline int uniform(int v) { return v; }
 inline void sched_fence() {}
 inline void count_one(int *p) { ++*p; }
+inline int fetch_add(int *p) { return (*p)++; }
 
 inline double frcp(double x) { return 1.0 / x; }
 inline double frsqrt(double x) { return 1.0 / std::sqrt(x); }
@@ -95,21 +99,23 @@ inline double frsqrt(double x) { return 1.0 / std::sqrt(x); }
 // lane index inside the (emulated) wave: the group's quarter of its 4-group tile
 inline unsigned wave_lane() { return (unsigned)((g_emu.group & 3) * 16 + g_emu.cur); }
 
-// one wave's tile of lane-major planes [nplanes][64] (plain pointers here; a buffer resource on the GPU)
+// the planes of one stage [group][plane][16] (plain pointers here; a buffer resource on the GPU)
 struct Planes {
     double *base;
-    int nplanes;
-    unsigned wl;
-    Planes(const double *tile, int n, unsigned w) : base(const_cast<double *>(tile)), nplanes(n), wl(w) {}
+    unsigned nbytes, voff;
+    static unsigned lane_offset(long group, int nplanes, int lane) { return (unsigned)(group * nplanes * 128 + lane * 8); }
+    Planes(const double *b, unsigned n, unsigned v) : base(const_cast<double *>(b)), nbytes(n), voff(v) {}
     double ld(int plane) const
     {
-        if (plane < 0 || plane >= nplanes) { std::fprintf(stderr, "Planes::ld out of window (%d of %d)\n", plane, nplanes); std::abort(); }
-        return base[(long)plane * 64 + wl];
+        const unsigned o = voff + (unsigned)plane * 128u;
+        if (plane < 0 || o + 8 > nbytes) { std::fprintf(stderr, "Planes::ld out of window (plane %d)\n", plane); std::abort(); }
+        return base[o / 8];
     }
     void st(int plane, double x) const
     {
-        if (plane < 0 || plane >= nplanes) { std::fprintf(stderr, "Planes::st out of window (%d of %d)\n", plane, nplanes); std::abort(); }
-        base[(long)plane * 64 + wl] = x;
+        const unsigned o = voff + (unsigned)plane * 128u;
+        if (plane < 0 || o + 8 > nbytes) { std::fprintf(stderr, "Planes::st out of window (plane %d)\n", plane); std::abort(); }
+        base[o / 8] = x;
     }
 };
 

@@ -37,8 +37,14 @@ __global__ void __launch_bounds__(256, 2) usv_linearize(DevPtrs P, long ngroups)
 #ifndef USV_QP_WAVES
 #define USV_QP_WAVES 2 // waves per SIMD the QP kernel is compiled for (register budget 512 / USV_QP_WAVES)
 #endif
+// Two obstacle chunks (K > 16) or soft state bounds keep twice the row state in flight: those instantiations get the whole
+// register file of a SIMD (one wave, 512 registers) instead of spilling 100-280 registers at two waves - the kernel is
+// issue-bound, a second wave buys little and scratch traffic costs a lot.
+template <int KCH, bool SOFTBOX>
+constexpr int qp_waves() { return (KCH >= 2 || SOFTBOX) ? 1 : USV_QP_WAVES; }
+
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX>
-__global__ void __launch_bounds__(64, USV_QP_WAVES) usv_qp_rti(DevPtrs P, long ngroups, int phase, int queue0)
+__global__ void __launch_bounds__(64, (qp_waves<KCH, SOFTBOX>())) usv_qp_rti(DevPtrs P, long ngroups, int phase, int queue0)
 {
     const long gid = lanes::group_linear();
     if (gid >= ngroups) return;

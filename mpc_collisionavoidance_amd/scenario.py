@@ -86,7 +86,8 @@ def _pf_ca_rollout(x0, N, dt, steps):
     return out
 
 
-def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None, generator="beside", sim_steps=1):
+def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None, generator="beside", sim_steps=1,
+               max_range=6.0, clip_time=1.2):
     """Returns dict(x0 [B,nx], yref [B,N,ny], yref_e [B,nx], p [B,N+1,2K], lh [B,N,K],
     x_init [B,N+1,nx], u_init [B,N,nu]).
 
@@ -151,12 +152,12 @@ def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None, g
         lhv = R + margin
         if name == "usv_model_guidance_ca1" or survey:
             # polar about the vehicle: bearing within +-60 deg of the course, range R+0.7 .. 6 m
-            rad = (R + 0.7) + rng.uniform(0.0, 1.0, (B, K)) * np.maximum(6.0 - (R + 0.7), 0.0)
+            rad = (R + 0.7) + rng.uniform(0.0, 1.0, (B, K)) * np.maximum(max_range - (R + 0.7), 0.0)
             rel = rng.uniform(-np.pi / 3, np.pi / 3, (B, K))
             if survey:
                 # hard rows: the course ray enters the keep-out circle (radius lh) at s = lon - sqrt(lh^2 - lat^2);
                 # obstacles with s < s_min(u) move out along their bearing to the range where s = s_min
-                smin = (0.4 + 1.2 * u)[:, None]
+                smin = (0.4 + clip_time * u)[:, None]
                 lat, lon = rad * np.sin(rel), rad * np.cos(rel)
                 hit = np.abs(lat) < lhv
                 s_enter = np.where(hit, lon - np.sqrt(np.maximum(lhv ** 2 - lat ** 2, 0.0)), np.inf)
@@ -189,6 +190,13 @@ def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None, g
             vel = np.zeros((B, K, 2))
         elif name == "usv_model_guidance_ca1" or survey:
             vel = rng.uniform(-0.3, 0.3, (B, K, 2))
+            if survey:
+                # hard rows: an obstacle that closes in on the vehicle cannot be answered by a slack; the component of its
+                # velocity towards the vehicle's position is removed (it may still cross the path ahead)
+                er = np.stack([ox - nedx[:, None], oy - nedy[:, None]], axis=2)
+                er /= np.linalg.norm(er, axis=2, keepdims=True)
+                vr = (vel * er).sum(axis=2, keepdims=True)
+                vel = vel - np.minimum(vr, 0.0) * er
         else:
             # hard rows: obstacles slide parallel to the course, which keeps their lateral clearance
             # (a drift towards the path would make the hard-constrained QPs infeasible)
@@ -222,9 +230,15 @@ def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None, g
 
 
 def make_bench_batch(name, N, K, B, seed=1234, moving=False):
-    """The benchmark workload of SURVEY.md 8(d) for `name`: dt = 0.05 s, the "survey" generator."""
+    """The benchmark workload of SURVEY.md 8(d) for `name`: dt = 0.05 s, the "survey" generator.  SURVEY's obstacle field
+    (range up to 6 m, course ray clear for 0.4 m + 1.2 s * u) is sized for the 2 s look-ahead of N = 40; a longer horizon
+    scales both with it (range up to 3 Tf metres, course ray clear for 1.1 Tf): at N = 80 the same circles in the same
+    6 m sector wall the vehicle in and a third of the hard-row QPs have no feasible point."""
+    Tf = N * BENCH_DT
+    long_h = Tf > 2.0 + 1e-9
     return make_batch(name, N, K, B, dt=BENCH_DT, seed=seed, moving=moving, generator="survey",
-                      sim_steps=BENCH_SIM_STEPS[name])
+                      sim_steps=BENCH_SIM_STEPS[name], max_range=3.0 * Tf if long_h else 6.0,
+                      clip_time=1.1 * Tf if long_h else 1.2)
 
 
 def load_into(solver, wl):

@@ -110,7 +110,7 @@ int usvmpc_get(usvmpc_handle *h, const char *field, int stage, double *out, size
 /* further get fields: "obs_tmin" (stage ignored, n = 1): the smallest lower-side slack t_l over the instance's obstacle rows
  * in the last QP (1e300 without rows) - below ~1e-3 the solution touches a keep-out circle, i.e. an obstacle row is active */
 /* integer per-instance results: "status" (0 | 4; after usvmpc_solve_sqp 0 | 2 | 4), "qp_status" (0 ok,
- * 1 max iter,2 min step, 3 nan), "qp_iter", "sqp_iter" */
+ * 1 max iter, 2 min step, 3 nan, 4 x0 violates a hard obstacle row of stage 0 - the QP has no feasible point), "qp_iter", "sqp_iter" */
 int usvmpc_get_int(usvmpc_handle *h, const char *field, int *out);
 
 /* One SQP-RTI iteration for every instance; returns the worst status. status may be NULL. */

@@ -177,6 +177,12 @@ class BatchOcpSolver:
             self.nx, self.nu = _capi.MODEL_DIMS[self._desc.model]
             self._lib = _capi.lib()
         self.ny, self.ny_e = self.nx + self.nu, self.nx
+        # (acados' make_consistent rejects a reference of the wrong length; an unset one - None or empty - stays zero)
+        for nm, want in (("yref", self.ny), ("yref_e", self.ny_e)):
+            v = getattr(ocp.cost, nm, None)
+            if v is not None and np.asarray(v).size not in (0, want):
+                raise Exception("inconsistent dimension: cost.%s has %d entries, the cost has ny%s = %d"
+                                % (nm, np.asarray(v).size, "_e" if nm == "yref_e" else "", want))
         h = C.c_void_p()
         rc = self._lib.usvmpc_create(C.byref(self._desc), C.byref(h))
         if rc != 0:
@@ -346,10 +352,9 @@ class AcadosOcpSolver:
                 raise Exception("lbx/ubx can be set at stage 0 only (x0 embedding); state bounds are part of the OCP definition")
             v = self._vec(value_, b.nx, field_)
             setattr(self, "_" + field_, v)
-            other = getattr(self, "_ubx" if field_ == "lbx" else "_lbx", None)
-            # the reference always writes lbx = ubx = x0 (usv_guidance_ca1/main.py:111-112)
-            if other is None or np.array_equal(other, v):
-                b.set("x0", 0, v)
+            # the reference always writes lbx = ubx = x0 (usv_guidance_ca1/main.py:111-112): every write moves x0, and
+            # solve() refuses to run while the two bounds disagree (a genuine stage-0 box is not supported)
+            b.set("x0", 0, v)
             return
         if field_ == "yref":
             n = b.ny_e if stage_ == b.N else b.ny
@@ -375,6 +380,10 @@ class AcadosOcpSolver:
             raise Exception("AcadosOcpSolver.constraints_set(): {} is not a valid argument.".format(field_))
 
     def solve(self):
+        lo, hi = getattr(self, "_lbx", None), getattr(self, "_ubx", None)
+        if lo is not None and hi is not None and not np.array_equal(lo, hi):
+            raise Exception("AcadosOcpSolver.solve(): lbx and ubx of stage 0 differ - this solver embeds the initial "
+                            "state as lbx = ubx = x0 and does not support a stage-0 box")
         if self._sqp:
             self.status = int(self._b.solve_sqp()[0])
         else:

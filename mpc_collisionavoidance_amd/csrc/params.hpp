@@ -134,7 +134,7 @@ struct DevPtrs {
     double *pi;           // [B][N][nx]  dynamics multipliers pi_1..pi_N of the last QP
     int *status;          // [B]
     int *qp_iter;         // [B]
-    int *qp_status;       // [B]   0 ok, 1 max iter, 2 min step, 3 nan
+    int *qp_status;       // [B]   0 ok, 1 max iter, 2 min step, 3 nan, 4 x0 violates a hard stage-0 obstacle row
     double *res;          // [B][4]      final QP residuals (stat, eq, ineq, comp)
     double *obs_tmin;     // [B]         smallest lower-side slack t_l over the obstacle rows of the last QP (1e300 without rows)
     int *fail_count;      // [1]         instances of THIS launch whose solve ended with status != 0 (host points it at a ring slot)

@@ -476,10 +476,13 @@ struct QpIpm {
 
     // ------------------------------------------------------------------ cold start
     // (an instance that a full SQP has frozen keeps the multipliers of its last QP: keep)
-    // sel: rows to cold-start
-    USV_DEV void init(bool sel)
+    // sel: rows to cold-start.  Returns whether x0 violates a HARD obstacle row of stage 0: acados applies the nh rows at
+    // stages 0..N-1; at stage 0 they depend on no free variable (D = 0, x_0 is pinned to x0) and are not rows of the QP
+    // solved here, but a violated hard one makes acados' QP infeasible - status 4, iterate untouched.
+    USV_DEV bool init(bool sel)
     {
         const bool wr = sel && !keep;
+        double bad0 = 0.0;
         for (int k = 0; k <= N; k++) {
             const Planes W = ws(k);
             const double zb = zbar(k);
@@ -519,9 +522,21 @@ struct QpIpm {
                         o.lsl = S.mu0 / o.tsl; o.lsu = S.mu0 / o.tsu;
                     }
                     if (wr) obs_store(W, c, o, (PACK && c == KCH - 1) ? pk : nullptr);
+                    if constexpr (!SOFT) {
+                        if (k == 0) { // wave-uniform
+                            const double e0 = xlane ? P.x0[(long)b * NX + (lane - NU)] - zb : 0.0; // x0 - xbar_0
+                            double d, ux, uy;
+                            obs_dist(zbx - raw[0], zby - raw[1], d, ux, uy);
+                            const double v0 = ux * lanes::bcast<PXL>(e0) + uy * lanes::bcast<PYL>(e0);
+                            const bool row = c * LANES + lane < Kn;
+                            const double tol = S.tol_ineq;
+                            bad0 = (row && (raw[2] - d - v0 > tol || d + v0 - c_uh[c] > tol)) ? 1.0 : bad0;
+                        }
+                    }
                 });
             }
         }
+        return lanes::gmax(bad0) > 0.5;
     }
 
     struct Norms { double rg, rb, rd, rm, musum, nan; };
@@ -1136,14 +1151,32 @@ struct QpIpm {
                 if (k >= 1 && xlane && P.pi) P.pi[((long)b * N + (k - 1)) * NX + (lane - NU)] = W.ld(P_PI);
             }
             if constexpr (KCH > 0 && SOFT) {
-                if (k < N) {
+                if (k >= 1 && k < N) {
                     sfor<0, KCH>([&](auto c) {
                         const int i = c * LANES + lane;
                         if (out && i < Kn && P.sl) {
-                            const bool act = k >= 1;
                             const int p0 = P_OBS + c * OBSN;
-                            P.sl[((long)b * N + k) * Kn + i] = act ? W.ld(p0 + 4) : 0.0;
-                            P.su[((long)b * N + k) * Kn + i] = act ? W.ld(p0 + 5) : 0.0;
+                            P.sl[((long)b * N + k) * Kn + i] = W.ld(p0 + 4);
+                            P.su[((long)b * N + k) * Kn + i] = W.ld(p0 + 5);
+                        }
+                    });
+                } else if (k == 0) { // wave-uniform
+                    // soft rows of stage 0 (see init): x_0 = x0 fixes their value, the slacks minimise their own penalty
+                    const double aux = W.ld(P_AUX);
+                    const double zbx = aux_zx(aux), zby = aux_zy(aux);
+                    const double e0 = z - pos_sel(zbx, zby); // x0 - xbar_0 on the position lanes
+                    sfor<0, KCH>([&](auto c) {
+                        const int i = c * LANES + lane;
+                        double raw[3], d, ux, uy;
+                        obs_raw<c>(0, raw);
+                        obs_dist(zbx - raw[0], zby - raw[1], d, ux, uy);
+                        const double v0 = ux * lanes::bcast<PXL>(e0) + uy * lanes::bcast<PYL>(e0);
+                        double a = fmax(c_bsl[c], raw[2] - d - v0), q = fmax(c_bsu[c], d + v0 - c_uh[c]);
+                        if (c_Zl[c] > 0.0) a = fmax(a, -c_zl[c] / c_Zl[c]);
+                        if (c_Zu[c] > 0.0) q = fmax(q, -c_zu[c] / c_Zu[c]);
+                        if (out && i < Kn && P.sl) {
+                            P.sl[(long)b * N * Kn + i] = a;
+                            P.su[(long)b * N * Kn + i] = q;
                         }
                     });
                 }
@@ -1191,15 +1224,17 @@ struct QpIpm {
             if (!lanes::wave_any(!frozen)) return;
         }
         keep = frozen;
-        init(true);
+        const bool bad0 = init(true);
         // ---- per-row state of the IPM (every row is in its own iteration)
         rbscale = 1.0;
         bool real = g < nB && !frozen;   // the row holds an instance whose results are to be written
         bool done = frozen;              // nothing (more) to iterate on in this row
         bool pend = false;               // a step of the previous iteration is waiting to be applied
         bool fresh = false;              // cold-started after this pass's factorisation sweep: sits out the rest of the pass
-        bool late = false;               // stopped by the step-length floor after the factorisation sweep: results next pass
-        int status = 1, iters = 0, it = 0;
+        bool late = bad0 && !frozen;     // stopped after the factorisation sweep (step-length floor), or never started
+                                         // (x0 inside a hard keep-out circle): results at the next pass
+        int status = late ? 4 : 1, iters = 0, it = 0;
+        done = done || late;
         Norms nm;
         double a_prev = 0.0, sig_prev = 0.0;
         const double nc = (double)S.nc;
@@ -1231,14 +1266,16 @@ struct QpIpm {
                     const bool take = fin && gn < nB;
                     if (lanes::wave_any(take)) { // wave-uniform
                         bind((long)gn, take);
-                        init(take);
+                        const bool bad = init(take) && take;
                         real = take ? true : real;
-                        done = take ? false : done;
+                        done = take ? bad : done;
+                        late = bad;
                         fresh = take;
                         pend = take ? false : pend;
                         rbscale = take ? 1.0 : rbscale;
                         it = take ? 0 : it;
-                        status = take ? 1 : status;
+                        iters = take ? 0 : iters;
+                        status = take ? (bad ? 4 : 1) : status;
                     }
                 }
             }

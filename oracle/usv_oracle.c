@@ -1343,6 +1343,18 @@ static int rti_core(const usv_spec *s, usv_qp *q, usv_qp_sol *sol, double *x, do
     const int N = s->N, nx = s->nx, nu = s->nu, nz = nx + nu, K = s->K;
     int k, i, qs, status;
     usv_linearize(s, x, u, x0, yref, yref_e, p, lh, q);
+    /* Stage-0 obstacle rows.  acados applies the nh rows at stages 0..N-1; at stage 0 they depend on no free variable
+     * (D = 0 and x_0 is pinned to x0), so they are not rows of the QP solved here - but a HARD row that x0 violates
+     * makes acados' QP infeasible: status 4 and an untouched iterate, reported here without iterating (qp_status 4). */
+    if (K > 0 && !q->soft) {
+        for (i = 0; i < K; i++) {
+            const double v0 = q->Cxy[2 * i] * q->dx0[q->ipx] + q->Cxy[2 * i + 1] * q->dx0[q->ipy];
+            if (q->lg[i] - v0 > s->opts.tol_ineq || v0 - q->ug[i] > s->opts.tol_ineq) {
+                if (info) { info[0] = 0; info[1] = 4; for (k = 0; k < 4; k++) info[2 + k] = 0.0; info[6] = 0; info[7] = 0; }
+                return 4;
+            }
+        }
+    }
     qs = usv_qp_solve(q, &s->opts, sol);
     status = (qs == 0 || qs == 1) ? 0 : 4; /* max-iter tolerated in RTI */
     if (status == 0) {
@@ -1357,6 +1369,15 @@ static int rti_core(const usv_spec *s, usv_qp *q, usv_qp_sol *sol, double *x, do
             if (sl) sl[k * K + i] = sol->sl[k * K + i];
             if (su) su[k * K + i] = sol->su[k * K + i];
         }
+        if (k == 0 && q->soft) /* soft stage-0 rows: the slacks are constants, the minimisers of their own penalty */
+            for (i = 0; i < K; i++) {
+                const double v0 = q->Cxy[2 * i] * q->dx0[q->ipx] + q->Cxy[2 * i + 1] * q->dx0[q->ipy];
+                double a = fmax(q->lsl[i], q->lg[i] - v0), c = fmax(q->lsu[i], v0 - q->ug[i]);
+                if (q->Zl[i] > 0.0) a = fmax(a, -q->zl[i] / q->Zl[i]);
+                if (q->Zu[i] > 0.0) c = fmax(c, -q->zu[i] / q->Zu[i]);
+                if (sl) sl[i] = a;
+                if (su) su[i] = c;
+            }
         if (pi)
             for (i = 0; i < nx; i++) pi[k * nx + i] = sol->pi[(k + 1) * nx + i];
     }

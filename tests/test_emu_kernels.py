@@ -111,7 +111,8 @@ def test_soft_slacks_and_multipliers_exported(oracle, emu):
         o = oracle.rti(spec, wl["x_init"][b], wl["u_init"][b], wl["x0"][b], wl["yref"][b], wl["yref_e"][b], wl["p"][b], wl["lh"][b])
         assert np.allclose(r["sl"][b], o["sl"], atol=1e-7) and np.allclose(r["su"][b], o["su"], atol=1e-7)
         assert np.allclose(r["pi"][b], o["pi"], rtol=1e-6, atol=1e-7)
-        assert np.allclose(r["sl"][b][0], 0.0)  # stage 0 carries no h rows
+        # stage 0: the rows take no part in the QP, their slacks are the constants max(lsh, lh - h(x0)) = lsh here
+        assert np.allclose(r["sl"][b][0], -0.2) and np.allclose(r["su"][b][0], 0.0)
 
 
 @pytest.mark.parametrize("name,K", [("usv_model_guidance_ca1", 5), ("usv_model_pf_ca", 20)])
@@ -128,3 +129,36 @@ def test_stage_dependent_obstacle_set(oracle, emu, name, K):
     assert np.array_equal(r["status"], sto)
     ok = sto == 0
     assert util.rel_err(r["x"][ok], xo[ok]) < 1e-8 and util.rel_err(r["u"][ok], uo[ok]) < 1e-8
+
+
+def test_stage0_obstacle_rows(oracle, emu):
+    """acados applies the nh rows at stages 0..N-1.  At stage 0 they depend on no free variable (x_0 is pinned to x0), so
+    they are not rows of the QP - but x0 inside a HARD keep-out circle makes acados' QP infeasible: status 4 and an
+    untouched iterate (here without iterating, qp_status 4); a SOFT stage-0 row reports the constant slack
+    max(lsh, lh - h(x0)).  Kernel bodies and oracle agree on both."""
+    # hard rows: instance 1 starts inside its first circle, the other instances do not
+    name, N, K, B = "usv_model_pf_ca", 6, 4, 3
+    ocp, wl = util.make(name, N, K, B, seed=31)
+    wl["p"][1, :, 0:2] = wl["x0"][1, 10:12] + np.array([0.3, 0.0])     # centre 0.3 m away, lh >= 1.0
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    spec = util.oracle_spec(oracle, name, N, scenario.DT[name], K)
+    r = emu_rti(emu, desc, wl, wl["x_init"], wl["u_init"])
+    xo, uo, sto, ito = util.oracle_rti(oracle, spec, wl, wl["x_init"], wl["u_init"])
+    assert list(r["status"]) == list(sto) == [0, 4, 0]
+    assert r["qp_status"][1] == 4 and r["qp_iter"][1] == 0 and ito[1] == 0
+    assert np.array_equal(r["x"][1], wl["x_init"][1]) and np.array_equal(xo[1], wl["x_init"][1])
+    assert util.rel_err(r["x"][[0, 2]], xo[[0, 2]]) < 1e-8
+    # soft rows: the stage-0 slacks
+    name, N, K, B = "usv_model_guidance_ca1", 6, 5, 3
+    ocp, wl = util.make(name, N, K, B, seed=31)
+    wl["p"][2, :, 0:2] = wl["x0"][2, 5:7] + np.array([0.2, 0.1])       # instance 2 starts inside obstacle 0
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    spec = util.oracle_spec(oracle, name, N, scenario.DT[name], K)
+    r = emu_rti(emu, desc, wl, wl["x_init"], wl["u_init"])
+    for b in range(B):
+        ro = oracle.rti(spec, wl["x_init"][b], wl["u_init"][b], wl["x0"][b], wl["yref"][b], wl["yref_e"][b], wl["p"][b], wl["lh"][b])
+        assert r["status"][b] == ro["status"] == 0
+        assert np.allclose(r["sl"][b], ro["sl"], rtol=0, atol=1e-8) and np.allclose(r["su"][b], ro["su"], rtol=0, atol=1e-8)
+        h0 = np.hypot(*(wl["x0"][b, 5:7] - wl["p"][b, 0].reshape(K, 2)).T)
+        assert np.allclose(ro["sl"][0], np.maximum(-0.2, wl["lh"][b, 0] - h0), rtol=0, atol=1e-12)
+    assert r["sl"][2, 0, 0] > 0.5       # the violated row's slack is the violation itself

@@ -117,3 +117,20 @@ def test_closed_loop_advance_matches_host_round_trip():
     a.solve(); b.solve()
     assert np.array_equal(a.get_all("x"), b.get_all("x")) and np.array_equal(a.get_all("u"), b.get_all("u"))
     a.close(); b.close()
+
+
+def test_stage0_bounds_move_x0_and_must_coincide():
+    """set(0, "lbx") / set(0, "ubx") are the x0 embedding: every write moves x0 (a caller that only rewrites one of the two
+    each tick is not silently ignored), and solve() refuses to run while the two disagree."""
+    from mpc_collisionavoidance_amd import usv_models
+    constraint, model, solver = usv_models.acados_settings(1.0, 10, name="usv_model", n_obstacles=None)
+    xa = np.array([0.5, 0.0, 0.0, 1.0, 1.0])
+    xb = np.array([0.6, 0.01, 0.0, 2.0, 2.0])
+    solver.set(0, "lbx", xa)
+    solver.set(0, "ubx", xa)
+    assert solver.solve() == 0 and np.allclose(solver.get(0, "x"), xa, atol=1e-9)
+    solver.set(0, "lbx", xb)                       # only one of the two: x0 follows, but the pair is inconsistent
+    with pytest.raises(Exception, match="lbx and ubx of stage 0 differ"):
+        solver.solve()
+    solver.set(0, "ubx", xb)
+    assert solver.solve() == 0 and np.allclose(solver.get(0, "x"), xb, atol=1e-9)

@@ -121,3 +121,17 @@ def test_scenario_shapes_and_determinism():
             assert (d > a["lh"][:, 0]).all()  # every vessel starts outside every keep-out circle
     m = scenario.make_batch("usv_model_pf_ca", 8, 4, 3, moving=True)
     assert not np.array_equal(m["p"][:, 0], m["p"][:, 8])
+
+
+def test_reference_of_the_wrong_length_is_refused():
+    """acados raises a dimension error for a yref / yref_e that does not match ny / ny_e; so does the constructor
+    (before any device is touched)."""
+    from mpc_collisionavoidance_amd import BatchOcpSolver
+    ocp = usv_models.make_ocp("usv_model_pf_ca", 1.0, 10, 4)
+    ocp.cost.yref = np.zeros(5)
+    with pytest.raises(Exception, match="inconsistent dimension"):
+        BatchOcpSolver(ocp, 2)
+    ocp = usv_models.make_ocp("usv_model_pf_ca", 1.0, 10, 4)
+    ocp.cost.yref_e = np.zeros(3)
+    with pytest.raises(Exception, match="inconsistent dimension"):
+        BatchOcpSolver(ocp, 2)

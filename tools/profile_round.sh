@@ -1,13 +1,13 @@
 #!/bin/bash
 # rocprofv3 evidence for the bench workload: kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in separate passes.
-# usage (on the GPU box): tools/profile_round.sh <tag>    -> gpurun_out/prof_<tag>/
+# usage (on the GPU box): [BENCH_ARGS='--workload r01 --steps 10'] tools/profile_round.sh <tag>    -> gpurun_out/prof_<tag>/
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 tag=$1; out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python bench.py --cpu-sample 0 > $out/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python bench.py --cpu-sample 0 > $out/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python bench.py --cpu-sample 0 > $out/write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python bench.py --cpu-sample 0 $BENCH_ARGS > $out/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python bench.py --cpu-sample 0 $BENCH_ARGS > $out/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python bench.py --cpu-sample 0 $BENCH_ARGS > $out/write.log 2>&1
 python - <<PY
 import csv, glob, collections, json
 out = "$out"

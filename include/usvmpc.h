@@ -144,12 +144,17 @@ int usvmpc_fail_counts(usvmpc_handle *h, int n, int *counts);
 int usvmpc_advance(usvmpc_handle *h, double sigma, unsigned long long seed);
 /* Adopt a caller-owned HIP stream (e.g. torch's current stream) for all subsequent work */
 int usvmpc_set_stream(usvmpc_handle *h, void *stream);
-/* run-time options (none changes a result bit):
+/* run-time options (scheduling / placement only; none changes the arithmetic):
  *   "sort_by_difficulty" (default 1) - group instances of similar IPM iteration count (from their previous
  *       solve) into the same wavefront;
  *   "static_obstacles" (default 0) - every stage uses stage 0's p and lh (what the reference's callers set:
  *       scripts/usv_pf_ca/main.py puts one obstacle set on all stages), which the kernel then keeps in registers;
  *   "pack_box_rows" (default 1 when the rows fit) - box-row multipliers share the obstacle rows' planes;
+ *   "dynamic_rows" (default 1) - an RTI solve is one persistent launch whose wavefront rows pull instances from a device
+ *       queue as their QPs converge (0: every row keeps its first instance and idles until its wave is done);
+ *   "lds_workspace" (default -1) - per-stage planes of the QP in the CU's LDS instead of HBM: -1 when one round of
+ *       workgroups covers the batch (an instance's whole horizon must fit in 160 KB), 0 never, 1 whenever it fits.  Results
+ *       agree with the HBM placement to rounding (a separately compiled instantiation of the same code);
  *   "disturbance_mask" (default all ones) - bit j set: usvmpc_advance adds its noise to state j (the reference's commented
  *       hooks disturb x0[3] and x0[5] only: catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/main.py:181-183). */
 int usvmpc_set_option(usvmpc_handle *h, const char *name, double value);

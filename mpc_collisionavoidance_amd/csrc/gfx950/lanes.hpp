@@ -184,4 +184,23 @@ struct Planes {
     }
 };
 
+// The same planes held in the CU's LDS instead of HBM (small batches: the whole horizon of an instance's planes fits in
+// the 160 KB of a CU, so no sweep waits for HBM).  Layout inside a workgroup's LDS: [row][stage][plane][16 lanes]; `off` is
+// this lane's entry of plane 0 of the stage, in doubles; rows without an instance of their own never store (live).
+struct PlanesLds {
+    unsigned off;
+    bool live;
+    USV_DEV PlanesLds(unsigned off_, bool live_) : off(off_), live(live_) {}
+    USV_DEV double ld(int plane) const
+    {
+        extern __shared__ double usv_lds[];
+        return usv_lds[off + plane * 16];
+    }
+    USV_DEV void st(int plane, double x) const
+    {
+        extern __shared__ double usv_lds[];
+        if (live) usv_lds[off + plane * 16] = x;
+    }
+};
+
 } // namespace lanes

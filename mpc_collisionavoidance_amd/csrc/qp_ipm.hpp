@@ -189,7 +189,9 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
     ux = dx * id; uy = dy * id;
 }
 
-template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false>
+// LDSWS: the workspace planes of a row's instance live in LDS for the whole solve (lanes::PlanesLds) - for batches small
+// enough that every instance in flight fits (host: usvmpc.hip); the lineariser's planes are copied in at the cold start.
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false>
 struct QpIpm {
     static_assert(!PACK || KCH > 0, "box rows are packed into obstacle planes");
     static_assert(!(PACK && SOFTBOX), "soft state bounds are not packed");
@@ -213,7 +215,7 @@ struct QpIpm {
 
     using BoxRow = RowCalc<SOFTBOX, SOFTBOX>;
     using ObsRow = RowCalc<SOFT>;
-    using Planes = lanes::Planes;
+    using Planes = std::conditional_t<LDSWS, lanes::PlanesLds, lanes::Planes>;
 
     const DevPtrs &P;
     const DevSpec &S;
@@ -228,6 +230,8 @@ struct QpIpm {
     // per row (the same in its 16 lanes): the group it works on, that group's instance, the lane's offset in a stage window
     long g, b;
     unsigned voff;
+    unsigned loff;   // LDSWS: this lane's entry of (stage 0, plane 0) of its row's LDS region, in doubles
+    bool live;       // the row owns a workspace (LDSWS: surplus rows of a wave share row 0's region read-only)
     long stage_stride;     // doubles between consecutive stages of the workspace: Bp * NPL * 16
     unsigned stage_bytes;  // bytes of one stage's window
     bool xlane, ulane, valid, isPX, isPY;
@@ -254,7 +258,8 @@ struct QpIpm {
     // stage (DevSpec::p_static, what the reference's callers do) - centre and lower bound held in registers
     double c_uh[KCH > 0 ? KCH : 1], c_ox[KCH > 0 ? KCH : 1], c_oy[KCH > 0 ? KCH : 1], c_lh[KCH > 0 ? KCH : 1];
 
-    USV_DEV QpIpm(const DevPtrs &P_, long g_) : P(P_), S(*P_.spec)
+    // lds_row: which of the workgroup's LDS regions the row owns (LDSWS), < 0: none
+    USV_DEV QpIpm(const DevPtrs &P_, long g_, int lds_row = 0) : P(P_), S(*P_.spec)
     {
         lane = lanes::lane();
         N = lanes::uniform(S.N);
@@ -295,6 +300,8 @@ struct QpIpm {
             });
         }
         g = 0; b = 0;
+        live = lds_row >= 0;
+        loff = (unsigned)((lds_row > 0 ? lds_row : 0) * (N + 1) * NPL * LANES + lane);
         if constexpr (KCH > 0) sfor<0, KCH>([&](auto c) { c_ox[c] = c_oy[c] = c_lh[c] = 0.0; });
         bind(g_, true);
         if constexpr (KCH > 0 && SOFT) {
@@ -316,7 +323,7 @@ struct QpIpm {
         const long gi = g < nB ? g : (long)nB - 1;
         const long bn = P.perm ? (long)P.perm[gi] : gi;
         b = sel ? bn : b;
-        voff = Planes::lane_offset(g, NPL, lane);
+        voff = lanes::Planes::lane_offset(g, NPL, lane);
         if constexpr (KCH > 0) {
             sfor<0, KCH>([&](auto c) {
                 const int i = c * LANES + lane;
@@ -328,7 +335,13 @@ struct QpIpm {
         }
     }
 
-    USV_DEV Planes ws(int k) const { return Planes(P.ws + (long)k * stage_stride, stage_bytes, voff); }
+    // the row's planes of stage k in HBM (where the lineariser writes; the whole workspace unless LDSWS)
+    USV_DEV lanes::Planes wsg(int k) const { return lanes::Planes(P.ws + (long)k * stage_stride, stage_bytes, voff); }
+    USV_DEV Planes ws(int k) const
+    {
+        if constexpr (LDSWS) return Planes(loff + (unsigned)(k * NPL * LANES), live);
+        else return wsg(k);
+    }
     // iterate value of this lane's variable at stage k (caller-visible arrays)
     USV_DEV double zbar(int k) const
     {
@@ -486,6 +499,19 @@ struct QpIpm {
         for (int k = 0; k <= N; k++) {
             const Planes W = ws(k);
             const double zb = zbar(k);
+            if constexpr (LDSWS) { // the linearisation of this stage comes in from HBM
+                const lanes::Planes G = wsg(k);
+                const double gq = G.ld(P_GQ), rb = (k < N) ? G.ld(P_RB0) : 0.0;
+                double mpk[MP::NPK];
+                if (k < N) sfor<0, MP::NPK>([&](auto q) { mpk[q] = G.ld(P_MAT + q); });
+                if (wr) {
+                    W.st(P_GQ, gq);
+                    if (k < N) {
+                        W.st(P_RB0, rb);
+                        sfor<0, MP::NPK>([&](auto q) { W.st(P_MAT + q, mpk[q]); });
+                    }
+                }
+            }
             if (wr) {
                 W.st(P_Z, zb); // z = 0
                 if (k == 0) W.st(P_DX0, xlane ? P.x0[(long)b * NX + (lane - NU)] : 0.0);
@@ -1227,11 +1253,11 @@ struct QpIpm {
         const bool bad0 = init(true);
         // ---- per-row state of the IPM (every row is in its own iteration)
         rbscale = 1.0;
-        bool real = g < nB && !frozen;   // the row holds an instance whose results are to be written
-        bool done = frozen;              // nothing (more) to iterate on in this row
+        bool real = g < nB && !frozen && live;   // the row holds an instance whose results are to be written
+        bool done = frozen || !live;             // nothing (more) to iterate on in this row
         bool pend = false;               // a step of the previous iteration is waiting to be applied
         bool fresh = false;              // cold-started after this pass's factorisation sweep: sits out the rest of the pass
-        bool late = bad0 && !frozen;     // stopped after the factorisation sweep (step-length floor), or never started
+        bool late = bad0 && !frozen && live;     // stopped after the factorisation sweep (step-length floor), or never started
                                          // (x0 inside a hard keep-out circle): results at the next pass
         int status = late ? 4 : 1, iters = 0, it = 0;
         done = done || late;

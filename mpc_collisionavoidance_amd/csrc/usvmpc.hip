@@ -18,6 +18,7 @@
 #include USV_GEN_MODEL_HEADER
 #endif
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -43,12 +44,16 @@ __global__ void __launch_bounds__(256, 2) usv_linearize(DevPtrs P, long ngroups)
 template <int KCH, bool SOFTBOX>
 constexpr int qp_waves() { return (KCH >= 2 || SOFTBOX) ? 1 : USV_QP_WAVES; }
 
-template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX>
-__global__ void __launch_bounds__(64, (qp_waves<KCH, SOFTBOX>())) usv_qp_rti(DevPtrs P, long ngroups, int phase, int queue0)
+// rows: instances a wave starts on (4; fewer when the workspace lives in LDS and only that many fit: LDSWS) - row r of block b
+// starts on group b * rows + r, surplus rows stay idle.
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX, bool LDSWS = false>
+__global__ void __launch_bounds__(64, (LDSWS ? 1 : qp_waves<KCH, SOFTBOX>())) usv_qp_rti(DevPtrs P, long ngroups, int phase, int queue0, int rows)
 {
-    const long gid = lanes::group_linear();
-    if (gid >= ngroups) return;
-    QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX> q(P, gid);
+    const int row = (int)(threadIdx.x >> 4);
+    const long g0 = (long)blockIdx.x * rows;
+    if (g0 >= ngroups) return;
+    const bool has = row < rows;
+    QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, LDSWS> q(P, has ? g0 + row : g0, has ? row : -1);
     q.solve(phase, queue0);
 }
 
@@ -191,6 +196,8 @@ struct usvmpc_handle {
     size_t gd_world_cap;
     bool sort_enabled;
     bool dynamic_rows;        // QP kernel as a persistent launch whose rows pull instances from a queue (option "dynamic_rows")
+    int lds_mode;             // workspace of the QP kernel in LDS: -1 when the batch is small enough (default), 0 never, 1 whenever it fits
+    long lds_cap;             // waves an LDS-workspace launch holds at once (0: not yet known)
     int ncu;                  // compute units of the device
     long qp_cap;              // groups a full-occupancy launch of the QP kernel holds at once (0: not yet known)
     bool map_changed;         // the group -> instance map differs from the one the workspace's multipliers were written under
@@ -351,7 +358,35 @@ int launch_pair(usvmpc_handle *h, int phase)
     // An RTI solve is ONE launch of as many waves as the device holds at once; their rows start on the first groups and
     // pull the remaining ones from a queue as they finish (qp_ipm.hpp).  The full SQP keeps one group per row: its later
     // iterations find their multipliers in the group's part of the workspace.
-    auto launch_qp = [&](auto kern) -> int {
+    // Small batches: the planes of every instance in flight fit in LDS (160 KB per CU), and a solve whose sweeps wait for
+    // HBM at every stage - nothing else runs on the CU to hide it - becomes a solve on LDS.  rows_lds instances per wave
+    // (as many whole horizons as fit), one wave per CU at a time; further instances come through the same queue.
+    auto launch_qp = [&](auto kern, decltype(kern) kern_lds) -> int {
+        const long lds_inst = (long)(h->N + 1) * h->spec.npt * 128;
+        const int rows_lds = (int)std::min<long>(4, (160L * 1024) / lds_inst);
+        bool use_lds = phase == 0 && h->lds_mode != 0 && kern_lds != nullptr && rows_lds >= 1 && h->ncu > 0;
+        // by default only while one round of workgroups covers the batch: measured on usv_model_pf_ca, N = 20 / K = 3, the solve
+        // of 512 instances takes 5.9 ms with the planes in LDS against 6.5 ms in HBM, at 1024 (two rounds) 7.5 against 7.1
+        if (use_lds && h->lds_mode < 0) use_lds = (long)h->B <= (long)rows_lds * h->ncu;
+        if (use_lds) {
+            const size_t bytes = (size_t)rows_lds * lds_inst;
+            if (h->lds_cap == 0) {
+                int nb = 0;
+                if (hipFuncSetAttribute((const void *)kern_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess &&
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern_lds, qp_block, bytes) == hipSuccess && nb > 0)
+                    h->lds_cap = (long)nb * h->ncu;
+                else
+                    h->lds_cap = -1;
+            }
+            if (h->lds_cap > 0) {
+                long nw = ((long)h->B + rows_lds - 1) / rows_lds;
+                int q0 = -1;
+                if (h->dynamic_rows && nw > h->lds_cap) { nw = h->lds_cap; q0 = (int)(nw * rows_lds); }
+                if (q0 >= 0) HIP_TRY(h, hipMemsetAsync(h->ptrs.queue, 0, sizeof(int), h->stream));
+                hipLaunchKernelGGL(kern_lds, dim3((unsigned)nw), dim3(qp_block), bytes, h->stream, h->ptrs, nw * rows_lds, phase, q0, rows_lds);
+                return 0;
+            }
+        }
         long ng = qp_groups;
         int q0 = -1;
         if (h->dynamic_rows && phase == 0) {
@@ -366,20 +401,21 @@ int launch_pair(usvmpc_handle *h, int phase)
         }
         if (q0 >= 0) HIP_TRY(h, hipMemsetAsync(h->ptrs.queue, 0, sizeof(int), h->stream));
         const dim3 qg((unsigned)((ng * LANES + qp_block - 1) / qp_block)), qb(qp_block);
-        hipLaunchKernelGGL(kern, qg, qb, 0, h->stream, h->ptrs, ng, phase, q0);
+        hipLaunchKernelGGL(kern, qg, qb, 0, h->stream, h->ptrs, ng, phase, q0, 4);
         return 0;
     };
     int rcq = 0;
 #ifdef USV_BENCH_ONLY // development builds (tools/dev_build.sh): only the instantiation the bench workload runs
     if (!(h->spec.hdiag && pack && !h->spec.any_bsoft)) { h->err = "development build: bench instantiation only"; return USVMPC_E_ARG; }
-    rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>);
+    rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>);
 #else
     if (h->spec.any_bsoft) { // soft state bounds: rows with slacks, ten planes of their own
-        rcq = h->spec.hdiag ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, true>) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, true>);
-    } else if (h->spec.hdiag) {
-        rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>) : launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, false>);
+        rcq = h->spec.hdiag ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, true>, nullptr) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, true>, nullptr);
+    } else if (h->spec.hdiag) { // (every OCP of the reference: the only instantiations that also come with the workspace in LDS)
+        rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>)
+                   : launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, false>, &usv_qp_rti<M, KCH, SOFT, true, false, false, true>);
     } else {
-        rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, false, CANPACK, false>) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, false>);
+        rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, false, CANPACK, false>, nullptr) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, false>, nullptr);
     }
 #endif
     if (rcq) return rcq;
@@ -496,6 +532,8 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->noise_mask = ~0u;
     h->dynamic_rows = true;
     h->qp_cap = 0;
+    h->lds_mode = -1;
+    h->lds_cap = 0;
     {
         hipDeviceProp_t prop;
         h->ncu = (hipGetDeviceProperties(&prop, d->device) == hipSuccess) ? prop.multiProcessorCount : 0;
@@ -789,6 +827,11 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         if (!h->sort_enabled && h->ptrs.perm) { h->ptrs.perm = nullptr; h->map_changed = true; }
         return 0;
     }
+    if (s == "lds_workspace") { // -1: when the batch is small (default), 0: never, 1: whenever an instance's planes fit in LDS
+        h->lds_mode = value < 0.0 ? -1 : (value > 0.0 ? 1 : 0);
+        h->lds_cap = 0;
+        return 0;
+    }
     if (s == "dynamic_rows") { // 0: one group per row for the whole launch (the rows of a wave wait for its slowest)
         h->dynamic_rows = value != 0.0;
         h->qp_cap = 0;
@@ -800,7 +843,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
     }
     if (s == "static_obstacles" || s == "pack_box_rows") {
         if (s == "static_obstacles") h->spec.p_static = value != 0.0;
-        else { h->spec.boxpack = (value != 0.0 && h->spec.boxpack_ok) ? 1 : 0; h->qp_cap = 0; }
+        else { h->spec.boxpack = (value != 0.0 && h->spec.boxpack_ok) ? 1 : 0; h->qp_cap = 0; h->lds_cap = 0; }
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipMemcpyAsync(h->d_spec, &h->spec, sizeof(DevSpec), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));

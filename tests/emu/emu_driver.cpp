@@ -18,6 +18,7 @@
 namespace lanes {
 
 Emu g_emu;
+double *g_emu_lds = nullptr;
 
 // minimal x86-64 SysV context switch: callee-saved registers + stack pointer
 asm(R"(
@@ -102,6 +103,7 @@ namespace {
 using namespace usv;
 
 struct Job { const DevPtrs *P; long gid; int qp_phase; int queue0; };
+int g_emu_lds_mode = 0; // 1: run the RTI solves with the workspace in (emulated) LDS
 
 template <class M, int KCH, bool SOFT>
 void lin_body(void *a)
@@ -114,6 +116,11 @@ template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = fal
 void qp_body(void *a)
 {
     Job *j = (Job *)a;
+    if constexpr (HDIAG && !SOFTBOX) if (g_emu_lds_mode && j->qp_phase == 0) { // the workspace of the (single) emulated row in "LDS"
+        QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, true> q(*j->P, j->gid, 0);
+        q.solve(j->qp_phase, j->queue0);
+        return;
+    }
     QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX> q(*j->P, j->gid);
     q.solve(j->qp_phase, j->queue0);
 }
@@ -174,6 +181,9 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
     if (queue) *P.queue = 0;
     if (phase & 2)
         for (long g = 0; g < nrows; g++) {
+            static std::vector<double> lds; // the emulated row's LDS region (allocated here: the body runs once per lane)
+            lds.assign((size_t)(S.N + 1) * S.npt * LANES, 0.0);
+            lanes::g_emu_lds = lds.data();
             Job j{&P, g, qp_phase, queue ? (int)nrows : -1};
             constexpr bool CANPACK = KCH > 0;
             const bool pack = CANPACK && S.boxpack != 0;
@@ -268,6 +278,9 @@ static int emu_run(const usvmpc_desc *d, int sqp, double *x, double *u, const do
     }
     return 0;
 }
+
+// test switches: workspace of the RTI solves in emulated LDS (lds != 0); persistent rows pulling from the queue (rows, 0 = none)
+extern "C" void usv_emu_set_mode(int lds, long rows) { g_emu_lds_mode = lds; g_emu_rows = rows; }
 
 extern "C" int usv_emu_solve(const usvmpc_desc *d, double *x, double *u, const double *x0,
                              const double *yref, const double *yref_e, const double *p,

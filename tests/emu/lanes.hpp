@@ -119,6 +119,16 @@ struct Planes {
     }
 };
 
+// the workgroup's LDS (one emulated row per "wave")
+extern double *g_emu_lds;
+struct PlanesLds {
+    unsigned off;
+    bool live;
+    PlanesLds(unsigned o, bool l) : off(o), live(l) {}
+    double ld(int plane) const { return g_emu_lds[off + plane * 16]; }
+    void st(int plane, double x) const { if (live) g_emu_lds[off + plane * 16] = x; }
+};
+
 // run body(lane) on 16 fibers in lock step
 void run_group(long group, void (*body)(void *), void *arg);
 

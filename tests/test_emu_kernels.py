@@ -162,3 +162,25 @@ def test_stage0_obstacle_rows(oracle, emu):
         h0 = np.hypot(*(wl["x0"][b, 5:7] - wl["p"][b, 0].reshape(K, 2)).T)
         assert np.allclose(ro["sl"][0], np.maximum(-0.2, wl["lh"][b, 0] - h0), rtol=0, atol=1e-12)
     assert r["sl"][2, 0, 0] > 0.5       # the violated row's slack is the violation itself
+
+
+@pytest.mark.parametrize("name,N,K", [("usv_model_pf_ca", 8, 4), ("usv_model_guidance_ca1", 7, 5), ("usv_model", 6, 0)])
+def test_scheduling_and_workspace_placement_do_not_change_results(emu, name, N, K):
+    """The same arithmetic whatever carries it: one row per instance, two persistent rows pulling instances from the queue,
+    and the workspace in (emulated) LDS instead of HBM return bit-identical iterates, statuses and iteration counts."""
+    B = 7
+    ocp, wl = util.make(name, N, K, B, seed=3)
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    emu.usv_emu_set_mode.argtypes = [C.c_int, C.c_long]
+    out = []
+    try:
+        for lds, rows in ((0, 0), (0, 2), (1, 2), (1, 0)):
+            emu.usv_emu_set_mode(lds, rows)
+            r = emu_rti(emu, desc, wl, wl["x_init"], wl["u_init"])
+            r2 = emu_rti(emu, desc, wl, r["x"], r["u"])
+            out.append((r2["x"], r2["u"], r2["status"], r2["qp_iter"], r2["sl"], r2["pi"]))
+    finally:
+        emu.usv_emu_set_mode(0, 2)
+    for o in out[1:]:
+        for a, b in zip(o, out[0]):
+            assert np.array_equal(a, b)

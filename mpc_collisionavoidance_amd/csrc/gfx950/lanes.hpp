@@ -184,6 +184,26 @@ struct Planes {
     }
 };
 
+// Wave-private exchange area in LDS: every row (16 lanes = one OCP instance) has NENT double slots, laid out
+// [slot][4 rows] so that the 64 lanes of a "lane L writes slot 16 q + L" store cover 512 contiguous bytes.  A lane puts
+// values into slots and any lane of the same row reads any slot back: the run-time lane permutation that would otherwise
+// cost two ds_bpermute plus address arithmetic and selects PER VALUE becomes one ds_read_b64 at a per-lane slot number -
+// and slots holding constants (0.0, 1.0) replace the selects for entries that are structurally zero / one.  This is how
+// the packed stage matrix is turned into the row (backward sweeps) or column (forward sweeps) form the products need.
+// LDS operations of one wave execute in order; sync() only keeps the compiler from moving reads above the writes.
+template <int NENT>
+struct Xpose {
+    USV_DEV static double *area()
+    {
+        __shared__ double s[NENT * 4];
+        return s;
+    }
+    USV_DEV static unsigned row() { return (threadIdx.x >> 4) & 3u; }
+    USV_DEV static void put(int slot, double v) { area()[slot * 4 + row()] = v; }
+    USV_DEV static double get(int slot) { return area()[slot * 4 + row()]; }
+    USV_DEV static void sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+};
+
 // The same planes held in the CU's LDS instead of HBM (small batches: the whole horizon of an instance's planes fits in
 // the 160 KB of a CU, so no sweep waits for HBM).  Layout inside a workgroup's LDS: [row][stage][plane][16 lanes]; `off` is
 // this lane's entry of plane 0 of the stage, in doubles; rows without an instance of their own never store (live).

@@ -63,6 +63,12 @@ struct MatPack {
         return s;
     }
     static constexpr bool diag_one(int j) { return ((M::DIAG_ONE >> j) & 1u) != 0u; }
+    static constexpr unsigned col_mask() // variables that appear in some row's pattern
+    {
+        unsigned m = 0;
+        for (int j = 0; j < NX; j++) m |= M::SENS[j];
+        return m;
+    }
     static constexpr int NE = start(NX);                                // stored entries per stage
     static constexpr int NPK = (NE + 15) / 16;                          // planes per stage
     static constexpr int nth(unsigned mask, int i)                      // position of the i-th set bit

@@ -245,7 +245,16 @@ struct QpIpm {
     //   ssrc   : variable whose row this lane stores (as slot lane or as dense lane)
     //   isslot / isdense : what this lane stores
     bool ounit; // this lane is the state of a structurally unit row of [A B] (M::OUT_UNIT)
-    unsigned lt_mask; // (1 << lane) - 1: ranks this lane's variable inside a row's pattern (MatPack)
+    // The packed stage matrix goes through a wave-private LDS exchange area (lanes::Xpose): the lanes put the planes as they
+    // were loaded, and every lane reads back the slots it needs - row form (lane r: entry (j, r) of every stored row j) for
+    // the backward sweeps, column form (lane nu+j: entry (j, c) of every stored column c) for the forward product.  Slot
+    // numbers per lane, one byte each; structural zeros / unit diagonals read the constant slots ZSLOT / OSLOT.
+    static constexpr unsigned CMASK = MP::col_mask();
+    static constexpr int NCOL = __builtin_popcount(CMASK);
+    static constexpr int ZSLOT = MP::NPK * 16, OSLOT = ZSLOT + 1;
+    using XP = lanes::Xpose<MP::NPK * 16 + 2>;
+    unsigned rowtab[(NX + 3) / 4], coltab[(NCOL + 3) / 4];
+    bool selfone; // this lane's state has the exact unit diagonal and its own column is not among the stored ones
     bool isslot, isdense, anydense;
     int bsrc, bstep, ssrc;
     bool hasb;
@@ -279,7 +288,35 @@ struct QpIpm {
         isPY = KCH > 0 && lane == PYL;
         hasb = S.has_b[lane] != 0;
         ounit = xlane && ((M::OUT_UNIT >> (xlane ? lane - NU : 0)) & 1u) != 0u;
-        lt_mask = (1u << lane) - 1u;
+        {
+            sfor<0, (NX + 3) / 4>([&](auto w) { rowtab[w] = 0u; });
+            sfor<0, (NCOL + 3) / 4>([&](auto w) { coltab[w] = 0u; });
+            sfor<0, NX>([&](auto j) {
+                constexpr unsigned m = MP::row_mask(j);
+                const unsigned slot = ((m >> lane) & 1u) ? (unsigned)(MP::start(j) + __builtin_popcount(m & ((1u << lane) - 1u)))
+                                                         : ((MP::diag_one(j) && lane == NU + j) ? (unsigned)OSLOT : (unsigned)ZSLOT);
+                rowtab[j / 4] |= slot << (8 * (j % 4));
+            });
+            sfor<0, NCOL>([&](auto ci) {
+                constexpr int c = MP::nth(CMASK, ci);
+                unsigned slot = (unsigned)ZSLOT;
+                sfor<0, NX>([&](auto j) { // the row this lane owns (if it is a state lane)
+                    constexpr unsigned m = MP::row_mask(j);
+                    if (lane == NU + j) {
+                        if constexpr (((m >> c) & 1u) != 0u) slot = (unsigned)(MP::start(j) + MP::rank(m, c));
+                        else if constexpr (MP::diag_one(j) && c == NU + j) slot = (unsigned)OSLOT;
+                    }
+                });
+                coltab[ci / 4] |= slot << (8 * (ci % 4));
+            });
+            bool so = false;
+            sfor<0, NX>([&](auto j) {
+                if constexpr (MP::diag_one(j) && ((CMASK >> (NU + j)) & 1u) == 0u) so = (lane == NU + j) ? true : so;
+            });
+            selfone = so;
+            XP::put(ZSLOT, 0.0);
+            XP::put(OSLOT, 1.0);
+        }
         isslot = PACK && S.slot_is[lane] == 1;
         isdense = PACK && S.slot_is[lane] == 2;
         anydense = PACK && lanes::uniform(S.box_dense) != 0; // wave-uniform
@@ -460,27 +497,30 @@ struct QpIpm {
         const Planes W = ws(k);
         sfor<0, MP::NPK>([&](auto q) { pk[q] = W.ld(P_MAT + q); });
     }
+    // (call under wave-uniform control flow)
+    USV_DEV void mat_put(const double *pk) const
+    {
+        sfor<0, MP::NPK>([&](auto q) { XP::put(16 * q + lane, pk[q]); });
+        XP::sync();
+    }
     USV_DEV void mat_unpack(const double *pk, double *bat) const
     {
+        mat_put(pk);
         sfor<0, NX>([&](auto j) {
-            if constexpr (out_unit(j)) {
-                bat[j] = 0.0; // never read: unit rows are handled structurally
-            } else {
-                constexpr unsigned m = MP::row_mask(j);
-                constexpr int s0 = MP::start(j), cnt = MP::count(j);
-                constexpr int q0 = s0 / 16, q1 = (s0 + cnt - 1) / 16;
-                const bool st = ((m >> lane) & 1u) != 0u;
-                const int pos = s0 + __builtin_popcount(m & lt_mask);
-                double v = lanes::gather(pk[q0], pos & 15);
-                if constexpr (q1 != q0) {
-                    const double v1 = lanes::gather(pk[q1], pos & 15);
-                    v = (pos >> 4) == q0 ? v : v1;
-                }
-                // entries outside the pattern are exact zeros, or the exact unit diagonal of a state that does not
-                // feed itself
-                bat[j] = st ? v : ((MP::diag_one(j) && lane == NU + j) ? 1.0 : 0.0);
-            }
+            if constexpr (out_unit(j)) bat[j] = 0.0; // never read: unit rows are handled structurally
+            else bat[j] = XP::get((int)((rowtab[j / 4] >> (8 * (j % 4))) & 0xffu));
         });
+    }
+    // x+ = [B A] dz (+ acc) on the state lanes: lane nu+j reads row j of the matrix column by column
+    USV_DEV double mat_apply(const double *pk, double dz, double acc) const
+    {
+        mat_put(pk);
+        sfor<0, NCOL>([&](auto ci) {
+            constexpr int c = MP::nth(CMASK, ci);
+            const double v = XP::get((int)((coltab[ci / 4] >> (8 * (ci % 4))) & 0xffu));
+            lanes::fma_bc<c>(acc, dz, v);
+        });
+        return acc + (selfone ? dz : 0.0);
     }
     USV_DEV static double obs_dot(double cx, double cy, double vec)
     {
@@ -1034,19 +1074,9 @@ struct QpIpm {
             }
             dfr_dz = dz;
             if (k < N) {
-                // dx+_j = b_j + sum_c [B A][j][c] dz_c: lane c holds [B A][j][c] in bat[j], so the row sum is a
-                // group reduction delivered to lane nu+j (no transposed copy of the matrix in HBM)
-                double bat[NX];
-                mat_unpack(mpk, bat);
-                double dxn = in.rb * rbscale;
-                sfor<0, NX>([&](auto j) {
-                    if constexpr (out_unit(j)) {
-                        dxn += (lane == NU + j) ? dz : 0.0;
-                    } else {
-                        const double sj = lanes::gsum(bat[j] * dz);
-                        dxn += (lane == NU + j) ? sj : 0.0;
-                    }
-                });
+                // dx+ = b + [B A] dz: the state lanes read their rows of the matrix column by column from the exchange area
+                // (no row-wise reductions, no transposed copy of the matrix in HBM)
+                const double dxn = mat_apply(mpk, dz, in.rb * rbscale);
                 dzx = xlane ? dxn : 0.0;
             }
         }

@@ -198,6 +198,7 @@ struct usvmpc_handle {
     bool dynamic_rows;        // QP kernel as a persistent launch whose rows pull instances from a queue (option "dynamic_rows")
     int lds_mode;             // workspace of the QP kernel in LDS: -1 when the batch is small enough (default), 0 never, 1 whenever it fits
     long lds_cap;             // waves an LDS-workspace launch holds at once (0: not yet known)
+    long max_waves;           // cap on the persistent waves of the QP kernel (0: as many as the device holds)
     int ncu;                  // compute units of the device
     long qp_cap;              // groups a full-occupancy launch of the QP kernel holds at once (0: not yet known)
     bool map_changed;         // the group -> instance map differs from the one the workspace's multipliers were written under
@@ -397,7 +398,9 @@ int launch_pair(usvmpc_handle *h, int phase)
                 else
                     h->qp_cap = -1;
             }
-            if (h->qp_cap > 0 && h->qp_cap < qp_groups) { ng = h->qp_cap; q0 = (int)ng; }
+            long cap = h->qp_cap;
+            if (h->max_waves > 0 && 4L * h->max_waves < cap) cap = 4L * h->max_waves; // option "max_waves": fewer resident waves
+            if (cap > 0 && cap < qp_groups) { ng = cap; q0 = (int)ng; }
         }
         if (q0 >= 0) HIP_TRY(h, hipMemsetAsync(h->ptrs.queue, 0, sizeof(int), h->stream));
         const dim3 qg((unsigned)((ng * LANES + qp_block - 1) / qp_block)), qb(qp_block);
@@ -534,6 +537,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->qp_cap = 0;
     h->lds_mode = -1;
     h->lds_cap = 0;
+    h->max_waves = 0;
     {
         hipDeviceProp_t prop;
         h->ncu = (hipGetDeviceProperties(&prop, d->device) == hipSuccess) ? prop.multiProcessorCount : 0;
@@ -827,6 +831,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         if (!h->sort_enabled && h->ptrs.perm) { h->ptrs.perm = nullptr; h->map_changed = true; }
         return 0;
     }
+    if (s == "max_waves") { h->max_waves = (long)value; return 0; }
     if (s == "lds_workspace") { // -1: when the batch is small (default), 0: never, 1: whenever an instance's planes fit in LDS
         h->lds_mode = value < 0.0 ? -1 : (value > 0.0 ? 1 : 0);
         h->lds_cap = 0;

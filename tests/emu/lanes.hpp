@@ -119,6 +119,15 @@ struct Planes {
     }
 };
 
+// wave-private exchange area (gfx950/lanes.hpp): one emulated row, sync() is a rendezvous of its 16 lanes
+template <int NENT>
+struct Xpose {
+    static double *area() { static double s[NENT]; return s; }
+    static void put(int slot, double v) { area()[slot] = v; }
+    static double get(int slot) { return area()[slot]; }
+    static void sync() { (void)exchange(0.0, 0); }
+};
+
 // the workgroup's LDS (one emulated row per "wave")
 extern double *g_emu_lds;
 struct PlanesLds {

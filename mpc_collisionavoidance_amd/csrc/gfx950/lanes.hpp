@@ -49,18 +49,74 @@ USV_DEV int bcast_i(int v)
     return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, true);
 }
 
+#ifndef USV_FUSED_DPP_FMA
+#define USV_FUSED_DPP_FMA 1
+#endif
+
 // c += bcast<K>(b_remote) * a_own
 template <int K>
 USV_DEV void fma_bc(double &c, double b_remote, double a_own)
 {
 #if USV_FUSED_DPP_FMA
-    // v_fmac_f64_dpp with row_newbcast is the one DP-ALU DPP form gfx950 has; hipcc cannot select
-    // it from builtins, and it does not pad the VALU-write -> DPP-read hazard inside asm, hence
-    // the leading s_nop 1.
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                 : "+v"(c) : "v"(b_remote), "v"(a_own), "n"(K));
+    // v_fmac_f64_dpp with row_newbcast is the one DP-ALU DPP form gfx950 has and costs what a plain v_fma_f64 costs
+    // (profiles/r02_microbench.txt), but hipcc does not select it from builtins.  Inside asm the compiler cannot pad the
+    // one hazard it has (a VALU write of the DPP source b_remote within the 2 preceding wait states - measured on the
+    // part: tools/micro/dpp_hazard.hip; accumulator and plain source are forwarded normally), so the BINARY is checked
+    // instead: tools/check_dpp_hazard.py walks the disassembly and build() fails on a violation; lanes::settle() is the
+    // cure at a site it flags.
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(c) : "v"(b_remote), "v"(a_own), "n"(K));
 #else
     c = __builtin_fma(bcast<K>(b_remote), a_own, c);
+#endif
+}
+
+// The same for up to four terms into one accumulator, in the order given: c += bcast<K0>(b0) * a0; c += bcast<K1>(b1) * a1; ...
+// One asm statement per group: between two asm statements that touch the same register the compiler pads a wait state
+// (s_nop 0) it cannot prove unnecessary - a chain of single-term statements was one fifth s_nop (measured on the part,
+// tools/micro/dpp_hazard.hip: dependent v_fmac_f64_dpp issue back to back correctly).  The accumulator is early-clobber:
+// it is written while later sources are still to be read.
+template <int K0, int K1>
+USV_DEV void fma_bc2(double &c, double b0, double a0, double b1, double a1)
+{
+#if USV_FUSED_DPP_FMA
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+        : "+&v"(c) : "v"(b0), "v"(a0), "v"(b1), "v"(a1), "n"(K0), "n"(K1));
+#else
+    fma_bc<K0>(c, b0, a0); fma_bc<K1>(c, b1, a1);
+#endif
+}
+template <int K0, int K1, int K2>
+USV_DEV void fma_bc3(double &c, double b0, double a0, double b1, double a1, double b2, double a2)
+{
+#if USV_FUSED_DPP_FMA
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %3, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %5, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+        : "+&v"(c) : "v"(b0), "v"(a0), "v"(b1), "v"(a1), "v"(b2), "v"(a2), "n"(K0), "n"(K1), "n"(K2));
+#else
+    fma_bc<K0>(c, b0, a0); fma_bc<K1>(c, b1, a1); fma_bc<K2>(c, b2, a2);
+#endif
+}
+template <int K0, int K1, int K2, int K3>
+USV_DEV void fma_bc4(double &c, double b0, double a0, double b1, double a1, double b2, double a2, double b3, double a3)
+{
+#if USV_FUSED_DPP_FMA
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %3, %4 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %5, %6 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %7, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf"
+        : "+&v"(c) : "v"(b0), "v"(a0), "v"(b1), "v"(a1), "v"(b2), "v"(a2), "v"(b3), "v"(a3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
+#else
+    fma_bc<K0>(c, b0, a0); fma_bc<K1>(c, b1, a1); fma_bc<K2>(c, b2, a2); fma_bc<K3>(c, b3, a3);
+#endif
+}
+
+// two wait states on a value that is about to be a DPP source (see fma_bc)
+USV_DEV void settle(double &v)
+{
+#if USV_FUSED_DPP_FMA
+    asm volatile("s_nop 1" : "+v"(v));
 #endif
 }
 
@@ -174,13 +230,15 @@ struct Planes {
     USV_DEV double ld(int plane) const
     {
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, plane * 128, USV_PLANE_LOAD_AUX);
+        // (plane offset added to the VGPR offset: the compiler folds the constant into the instruction's 12-bit offset field;
+        // passed as the scalar offset operand it costs an s_movk per access)
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff + (unsigned)(plane * 128)), 0, USV_PLANE_LOAD_AUX);
         return __builtin_bit_cast(double, v);
     }
     USV_DEV void st(int plane, double x) const
     {
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), rsrc, (int)voff, plane * 128, USV_PLANE_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), rsrc, (int)(voff + (unsigned)(plane * 128)), 0, USV_PLANE_STORE_AUX);
     }
 };
 
@@ -202,6 +260,22 @@ struct Xpose {
     USV_DEV static void put(int slot, double v) { area()[slot * 4 + row()] = v; }
     USV_DEV static double get(int slot) { return area()[slot * 4 + row()]; }
     USV_DEV static void sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+};
+
+// Per-lane constants of a wave parked in LDS ([slot][64 lanes], wave-private): values that live for the whole kernel and are
+// read once or twice per stage.  In VGPRs they are what the register allocator spills first - and a spill reload is a
+// scratch (vector-memory) load, whose s_waitcnt vmcnt(0) waits for every plane load issued before it: the reload in the
+// middle of a stage drains the prefetch queue (this was the largest single stall of the QP kernel).
+// An LDS read waits on lgkmcnt only.
+template <int NSLOT>
+struct Stash {
+    USV_DEV static double *area()
+    {
+        __shared__ double s[NSLOT * 64];
+        return s;
+    }
+    USV_DEV static void put(int slot, double v) { area()[slot * 64 + (threadIdx.x & 63u)] = v; }
+    USV_DEV static double get(int slot) { return area()[slot * 64 + (threadIdx.x & 63u)]; }
 };
 
 // The same planes held in the CU's LDS instead of HBM (small batches: the whole horizon of an instance's planes fits in

@@ -212,6 +212,45 @@ struct QpIpm {
     static constexpr int NPL = WL::NPT;
 
     static constexpr bool out_unit(int j) { return ((M::OUT_UNIT >> j) & 1u) != 0u; }
+    static constexpr unsigned XMASK = (1u << NX) - 1u, ZMASK = (1u << NZ) - 1u;
+    static constexpr unsigned NONUNIT = XMASK & ~(unsigned)M::OUT_UNIT; // rows of [B A] that are stored
+
+    // Row-times-broadcast sums, terms in ascending order of the set bits j of MASK, four per instruction group (lanes::fma_bc4):
+    //   dot_lanes: acc += sum_j bcast<KOFF + j>(b) * a_of(j)     one source vector, its lanes KOFF + j
+    //   dot_col  : acc += sum_j bcast<K>(b_of(j)) * a_of(j)      lane K of a different vector per term
+    // a_of / b_of take std::integral_constant<int, j>.
+    template <unsigned MASK, class F>
+    USV_DEV static void groups_of_four(F f)
+    {
+        constexpr int n = __builtin_popcount(MASK);
+        sfor<0, (n + 3) / 4>([&](auto g) {
+            constexpr int i0 = 4 * g, m = (n - i0 < 4) ? n - i0 : 4;
+            constexpr int j0 = MP::nth(MASK, i0), j1 = m > 1 ? MP::nth(MASK, i0 + 1) : 0, j2 = m > 2 ? MP::nth(MASK, i0 + 2) : 0,
+                          j3 = m > 3 ? MP::nth(MASK, i0 + 3) : 0;
+            f(std::integral_constant<int, m>{}, std::integral_constant<int, j0>{}, std::integral_constant<int, j1>{},
+              std::integral_constant<int, j2>{}, std::integral_constant<int, j3>{});
+        });
+    }
+    template <unsigned MASK, int KOFF, class FA>
+    USV_DEV static void dot_lanes(double &acc, double b, FA a_of)
+    {
+        groups_of_four<MASK>([&](auto m, auto j0, auto j1, auto j2, auto j3) {
+            if constexpr (m == 4) lanes::fma_bc4<KOFF + j0, KOFF + j1, KOFF + j2, KOFF + j3>(acc, b, a_of(j0), b, a_of(j1), b, a_of(j2), b, a_of(j3));
+            else if constexpr (m == 3) lanes::fma_bc3<KOFF + j0, KOFF + j1, KOFF + j2>(acc, b, a_of(j0), b, a_of(j1), b, a_of(j2));
+            else if constexpr (m == 2) lanes::fma_bc2<KOFF + j0, KOFF + j1>(acc, b, a_of(j0), b, a_of(j1));
+            else lanes::fma_bc<KOFF + j0>(acc, b, a_of(j0));
+        });
+    }
+    template <unsigned MASK, int K, class FB, class FA>
+    USV_DEV static void dot_col(double &acc, FB b_of, FA a_of)
+    {
+        groups_of_four<MASK>([&](auto m, auto j0, auto j1, auto j2, auto j3) {
+            if constexpr (m == 4) lanes::fma_bc4<K, K, K, K>(acc, b_of(j0), a_of(j0), b_of(j1), a_of(j1), b_of(j2), a_of(j2), b_of(j3), a_of(j3));
+            else if constexpr (m == 3) lanes::fma_bc3<K, K, K>(acc, b_of(j0), a_of(j0), b_of(j1), a_of(j1), b_of(j2), a_of(j2));
+            else if constexpr (m == 2) lanes::fma_bc2<K, K>(acc, b_of(j0), a_of(j0), b_of(j1), a_of(j1));
+            else lanes::fma_bc<K>(acc, b_of(j0), a_of(j0));
+        });
+    }
 
     using BoxRow = RowCalc<SOFTBOX, SOFTBOX>;
     using ObsRow = RowCalc<SOFT>;
@@ -258,14 +297,37 @@ struct QpIpm {
     bool isslot, isdense, anydense;
     int bsrc, bstep, ssrc;
     bool hasb;
-    double lbv, ubv, hd_stage, hd_term;
+    // These per-lane constants live in LDS (lanes::Stash), not in registers: see there.
+    static constexpr int KC = KCH > 0 ? KCH : 1;
+    enum : int {
+        ST_LB = 0, ST_UB, ST_HDS, ST_HDT, ST_UH, ST_OX = ST_UH + KC, ST_OY = ST_OX + KC, ST_LH = ST_OY + KC, ST_SOFT = ST_LH + KC,
+        ST_ZL = ST_SOFT, ST_ZU = ST_ZL + (SOFT ? KC : 0), ST_QL = ST_ZU + (SOFT ? KC : 0), ST_QU = ST_QL + (SOFT ? KC : 0),
+        ST_BSL = ST_QU + (SOFT ? KC : 0), ST_BSU = ST_BSL + (SOFT ? KC : 0), ST_BOX = ST_BSU + (SOFT ? KC : 0),
+        ST_N = ST_BOX + (SOFTBOX ? 6 : 0)
+    };
+    using ST = lanes::Stash<ST_N>;
+    struct CRef {
+        int slot;
+        USV_DEV operator double() const { return ST::get(slot); }
+        USV_DEV void operator=(double v) const { ST::put(slot, v); }
+    };
+    template <int SLOT0>
+    struct CArr {
+        USV_DEV CRef operator[](int c) const { return CRef{SLOT0 + c}; }
+    };
+    template <int SLOT>
+    struct CVal {
+        USV_DEV operator double() const { return ST::get(SLOT); }
+        USV_DEV void operator=(double v) const { ST::put(SLOT, v); }
+    };
+    CVal<ST_LB> lbv; CVal<ST_UB> ubv; CVal<ST_HDS> hd_stage; CVal<ST_HDT> hd_term;
     bool bsoft;                               // SOFTBOX: this lane's state bound is soft
-    double bzl, bzu, bZl, bZu, bbsl, bbsu;    // its slack penalties (scaled by dt) and slack lower bounds
-    double c_zl[KCH > 0 ? KCH : 1], c_zu[KCH > 0 ? KCH : 1], c_Zl[KCH > 0 ? KCH : 1], c_Zu[KCH > 0 ? KCH : 1],
-        c_bsl[KCH > 0 ? KCH : 1], c_bsu[KCH > 0 ? KCH : 1];
+    // its slack penalties (scaled by dt) and slack lower bounds
+    CVal<ST_BOX + 0> bzl; CVal<ST_BOX + 1> bzu; CVal<ST_BOX + 2> bZl; CVal<ST_BOX + 3> bZu; CVal<ST_BOX + 4> bbsl; CVal<ST_BOX + 5> bbsu;
+    CArr<ST_ZL> c_zl; CArr<ST_ZU> c_zu; CArr<ST_QL> c_Zl; CArr<ST_QU> c_Zu; CArr<ST_BSL> c_bsl; CArr<ST_BSU> c_bsu;
     // obstacle data of this lane's row(s): upper bound, and - when the obstacle set is the same on every
-    // stage (DevSpec::p_static, what the reference's callers do) - centre and lower bound held in registers
-    double c_uh[KCH > 0 ? KCH : 1], c_ox[KCH > 0 ? KCH : 1], c_oy[KCH > 0 ? KCH : 1], c_lh[KCH > 0 ? KCH : 1];
+    // stage (DevSpec::p_static, what the reference's callers do) - centre and lower bound
+    CArr<ST_UH> c_uh; CArr<ST_OX> c_ox; CArr<ST_OY> c_oy; CArr<ST_LH> c_lh;
 
     // lds_row: which of the workgroup's LDS regions the row owns (LDSWS), < 0: none
     USV_DEV QpIpm(const DevPtrs &P_, long g_, int lds_row = 0) : P(P_), S(*P_.spec)
@@ -328,8 +390,10 @@ struct QpIpm {
         hd_stage = S.Hc[lane * LANES + lane];
         hd_term = S.He[lane * LANES + lane];
         bsoft = SOFTBOX && S.bsoft[lane] != 0;
-        bzl = S.b_zl[lane]; bzu = S.b_zu[lane]; bZl = bsoft ? S.b_Zl[lane] : 1.0; bZu = bsoft ? S.b_Zu[lane] : 1.0;
-        bbsl = S.b_lsl[lane]; bbsu = S.b_lsu[lane];
+        if constexpr (SOFTBOX) { // (their stash slots exist only then)
+            bzl = S.b_zl[lane]; bzu = S.b_zu[lane]; bZl = bsoft ? S.b_Zl[lane] : 1.0; bZu = bsoft ? S.b_Zu[lane] : 1.0;
+            bbsl = S.b_lsl[lane]; bbsu = S.b_lsu[lane];
+        }
         if constexpr (KCH > 0) {
             sfor<0, KCH>([&](auto c) {
                 const int i = c * LANES + lane;
@@ -339,7 +403,7 @@ struct QpIpm {
         g = 0; b = 0;
         live = lds_row >= 0;
         loff = (unsigned)((lds_row > 0 ? lds_row : 0) * (N + 1) * NPL * LANES + lane);
-        if constexpr (KCH > 0) sfor<0, KCH>([&](auto c) { c_ox[c] = c_oy[c] = c_lh[c] = 0.0; });
+        if constexpr (KCH > 0) sfor<0, KCH>([&](auto c) { c_ox[c] = 0.0; c_oy[c] = 0.0; c_lh[c] = 0.0; });
         bind(g_, true);
         if constexpr (KCH > 0 && SOFT) {
             sfor<0, KCH>([&](auto c) {
@@ -515,11 +579,9 @@ struct QpIpm {
     USV_DEV double mat_apply(const double *pk, double dz, double acc) const
     {
         mat_put(pk);
-        sfor<0, NCOL>([&](auto ci) {
-            constexpr int c = MP::nth(CMASK, ci);
-            const double v = XP::get((int)((coltab[ci / 4] >> (8 * (ci % 4))) & 0xffu));
-            lanes::fma_bc<c>(acc, dz, v);
-        });
+        double v[NCOL];
+        sfor<0, NCOL>([&](auto ci) { v[ci] = XP::get((int)((coltab[ci / 4] >> (8 * (ci % 4))) & 0xffu)); });
+        dot_lanes<CMASK, 0>(acc, dz, [&](auto c) { return v[__builtin_popcount(CMASK & ((1u << c) - 1u))]; });
         return acc + (selfone ? dz : 0.0);
     }
     USV_DEV static double obs_dot(double cx, double cy, double vec)
@@ -845,10 +907,9 @@ struct QpIpm {
                 // recursion, stationarity in x holds by construction);  u lanes: residual r_g
                 double t = in.gq;
                 if constexpr (HDIAG) t = fma(hd, z, t);
-                else sfor<0, NZ>([&](auto c) { lanes::fma_bc<c>(t, z, Hrow[c]); });
-                sfor<0, NX>([&](auto j) {
-                    if constexpr (!out_unit(j)) lanes::fma_bc<NU + j>(t, pin, bat[j]);
-                });
+                else dot_lanes<ZMASK, 0>(t, z, [&](auto c) { return Hrow[c]; });
+                lanes::settle(pin); // (a constant 0.0 in the peeled terminal stage: materialised right in front of its use)
+                dot_lanes<NONUNIT, NU>(t, pin, [&](auto j) { return bat[j]; });
                 if constexpr (M::OUT_UNIT != 0u) t += ounit ? pin : 0.0;
                 t -= br.act ? br.ll - br.lu : 0.0;
                 t -= isPX ? lx : (isPY ? ly : 0.0);
@@ -890,14 +951,12 @@ struct QpIpm {
                 if (FACT) {
                     // P_{k+1} b_k first: each column of P_{k+1} then dies as soon as its column of T is formed
                     Pb = 0.0;
-                    sfor<0, NX>([&](auto c) { lanes::fma_bc<NU + c>(Pb, rb, Pn[c]); });
+                    dot_lanes<XMASK, NU>(Pb, rb, [&](auto c) { return Pn[c]; });
                     // T = [B A]' P_{k+1}   (row r: sum_j bat_j * P_{k+1}[j][:])
                     double T[NX];
                     sfor<0, NX>([&](auto c) {
                         double a = 0.0;
-                        sfor<0, NX>([&](auto j) {
-                            if constexpr (!out_unit(j)) lanes::fma_bc<NU + j>(a, Pn[c], bat[j]);
-                        });
+                        dot_lanes<NONUNIT, NU>(a, Pn[c], [&](auto j) { return bat[j]; });
                         // unit rows of [A B] (x+_j = x_j): row nu+j of T receives row j of P, which that lane owns
                         if constexpr (M::OUT_UNIT != 0u) a += ounit ? Pn[c] : 0.0;
                         T[c] = a;
@@ -916,10 +975,9 @@ struct QpIpm {
                             // whole sum collapses to one term
                             if constexpr (c >= NU) a += T[c - NU];
                         } else {
-                            sfor<0, NX>([&](auto j) {
-                                if constexpr (!out_unit(j)) lanes::fma_bc<c>(a, bat[j], T[j]);
-                                else if constexpr (c == NU + j) a += T[j]; // column nu+j of a unit row is e_j
-                            });
+                            dot_col<NONUNIT, c>(a, [&](auto j) { return bat[j]; }, [&](auto j) { return T[j]; });
+                            // column nu+j of a unit row is e_j
+                            if constexpr (c >= NU) { if constexpr (out_unit(c - NU)) a += T[c - NU]; }
                         }
                         return a;
                     };
@@ -936,7 +994,7 @@ struct QpIpm {
                     // of G are never alive together)
                     sfor<0, NX>([&](auto c) {
                         double a = gcol(std::integral_constant<int, NU + c>{});
-                        sfor<0, NU>([&](auto l) { lanes::fma_bc<NU + c>(a, Lzu[l], -Lzu[l]); });
+                        dot_col<(1u << NU) - 1u, NU + c>(a, [&](auto l) { return Lzu[l]; }, [&](auto l) { return -Lzu[l]; });
                         Pn[c] = xlane ? a : 0.0;
                     });
                     sfor<0, NU>([&](auto l) { dfr_lz[l] = Lzu[l]; });
@@ -948,11 +1006,10 @@ struct QpIpm {
                     });
                 }
                 // vector recursion
-                const double h = Pb + pn;
+                double h = Pb + pn;
+                lanes::settle(h);
                 double rq = gt;
-                sfor<0, NX>([&](auto j) {
-                    if constexpr (!out_unit(j)) lanes::fma_bc<NU + j>(rq, h, bat[j]);
-                });
+                dot_lanes<NONUNIT, NU>(rq, h, [&](auto j) { return bat[j]; });
                 if constexpr (M::OUT_UNIT != 0u) rq += ounit ? h : 0.0;
                 double lu[NU], luv = 0.0;
                 sfor<0, NU>([&](auto l) {

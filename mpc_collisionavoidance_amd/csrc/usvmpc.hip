@@ -364,7 +364,13 @@ int launch_pair(usvmpc_handle *h, int phase)
     // (as many whole horizons as fit), one wave per CU at a time; further instances come through the same queue.
     auto launch_qp = [&](auto kern, decltype(kern) kern_lds) -> int {
         const long lds_inst = (long)(h->N + 1) * h->spec.npt * 128;
-        const int rows_lds = (int)std::min<long>(4, (160L * 1024) / lds_inst);
+        // (the kernel's own static LDS - exchange area, parked constants - comes out of the same 160 KB)
+        long lds_static = 0;
+        if (kern_lds != nullptr) {
+            hipFuncAttributes fa;
+            if (hipFuncGetAttributes(&fa, (const void *)kern_lds) == hipSuccess) lds_static = (long)fa.sharedSizeBytes;
+        }
+        const int rows_lds = (int)std::min<long>(4, (160L * 1024 - lds_static) / lds_inst);
         bool use_lds = phase == 0 && h->lds_mode != 0 && kern_lds != nullptr && rows_lds >= 1 && h->ncu > 0;
         // by default only while one round of workgroups covers the batch: measured on usv_model_pf_ca, N = 20 / K = 3, the solve
         // of 512 instances takes 5.9 ms with the planes in LDS against 6.5 ms in HBM, at 1024 (two rounds) 7.5 against 7.1

@@ -53,6 +53,13 @@ inline int bcast_i(int v) { return (int)exchange((double)v, K); }
 
 template <int K>
 inline void fma_bc(double &c, double b_remote, double a_own) { c = std::fma(bcast<K>(b_remote), a_own, c); }
+template <int K0, int K1>
+inline void fma_bc2(double &c, double b0, double a0, double b1, double a1) { fma_bc<K0>(c, b0, a0); fma_bc<K1>(c, b1, a1); }
+template <int K0, int K1, int K2>
+inline void fma_bc3(double &c, double b0, double a0, double b1, double a1, double b2, double a2) { fma_bc2<K0, K1>(c, b0, a0, b1, a1); fma_bc<K2>(c, b2, a2); }
+template <int K0, int K1, int K2, int K3>
+inline void fma_bc4(double &c, double b0, double a0, double b1, double a1, double b2, double a2, double b3, double a3) { fma_bc2<K0, K1>(c, b0, a0, b1, a1); fma_bc2<K2, K3>(c, b2, a2, b3, a3); }
+inline void settle(double &) {} // hazard padding of the device build: nothing to emulate
 
 inline double gather(double v, int src) { return exchange(v, src); }
 
@@ -126,6 +133,14 @@ struct Xpose {
     static void put(int slot, double v) { area()[slot] = v; }
     static double get(int slot) { return area()[slot]; }
     static void sync() { (void)exchange(0.0, 0); }
+};
+
+// per-lane constants parked in LDS (gfx950/lanes.hpp): one emulated row
+template <int NSLOT>
+struct Stash {
+    static double *area() { static double s[NSLOT * 16]; return s; }
+    static void put(int slot, double v) { area()[slot * 16 + lane()] = v; }
+    static double get(int slot) { return area()[slot * 16 + lane()]; }
 };
 
 // the workgroup's LDS (one emulated row per "wave")

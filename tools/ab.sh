@@ -3,9 +3,10 @@ cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 tag=$1; shift
 mkdir -p gpurun_out/$tag
 for lib in "$@"; do
-  for wl in survey r01; do
+  for wl in survey r01 ${EXTRA:-}; do
     if [ "$lib" = stock ]; then unset USVMPC_LIB; else export USVMPC_LIB=$PWD/build_ab/libusvmpc_$lib.so; fi
-    python bench.py --workload $wl --steps 10 --cpu-sample ${CPUS:-0} > gpurun_out/$tag/${lib}_$wl.json 2> gpurun_out/$tag/${lib}_$wl.err
+    args="--workload $wl"; [ "$wl" = m1 ] && args="--model usv_model_guidance_ca1"
+    python bench.py $args --steps 10 --cpu-sample ${CPUS:-0} > gpurun_out/$tag/${lib}_$wl.json 2> gpurun_out/$tag/${lib}_$wl.err
     python - <<PY
 import json
 try:

@@ -181,20 +181,27 @@ USV_DEV int fetch_add(int *p) { return atomicAdd(p, 1); }
 // true if the predicate holds in any lane of the wave (four instances)
 USV_DEV bool wave_any(bool p) { return __any((int)p) != 0; }
 
+#ifndef USV_NEWTON_STEPS
+#define USV_NEWTON_STEPS 2
+#endif
 // 1/x and 1/sqrt(x) from the hardware estimate + two Newton steps (full FP64 accuracy for the
 // normal-range operands of the IPM; ~10 instructions instead of the ~25 of an IEEE division)
 USV_DEV double frcp(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+#if USV_NEWTON_STEPS > 1
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+#endif
     return r;
 }
 USV_DEV double frsqrt(double x)
 {
     double y = __builtin_amdgcn_rsq(x);
     y = __builtin_fma(0.5 * y, __builtin_fma(-x * y, y, 1.0), y);
+#if USV_NEWTON_STEPS > 1
     y = __builtin_fma(0.5 * y, __builtin_fma(-x * y, y, 1.0), y);
+#endif
     return y;
 }
 

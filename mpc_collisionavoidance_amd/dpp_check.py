@@ -23,21 +23,22 @@ WAIT_STATES = 2
 
 
 def code_objects(path):
-    """gfx950 code objects inside `path` (a host shared library with an offload bundle, or already a code object)."""
-    head = open(path, "rb").read(64)
-    out = subprocess.run([f"{LLVM}/llvm-readelf", "-h", path], capture_output=True, text=True).stdout
-    if "AMDGPU" in out or "AMD GPU" in out:
-        return [path], None
-    tmp = tempfile.mkdtemp(prefix="dppchk_")
-    # the bundle sits in section .hip_fatbin
-    fat = os.path.join(tmp, "fat.bin")
-    subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", path, os.path.join(tmp, "stripped")], check=True)
-    res = []
-    i = 0
-    data = open(fat, "rb").read()
-    # one or more concatenated bundles: let clang-offload-bundler list and extract each
-    off = 0
+    """gfx950 code objects inside `path`: a host shared library with an offload bundle, a bare bundle, or already a code object."""
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    head = open(path, "rb").read(64)
+    if not head.startswith(magic):
+        out = subprocess.run([f"{LLVM}/llvm-readelf", "-h", path], capture_output=True, text=True).stdout
+        if "AMDGPU" in out or "AMD GPU" in out:
+            return [path], None
+    tmp = tempfile.mkdtemp(prefix="dppchk_")
+    if head.startswith(magic):
+        data = open(path, "rb").read()
+    else:   # the bundle sits in section .hip_fatbin of the host library
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", path, os.path.join(tmp, "stripped")], check=True)
+        data = open(fat, "rb").read()
+    res = []
+    # one or more concatenated bundles: let clang-offload-bundler list and extract each
     starts = [m.start() for m in re.finditer(re.escape(magic), data)]
     for n, st in enumerate(starts):
         en = starts[n + 1] if n + 1 < len(starts) else len(data)

@@ -1,0 +1,63 @@
+"""The static hazard check of hand-placed DPP instructions (mpc_collisionavoidance_amd/dpp_check.py).
+
+lanes::fma_bc places v_fmac_f64_dpp through inline asm; the compiler does not pad the one hazard that instruction has (a VALU
+write of its DPP source within the two preceding wait states: tools/micro/dpp_hazard.hip measured it on the part), so every
+library the build produces is disassembled and checked.  Here: the in-tree library is clean and actually contains the fused
+instructions, and the checker does flag a kernel written to violate the rule (also across a branch)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mpc_collisionavoidance_amd import dpp_check  # noqa: E402
+
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def test_in_tree_library_is_clean():
+    import __graft_entry__ as g
+    lib = g.build_hip()
+    n, bad = dpp_check.check_library(lib)
+    assert n > 1000, "the fused DPP FMAs are not in the built library (%d found)" % n
+    assert bad == []
+
+
+BAD = r"""
+#include <hip/hip_runtime.h>
+__global__ void straight(double *p)
+{
+    double acc = p[threadIdx.x], b = p[64 + threadIdx.x], a = 2.0;
+    asm volatile("v_add_f64 %1, %1, %1\n v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(acc), "+v"(b) : "v"(a));
+    p[threadIdx.x] = acc;
+}
+__global__ void padded(double *p)
+{
+    double acc = p[threadIdx.x], b = p[64 + threadIdx.x], a = 2.0;
+    asm volatile("v_add_f64 %1, %1, %1\n s_nop 1\n v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(acc), "+v"(b) : "v"(a));
+    p[threadIdx.x] = acc;
+}
+__global__ void across_branch(double *p, int n)
+{
+    double acc = p[threadIdx.x], b = p[64 + threadIdx.x], a = 2.0;
+    asm volatile("s_cmp_eq_u32 %3, 0\n s_cbranch_scc1 1f\n v_add_f64 %1, %1, %1\n 1:\n v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc), "+v"(b) : "v"(a), "s"(n) : "scc");
+    p[threadIdx.x] = acc;
+}
+"""
+
+
+def test_checker_flags_a_violation(tmp_path):
+    src = tmp_path / "bad.hip"
+    src.write_text(BAD)
+    out = tmp_path / "bad.co"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O2", "--cuda-device-only", "-c", "-o", str(out), str(src)], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("hipcc could not build the probe: " + r.stderr[-300:])
+    n, bad = dpp_check.check_library(str(out))
+    assert n == 3
+    assert any("straight" in b for b in bad)
+    assert any("across_branch" in b for b in bad)
+    assert not any("padded" in b for b in bad)

@@ -827,6 +827,8 @@ struct QpIpm {
             double z = in.z; // the absolute iterate zbar + z
             const double zbx = aux_zx(in.aux), zby = aux_zy(in.aux);
             const double psel = pos_sel(zbx, zby);
+            // 1.0 on the state lanes of structurally unit rows of [A B]: "x += unit ? y : 0" as one FMA instead of two selects and an add
+            const double ou1 = ounit ? 1.0 : 0.0;
             const double *Hrow = (k < N ? S.Hc : S.He) + lane * LANES; // only read when !HDIAG
             const double hd = (k < N) ? hd_stage : hd_term;
             const double dza = FACT ? 0.0 : in.dza;
@@ -910,7 +912,7 @@ struct QpIpm {
                 else dot_lanes<ZMASK, 0>(t, z, [&](auto c) { return Hrow[c]; });
                 lanes::settle(pin); // (a constant 0.0 in the peeled terminal stage: materialised right in front of its use)
                 dot_lanes<NONUNIT, NU>(t, pin, [&](auto j) { return bat[j]; });
-                if constexpr (M::OUT_UNIT != 0u) t += ounit ? pin : 0.0;
+                if constexpr (M::OUT_UNIT != 0u) t = fma(ou1, pin, t);
                 t -= br.act ? br.ll - br.lu : 0.0;
                 t -= isPX ? lx : (isPY ? ly : 0.0);
                 pik = xlane ? t : 0.0;
@@ -951,6 +953,7 @@ struct QpIpm {
                 if (FACT) {
                     // P_{k+1} b_k first: each column of P_{k+1} then dies as soon as its column of T is formed
                     Pb = 0.0;
+                    lanes::settle(rb); // (scaled a few instructions ago)
                     dot_lanes<XMASK, NU>(Pb, rb, [&](auto c) { return Pn[c]; });
                     // T = [B A]' P_{k+1}   (row r: sum_j bat_j * P_{k+1}[j][:])
                     double T[NX];
@@ -958,7 +961,7 @@ struct QpIpm {
                         double a = 0.0;
                         dot_lanes<NONUNIT, NU>(a, Pn[c], [&](auto j) { return bat[j]; });
                         // unit rows of [A B] (x+_j = x_j): row nu+j of T receives row j of P, which that lane owns
-                        if constexpr (M::OUT_UNIT != 0u) a += ounit ? Pn[c] : 0.0;
+                        if constexpr (M::OUT_UNIT != 0u) a = fma(ou1, Pn[c], a);
                         T[c] = a;
                     });
                     // G = H~ + T [B A]     (row r, column c': sum_j T_j * BAt[c'][j]), one column at a time
@@ -987,6 +990,7 @@ struct QpIpm {
                     sfor<0, NU>([&](auto l) {
                         const double il = lanes::frsqrt(lanes::bcast<l>(Gu[l]));
                         Lzu[l] = Gu[l] * il;
+                        lanes::settle(Lzu[l]); // DPP source of the updates below
                         iLd[l] = il;
                         sfor<l + 1, NU>([&](auto m) { lanes::fma_bc<m>(Gu[m], Lzu[l], -Lzu[l]); });
                     });
@@ -995,7 +999,9 @@ struct QpIpm {
                     sfor<0, NX>([&](auto c) {
                         double a = gcol(std::integral_constant<int, NU + c>{});
                         dot_col<(1u << NU) - 1u, NU + c>(a, [&](auto l) { return Lzu[l]; }, [&](auto l) { return -Lzu[l]; });
-                        Pn[c] = xlane ? a : 0.0;
+                        // (all 16 lanes keep their value: nothing reads the control lanes of a column of P - T broadcasts
+                        // state lanes only, P b and the vector recursion are masked where they are stored or summed)
+                        Pn[c] = a;
                     });
                     sfor<0, NU>([&](auto l) { dfr_lz[l] = Lzu[l]; });
                 } else {
@@ -1010,7 +1016,7 @@ struct QpIpm {
                 lanes::settle(h);
                 double rq = gt;
                 dot_lanes<NONUNIT, NU>(rq, h, [&](auto j) { return bat[j]; });
-                if constexpr (M::OUT_UNIT != 0u) rq += ounit ? h : 0.0;
+                if constexpr (M::OUT_UNIT != 0u) rq = fma(ou1, h, rq);
                 double lu[NU], luv = 0.0;
                 sfor<0, NU>([&](auto l) {
                     double a = lanes::bcast<l>(rq);

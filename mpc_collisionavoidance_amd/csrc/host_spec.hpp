@@ -4,6 +4,7 @@
 #include "../../include/usvmpc.h"
 #include "params.hpp"
 #include <cstring>
+#include <cmath>
 #include <string>
 
 namespace usv {
@@ -32,6 +33,14 @@ inline std::string build_spec(const usvmpc_desc &d, DevSpec &S)
     if (d.K < 0 || d.K > KMAX) return "K out of range (0..32)";
     if (d.model == USVMPC_MODEL_USV && d.K != 0) return "model usv_model has no obstacle rows (K must be 0)";
     if (d.nbu < 0 || d.nbu > nu || d.nbx < 0 || d.nbx > nx) return "nbu/nbx out of range";
+    // The IPM forms products of two slacks / two multipliers of a row (paired reciprocals, qp_ipm.hpp): bounds standing in for
+    // "none" must stay representable next to them.  acados' own ACADOS_INFTY is 1e10.
+    {
+        const double BIG = 1e100;
+        for (int i = 0; i < d.nbu; i++) if (!(std::fabs(d.lbu[i]) <= BIG && std::fabs(d.ubu[i]) <= BIG)) return "lbu / ubu beyond 1e100 (or NaN)";
+        for (int i = 0; i < d.nbx; i++) if (!(std::fabs(d.lbx[i]) <= BIG && std::fabs(d.ubx[i]) <= BIG)) return "lbx / ubx beyond 1e100 (or NaN)";
+        for (int i = 0; i < d.K; i++) if (!(std::fabs(d.uh[i]) <= BIG)) return "uh beyond 1e100 (or NaN)";
+    }
     const int nz = nx + nu, ny = nx + nu, ny_e = nx;
     std::memset(&S, 0, sizeof(S));
     S.dt = d.Tf / d.N;

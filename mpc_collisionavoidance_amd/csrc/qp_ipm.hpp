@@ -41,6 +41,10 @@
 #include "params.hpp"
 #include "sfor.hpp"
 
+#ifndef USV_PAIRED_RCP
+#define USV_PAIRED_RCP 1 // both reciprocals of a row's slack pair / multiplier pair from one v_rcp_f64 (lanes::frcp2)
+#endif
+
 namespace usv {
 
 // One two-sided inequality row  dl <= v (+ sl),  v (- su) <= du  with its multipliers/slacks,
@@ -74,15 +78,23 @@ struct RowCalc {
     {
         rdl = v + sl - dl - tl;
         rdu = du - v + su - tu;
+#if USV_PAIRED_RCP
+        lanes::frcp2(tl, tu, itl, itu);
+#else
         itl = lanes::frcp(tl);
         itu = lanes::frcp(tu);
+#endif
         if constexpr (SOFTROW) {
             rsl = Zl * sl + zl - ll - lsl;
             rsu = Zu * su + zu - lu - lsu;
             rdsl = sl - bsl - tsl;
             rdsu = su - bsu - tsu;
+#if USV_PAIRED_RCP
+            lanes::frcp2(tsl, tsu, itsl, itsu);
+#else
             itsl = lanes::frcp(tsl);
             itsu = lanes::frcp(tsu);
+#endif
             if constexpr (MIXED) {
                 if (!soft) { rsl = 0.0; rsu = 0.0; rdsl = 0.0; rdsu = 0.0; }
             }
@@ -158,11 +170,23 @@ struct RowCalc {
     {
         if (!act) return q;
         q = fmax(q, -dtl * itl); q = fmax(q, -dtu * itu);
+#if USV_PAIRED_RCP
+        double ill, ilu;
+        lanes::frcp2(ll, lu, ill, ilu);
+        q = fmax(q, -dll * ill); q = fmax(q, -dlu * ilu);
+#else
         q = fmax(q, -dll * lanes::frcp(ll)); q = fmax(q, -dlu * lanes::frcp(lu));
+#endif
         if constexpr (SOFTROW) {
             if (is_soft()) {
                 q = fmax(q, -dtsl * itsl); q = fmax(q, -dtsu * itsu);
+#if USV_PAIRED_RCP
+                double ilsl, ilsu;
+                lanes::frcp2(lsl, lsu, ilsl, ilsu);
+                q = fmax(q, -dlsl * ilsl); q = fmax(q, -dlsu * ilsu);
+#else
                 q = fmax(q, -dlsl * lanes::frcp(lsl)); q = fmax(q, -dlsu * lanes::frcp(lsu));
+#endif
             }
         }
         return q;
@@ -1003,12 +1027,13 @@ struct QpIpm {
                         // state lanes only, P b and the vector recursion are masked where they are stored or summed)
                         Pn[c] = a;
                     });
-                    sfor<0, NU>([&](auto l) { dfr_lz[l] = Lzu[l]; });
+                    // stored with the RECIPROCAL of the diagonal entry in its place: that is all the three later sweeps want of it
+                    sfor<0, NU>([&](auto l) { dfr_lz[l] = (lane == l) ? iLd[l] : Lzu[l]; });
                 } else {
                     Pb = xlane ? in.pb : 0.0;
                     sfor<0, NU>([&](auto l) {
                         Lzu[l] = in.lzu[l];
-                        iLd[l] = lanes::frcp(lanes::bcast<l>(Lzu[l]));
+                        iLd[l] = lanes::bcast<l>(Lzu[l]); // (stored as the reciprocal)
                     });
                 }
                 // vector recursion
@@ -1086,7 +1111,7 @@ struct QpIpm {
                     constexpr int l = NU - 1 - qq;
                     double acc = t[l];
                     sfor<l + 1, NU>([&](auto m) { acc -= lanes::bcast<m>(in.lzu[l]) * du[m]; });
-                    du[l] = acc * lanes::frcp(lanes::bcast<l>(in.lzu[l]));
+                    du[l] = acc * lanes::bcast<l>(in.lzu[l]); // (the diagonal entry is stored as its reciprocal)
                 });
                 dz = xlane ? dzx : 0.0;
                 sfor<0, NU>([&](auto l) { dz = (lane == l) ? -du[l] : dz; });

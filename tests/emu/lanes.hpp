@@ -101,6 +101,7 @@ inline void count_one(int *p) { ++*p; }
 inline int fetch_add(int *p) { return (*p)++; }
 
 inline double frcp(double x) { return 1.0 / x; }
+inline void frcp2(double a, double b, double &ia, double &ib) { const double r = 1.0 / (a * b); ia = r * b; ib = r * a; }
 inline double frsqrt(double x) { return 1.0 / std::sqrt(x); }
 
 // lane index inside the (emulated) wave: the group's quarter of its 4-group tile

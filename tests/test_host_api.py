@@ -135,3 +135,17 @@ def test_reference_of_the_wrong_length_is_refused():
     ocp.cost.yref_e = np.zeros(3)
     with pytest.raises(Exception, match="inconsistent dimension"):
         BatchOcpSolver(ocp, 2)
+
+
+def test_bounds_beyond_1e100_are_refused():
+    """The IPM multiplies the two slacks (and the two multipliers) of a row: a bound that stands for "none" has to stay inside
+    the double range next to them (host_spec.hpp).  Refused at create, before any device is touched."""
+    ocp = usv_models.make_ocp("usv_model_pf_ca", 0.4, 40, 10)
+    ocp.constraints.uh = 1e300 * np.ones(10)
+    d = _capi.desc_from_ocp(ocp, batch=2)
+    h = C.c_void_p()
+    assert _capi.lib().usvmpc_create(C.byref(d), C.byref(h)) == -1 and not h.value
+    ocp = usv_models.make_ocp("usv_model", 1.0, 20)
+    ocp.constraints.ubu = np.array([np.inf, 1.0])
+    d = _capi.desc_from_ocp(ocp, batch=2)
+    assert _capi.lib().usvmpc_create(C.byref(d), C.byref(h)) == -1 and not h.value

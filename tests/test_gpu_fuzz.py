@@ -1,0 +1,64 @@
+"""Seeded sweep of shapes and options through the C ABI against the CPU oracle (`pytest -m gpu`): horizon, obstacle count (one
+and two lane chunks, none), batch sizes that leave rows of a wave idle, static / per-stage obstacle sets, the workspace in LDS or
+in HBM, the queue on or off - the corners that the fixed parity cases of test_gpu_parity.py do not visit.  Same bar as there:
+statuses agree, iterates of instances converged on both sides within 1e-7 (relative, per component), IPM iteration counts
+within one."""
+import numpy as np
+import pytest
+
+from mpc_collisionavoidance_amd import BatchOcpSolver, scenario
+from tests import util
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-7
+
+
+def _case(oracle, name, N, K, B, seed, static, lds, dyn, ticks=2):
+    ocp, wl = util.make(name, N, K, B, seed=seed)
+    dt = scenario.DT[name]
+    s = BatchOcpSolver(ocp, B)
+    scenario.load_into(s, wl)
+    if K > 0:
+        s.set_option("static_obstacles", static)
+    s.set_option("lds_workspace", lds)
+    s.set_option("dynamic_rows", dyn)
+    spec = util.oracle_spec(oracle, name, N, dt, K)
+    xo, uo = wl["x_init"].copy(), wl["u_init"].copy()
+    good = np.ones(B, dtype=bool)
+    slack = max(1, int(0.03 * B))
+    tag = (name, N, K, B, seed, static, lds, dyn)
+    for it in range(ticks):
+        st = s.solve()
+        xo, uo, sto, ito = util.oracle_rti(oracle, spec, wl, xo, uo)
+        xg, ug = s.get_all("x"), s.get_all("u")
+        qs, qi = s.get_int("qp_status"), s.get_int("qp_iter")
+        conv_g, conv_o = qs == 0, (sto == 0) & (ito < spec.opts.qp_iter_max)
+        assert (conv_g != conv_o)[good].sum() <= slack, (tag, it)
+        assert ((st != sto) & good).sum() <= slack, (tag, it, st, sto)
+        good &= conv_g & conv_o
+        print("fuzz", tag, "tick", it, "compared %d / %d" % (good.sum(), B), "iters", float(qi.mean()))
+        if good.sum() == 0:
+            break
+        assert np.isfinite(xg[good]).all() and np.isfinite(ug[good]).all(), tag
+        ex, eu = util.rel_err(xg[good], xo[good]), util.rel_err(ug[good], uo[good])
+        assert ex <= TOL and eu <= TOL, (tag, it, ex, eu)
+        dit = np.abs(qi - ito)[good]
+        assert dit.max() <= 1 and (dit > 0).sum() <= slack, (tag, it, dit.max())
+    s.close()
+
+
+def _cases():
+    rng = np.random.default_rng(20260929)
+    out = []
+    for i in range(18):
+        name = ["usv_model", "usv_model_guidance_ca1", "usv_model_pf_ca"][i % 3]
+        N = int(rng.choice([2, 3, 7, 20, 33]))
+        K = 0 if name == "usv_model" else int(rng.choice([1, 4, 9, 16, 17, 24]))
+        B = int(rng.choice([1, 2, 3, 6, 9, 30, 67]))
+        out.append((name, N, K, B, int(rng.integers(1, 1000)), int(rng.integers(0, 2)), int(rng.choice([-1, 0, 1])), int(rng.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("name,N,K,B,seed,static,lds,dyn", _cases())
+def test_shape_and_option_sweep(oracle, name, N, K, B, seed, static, lds, dyn):
+    _case(oracle, name, N, K, B, seed, static, lds, dyn)

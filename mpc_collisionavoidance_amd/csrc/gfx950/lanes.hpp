@@ -148,12 +148,33 @@ USV_DEV double gsum(double v)
     v += ror<1>(v);
     return v;
 }
+// max(a, b), max(a, |b|), max(|a|, |b|) as ONE v_max_f64 each.  fmax() costs two where the compiler cannot prove an operand
+// canonical (anything that went through a select or a load): it puts a v_max_f64 x, x, x in front - half of the kernel's
+// v_max_f64 were those.  The instruction itself returns the other operand for a NaN one, as fmax does.
+USV_DEV double vmax(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+USV_DEV double vmax_abs(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+USV_DEV double vmax_abs2(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 USV_DEV double gmax(double v)
 {
-    v = fmax(v, ror<8>(v));
-    v = fmax(v, ror<4>(v));
-    v = fmax(v, ror<2>(v));
-    v = fmax(v, ror<1>(v));
+    v = vmax(v, ror<8>(v));
+    v = vmax(v, ror<4>(v));
+    v = vmax(v, ror<2>(v));
+    v = vmax(v, ror<1>(v));
     return v;
 }
 USV_DEV double gmin(double v)

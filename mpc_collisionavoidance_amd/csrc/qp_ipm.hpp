@@ -169,23 +169,23 @@ struct RowCalc {
     USV_DEV double blocking(double q) const
     {
         if (!act) return q;
-        q = fmax(q, -dtl * itl); q = fmax(q, -dtu * itu);
+        q = lanes::vmax(q, -dtl * itl); q = lanes::vmax(q, -dtu * itu);
 #if USV_PAIRED_RCP
         double ill, ilu;
         lanes::frcp2(ll, lu, ill, ilu);
-        q = fmax(q, -dll * ill); q = fmax(q, -dlu * ilu);
+        q = lanes::vmax(q, -dll * ill); q = lanes::vmax(q, -dlu * ilu);
 #else
-        q = fmax(q, -dll * lanes::frcp(ll)); q = fmax(q, -dlu * lanes::frcp(lu));
+        q = lanes::vmax(q, -dll * lanes::frcp(ll)); q = lanes::vmax(q, -dlu * lanes::frcp(lu));
 #endif
         if constexpr (SOFTROW) {
             if (is_soft()) {
-                q = fmax(q, -dtsl * itsl); q = fmax(q, -dtsu * itsu);
+                q = lanes::vmax(q, -dtsl * itsl); q = lanes::vmax(q, -dtsu * itsu);
 #if USV_PAIRED_RCP
                 double ilsl, ilsu;
                 lanes::frcp2(lsl, lsu, ilsl, ilsu);
-                q = fmax(q, -dlsl * ilsl); q = fmax(q, -dlsu * ilsu);
+                q = lanes::vmax(q, -dlsl * ilsl); q = lanes::vmax(q, -dlsu * ilsu);
 #else
-                q = fmax(q, -dlsl * lanes::frcp(lsl)); q = fmax(q, -dlsu * lanes::frcp(lsu));
+                q = lanes::vmax(q, -dlsl * lanes::frcp(lsl)); q = lanes::vmax(q, -dlsu * lanes::frcp(lsu));
 #endif
             }
         }
@@ -899,14 +899,14 @@ struct QpIpm {
                         const double dl_ = o.act ? o.ll - o.lu : 0.0;
                         lx += dl_ * cx; ly += dl_ * cy;
                         if (o.act) {
-                            nm.rd = fmax(nm.rd, fmax(fabs(o.rdl), fabs(o.rdu)));
-                            nm.rm = fmax(nm.rm, fmax(o.ll * o.tl, o.lu * o.tu));
+                            nm.rd = lanes::vmax(nm.rd, lanes::vmax_abs2(o.rdl, o.rdu));
+                            nm.rm = lanes::vmax(nm.rm, lanes::vmax(o.ll * o.tl, o.lu * o.tu));
                             nm.musum += o.ll * o.tl + o.lu * o.tu;
                             nm.nan = fma(0.0, o.rdl + o.rdu, nm.nan);
                             if constexpr (SOFT) {
-                                nm.rg = fmax(nm.rg, fmax(fabs(o.rsl), fabs(o.rsu)));
-                                nm.rd = fmax(nm.rd, fmax(fabs(o.rdsl), fabs(o.rdsu)));
-                                nm.rm = fmax(nm.rm, fmax(o.lsl * o.tsl, o.lsu * o.tsu));
+                                nm.rg = lanes::vmax(nm.rg, lanes::vmax_abs2(o.rsl, o.rsu));
+                                nm.rd = lanes::vmax(nm.rd, lanes::vmax_abs2(o.rdsl, o.rdsu));
+                                nm.rm = lanes::vmax(nm.rm, lanes::vmax(o.lsl * o.tsl, o.lsu * o.tsu));
                                 nm.musum += o.lsl * o.tsl + o.lsu * o.tsu;
                                 nm.nan = fma(0.0, o.rsl + o.rsu + o.rdsl + o.rdsu, nm.nan);
                             }
@@ -942,24 +942,24 @@ struct QpIpm {
                 pik = xlane ? t : 0.0;
                 rg = (ulane && k < N) ? t : 0.0;
                 dfr_pi = rg + pik; // rg lives on the u lanes, pik on the x lanes
-                nm.rg = fmax(nm.rg, fabs(rg));
+                nm.rg = lanes::vmax_abs(nm.rg, rg);
                 nm.nan = fma(0.0, t, nm.nan);
                 if (br.act) {
-                    nm.rd = fmax(nm.rd, fmax(fabs(br.rdl), fabs(br.rdu)));
-                    nm.rm = fmax(nm.rm, fmax(br.ll * br.tl, br.lu * br.tu));
+                    nm.rd = lanes::vmax(nm.rd, lanes::vmax_abs2(br.rdl, br.rdu));
+                    nm.rm = lanes::vmax(nm.rm, lanes::vmax(br.ll * br.tl, br.lu * br.tu));
                     nm.musum += br.ll * br.tl + br.lu * br.tu;
                     nm.nan = fma(0.0, br.rdl + br.rdu, nm.nan);
                     if constexpr (SOFTBOX) {
                         if (br.soft) {
-                            nm.rg = fmax(nm.rg, fmax(fabs(br.rsl), fabs(br.rsu)));
-                            nm.rd = fmax(nm.rd, fmax(fabs(br.rdsl), fabs(br.rdsu)));
-                            nm.rm = fmax(nm.rm, fmax(br.lsl * br.tsl, br.lsu * br.tsu));
+                            nm.rg = lanes::vmax(nm.rg, lanes::vmax_abs2(br.rsl, br.rsu));
+                            nm.rd = lanes::vmax(nm.rd, lanes::vmax_abs2(br.rdsl, br.rdsu));
+                            nm.rm = lanes::vmax(nm.rm, lanes::vmax(br.lsl * br.tsl, br.lsu * br.tsu));
                             nm.musum += br.lsl * br.tsl + br.lsu * br.tsu;
                             nm.nan = fma(0.0, br.rsl + br.rsu + br.rdsl + br.rdsu, nm.nan);
                         }
                     }
                 }
-                nm.rb = fmax(nm.rb, fabs(rb));
+                nm.rb = lanes::vmax_abs(nm.rb, rb);
             } else {
                 rg = (k < N) ? aux_ulane<AXL_RG>(in.aux) : 0.0;
             }

@@ -74,6 +74,9 @@ inline double gsum(double v)
     v += ror<1>(v);
     return v;
 }
+inline double vmax(double a, double b) { return std::fmax(a, b); }
+inline double vmax_abs(double a, double b) { return std::fmax(a, std::fabs(b)); }
+inline double vmax_abs2(double a, double b) { return std::fmax(std::fabs(a), std::fabs(b)); }
 inline double gmax(double v)
 {
     v = std::fmax(v, ror<8>(v));

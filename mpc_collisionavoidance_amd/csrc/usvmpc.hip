@@ -27,8 +27,11 @@
 using namespace usv;
 
 // ---------------------------------------------------------------------------------- kernels
+#ifndef USV_LIN_BLOCKS
+#define USV_LIN_BLOCKS 2 // 256-thread blocks per CU the lineariser is compiled for (2: 2 waves per SIMD, 256 registers)
+#endif
 template <class M, int KCH, bool SOFT, bool MULTI>
-__global__ void __launch_bounds__(256, 2) usv_linearize(DevPtrs P, long ngroups)
+__global__ void __launch_bounds__(256, USV_LIN_BLOCKS) usv_linearize(DevPtrs P, long ngroups)
 {
     const long gid = lanes::group_linear();
     if (gid >= ngroups) return; // ngroups is a multiple of 4: whole waves leave together

@@ -152,10 +152,17 @@ __global__ void __launch_bounds__(64) usv_calib_stream(DevPtrs P, long ngroups, 
 // changes; the arithmetic of an instance does not depend on its neighbours.
 constexpr int SORT_BINS = 64;
 
-__global__ void usv_sort_hist(const int *qp_iter, int B, int *hist)
+// (histogram and ranks are formed per workgroup in LDS; a workgroup then touches each global bin once - 65 536 threads
+// hammering 64 global counters took 0.19 ms per kernel)
+__global__ void __launch_bounds__(256) usv_sort_hist(const int *qp_iter, int B, int *hist)
 {
+    __shared__ int loc[SORT_BINS];
+    if (threadIdx.x < SORT_BINS) loc[threadIdx.x] = 0;
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) atomicAdd(&hist[min(max(qp_iter[i], 0), SORT_BINS - 1)], 1);
+    if (i < B) atomicAdd(&loc[min(max(qp_iter[i], 0), SORT_BINS - 1)], 1);
+    __syncthreads();
+    if (threadIdx.x < SORT_BINS && loc[threadIdx.x] != 0) atomicAdd(&hist[threadIdx.x], loc[threadIdx.x]);
 }
 
 __global__ void usv_sort_scan(int *hist, int *cursor)
@@ -170,10 +177,21 @@ __global__ void usv_sort_scan(int *hist, int *cursor)
     }
 }
 
-__global__ void usv_sort_scatter(const int *qp_iter, int B, int *cursor, int *perm)
+__global__ void __launch_bounds__(256) usv_sort_scatter(const int *qp_iter, int B, int *cursor, int *perm)
 {
+    __shared__ int loc[SORT_BINS], base[SORT_BINS];
+    if (threadIdx.x < SORT_BINS) loc[threadIdx.x] = 0;
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) perm[atomicAdd(&cursor[min(max(qp_iter[i], 0), SORT_BINS - 1)], 1)] = i;
+    int bin = 0, rank = 0;
+    if (i < B) {
+        bin = min(max(qp_iter[i], 0), SORT_BINS - 1);
+        rank = atomicAdd(&loc[bin], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < SORT_BINS && loc[threadIdx.x] != 0) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], loc[threadIdx.x]);
+    __syncthreads();
+    if (i < B) perm[base[bin] + rank] = i;
 }
 
 // ---------------------------------------------------------------------------------- handle

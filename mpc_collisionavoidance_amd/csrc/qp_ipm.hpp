@@ -215,8 +215,12 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 
 // LDSWS: the workspace planes of a row's instance live in LDS for the whole solve (lanes::PlanesLds) - for batches small
 // enough that every instance in flight fits (host: usvmpc.hip); the lineariser's planes are copied in at the cold start.
-template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false>
+// MERGE (with PACK, no dense rows: host_spec.hpp / usvmpc.hip): the box rows are processed where they are stored - as rows of the
+// last obstacle chunk, in its idle lanes - instead of being gathered to their variables' lanes for a row pass of their own:
+// one RowCalc pass per sweep instead of two.  The workspace layout is the one of PACK; only the four sweeps differ.
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false, bool MERGE = false>
 struct QpIpm {
+    static_assert(!MERGE || PACK, "merged row pass works on the packed layout");
     static_assert(!PACK || KCH > 0, "box rows are packed into obstacle planes");
     static_assert(!(PACK && SOFTBOX), "soft state bounds are not packed");
     static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
@@ -277,7 +281,7 @@ struct QpIpm {
     }
 
     using BoxRow = RowCalc<SOFTBOX, SOFTBOX>;
-    using ObsRow = RowCalc<SOFT>;
+    using ObsRow = RowCalc<SOFT, SOFT && MERGE>; // (merged: the chunk's slot lanes carry hard box rows next to soft obstacle rows)
     using Planes = std::conditional_t<LDSWS, lanes::PlanesLds, lanes::Planes>;
 
     const DevPtrs &P;
@@ -319,6 +323,7 @@ struct QpIpm {
     unsigned rowtab[(NX + 3) / 4], coltab[(NCOL + 3) / 4];
     bool selfone; // this lane's state has the exact unit diagonal and its own column is not among the stored ones
     bool isslot, isdense, anydense;
+    bool slot_u; // MERGE: the box row this slot lane carries belongs to a control (active at stages 0..N-1; a state's: 1..N-1)
     int bsrc, bstep, ssrc;
     bool hasb;
     // These per-lane constants live in LDS (lanes::Stash), not in registers: see there.
@@ -327,7 +332,8 @@ struct QpIpm {
         ST_LB = 0, ST_UB, ST_HDS, ST_HDT, ST_UH, ST_OX = ST_UH + KC, ST_OY = ST_OX + KC, ST_LH = ST_OY + KC, ST_SOFT = ST_LH + KC,
         ST_ZL = ST_SOFT, ST_ZU = ST_ZL + (SOFT ? KC : 0), ST_QL = ST_ZU + (SOFT ? KC : 0), ST_QU = ST_QL + (SOFT ? KC : 0),
         ST_BSL = ST_QU + (SOFT ? KC : 0), ST_BSU = ST_BSL + (SOFT ? KC : 0), ST_BOX = ST_BSU + (SOFT ? KC : 0),
-        ST_N = ST_BOX + (SOFTBOX ? 6 : 0)
+        ST_SLOT = ST_BOX + (SOFTBOX ? 6 : 0), // MERGE: bounds of the box row a slot lane carries
+        ST_N = ST_SLOT + (MERGE ? 2 : 0)
     };
     using ST = lanes::Stash<ST_N>;
     struct CRef {
@@ -345,6 +351,7 @@ struct QpIpm {
         USV_DEV void operator=(double v) const { ST::put(SLOT, v); }
     };
     CVal<ST_LB> lbv; CVal<ST_UB> ubv; CVal<ST_HDS> hd_stage; CVal<ST_HDT> hd_term;
+    CVal<ST_SLOT> slot_lb; CVal<ST_SLOT + 1> slot_ub;
     bool bsoft;                               // SOFTBOX: this lane's state bound is soft
     // its slack penalties (scaled by dt) and slack lower bounds
     CVal<ST_BOX + 0> bzl; CVal<ST_BOX + 1> bzu; CVal<ST_BOX + 2> bZl; CVal<ST_BOX + 3> bZu; CVal<ST_BOX + 4> bbsl; CVal<ST_BOX + 5> bbsu;
@@ -409,6 +416,11 @@ struct QpIpm {
         bsrc = S.box_slot[lane];
         bstep = S.box_step[lane];
         ssrc = S.slot_var[lane];
+        slot_u = isslot && ssrc < NU;
+        if constexpr (MERGE) {
+            slot_lb = S.lb[isslot ? ssrc : 0];
+            slot_ub = S.ub[isslot ? ssrc : 0];
+        }
         lbv = S.lb[lane];
         ubv = S.ub[lane];
         hd_stage = S.Hc[lane * LANES + lane];
@@ -781,7 +793,8 @@ struct QpIpm {
             r.tsl = r.soft ? in.bxs[4] : 1.0; r.tsu = r.soft ? in.bxs[5] : 1.0;
         }
     }
-    template <int C>
+    // SLOTROWS = false: obstacle rows only, whatever MERGE says (nlp_residual keeps the two-pass form)
+    template <int C, bool SLOTROWS = true>
     USV_DEV void obs_from(const StageIn &in, int k, double zbx, double zby, ObsRow &r, double &cx, double &cy) const
     {
         r.neutral();
@@ -795,13 +808,38 @@ struct QpIpm {
                 r.zl = c_zl[C]; r.zu = c_zu[C]; r.Zl = c_Zl[C]; r.Zu = c_Zu[C]; r.bsl = c_bsl[C]; r.bsu = c_bsu[C];
             }
         }
+        bool softrow = r.act; // lanes whose slack values are live
+        if constexpr (MERGE) {
+            if constexpr (SOFT) r.soft = r.act; // obstacle rows soft, box rows hard
+            if constexpr (C == KCH - 1 && SLOTROWS) {
+                // the box row riding in this slot lane: a row like the others, with the variable's bounds (its value and its
+                // step come by gather: rowdot)
+                const bool sact = isslot && (slot_u ? k < N : (k >= 1 && k < N));
+                r.dl = sact ? (double)slot_lb : r.dl;
+                r.du = sact ? (double)slot_ub : r.du;
+                r.act = r.act || sact;
+            }
+        }
         r.ll = r.act ? in.obs[C][0] : 0.0; r.lu = r.act ? in.obs[C][1] : 0.0;
         r.tl = r.act ? in.obs[C][2] : 1.0; r.tu = r.act ? in.obs[C][3] : 1.0;
         if constexpr (SOFT) {
-            r.sl = r.act ? in.obs[C][4] : 0.0; r.su = r.act ? in.obs[C][5] : 0.0;
-            r.lsl = r.act ? in.obs[C][6] : 0.0; r.lsu = r.act ? in.obs[C][7] : 0.0;
-            r.tsl = r.act ? in.obs[C][8] : 1.0; r.tsu = r.act ? in.obs[C][9] : 1.0;
+            r.sl = softrow ? in.obs[C][4] : 0.0; r.su = softrow ? in.obs[C][5] : 0.0;
+            r.lsl = softrow ? in.obs[C][6] : 0.0; r.lsu = softrow ? in.obs[C][7] : 0.0;
+            r.tsl = softrow ? in.obs[C][8] : 1.0; r.tsu = softrow ? in.obs[C][9] : 1.0;
         }
+    }
+    // c' vec of the row in this lane of chunk C: an obstacle row's gradient sits on the two position lanes (vobs: the vector it
+    // multiplies), a box row's (MERGE, slot lanes of the last chunk) is the unit vector of its variable (vbox).  Wave-uniform
+    // control flow.
+    template <int C>
+    USV_DEV double rowdot(double cx, double cy, double vobs, double vbox) const
+    {
+        double d = obs_dot(cx, cy, vobs);
+        if constexpr (MERGE && C == KCH - 1) {
+            const double g = lanes::gather(vbox, ssrc);
+            d = isslot ? g : d;
+        }
+        return d;
     }
 
     // ------------------------------------------------------------------ backward sweeps
@@ -859,21 +897,25 @@ struct QpIpm {
             double rb = FACT ? in.rb * rbscale : 0.0;
             // ---- rows (with the pending update of the previous iteration applied first)
             BoxRow br;
-            box_from(in, k, br);
-            double Ghb, gamb;
+            double Ghb = 0.0, gamb = 0.0, dlb = 0.0; // the box row of this lane's variable: Hessian / gradient terms, ll - lu
             const double dzp = FACT ? in.dz : 0.0, dzap = FACT ? in.dza : 0.0;
-            if (FACT) {
-                if (pend && br.act) {
-                    chain(br, z, true, dzap, sigmu_prev, Ghb, gamb);
-                    br.expand(dzp);
-                    br.apply(a_prev);
-                    if constexpr (!PACK) box_store(W, br);
-                }
-            }
             double pk[4], dv = in.aux; // dense part of the aux plane: rebuilt where the rows change, else as loaded
-            if constexpr (FACT && PACK) dv = box_pack(br, pk);
             const double znew = (FACT && pend) ? z + a_prev * dzp : z;
-            chain(br, znew, !FACT, dza, sigmu, Ghb, gamb);
+            if constexpr (!MERGE) {
+                box_from(in, k, br);
+                if (FACT) {
+                    if (pend && br.act) {
+                        chain(br, z, true, dzap, sigmu_prev, Ghb, gamb);
+                        br.expand(dzp);
+                        br.apply(a_prev);
+                        if constexpr (!PACK) box_store(W, br);
+                    }
+                }
+                if constexpr (FACT && PACK) dv = box_pack(br, pk);
+                chain(br, znew, !FACT, dza, sigmu, Ghb, gamb);
+                dlb = br.act ? br.ll - br.lu : 0.0;
+            }
+            double Gh_m = 0.0, gam_m = 0.0, dl_m = 0.0; // MERGE: the last chunk's per-row terms, for the box rows among them
             double Sxx = 0.0, Sxy = 0.0, Syy = 0.0, gx = 0.0, gy = 0.0, lx = 0.0, ly = 0.0;
             if constexpr (KCH > 0) {
                 sfor<0, KCH>([&](auto c) {
@@ -881,22 +923,24 @@ struct QpIpm {
                     double cx, cy, Gh, gam;
                     obs_from<c>(in, k, zbx, zby, o, cx, cy);
                     if (FACT) {
-                        const double vo = obs_dot(cx, cy, z - psel), wp = obs_dot(cx, cy, dzp), wap = obs_dot(cx, cy, dzap);
+                        const double vo = rowdot<c>(cx, cy, z - psel, z), wp = rowdot<c>(cx, cy, dzp, dzp), wap = rowdot<c>(cx, cy, dzap, dzap);
                         if (pend && o.act) {
                             chain(o, vo, true, wap, sigmu_prev, Gh, gam);
                             o.expand(wp);
                             o.apply(a_prev);
                         }
                         const bool slot_here = c == KCH - 1 && isslot;
-                        if (pend && (o.act || slot_here)) obs_store(W, c, o, (PACK && c == KCH - 1) ? pk : nullptr);
+                        if (pend && (o.act || slot_here)) obs_store(W, c, o, (PACK && !MERGE && c == KCH - 1) ? pk : nullptr);
                     }
-                    const double v = obs_dot(cx, cy, znew - psel);
-                    const double wa = FACT ? 0.0 : obs_dot(cx, cy, dza);
+                    const double v = rowdot<c>(cx, cy, znew - psel, znew);
+                    const double wa = FACT ? 0.0 : rowdot<c>(cx, cy, dza, dza);
                     chain(o, v, !FACT, wa, sigmu, Gh, gam);
                     gx += gam * cx; gy += gam * cy;
+                    if constexpr (MERGE && c == KCH - 1) { Gh_m = Gh; gam_m = gam; }
                     if (FACT) {
                         Sxx += Gh * cx * cx; Sxy += Gh * cx * cy; Syy += Gh * cy * cy;
                         const double dl_ = o.act ? o.ll - o.lu : 0.0;
+                        if constexpr (MERGE && c == KCH - 1) dl_m = dl_;
                         lx += dl_ * cx; ly += dl_ * cy;
                         if (o.act) {
                             nm.rd = lanes::vmax(nm.rd, lanes::vmax_abs2(o.rdl, o.rdu));
@@ -918,6 +962,15 @@ struct QpIpm {
                     Sxx = lanes::gsum(Sxx); Sxy = lanes::gsum(Sxy); Syy = lanes::gsum(Syy);
                     lx = lanes::gsum(lx); ly = lanes::gsum(ly);
                 }
+                if constexpr (MERGE) { // the box rows' terms come home from their slot lanes (an inactive row has delivered zeros)
+                    const double g1 = lanes::gather(gam_m, bsrc);
+                    gamb = hasb ? g1 : 0.0;
+                    if (FACT) {
+                        const double g0 = lanes::gather(Gh_m, bsrc), g2 = lanes::gather(dl_m, bsrc);
+                        Ghb = hasb ? g0 : 0.0;
+                        dlb = hasb ? g2 : 0.0;
+                    }
+                }
             }
             z = znew;
             if (FACT && pend) W.st(P_Z, z);
@@ -937,14 +990,14 @@ struct QpIpm {
                 lanes::settle(pin); // (a constant 0.0 in the peeled terminal stage: materialised right in front of its use)
                 dot_lanes<NONUNIT, NU>(t, pin, [&](auto j) { return bat[j]; });
                 if constexpr (M::OUT_UNIT != 0u) t = fma(ou1, pin, t);
-                t -= br.act ? br.ll - br.lu : 0.0;
+                t -= dlb;
                 t -= isPX ? lx : (isPY ? ly : 0.0);
                 pik = xlane ? t : 0.0;
                 rg = (ulane && k < N) ? t : 0.0;
                 dfr_pi = rg + pik; // rg lives on the u lanes, pik on the x lanes
                 nm.rg = lanes::vmax_abs(nm.rg, rg);
                 nm.nan = fma(0.0, t, nm.nan);
-                if (br.act) {
+                if constexpr (!MERGE) if (br.act) { // (MERGE: the box rows have been counted with the rows of their chunk)
                     nm.rd = lanes::vmax(nm.rd, lanes::vmax_abs2(br.rdl, br.rdu));
                     nm.rm = lanes::vmax(nm.rm, lanes::vmax(br.ll * br.tl, br.lu * br.tu));
                     nm.musum += br.ll * br.tl + br.lu * br.tu;
@@ -1122,19 +1175,21 @@ struct QpIpm {
             {
                 const double z = in.z;
                 const double dza = FINAL ? in.dza : dz;
-                BoxRow br;
-                box_from(in, k, br);
-                double Gh, gam;
-                chain(br, z, FINAL, dza, sigmu, Gh, gam);
-                br.expand(dz);
-                q = br.blocking(q);
-                if (!FINAL && br.act) {
-                    s1 += br.ll * br.dtl + br.tl * br.dll + br.lu * br.dtu + br.tu * br.dlu;
-                    s2 += br.dll * br.dtl + br.dlu * br.dtu;
-                    if constexpr (SOFTBOX) {
-                        if (br.soft) {
-                            s1 += br.lsl * br.dtsl + br.tsl * br.dlsl + br.lsu * br.dtsu + br.tsu * br.dlsu;
-                            s2 += br.dlsl * br.dtsl + br.dlsu * br.dtsu;
+                if constexpr (!MERGE) { // (MERGE: the box rows are rows of the last chunk below)
+                    BoxRow br;
+                    box_from(in, k, br);
+                    double Gh, gam;
+                    chain(br, z, FINAL, dza, sigmu, Gh, gam);
+                    br.expand(dz);
+                    q = br.blocking(q);
+                    if (!FINAL && br.act) {
+                        s1 += br.ll * br.dtl + br.tl * br.dll + br.lu * br.dtu + br.tu * br.dlu;
+                        s2 += br.dll * br.dtl + br.dlu * br.dtu;
+                        if constexpr (SOFTBOX) {
+                            if (br.soft) {
+                                s1 += br.lsl * br.dtsl + br.tsl * br.dlsl + br.lsu * br.dtsu + br.tsu * br.dlsu;
+                                s2 += br.dlsl * br.dtsl + br.dlsu * br.dtsu;
+                            }
                         }
                     }
                 }
@@ -1143,9 +1198,9 @@ struct QpIpm {
                         ObsRow o;
                         double cx, cy, Gh2, gam2;
                         obs_from<c>(in, k, zbx, zby, o, cx, cy);
-                        const double v = obs_dot(cx, cy, z - pos_sel(zbx, zby));
-                        const double w = obs_dot(cx, cy, dz);
-                        const double wa = FINAL ? obs_dot(cx, cy, dza) : w;
+                        const double v = rowdot<c>(cx, cy, z - pos_sel(zbx, zby), z);
+                        const double w = rowdot<c>(cx, cy, dz, dz);
+                        const double wa = FINAL ? rowdot<c>(cx, cy, dza, dza) : w;
                         chain(o, v, FINAL, wa, sigmu, Gh2, gam2);
                         o.expand(w);
                         q = o.blocking(q);
@@ -1232,7 +1287,7 @@ struct QpIpm {
                 sfor<0, KCH>([&](auto c) {
                     ObsRow o;
                     double cx, cy;
-                    obs_from<c>(in, k, zbx, zby, o, cx, cy);
+                    obs_from<c, false>(in, k, zbx, zby, o, cx, cy);
                     if (first) { o.tl = 0.0; o.tu = 0.0; if constexpr (SOFT) { o.tsl = 0.0; o.tsu = 0.0; } }
                     if (o.act) {
                         rd = fmax(rd, fmax(fabs(o.sl - o.dl - o.tl), fabs(o.du + o.su - o.tu)));

@@ -49,14 +49,14 @@ constexpr int qp_waves() { return (KCH >= 2 || SOFTBOX) ? 1 : USV_QP_WAVES; }
 
 // rows: instances a wave starts on (4; fewer when the workspace lives in LDS and only that many fit: LDSWS) - row r of block b
 // starts on group b * rows + r, surplus rows stay idle.
-template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX, bool LDSWS = false>
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX, bool LDSWS = false, bool MERGE = false>
 __global__ void __launch_bounds__(64, (LDSWS ? 1 : qp_waves<KCH, SOFTBOX>())) usv_qp_rti(DevPtrs P, long ngroups, int phase, int queue0, int rows)
 {
     const int row = (int)(threadIdx.x >> 4);
     const long g0 = (long)blockIdx.x * rows;
     if (g0 >= ngroups) return;
     const bool has = row < rows;
-    QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, LDSWS> q(P, has ? g0 + row : g0, has ? row : -1);
+    QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, LDSWS, MERGE> q(P, has ? g0 + row : g0, has ? row : -1);
     q.solve(phase, queue0);
 }
 
@@ -216,6 +216,7 @@ struct usvmpc_handle {
     double *gd_world;   // [B][n_world][3] world obstacles of the last usvmpc_guidance_sense
     size_t gd_world_cap;
     bool sort_enabled;
+    bool merge_rows;
     bool dynamic_rows;        // QP kernel as a persistent launch whose rows pull instances from a queue (option "dynamic_rows")
     int lds_mode;             // workspace of the QP kernel in LDS: -1 when the batch is small enough (default), 0 never, 1 whenever it fits
     long lds_cap;             // waves an LDS-workspace launch holds at once (0: not yet known)
@@ -437,13 +438,21 @@ int launch_pair(usvmpc_handle *h, int phase)
     int rcq = 0;
 #ifdef USV_BENCH_ONLY // development builds (tools/dev_build.sh): only the instantiation the bench workload runs
     if (!(h->spec.hdiag && pack && !h->spec.any_bsoft)) { h->err = "development build: bench instantiation only"; return USVMPC_E_ARG; }
-    rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>);
+    // (one row pass when every box row rides in a slot lane: qp_ipm.hpp, MERGE)
+    if (h->merge_rows && !h->spec.box_dense)
+        rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true, CANPACK>);
+    else
+        rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>);
 #else
     if (h->spec.any_bsoft) { // soft state bounds: rows with slacks, ten planes of their own
         rcq = h->spec.hdiag ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, true>, nullptr) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, true>, nullptr);
     } else if (h->spec.hdiag) { // (every OCP of the reference: the only instantiations that also come with the workspace in LDS)
-        rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>)
-                   : launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, false>, &usv_qp_rti<M, KCH, SOFT, true, false, false, true>);
+        // (one row pass when every box row rides in a slot lane: qp_ipm.hpp, MERGE)
+        if (pack && h->merge_rows && !h->spec.box_dense)
+            rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true, CANPACK>);
+        else
+            rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>)
+                       : launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, false>, &usv_qp_rti<M, KCH, SOFT, true, false, false, true>);
     } else {
         rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, false, CANPACK, false>, nullptr) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, false>, nullptr);
     }
@@ -616,6 +625,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     TRY_C(dev_alloc(h, &h->d_hist, SORT_BINS, true));
     TRY_C(dev_alloc(h, &h->d_cursor, SORT_BINS, true));
     h->sort_enabled = true;
+    h->merge_rows = true;
     h->gd_ready = false; h->gd_npts_cap = 0; h->gd_psi = nullptr; h->gd_world = nullptr; h->gd_world_cap = 0;
     std::memset(&h->gd, 0, sizeof(h->gd));
     TRY_C(dev_alloc(h, &P.ws, (N + 1) * (size_t)ws_planes(h->nx, h->nu, h->kch, h->soft, model_mat_planes(h->desc.model), h->spec.any_bsoft != 0) * stride, true));
@@ -871,6 +881,11 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
     }
     if (s == "disturbance_mask") { // bit j: usvmpc_advance adds its noise to state j
         h->noise_mask = (unsigned)value;
+        return 0;
+    }
+    if (s == "merge_box_rows") { // 1 (default): box rows processed in their slot lanes when all of them ride there
+        h->merge_rows = value != 0.0;
+        h->qp_cap = 0; h->lds_cap = 0;
         return 0;
     }
     if (s == "static_obstacles" || s == "pack_box_rows") {

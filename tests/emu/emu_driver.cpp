@@ -104,6 +104,7 @@ using namespace usv;
 
 struct Job { const DevPtrs *P; long gid; int qp_phase; int queue0; };
 int g_emu_lds_mode = 0; // 1: run the RTI solves with the workspace in (emulated) LDS
+int g_emu_merge = 1;    // 1: box rows processed in their slot lanes when all of them ride there (as the device library does)
 
 template <class M, int KCH, bool SOFT>
 void lin_body(void *a)
@@ -112,16 +113,16 @@ void lin_body(void *a)
     if (j->P->spec->sim_steps > 1) Linearize<M, KCH, SOFT, true>::run(*j->P, j->gid);
     else Linearize<M, KCH, SOFT, false>::run(*j->P, j->gid);
 }
-template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false>
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool MERGE = false>
 void qp_body(void *a)
 {
     Job *j = (Job *)a;
     if constexpr (HDIAG && !SOFTBOX) if (g_emu_lds_mode && j->qp_phase == 0) { // the workspace of the (single) emulated row in "LDS"
-        QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, true> q(*j->P, j->gid, 0);
+        QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, true, MERGE> q(*j->P, j->gid, 0);
         q.solve(j->qp_phase, j->queue0);
         return;
     }
-    QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX> q(*j->P, j->gid);
+    QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, false, MERGE> q(*j->P, j->gid);
     q.solve(j->qp_phase, j->queue0);
 }
 
@@ -192,7 +193,8 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
                 else lanes::run_group(g, &qp_body<M, KCH, SOFT, false, false, true>, &j);
                 continue;
             }
-            if (S.hdiag) lanes::run_group(g, pack ? &qp_body<M, KCH, SOFT, true, CANPACK> : &qp_body<M, KCH, SOFT, true, false>, &j);
+            if (S.hdiag && pack && g_emu_merge && !S.box_dense) lanes::run_group(g, &qp_body<M, KCH, SOFT, true, CANPACK, false, CANPACK>, &j);
+            else if (S.hdiag) lanes::run_group(g, pack ? &qp_body<M, KCH, SOFT, true, CANPACK> : &qp_body<M, KCH, SOFT, true, false>, &j);
             else lanes::run_group(g, pack ? &qp_body<M, KCH, SOFT, false, CANPACK> : &qp_body<M, KCH, SOFT, false, false>, &j);
         }
 }
@@ -281,6 +283,7 @@ static int emu_run(const usvmpc_desc *d, int sqp, double *x, double *u, const do
 
 // test switches: workspace of the RTI solves in emulated LDS (lds != 0); persistent rows pulling from the queue (rows, 0 = none)
 extern "C" void usv_emu_set_mode(int lds, long rows) { g_emu_lds_mode = lds; g_emu_rows = rows; }
+extern "C" void usv_emu_set_merge(int merge) { g_emu_merge = merge; }
 
 extern "C" int usv_emu_solve(const usvmpc_desc *d, double *x, double *u, const double *x0,
                              const double *yref, const double *yref_e, const double *p,

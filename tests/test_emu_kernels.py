@@ -184,3 +184,29 @@ def test_scheduling_and_workspace_placement_do_not_change_results(emu, name, N, 
     for o in out[1:]:
         for a, b in zip(o, out[0]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name,N,K", [("usv_model_pf_ca", 8, 4), ("usv_model_pf_ca", 6, 9), ("usv_model_pf_ca", 5, 20),
+                                      ("usv_model_guidance_ca1", 7, 10), ("usv_model_guidance_ca1", 5, 15), ("usv_model_guidance_ca1", 5, 19)])
+def test_one_row_pass_equals_two(emu, name, N, K):
+    """Box rows processed where they are stored - as rows of the last obstacle chunk (MERGE: whenever all of them ride in its idle
+    lanes) - against the two-pass form that gathers them to their variables' lanes: the same rows, the same arithmetic per row;
+    only the lane in which a row's share of the complementarity sums is accumulated differs, so the comparison is to rounding,
+    statuses and iteration counts exactly."""
+    B = 6
+    ocp, wl = util.make(name, N, K, B, seed=11)
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    emu.usv_emu_set_merge.argtypes = [C.c_int]
+    out = []
+    try:
+        for merge in (0, 1):
+            emu.usv_emu_set_merge(merge)
+            r = emu_rti(emu, desc, wl, wl["x_init"], wl["u_init"])
+            r2 = emu_rti(emu, desc, wl, r["x"], r["u"])
+            out.append(r2)
+    finally:
+        emu.usv_emu_set_merge(1)
+    a, b = out
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["qp_iter"], b["qp_iter"])
+    for f in ("x", "u", "pi", "sl", "su"):
+        assert util.rel_err(a[f], b[f]) <= 1e-9, (f, util.rel_err(a[f], b[f]))

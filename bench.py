@@ -138,7 +138,9 @@ def main():
 
     dist = None
     ranks_seen = 1
-    if world > 1:
+    # under a launcher (WORLD_SIZE set) the ranks form an RCCL process group - also a single rank, so that the N > 1 code path
+    # (barrier, max-reduction of the time, all-gather on the solver's device buffers) can be exercised on one GPU
+    if world > 1 or "WORLD_SIZE" in os.environ:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -194,7 +196,9 @@ def main():
         spec = ob.spec(_ID[name], N, N * dt, K, sim_steps=steps)
         x0o = wl["x0"][:S1].copy()
         errs = []
-        same_status = n_ok = 0
+        same_status = n_ok = n_conv_dev = n_cert = 0
+        from tests import kkt as kkt_check   # independent acceptance: KKT conditions of every device solution (tests/kkt.py)
+        soft_rows = name == "usv_model_guidance_ca1" and K > 0
     for w in range(args.warmup):
         if check:   # the oracle starts every tick from the iterate and x0 the device starts it from ("same inputs")
             solver.sync()
@@ -202,10 +206,25 @@ def main():
         solver.solve_async()
         if check:
             solver.sync()
+            xo_in, uo_in = xo, uo
+            xo, uo = xo.copy(), uo.copy()
             sto, ito = ob.rti_batch(spec, xo, uo, x0o, wl["yref"][:S1], wl["yref_e"][:S1], wl["p"][:S1], wl["lh"][:S1],
                                     threads=usable_cores())
             xg, ug = solver.get_all("x")[:S1], solver.get_all("u")[:S1]
             stg, qsg = solver.get_int("status")[:S1], solver.get_int("qp_status")[:S1]
+            # every solve the DEVICE calls converged must satisfy the KKT conditions of its QP (stat <= 1e-6, eq / ineq / comp
+            # <= 1e-8), evaluated in numpy on the oracle's linearisation - independent of anybody's iteration path
+            qpd = kkt_check.linearize_batch(ob, spec, xo_in, uo_in, x0o, wl["yref"][:S1], wl["yref_e"][:S1], wl["p"][:S1], wl["lh"][:S1])
+            dzd = np.zeros((S1, N + 1, nx + nu))
+            dzd[:, :N, :nu], dzd[:, :, nu:] = ug - uo_in, xg - xo_in
+            pid = np.concatenate([np.zeros((S1, 1, nx)), solver.get_all("pi")[:S1]], axis=1)
+            pad = lambda a: np.concatenate([a, np.zeros_like(a[:, :1])], axis=1)   # noqa: E731
+            kr = kkt_check.kkt_batch(qpd, dzd, pid, solver.get_all("lam")[:S1], solver.get_all("t")[:S1],
+                                     pad(solver.get_all("sl")[:S1]) if soft_rows else None,
+                                     pad(solver.get_all("su")[:S1]) if soft_rows else None)
+            conv_dev = (qsg == 0) & (stg == 0)
+            n_conv_dev += int(conv_dev.sum())
+            n_cert += int((conv_dev & kkt_check.certified(kr, 1.02e-6, 1.02e-8, 1.02e-8, 1.02e-8)).sum())
             same_status += int((stg == sto).sum())
             ok = (sto == 0) & (ito < spec.opts.qp_iter_max) & (qsg == 0)
             n_ok += int(ok.sum())
@@ -224,6 +243,10 @@ def main():
                   "rel_err_per_instance": {"p50": float(np.percentile(np.concatenate(errs), 50)),
                                            "p99": float(np.percentile(np.concatenate(errs), 99)),
                                            "max": float(np.concatenate(errs).max())} if errs else None,
+                  "frac_above_1e-5": float((np.concatenate(errs) > 1e-5).mean()) if errs else None,
+                  "kkt_certified_frac": n_cert / float(max(1, n_conv_dev)),
+                  "kkt": "every solve the device reports converged, checked against the KKT conditions of its QP (stat <= 1e-6, "
+                         "eq / ineq / comp <= 1e-8, lam, t >= 0) by tests/kkt.py on the oracle's linearisation: %d of %d" % (n_cert, n_conv_dev),
                   "vs": "CPU oracle (port; parity vs acados itself is unpinned); closed loop, every tick from the iterate "
                         "and x0 the device starts it from; error of an instance = max over (x, u) components of |dev - oracle| / "
                         "(that component's max |oracle| over the sample)"}
@@ -270,16 +293,24 @@ def main():
     balg = algorithmic_bytes(nx, nu, N, K, moving=args.moving)
     qp_avg_s = float(qp_ms.mean()) * 1e-3
     achieved = balg * B / qp_avg_s / 1e9
-    traffic = None
+    # `traffic` comes from a rocprofv3 PMC profile (profiles/pmc_traffic.json, tools/profile_round.sh + save_profiles.py) and is
+    # only printed when that profile was taken with THIS binary: the entry carries the library's sha256
+    from mpc_collisionavoidance_amd import _capi
+    lib_hash = _capi.lib_sha256()
+    traffic, traffic_note = None, "no PMC profile of this workload in profiles/pmc_traffic.json"
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             for e in json.load(open(pmc)):
                 if (e.get("model") == name and e.get("N") == N and e.get("K") == K and e.get("batch") == B
-                        and e.get("workload", "r01") == args.workload):
-                    traffic = e.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+                        and e.get("workload", "r01") == args.workload and bool(e.get("moving", False)) == bool(args.moving)):
+                    if e.get("lib_sha256") == lib_hash:
+                        traffic, traffic_note = e.get("hbm_bytes_per_launch"), "profile %s (git %s), same library sha256" % (e.get("round"), e.get("git_head"))
+                    elif traffic is None:
+                        traffic_note = ("newest PMC profile of this workload (%s) was taken with another build of libusvmpc.so "
+                                        "(sha256 %s, loaded %s): not quoted" % (e.get("round"), e.get("lib_sha256"), lib_hash))
+        except Exception as ex:
+            traffic, traffic_note = None, "profiles/pmc_traffic.json unreadable: %r" % (ex,)
 
     # the algorithmic FP64 flop count of one solve (dense count, no sparsity credit), with the
     # measured mean IPM iteration count
@@ -336,13 +367,15 @@ def main():
                             % (baseline_config(name, B, world, N, K, args.moving), B, name, N, N * dt, dt, steps, K,
                                "moving" if args.moving else "static", wl["generator"], sigma, mask),
                 "ocp": name, "instances_per_gpu": B, "instances_total": world * B, "horizon": N, "obstacles": K,
-                "qp_solver_cond_N": args.cond_N if args.cond_N else N,
+                "qp_solver_cond_N": ("%d requested, not applied (uncondensed Riccati over the %d stages; DESIGN.md section 6)" % (args.cond_N, N))
+                if (args.cond_N and args.cond_N != N) else N,
+                "lib_sha256": lib_hash,
                 "sharding": "batch-sharded x%d, no data-path collective" % world, "ranks_seen": ranks_seen,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "usv_qp_rti",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_note,
                 "traffic_GBs": (traffic / qp_avg_s / 1e9) if traffic else None,
                 "traffic_frac": (traffic / qp_avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "traffic_over_algorithmic": (traffic / (balg * B)) if traffic else None,

@@ -107,6 +107,12 @@ int usvmpc_set(usvmpc_handle *h, const char *field, int stage, const double *v, 
  * n = 4: QP residuals stat/eq/ineq/comp), "nlp_res" (the same for the NLP, full SQP only); same stage = -1
  * convention. */
 int usvmpc_get(usvmpc_handle *h, const char *field, int stage, double *out, size_t n);
+/* "lam" / "t" (stage 0..N, n = 2 (nrow + ns)): the inequality multipliers and slacks of the last QP, what acados'
+ * ocp_nlp_out_get(.., stage, "lam" | "t") returns: rows of a stage in acados' order [bu.., bx.., h..] (nrow = nbu + nbx + K),
+ * slack rows [sbx.., sh..] (ns = soft state bounds + K when the h rows are soft); the vector is
+ * [lower (nrow) | upper (nrow) | lower-slack bound (ns) | upper-slack bound (ns)].  Rows a stage does not have (state bounds
+ * and h rows at stage 0 - x0 is eliminated -, everything at stage N) read 0.  Gathered from the solver workspace by a kernel
+ * of its own on the first such get after a solve. */
 /* further get fields: "obs_tmin" (stage ignored, n = 1): the smallest lower-side slack t_l over the instance's obstacle rows
  * in the last QP (1e300 without rows) - below ~1e-3 the solution touches a keep-out circle, i.e. an obstacle row is active */
 /* integer per-instance results: "status" (0 | 4; after usvmpc_solve_sqp 0 | 2 | 4), "qp_status" (0 ok,
@@ -144,7 +150,7 @@ int usvmpc_fail_counts(usvmpc_handle *h, int n, int *counts);
 int usvmpc_advance(usvmpc_handle *h, double sigma, unsigned long long seed);
 /* Adopt a caller-owned HIP stream (e.g. torch's current stream) for all subsequent work */
 int usvmpc_set_stream(usvmpc_handle *h, void *stream);
-/* run-time options (scheduling / placement only; none changes the arithmetic):
+/* run-time options (scheduling / placement only; none changes the arithmetic beyond rounding - see the two marked):
  *   "sort_by_difficulty" (default 1) - group instances of similar IPM iteration count (from their previous
  *       solve) into the same wavefront;
  *   "static_obstacles" (default 0) - every stage uses stage 0's p and lh (what the reference's callers set:
@@ -155,6 +161,14 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  *   "lds_workspace" (default -1) - per-stage planes of the QP in the CU's LDS instead of HBM: -1 when one round of
  *       workgroups covers the batch (an instance's whole horizon must fit in 160 KB), 0 never, 1 whenever it fits.  Results
  *       agree with the HBM placement to rounding (a separately compiled instantiation of the same code);
+ *   "merge_box_rows" (default 1) - when every box row rides in an idle lane of the last obstacle chunk's planes the sweeps
+ *       process them there (one row pass instead of two).  A separately compiled instantiation: statuses and iteration
+ *       counts equal, iterates agree to rounding - as with "lds_workspace";
+ *   "host_mirror" (default: on for handles whose caller-visible arrays total <= 1 MiB, i.e. the single-instance drop-in faces) -
+ *       usvmpc_set writes a pinned host mirror and the next solve uploads the dirty fields in one asynchronous copy instead
+ *       of one synchronising copy per call (the reference issues 3N+4 setters per tick: scripts/usv_guidance_ca1/main.py:
+ *       123-130, src/nmpc_guidance_ca1.cpp:567-574); x / u / status come back in one copy and usvmpc_get "x" / "u" is served
+ *       from it.  0 switches it off for the handle (it cannot be switched on again);
  *   "disturbance_mask" (default all ones) - bit j set: usvmpc_advance adds its noise to state j (the reference's commented
  *       hooks disturb x0[3] and x0[5] only: catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/main.py:181-183). */
 int usvmpc_set_option(usvmpc_handle *h, const char *name, double value);

@@ -71,6 +71,13 @@ def load(path):
             "HIP library %s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback)" % path)
     if not _libs:
+        # torch first, whenever it is installed: the two then share one HIP runtime and zero-copy views / RCCL on solver buffers
+        # work whatever the caller's import order was (USVMPC_NO_TORCH=1 skips this for torch-free deployments, e.g. the C shim's
+        # users; sharding.device_tensor then refuses with an explanation)
+        if "torch" not in sys.modules and not os.environ.get("USVMPC_NO_TORCH"):
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                import torch  # noqa: F401
         loaded_before_torch = "torch" not in sys.modules
     L = C.CDLL(path)
     L.usvmpc_model_dims.argtypes = [C.c_int, _ip, _ip]
@@ -106,6 +113,16 @@ def load(path):
     L.usvmpc_last_error.restype = C.c_char_p
     _libs[path] = L
     return L
+
+
+def lib_sha256(path=None):
+    """sha256 (first 16 hex digits) of a solver library file: ties a measurement to the binary that produced it."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(path or lib_path(), "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()[:16]
 
 
 def lib():

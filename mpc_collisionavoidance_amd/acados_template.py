@@ -177,6 +177,11 @@ class BatchOcpSolver:
             self.nx, self.nu = _capi.MODEL_DIMS[self._desc.model]
             self._lib = _capi.lib()
         self.ny, self.ny_e = self.nx + self.nu, self.nx
+        d = self._desc
+        # rows of a stage in acados' order [bu.., bx.., h..] and slack rows [sbx.., sh..]: the layout of get("lam" | "t")
+        self.nrow = d.nbu + d.nbx + d.K
+        self.ns = sum(1 for i in range(d.nbx) if d.sbx[i]) + (d.K if d.soft else 0)
+        self.nlam = 2 * (self.nrow + self.ns)
         # (acados' make_consistent rejects a reference of the wrong length; an unset one - None or empty - stays zero)
         for nm, want in (("yref", self.ny), ("yref_e", self.ny_e)):
             v = getattr(ocp.cost, nm, None)
@@ -208,7 +213,8 @@ class BatchOcpSolver:
     def _field(self, field, stage):
         N = self.N
         tab = {"x": (self.nx, N + 1), "u": (self.nu, N), "p": (2 * self.K, N + 1), "lh": (self.K, N),
-               "pi": (self.nx, N), "sl": (self.K, N), "su": (self.K, N), "x0": (self.nx, 1)}
+               "pi": (self.nx, N), "sl": (self.K, N), "su": (self.K, N), "x0": (self.nx, 1),
+               "lam": (self.nlam, N + 1), "t": (self.nlam, N + 1)}
         if field == "yref":
             return (self.ny_e, 1) if stage == N else (self.ny, N)
         if field not in tab:

@@ -205,10 +205,18 @@ USV_DEV bool wave_any(bool p) { return __any((int)p) != 0; }
 #ifndef USV_NEWTON_STEPS
 #define USV_NEWTON_STEPS 2
 #endif
+// 1: IEEE-correct division and square root in place of the estimate + Newton forms below (a second build of the library for
+// the parity experiments of tools/parity_tail.py: is a device-vs-oracle difference made by the reciprocals?)
+#ifndef USV_EXACT_DIV
+#define USV_EXACT_DIV 0
+#endif
 // 1/x and 1/sqrt(x) from the hardware estimate + two Newton steps (full FP64 accuracy for the
 // normal-range operands of the IPM; ~10 instructions instead of the ~25 of an IEEE division)
 USV_DEV double frcp(double x)
 {
+#if USV_EXACT_DIV
+    return 1.0 / x;
+#endif
     double r = __builtin_amdgcn_rcp(x);
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
 #if USV_NEWTON_STEPS > 1
@@ -221,12 +229,19 @@ USV_DEV double frcp(double x)
 // the double range (slacks and multipliers of the IPM: the C ABI refuses bounds beyond 1e100).
 USV_DEV void frcp2(double a, double b, double &ia, double &ib)
 {
+#if USV_EXACT_DIV
+    ia = 1.0 / a; ib = 1.0 / b;
+    return;
+#endif
     const double r = frcp(a * b);
     ia = r * b;
     ib = r * a;
 }
 USV_DEV double frsqrt(double x)
 {
+#if USV_EXACT_DIV
+    return 1.0 / sqrt(x);
+#endif
     double y = __builtin_amdgcn_rsq(x);
     y = __builtin_fma(0.5 * y, __builtin_fma(-x * y, y, 1.0), y);
 #if USV_NEWTON_STEPS > 1

@@ -94,9 +94,13 @@ inline std::string build_spec(const usvmpc_desc &d, DevSpec &S)
         if (j < 0 || j >= nx) return "idxbx out of range";
         S.has_b[nu + j] = 1; S.lb[nu + j] = d.lbx[i]; S.ub[nu + j] = d.ubx[i];
     }
+    S.nbu = d.nbu; S.nbx = d.nbx;
+    for (int i = 0; i < d.nbu; i++) S.box_pos[d.idxbu[i]] = i;
+    for (int i = 0; i < d.nbx; i++) S.box_pos[nu + d.idxbx[i]] = d.nbu + i;
     for (int i = 0; i < d.nbx; i++) {
         if (!d.sbx[i]) continue;
         const int r = nu + d.idxbx[i];
+        S.sbx_pos[r] = S.nsbx++;
         S.any_bsoft = 1;
         S.bsoft[r] = 1;
         S.b_zl[r] = S.dt * d.zl_bx[i]; S.b_zu[r] = S.dt * d.zu_bx[i];
@@ -158,6 +162,9 @@ inline std::string build_spec(const usvmpc_desc &d, DevSpec &S)
     if (d.nlp_max_iter < 0) return "nlp_max_iter must be >= 0";
     return "";
 }
+
+// entries per stage of the multiplier vectors usvmpc_get "lam" / "t" return (DevSpec: 2 (nrow + ns))
+inline int lam_len(const DevSpec &S, bool soft) { return 2 * (S.nbu + S.nbx + S.K + S.nsbx + (soft ? S.K : 0)); }
 
 inline void default_options(usvmpc_desc &d)
 {

@@ -41,6 +41,14 @@ struct DevSpec {
     int bsoft[LANES];
     double b_zl[LANES], b_zu[LANES], b_Zl[LANES], b_Zu[LANES], b_lsl[LANES], b_lsu[LANES];
     double nlp_tol[4];            // full SQP: exit tolerances on the NLP residuals (stat, eq, ineq, comp)
+    // multiplier read-back (usvmpc_get "lam" / "t"): rows of a stage in acados' order [bu.., bx.., h..], nrow = nbu + nbx + K;
+    // slack rows [sbx.., sh..], ns = nsbx + (soft ? K : 0); a stage's vector is [lower(nrow) | upper(nrow) | lower slack(ns) | upper slack(ns)]
+    int nbu, nbx, nsbx;
+    // timing experiments only (builds with -DUSV_TIMING_EXPERIMENT, tools/bound_experiment.sh; results are garbage):
+    int alias_groups;             // > 0: group g addresses the workspace planes of group g % alias_groups (resident set shrunk)
+    int fixed_iters;              // > 0: every instance runs exactly this many IPM iterations, whatever its residuals
+    int box_pos[LANES];           // variable r of [u;x] -> position of its row in [bu.., bx..] (only where has_b)
+    int sbx_pos[LANES];           // variable r -> position of its slack pair among the soft state bounds (only where bsoft)
 };
 
 // How the stage matrix [B A] (nx x nz) is kept in HBM.  Only entries that carry information are stored: the model
@@ -153,6 +161,9 @@ struct DevPtrs {
     // group g, lane r at (((k * Bp + g) * NPT + e) * 16 + r: linearisation output + QP state
     double *ws;
     int *queue;           // [1]  groups handed out beyond the waves' first four (work queue of the QP kernel)
+    // multiplier read-back (kernel usv_qp_export): [B][N+1][nlam] each, nlam = 2 (nrow + ns) - DevSpec
+    double *lam_out, *t_out;
+    int nlam;
 };
 
 } // namespace usv

@@ -208,9 +208,14 @@ struct RowCalc {
 USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 {
     const double d2 = dx * dx + dy * dy;
+#if defined(USV_EXACT_DIV) && USV_EXACT_DIV
+    d = sqrt(d2);
+    ux = dx / d; uy = dy / d;
+#else
     const double id = lanes::frsqrt(d2);
     d = d2 * id;
     ux = dx * id; uy = dy * id;
+#endif
 }
 
 // LDSWS: the workspace planes of a row's instance live in LDS for the whole solve (lanes::PlanesLds) - for batches small
@@ -226,6 +231,10 @@ struct QpIpm {
     static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
     static constexpr int PXL = NU + M::IPX, PYL = NU + M::IPY;
     using MP = MatPack<M>;
+    static_assert(NZ <= LANES, "one lane per variable of [u;x]");
+    // aux-plane lane map (WsLayout): dense box rows in lanes 0..7, l_u from lane 11 down, r_g from 13 down, position in 14 / 15
+    static_assert(NU <= 2, "the aux plane has room for two controls' r_g / l_u entries");
+    static_assert(MP::NPK * 16 + 2 <= 256, "slot numbers of the exchange area are kept in one byte");
     // plane map of the per-stage workspace window
     // (P_Z: zbar + z;  P_AUX: dense box rows | position of the linearisation point | r_g | l_u;  P_PB: P_{k+1} b_k;
     // P_PI: pi_k - see WsLayout)
@@ -460,7 +469,13 @@ struct QpIpm {
         const long gi = g < nB ? g : (long)nB - 1;
         const long bn = P.perm ? (long)P.perm[gi] : gi;
         b = sel ? bn : b;
+#ifdef USV_TIMING_EXPERIMENT
+        // same instruction stream, plane addresses folded onto the first alias_groups groups: what the sweeps stream then
+        // fits in the L2 / the Infinity Cache - is the kernel waiting for HBM?  (profiles/r03_bound_experiment.txt)
+        voff = lanes::Planes::lane_offset(S.alias_groups > 0 ? g % S.alias_groups : g, NPL, lane);
+#else
         voff = lanes::Planes::lane_offset(g, NPL, lane);
+#endif
         if constexpr (KCH > 0) {
             sfor<0, KCH>([&](auto c) {
                 const int i = c * LANES + lane;
@@ -1325,6 +1340,50 @@ struct QpIpm {
         res[0] = lanes::gmax(rg); res[1] = lanes::gmax(rbn); res[2] = lanes::gmax(rd); res[3] = lanes::gmax(rm);
     }
 
+    // ------------------------------------------------------------------ multiplier read-back (usvmpc_get "lam" / "t")
+    // The inequality multipliers and slacks the last QP of this row's instance left in the workspace, written in acados'
+    // row order (DevSpec::box_pos ...): what ocp_nlp_out_get(.., "lam" | "t") returns after acados_solve.  Rows that do not
+    // exist at a stage (state bounds and obstacle rows at stage 0, everything at stage N) stay at the zeros the host put there.
+    // Not part of a solve: its own kernel (usv_qp_export), run on demand.
+    USV_DEV void export_rows() const
+    {
+        const bool real = g < nB && live;
+        const int nrow = S.nbu + S.nbx + Kn, ns = S.nsbx + (SOFT ? Kn : 0), ns0 = 2 * nrow, nlam = P.nlam;
+        for (int k = 0; k <= N; k++) {
+            StageIn in = {};
+            load_in<SW_FWD_A>(k, in);
+            const double zbx = aux_zx(in.aux), zby = aux_zy(in.aux);
+            double *L = P.lam_out + ((long)b * (N + 1) + k) * nlam, *T = P.t_out + ((long)b * (N + 1) + k) * nlam;
+            BoxRow br;
+            box_from(in, k, br); // (lane gathers: wave-uniform control flow)
+            if (real && br.act) {
+                const int i = S.box_pos[lane];
+                L[i] = br.ll; L[nrow + i] = br.lu; T[i] = br.tl; T[nrow + i] = br.tu;
+                if constexpr (SOFTBOX) {
+                    if (br.soft) {
+                        const int j = S.sbx_pos[lane];
+                        L[ns0 + j] = br.lsl; L[ns0 + ns + j] = br.lsu; T[ns0 + j] = br.tsl; T[ns0 + ns + j] = br.tsu;
+                    }
+                }
+            }
+            if constexpr (KCH > 0) {
+                sfor<0, KCH>([&](auto c) {
+                    ObsRow o;
+                    double cx, cy;
+                    obs_from<c, false>(in, k, zbx, zby, o, cx, cy);
+                    const int i = S.nbu + S.nbx + c * LANES + lane;
+                    if (real && o.act) {
+                        L[i] = o.ll; L[nrow + i] = o.lu; T[i] = o.tl; T[nrow + i] = o.tu;
+                        if constexpr (SOFT) {
+                            const int j = S.nsbx + c * LANES + lane;
+                            L[ns0 + j] = o.lsl; L[ns0 + ns + j] = o.lsu; T[ns0 + j] = o.tsl; T[ns0 + ns + j] = o.tsu;
+                        }
+                    }
+                });
+            }
+        }
+    }
+
     // ------------------------------------------------------------------ results of a finished QP
     // RTI step and outputs of the rows selected by `fin` (acados ocp_nlp_update_variables; status 4 leaves the iterate
     // untouched).  real: the row holds an instance of the batch that this launch is solving.
@@ -1342,6 +1401,20 @@ struct QpIpm {
                         const double tl = W.ld(P_OBS + c * OBSN + 2);
                         tmin = (c * LANES + lane < Kn) ? fmin(tmin, tl) : tmin;
                     });
+                }
+            }
+            if constexpr (LDSWS) {
+                // the multipliers and slacks of this QP go back to the group's planes in HBM: that is where the multiplier
+                // read-back (export_rows) and the residual test of a later full SQP (nlp_residual) look for them
+                if (out) {
+                    const lanes::Planes G = wsg(k);
+                    G.st(P_AUX, W.ld(P_AUX));
+                    G.st(P_PI, W.ld(P_PI));
+                    if constexpr (!PACK) {
+                        G.st(P_BLL, W.ld(P_BLL)); G.st(P_BLU, W.ld(P_BLU)); G.st(P_BTL, W.ld(P_BTL)); G.st(P_BTU, W.ld(P_BTU));
+                        if constexpr (SOFTBOX) sfor<0, 6>([&](auto e) { G.st(P_BS + e, W.ld(P_BS + e)); });
+                    }
+                    if constexpr (KCH > 0) sfor<0, KCH * OBSN>([&](auto e) { G.st(P_OBS + e, W.ld(P_OBS + e)); });
                 }
             }
             if (out) {
@@ -1447,6 +1520,11 @@ struct QpIpm {
                     P.res[b * 4 + 0] = nm.rg; P.res[b * 4 + 1] = nm.rb; P.res[b * 4 + 2] = nm.rd; P.res[b * 4 + 3] = nm.rm;
                 }
                 iters = it;
+#ifdef USV_TIMING_EXPERIMENT
+                if (S.fixed_iters > 0) {
+                    if (it >= S.fixed_iters) { status = 0; fin = true; }
+                } else
+#endif
                 if (nm.nan != nm.nan) { status = 3; fin = true; }
                 else if (nm.rg <= S.tol_stat && nm.rb <= S.tol_eq && nm.rd <= S.tol_ineq && nm.rm <= S.tol_comp) {
                     status = 0; fin = true;
@@ -1491,6 +1569,9 @@ struct QpIpm {
             }
             backward<false>(nm, sigmu, false, 0.0, 0.0);
             forward<true>(sigmu, a, d1, d2);
+#ifdef USV_TIMING_EXPERIMENT
+            if (S.fixed_iters == 0)
+#endif
             if (run && a < S.alpha_min) { status = 2; done = true; late = true; iters = it; }
             a_prev = run ? a * ((1.0 - a) * 0.99 + a * 0.9999999) : a_prev;
             sig_prev = run ? sigmu : sig_prev;

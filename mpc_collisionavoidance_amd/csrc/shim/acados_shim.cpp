@@ -103,6 +103,13 @@ int ocp_nlp_cost_model_set(ocp_nlp_config *, ocp_nlp_dims *, ocp_nlp_in *, int s
     return usvmpc_set(g_h, "yref", stage, (const double *)value, stage == N ? NX : NY) ? fail("ocp_nlp_cost_model_set") : 0;
 }
 
+// not an acados symbol: kernel time of the last acados_solve (HIP events on the solver's stream), for the overhead measurement of
+// tests/shim_harness.cpp
+int usvmpc_shim_last_kernel_ms(float *linearize_ms, float *qp_ms)
+{
+    return g_h ? usvmpc_last_kernel_ms(g_h, linearize_ms, qp_ms) : -1;
+}
+
 void ocp_nlp_out_get(ocp_nlp_config *, ocp_nlp_dims *, ocp_nlp_out *, int stage, const char *field, void *value)
 {
     const std::string f(field ? field : "");

@@ -19,6 +19,7 @@
 #endif
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -58,6 +59,17 @@ __global__ void __launch_bounds__(64, (LDSWS ? 1 : qp_waves<KCH, SOFTBOX>())) us
     const bool has = row < rows;
     QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, LDSWS, MERGE> q(P, has ? g0 + row : g0, has ? row : -1);
     q.solve(phase, queue0);
+}
+
+// Multiplier read-back (usvmpc_get "lam" / "t"): the inequality multipliers and slacks of every instance's last QP, from the
+// group-indexed workspace planes into instance-major arrays in acados' row order (QpIpm::export_rows).  Run on demand.
+template <class M, int KCH, bool SOFT, bool PACK, bool SOFTBOX>
+__global__ void __launch_bounds__(64) usv_qp_export(DevPtrs P, long ngroups)
+{
+    const long g0 = (long)blockIdx.x * 4;
+    if (g0 >= ngroups) return;
+    QpIpm<M, KCH, SOFT, true, PACK, SOFTBOX> q(P, g0 + (long)(threadIdx.x >> 4));
+    q.export_rows();
 }
 
 // full SQP bookkeeping: start of a call (everything running) and end (still running = max iterations)
@@ -226,6 +238,21 @@ struct usvmpc_handle {
     bool map_changed;         // the group -> instance map differs from the one the workspace's multipliers were written under
     unsigned noise_mask;      // states usvmpc_advance disturbs (option "disturbance_mask"; default: all)
     int *d_fail_ring;         // [RING] instances with status != 0, one slot per solve
+    // Caller-visible arrays live in ONE device arena, in the order [x | u | status | x0 | yref | yref_e | p | lh] (256-byte aligned
+    // pieces).  Small handles (the single-instance drop-in faces: AcadosOcpSolver, the acados C shim) also keep a pinned host
+    // MIRROR of it: usvmpc_set then writes the mirror and marks the field dirty - no HIP call, no synchronisation - and the next
+    // launch uploads what is dirty (the reference protocol's 3N+4 setters per tick become ONE asynchronous copy: the dirty
+    // fields are adjacent); after a solve [x | u | status] comes back in ONE copy and usvmpc_get "x" / "u" is served from it.
+    enum { F_X = 0, F_U, F_STATUS, F_X0, F_YREF, F_YREF_E, F_P, F_LH, F_COUNT };
+    char *arena;              // device
+    char *mirror;             // pinned host copy of the arena, or nullptr (arena larger than MIRROR_MAX)
+    size_t arena_bytes, f_off[F_COUNT + 1], f_len[F_COUNT];
+    size_t dirty_lo[F_COUNT], dirty_hi[F_COUNT]; // byte range inside each field that the mirror holds newer than the device (lo >= hi: none)
+    bool inflight;            // a copy between mirror and arena may still be running on the stream
+    bool out_valid;           // the mirror's [x | u | status] is what the device holds (or newer)
+    bool extern_access;       // a device pointer was handed out: the device arrays may change behind the mirror
+    long export_at;           // nsolves the multiplier read-back buffers (ptrs.lam_out / t_out) were filled at; -1: never
+    bool layout_dirty;        // the row layout option changed after the last solve: the workspace cannot be read back
     size_t bytes;
     std::string err;
     std::vector<void *> allocs;
@@ -295,9 +322,60 @@ int lookup(usvmpc_handle *h, const char *f, int stage, bool set, Field &o)
     else if (!set && s == "res") o = {P.res, 4, 1, 0};
     else if (!set && s == "obs_tmin") o = {P.obs_tmin, 1, 1, 0};
     else if (!set && s == "nlp_res") o = {P.nlp_res, 4, 1, 0};
+    else if (!set && s == "lam" && P.lam_out) o = {P.lam_out, P.nlam, N + 1, 0};
+    else if (!set && s == "t" && P.t_out) o = {P.t_out, P.nlam, N + 1, 0};
     else {
         h->err = "unknown field '" + s + "'";
         return USVMPC_E_FIELD;
+    }
+    return 0;
+}
+
+int ensure_export(usvmpc_handle *h); // (below: needs the kernel dispatch)
+
+constexpr size_t MIRROR_MAX = 1u << 20; // arenas up to 1 MiB are mirrored on the host
+
+int field_index(const std::string &s, int stage, int N)
+{
+    if (s == "x") return usvmpc_handle::F_X;
+    if (s == "u") return usvmpc_handle::F_U;
+    if (s == "x0") return usvmpc_handle::F_X0;
+    if (s == "yref") return stage == N ? usvmpc_handle::F_YREF_E : usvmpc_handle::F_YREF;
+    if (s == "yref_e") return usvmpc_handle::F_YREF_E;
+    if (s == "p") return usvmpc_handle::F_P;
+    if (s == "lh") return usvmpc_handle::F_LH;
+    return -1;
+}
+
+// wait for a mirror <-> arena copy that may still be running before the host touches the mirror
+int mirror_quiesce(usvmpc_handle *h)
+{
+    if (h->inflight) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->inflight = false;
+    }
+    return 0;
+}
+
+// upload what the mirror holds newer than the device: consecutive dirty fields go as one copy
+int mirror_flush(usvmpc_handle *h)
+{
+    if (!h->mirror) return 0;
+    int f = 0;
+    while (f < usvmpc_handle::F_COUNT) {
+        if (h->dirty_lo[f] >= h->dirty_hi[f]) { f++; continue; }
+        size_t lo = h->f_off[f] + h->dirty_lo[f], hi = h->f_off[f] + h->dirty_hi[f];
+        // extend over the following fields while this one is dirty to its end and the next from its start
+        int g = f;
+        while (g + 1 < usvmpc_handle::F_COUNT && h->dirty_hi[g] == h->f_len[g] && h->dirty_lo[g + 1] == 0 && h->dirty_hi[g + 1] > 0) {
+            g++;
+            hi = h->f_off[g] + h->dirty_hi[g];
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->arena + lo, h->mirror + lo, hi - lo, hipMemcpyHostToDevice, h->stream));
+        h->inflight = true;
+        for (int i = f; i <= g; i++) { h->dirty_lo[i] = 1; h->dirty_hi[i] = 0; }
+        f = g + 1;
     }
     return 0;
 }
@@ -306,6 +384,10 @@ int copy_field(usvmpc_handle *h, const char *field, int stage, double *host, siz
 {
     if (!h) return USVMPC_E_ARG;
     if (!host) { h->err = "null buffer"; return USVMPC_E_ARG; }
+    if (!set && (std::string(field ? field : "") == "lam" || std::string(field ? field : "") == "t")) {
+        const int rce = ensure_export(h);
+        if (rce) return rce;
+    }
     Field f;
     if (std::string(field ? field : "") == "res" || std::string(field ? field : "") == "nlp_res" ||
         std::string(field ? field : "") == "obs_tmin" ||
@@ -319,9 +401,39 @@ int copy_field(usvmpc_handle *h, const char *field, int stage, double *host, siz
                  ", got " + std::to_string(n);
         return USVMPC_E_SIZE;
     }
-    HIP_TRY(h, hipSetDevice(h->device));
     if (f.n == 0) return 0;
     const size_t B = (size_t)h->B;
+    const int fi = h->mirror ? field_index(std::string(field ? field : ""), stage, h->N) : -1;
+    if (fi >= 0 && (set || ((fi == usvmpc_handle::F_X || fi == usvmpc_handle::F_U) && h->out_valid && !h->extern_access))) {
+        // ---- through the pinned mirror: no HIP call unless a copy is still in flight
+        const bool whole = stage < 0 || f.stages == 1;
+        if (!whole && (stage - f.stage_off < 0 || stage - f.stage_off >= f.stages)) {
+            h->err = std::string("stage ") + std::to_string(stage) + " out of range for field '" + field + "'";
+            return USVMPC_E_STAGE;
+        }
+        if (whole && stage >= 0 && stage - f.stage_off != 0) { h->err = "stage out of range"; return USVMPC_E_STAGE; }
+        rc = mirror_quiesce(h);
+        if (rc) return rc;
+        char *m = h->mirror + h->f_off[fi];
+        const size_t row = (size_t)f.n * sizeof(double), pitch = (size_t)f.stages * row;
+        const size_t first = whole ? 0 : (size_t)(stage - f.stage_off) * row;
+        if (whole) {
+            if (set) std::memcpy(m, host, B * pitch); else std::memcpy(host, m, B * pitch);
+        } else {
+            for (size_t b = 0; b < B; b++) {
+                if (set) std::memcpy(m + b * pitch + first, (const char *)host + b * row, row);
+                else std::memcpy((char *)host + b * row, m + b * pitch + first, row);
+            }
+        }
+        if (set) {
+            const size_t lo = first, hi = whole ? B * pitch : (B - 1) * pitch + first + row;
+            if (h->dirty_lo[fi] >= h->dirty_hi[fi]) { h->dirty_lo[fi] = lo; h->dirty_hi[fi] = hi; }
+            else { h->dirty_lo[fi] = std::min(h->dirty_lo[fi], lo); h->dirty_hi[fi] = std::max(h->dirty_hi[fi], hi); }
+        }
+        return 0;
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!set) { rc = mirror_flush(h); if (rc) return rc; } // (a get of a field with pending writes sees them)
     if (stage < 0 || f.stages == 1) {
         if (stage >= 0 && f.stages == 1 && stage - f.stage_off != 0) {
             h->err = "stage out of range"; return USVMPC_E_STAGE;
@@ -341,12 +453,17 @@ int copy_field(usvmpc_handle *h, const char *field, int stage, double *host, siz
         else HIP_TRY(h, hipMemcpy2DAsync(host, row, d, pitch, row, B, hipMemcpyDeviceToHost, h->stream));
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->inflight = false;
     return 0;
 }
 
 template <class M, int KCH, bool SOFT>
 int launch_pair(usvmpc_handle *h, int phase)
 {
+    {   // pending host writes go up first; the results come back below
+        const int rcf = mirror_flush(h);
+        if (rcf) return rcf;
+    }
     const long lin_groups = (long)(h->N + 1) * h->Bp;
     const long qp_groups = h->Bp;
     const int lin_block = 256, qp_block = 64;
@@ -355,7 +472,8 @@ int launch_pair(usvmpc_handle *h, int phase)
     // (the later iterations of a full SQP read the multipliers the previous launch left in the group-indexed
     // workspace: the group -> instance map must not change inside one SQP call)
     if (h->sort_enabled && h->nsolves > 0 && phase != 2) {
-        h->map_changed = true;
+        // (a phase-1 launch re-sorts BEFORE its QP writes the multipliers: map and workspace stay consistent)
+        if (phase == 0) h->map_changed = true;
         const int B = h->B;
         hipLaunchKernelGGL(usv_sort_hist, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_iter, B, h->d_hist);
         hipLaunchKernelGGL(usv_sort_scan, dim3(1), dim3(64), 0, h->stream, h->d_hist, h->d_cursor);
@@ -461,6 +579,12 @@ int launch_pair(usvmpc_handle *h, int phase)
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[2], h->stream));
     h->nsolves++;
+    h->layout_dirty = false;
+    if (h->mirror) { // [x | u | status] of this solve, one copy
+        HIP_TRY(h, hipMemcpyAsync(h->mirror, h->arena, h->f_off[usvmpc_handle::F_X0], hipMemcpyDeviceToHost, h->stream));
+        h->inflight = true;
+        h->out_valid = true;
+    }
     return 0;
 }
 
@@ -499,6 +623,56 @@ int launch(usvmpc_handle *h, int phase = 0)
     }
     h->err = "unknown model";
     return USVMPC_E_ARG;
+}
+
+// ---- multiplier read-back: buffers on first use, one kernel per solve they are asked for
+template <class M, int KCH, bool SOFT>
+int export_pair(usvmpc_handle *h)
+{
+    constexpr bool CANPACK = KCH > 0;
+    const bool pack = CANPACK && h->spec.boxpack != 0;
+    const dim3 grid((unsigned)((h->Bp + 3) / 4)), block(64);
+    if (h->spec.any_bsoft) hipLaunchKernelGGL((usv_qp_export<M, KCH, SOFT, false, true>), grid, block, 0, h->stream, h->ptrs, (long)h->Bp);
+    else if (pack) hipLaunchKernelGGL((usv_qp_export<M, KCH, SOFT, CANPACK, false>), grid, block, 0, h->stream, h->ptrs, (long)h->Bp);
+    else hipLaunchKernelGGL((usv_qp_export<M, KCH, SOFT, false, false>), grid, block, 0, h->stream, h->ptrs, (long)h->Bp);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int ensure_export(usvmpc_handle *h)
+{
+    if (h->nsolves == 0) { h->err = "no QP has been solved yet: nothing to read back"; return USVMPC_E_ARG; }
+    if (h->layout_dirty) { h->err = "the row layout option changed after the last solve: solve again before reading multipliers"; return USVMPC_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    DevPtrs &P = h->ptrs;
+    if (!P.lam_out) {
+        P.nlam = lam_len(h->spec, h->soft);
+        const size_t cnt = (size_t)h->B * (h->N + 1) * (size_t)(P.nlam > 0 ? P.nlam : 1);
+        if (dev_alloc(h, &P.lam_out, cnt, false)) return USVMPC_E_HIP;
+        if (dev_alloc(h, &P.t_out, cnt, false)) { P.lam_out = nullptr; return USVMPC_E_HIP; }
+        h->export_at = -1;
+    }
+    if (h->export_at == h->nsolves) return 0;
+    const size_t nbytes = (size_t)h->B * (h->N + 1) * (size_t)(P.nlam > 0 ? P.nlam : 1) * sizeof(double);
+    HIP_TRY(h, hipMemsetAsync(P.lam_out, 0, nbytes, h->stream));
+    HIP_TRY(h, hipMemsetAsync(P.t_out, 0, nbytes, h->stream));
+    int rc = USVMPC_E_ARG;
+    switch (h->desc.model) {
+#ifdef USV_BENCH_ONLY
+    case USVMPC_MODEL_PF_CA: if (h->kch <= 1) rc = export_pair<ModelM2, 1, false>(h); break;
+    case USVMPC_MODEL_GUIDANCE_CA1: if (h->kch <= 1) rc = export_pair<ModelM1, 1, true>(h); break;
+#elif !defined(USV_GEN_ONLY)
+    case USVMPC_MODEL_USV: rc = export_pair<ModelM0, 0, false>(h); break;
+    case USVMPC_MODEL_GUIDANCE_CA1: rc = h->kch <= 1 ? export_pair<ModelM1, 1, true>(h) : export_pair<ModelM1, 2, true>(h); break;
+    case USVMPC_MODEL_PF_CA: rc = h->kch <= 1 ? export_pair<ModelM2, 1, false>(h) : export_pair<ModelM2, 2, false>(h); break;
+#endif
+#if defined(USV_GEN_MODEL_HEADER) && !defined(USV_BENCH_ONLY)
+    case USVMPC_MODEL_GENERATED: rc = export_pair<ModelGen, USV_GEN_KCH, (USV_GEN_SOFT != 0)>(h); break;
+#endif
+    }
+    if (rc) { if (rc == USVMPC_E_ARG) h->err = "multiplier read-back: no kernel for this model in this library"; return rc; }
+    h->export_at = h->nsolves;
+    return 0;
 }
 
 } // namespace
@@ -568,6 +742,8 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->device = d->device;
     h->bytes = 0; h->nsolves = 0; h->own_stream = true;
     h->map_changed = false;
+    h->export_at = -1;
+    h->layout_dirty = false;
     h->noise_mask = ~0u;
     h->dynamic_rows = true;
     h->qp_cap = 0;
@@ -582,6 +758,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     auto fail = [&](int rc) {
         std::fprintf(stderr, "usvmpc_create: %s\n", h->err.c_str());
         for (void *a : h->allocs) (void)hipFree(a);
+        if (h->mirror) (void)hipHostFree(h->mirror);
         delete h;
         return rc;
     };
@@ -595,22 +772,48 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     const size_t stride = (size_t)h->Bp * LANES;
     const size_t kch = h->kch ? h->kch : 1;
     DevPtrs &P = h->ptrs;
-    TRY_C(dev_alloc(h, &h->d_spec, 1, false));
     h->spec.npt = ws_planes(h->nx, h->nu, h->kch, h->soft, model_mat_planes(h->desc.model), h->spec.any_bsoft != 0);
+    // one stage of the workspace is addressed through ONE 32-bit buffer window (lanes::Planes: group * npt * 128 + ...)
+    if ((size_t)h->Bp * (size_t)h->spec.npt * 128u > (size_t)UINT32_MAX) {
+        h->err = "batch too large for one handle: batch * " + std::to_string(h->spec.npt * 128) + " bytes per stage exceed the 4 GiB "
+                 "buffer window (at most " + std::to_string((size_t)UINT32_MAX / ((size_t)h->spec.npt * 128u) / 4 * 4) + " instances); use several handles";
+        return fail(USVMPC_E_ARG);
+    }
+    TRY_C(dev_alloc(h, &h->d_spec, 1, false));
     HIP_C(hipMemcpy(h->d_spec, &h->spec, sizeof(DevSpec), hipMemcpyHostToDevice));
     P.spec = h->d_spec;
-    double *t;
-    TRY_C(dev_alloc(h, &P.x, B * (N + 1) * h->nx, true));
-    TRY_C(dev_alloc(h, &P.u, B * N * h->nu, true));
-    TRY_C(dev_alloc(h, &t, B * h->nx, true)); P.x0 = t;
-    TRY_C(dev_alloc(h, &t, B * N * h->ny, true)); P.yref = t;
-    TRY_C(dev_alloc(h, &t, B * h->ny_e, true)); P.yref_e = t;
-    TRY_C(dev_alloc(h, &t, B * (N + 1) * 2 * K, true)); P.p = t;
-    TRY_C(dev_alloc(h, &t, B * N * K, true)); P.lh = t;
+    {   // the caller-visible arrays: one arena [x | u | status | x0 | yref | yref_e | p | lh]
+        const size_t len[usvmpc_handle::F_COUNT] = {B * (N + 1) * h->nx * sizeof(double), B * N * h->nu * sizeof(double), B * sizeof(int),
+                                                    B * h->nx * sizeof(double), B * N * h->ny * sizeof(double), B * h->ny_e * sizeof(double),
+                                                    B * (N + 1) * 2 * K * sizeof(double), B * N * K * sizeof(double)};
+        size_t off = 0;
+        for (int f = 0; f < usvmpc_handle::F_COUNT; f++) {
+            h->f_off[f] = off; h->f_len[f] = len[f];
+            off += (len[f] + 255) / 256 * 256;
+            h->dirty_lo[f] = 1; h->dirty_hi[f] = 0;
+        }
+        h->f_off[usvmpc_handle::F_COUNT] = off;
+        h->arena_bytes = off;
+        TRY_C(dev_alloc(h, &h->arena, off, true));
+        char *a = h->arena;
+        P.x = (double *)(a + h->f_off[usvmpc_handle::F_X]);
+        P.u = (double *)(a + h->f_off[usvmpc_handle::F_U]);
+        P.status = (int *)(a + h->f_off[usvmpc_handle::F_STATUS]);
+        P.x0 = (double *)(a + h->f_off[usvmpc_handle::F_X0]);
+        P.yref = (double *)(a + h->f_off[usvmpc_handle::F_YREF]);
+        P.yref_e = (double *)(a + h->f_off[usvmpc_handle::F_YREF_E]);
+        P.p = (double *)(a + h->f_off[usvmpc_handle::F_P]);
+        P.lh = (double *)(a + h->f_off[usvmpc_handle::F_LH]);
+        h->mirror = nullptr;
+        if (off <= MIRROR_MAX) {
+            HIP_C(hipHostMalloc((void **)&h->mirror, off, hipHostMallocDefault));
+            std::memset(h->mirror, 0, off);
+        }
+        h->inflight = false; h->out_valid = false; h->extern_access = false;
+    }
     TRY_C(dev_alloc(h, &P.sl, B * N * K, true));
     TRY_C(dev_alloc(h, &P.su, B * N * K, true));
     TRY_C(dev_alloc(h, &P.pi, B * N * h->nx, true));
-    TRY_C(dev_alloc(h, &P.status, B, true));
     TRY_C(dev_alloc(h, &P.qp_iter, B, true));
     TRY_C(dev_alloc(h, &P.qp_status, B, true));
     TRY_C(dev_alloc(h, &P.res, B * 4, true));
@@ -642,6 +845,7 @@ int usvmpc_destroy(usvmpc_handle *h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (void *a : h->allocs) (void)hipFree(a);
+    if (h->mirror) (void)hipHostFree(h->mirror);
     for (int r = 0; r < usvmpc_handle::RING; r++)
         for (int i = 0; i < 3; i++) (void)hipEventDestroy(h->ev[r][i]);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -684,6 +888,7 @@ int usvmpc_sync(usvmpc_handle *h)
     if (!h) return USVMPC_E_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->inflight = false;
     return 0;
 }
 
@@ -695,8 +900,11 @@ int usvmpc_solve(usvmpc_handle *h, int *status)
     if (rc) return rc;
     int worst = 0;
     if (status) {
-        rc = usvmpc_get_int(h, "status", status);
-        if (rc) return rc;
+        if (h->mirror && h->out_valid) std::memcpy(status, h->mirror + h->f_off[usvmpc_handle::F_STATUS], (size_t)h->B * sizeof(int)); // (came back with x | u)
+        else {
+            rc = usvmpc_get_int(h, "status", status);
+            if (rc) return rc;
+        }
         for (int b = 0; b < h->B; b++) worst = status[b] > worst ? status[b] : worst;
     }
     return worst;
@@ -752,6 +960,13 @@ int usvmpc_get_device_ptr(usvmpc_handle *h, const char *field, void **dptr)
                   : s == "obs_tmin" ? (const void *)P.obs_tmin
                   : s == "nlp_res" ? (const void *)P.nlp_res : s == "sqp_iter" ? (const void *)P.sqp_iter : nullptr;
     if (!p) { h->err = "unknown field '" + s + "'"; return USVMPC_E_FIELD; }
+    {   // the caller is about to read (or write) device memory directly: pending host writes go up, and the host mirror no longer
+        // vouches for the device's x / u
+        HIP_TRY(h, hipSetDevice(h->device));
+        const int rcf = mirror_flush(h);
+        if (rcf) return rcf;
+        h->extern_access = true;
+    }
     *dptr = const_cast<void *>(p);
     return 0;
 }
@@ -853,6 +1068,10 @@ int usvmpc_advance(usvmpc_handle *h, double sigma, unsigned long long seed)
 {
     if (!h) return USVMPC_E_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
+    {
+        const int rcf = mirror_flush(h);
+        if (rcf) return rcf;
+    }
     const long n = (long)h->B * h->nx;
     hipLaunchKernelGGL(usv_advance, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ptrs, h->nx, sigma, seed, h->noise_mask);
     HIP_TRY(h, hipGetLastError());
@@ -888,9 +1107,30 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         h->qp_cap = 0; h->lds_cap = 0;
         return 0;
     }
+#ifdef USV_TIMING_EXPERIMENT
+    if (s == "timing_alias_groups" || s == "timing_fixed_iters") {
+        (s == "timing_alias_groups" ? h->spec.alias_groups : h->spec.fixed_iters) = (int)value;
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipMemcpyAsync(h->d_spec, &h->spec, sizeof(DevSpec), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return 0;
+    }
+#endif
+    if (s == "host_mirror") { // 0: drop the pinned host mirror of the caller-visible arrays (every set / get then goes to the device)
+        if (value != 0.0) { if (!h->mirror) { h->err = "host_mirror cannot be switched on again"; return USVMPC_E_ARG; } return 0; }
+        if (!h->mirror) return 0;
+        HIP_TRY(h, hipSetDevice(h->device));
+        const int rcf = mirror_flush(h);
+        if (rcf) return rcf;
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->inflight = false; h->out_valid = false;
+        (void)hipHostFree(h->mirror);
+        h->mirror = nullptr;
+        return 0;
+    }
     if (s == "static_obstacles" || s == "pack_box_rows") {
         if (s == "static_obstacles") h->spec.p_static = value != 0.0;
-        else { h->spec.boxpack = (value != 0.0 && h->spec.boxpack_ok) ? 1 : 0; h->qp_cap = 0; h->lds_cap = 0; }
+        else { h->spec.boxpack = (value != 0.0 && h->spec.boxpack_ok) ? 1 : 0; h->qp_cap = 0; h->lds_cap = 0; h->layout_dirty = true; }
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipMemcpyAsync(h->d_spec, &h->spec, sizeof(DevSpec), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -959,6 +1199,10 @@ int usvmpc_guidance_prepare(usvmpc_handle *h, const double *vel_uv, const double
     if (!h || !vel_uv || !pose || lmax < 0 || lmax > GUIDANCE_LMAX) return USVMPC_E_ARG;
     if (!h->gd_ready || h->gd.npts < 2) { h->err = "usvmpc_guidance_reset must be called first"; return USVMPC_E_ARG; }
     HIP_TRY(h, hipSetDevice(h->device));
+    {
+        const int rcf = mirror_flush(h);
+        if (rcf) return rcf;
+    }
     GuidancePtrs &G = h->gd;
     const size_t B = h->B;
     HIP_TRY(h, hipMemcpyAsync(const_cast<double *>(G.vel), vel_uv, B * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1045,6 +1289,10 @@ int usvmpc_calibrate_traffic(usvmpc_handle *h, int nplanes, double *bytes_read, 
     const long stride = (long)h->Bp * LANES;
     const long avail = (long)(h->N + 1) * ws_planes(h->nx, h->nu, h->kch, h->soft, model_mat_planes(h->desc.model), h->spec.any_bsoft != 0);
     if (nplanes + 1 > avail) { h->err = "nplanes exceeds the workspace"; return USVMPC_E_ARG; }
+    if ((size_t)h->Bp * (size_t)(nplanes + 1) * 128u > (size_t)UINT32_MAX) { // (usv_calib_stream addresses it all through one 32-bit window)
+        h->err = "nplanes * batch exceeds the 4 GiB buffer window of the calibration kernel";
+        return USVMPC_E_ARG;
+    }
     const long groups = h->Bp;
     hipLaunchKernelGGL(usv_calib_stream, dim3((unsigned)((groups * LANES + 63) / 64)), dim3(64), 0, h->stream, h->ptrs, groups, nplanes);
     HIP_TRY(h, hipGetLastError());
@@ -1058,7 +1306,12 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream)
 {
     if (!h) return USVMPC_E_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
+    {
+        const int rcf = mirror_flush(h);
+        if (rcf) return rcf;
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->inflight = false;
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     h->stream = (hipStream_t)stream;
     h->own_stream = false;

@@ -163,8 +163,10 @@ def check(co):
     return count, bad, unknown_branch
 
 
-def check_library(path):
-    """(number of hand-placed DPP instructions, list of violation strings) for one library / code object."""
+def check_library(path, expect_fused=True):
+    """(number of hand-placed DPP instructions, list of violation strings) for one library / code object.
+    expect_fused: the library was built with USV_FUSED_DPP_FMA = 1 (the default), so finding NO such instruction means the
+    disassembly was not understood (objdump format change) - a violation, not a pass."""
     cos, tmp = code_objects(path)
     total, msgs = 0, []
     try:
@@ -177,6 +179,8 @@ def check_library(path):
                 msgs.append(f"{fn}: {a:#x} v_fmac_f64_dpp {ops}   <-   {wa:#x} {wmn} {wops}")
             if unk and n:
                 msgs.append("a branch the checker cannot follow next to hand-placed DPP code")
+        if cos and expect_fused and total == 0:
+            msgs.append("no v_fmac_f64_dpp found in a fused build: the disassembly was not parsed, nothing was checked")
     finally:
         if tmp:
             import shutil

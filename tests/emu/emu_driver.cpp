@@ -126,6 +126,16 @@ void qp_body(void *a)
     q.solve(j->qp_phase, j->queue0);
 }
 
+// multiplier read-back (QpIpm::export_rows) of one group, as the device's usv_qp_export kernel runs it
+template <class M, int KCH, bool SOFT, bool PACK, bool SOFTBOX>
+void export_body(void *a)
+{
+    Job *j = (Job *)a;
+    QpIpm<M, KCH, SOFT, true, PACK, SOFTBOX> q(*j->P, j->gid);
+    q.export_rows();
+}
+double *g_emu_lam = nullptr, *g_emu_t = nullptr; // [B][N+1][nlam] each: filled after the solve when set (usv_emu_set_export)
+
 // inspection copies of the lineariser's output: BAt [N][nx][Bp*16] (the packed planes expanded back to one plane
 // per row), rb0 [N][Bp*16], gq [N+1][Bp*16]
 double *g_dbg_BAt = nullptr, *g_dbg_rb0 = nullptr, *g_dbg_gq = nullptr;
@@ -197,6 +207,15 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
             else if (S.hdiag) lanes::run_group(g, pack ? &qp_body<M, KCH, SOFT, true, CANPACK> : &qp_body<M, KCH, SOFT, true, false>, &j);
             else lanes::run_group(g, pack ? &qp_body<M, KCH, SOFT, false, CANPACK> : &qp_body<M, KCH, SOFT, false, false>, &j);
         }
+    if ((phase & 2) && P.lam_out)
+        for (long g = 0; g < S.Bp; g++) {
+            Job j{&P, g, 0, -1};
+            constexpr bool CANPACK = KCH > 0;
+            const bool pack = CANPACK && S.boxpack != 0;
+            if (S.any_bsoft) lanes::run_group(g, &export_body<M, KCH, SOFT, false, true>, &j);
+            else if (pack) lanes::run_group(g, &export_body<M, KCH, SOFT, CANPACK, false>, &j);
+            else lanes::run_group(g, &export_body<M, KCH, SOFT, false, false>, &j);
+        }
 }
 
 } // namespace
@@ -239,6 +258,11 @@ static int emu_run(const usvmpc_desc *d, int sqp, double *x, double *u, const do
     P.nlp_res = nres.data(); P.sqp_iter = sit.data(); P.sqp_state = sstate.data(); P.sqp_running = &running;
     int queue = 0;
     P.queue = &queue;
+    if (g_emu_lam && g_emu_t) {
+        P.lam_out = g_emu_lam; P.t_out = g_emu_t; P.nlam = lam_len(S, soft);
+        std::memset(g_emu_lam, 0, sizeof(double) * (size_t)S.B * (N + 1) * P.nlam);
+        std::memset(g_emu_t, 0, sizeof(double) * (size_t)S.B * (N + 1) * P.nlam);
+    }
     g_dbg_BAt = dbg_BAt; g_dbg_rb0 = dbg_rb0; g_dbg_gq = dbg_gq;
     auto one = [&](int qp_phase) -> int {
         const int phase = 3;
@@ -284,6 +308,8 @@ static int emu_run(const usvmpc_desc *d, int sqp, double *x, double *u, const do
 // test switches: workspace of the RTI solves in emulated LDS (lds != 0); persistent rows pulling from the queue (rows, 0 = none)
 extern "C" void usv_emu_set_mode(int lds, long rows) { g_emu_lds_mode = lds; g_emu_rows = rows; }
 extern "C" void usv_emu_set_merge(int merge) { g_emu_merge = merge; }
+// the next solves also deliver the multipliers / slacks of their QPs (the device's usvmpc_get "lam" / "t"); NULL switches it off
+extern "C" void usv_emu_set_export(double *lam, double *t) { g_emu_lam = lam; g_emu_t = t; }
 
 extern "C" int usv_emu_solve(const usvmpc_desc *d, double *x, double *u, const double *x0,
                              const double *yref, const double *yref_e, const double *p,

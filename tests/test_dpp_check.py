@@ -61,3 +61,18 @@ def test_checker_flags_a_violation(tmp_path):
     assert any("straight" in b for b in bad)
     assert any("across_branch" in b for b in bad)
     assert not any("padded" in b for b in bad)
+
+
+def test_checker_refuses_a_fused_build_in_which_it_finds_nothing(tmp_path):
+    """A fused library in which no v_fmac_f64_dpp is recognised means the disassembly was not understood: a violation, not
+    a pass (an unfused build says so with expect_fused=False)."""
+    src = tmp_path / "plain.hip"
+    src.write_text('#include <hip/hip_runtime.h>\n__global__ void plain(double *p) { p[threadIdx.x] *= 2.0; }\n')
+    out = tmp_path / "plain.co"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O2", "--cuda-device-only", "-c", "-o", str(out), str(src)], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("hipcc could not build the probe: " + r.stderr[-300:])
+    n, bad = dpp_check.check_library(str(out))
+    assert n == 0 and any("nothing was checked" in b for b in bad)
+    n, bad = dpp_check.check_library(str(out), expect_fused=False)
+    assert n == 0 and not bad

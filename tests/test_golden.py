@@ -1,5 +1,10 @@
 """Golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py): the oracle must keep
-reproducing them (CPU), and the HIP path must reproduce them through the C ABI (GPU)."""
+reproducing them (CPU), and the HIP path must reproduce them through the C ABI (GPU).
+
+Two families.  m?_*: the reference's own step sizes, obstacles beside the roll-out (rows mostly inactive), consecutive RTI
+iterations.  m?s_*: the benchmark workloads of SURVEY.md 8(d) - BASELINE configs[1] / configs[2] shapes and a two-chunk shape,
+dt = 0.05 s - run closed loop until the obstacle rows bind (`active` in the fixture: instances with a row on its bound);
+every tick is compared from the fixture's own inputs of that tick."""
 import glob
 import os
 
@@ -9,47 +14,92 @@ import pytest
 from mpc_collisionavoidance_amd import scenario, usv_models
 from tests import util
 
-FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "m[0-9]_*.npz")))   # (ref_model_*.npz: test_ref_vectors.py)
+FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "m[0-9]*_*.npz")))   # (ref_model_*.npz: test_ref_vectors.py)
 
 
 def _load(f):
     g = np.load(f)
     wl = {k: g[k] for k in ("x0", "yref", "yref_e", "p", "lh", "x_init", "u_init")}
     wl["K"] = int(g["K"])
-    return g, wl
+    steps = int(g["sim_steps"]) if "sim_steps" in g.files else 1
+    closed = "generator" in g.files and str(g["generator"]) == "survey"
+    return g, wl, steps, closed
+
+
+def _inputs(g, wl, it, closed):
+    """(x, u, x0) tick `it` starts from"""
+    x = wl["x_init"] if it == 0 else g["x_out"][it - 1]
+    u = wl["u_init"] if it == 0 else g["u_out"][it - 1]
+    return x.copy(), u.copy(), (g["x0_in"][it] if closed else wl["x0"])
+
+
+def _tol(name, closed):
+    """1e-7 relative (north_star allows 1e-5).  usv_model_pf_ca on the survey workloads: 1e-6 - with R = 0 its QP solution is
+    itself known no better than ~1e-2 at the default IPM tolerances, and the kernels' classical Riccati
+    form and the oracle's square-root form then agree to a few 1e-7 (measured on the emulator: 2.4e-7 on m2s_n40_k20)."""
+    return 1e-6 if (closed and name == "usv_model_pf_ca") else 1e-7
 
 
 def test_fixtures_exist():
-    assert len(FILES) >= 6
+    assert len(FILES) >= 11
+    act = {os.path.basename(f)[:-4]: float(np.load(f)["active"].mean()) for f in FILES if "s_" in os.path.basename(f)}
+    assert len(act) >= 5 and min(act.values()) >= 0.5, act   # the survey fixtures exercise the inequality path
 
 
 @pytest.mark.parametrize("f", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
 def test_oracle_reproduces_golden(oracle, f):
-    g, wl = _load(f)
+    g, wl, steps, closed = _load(f)
     name, N, K = str(g["name"]), int(g["N"]), int(g["K"])
-    spec = util.oracle_spec(oracle, name, N, float(g["dt"]), K)
-    x, u = wl["x_init"].copy(), wl["u_init"].copy()
+    spec = util.oracle_spec(oracle, name, N, float(g["dt"]), K, sim_steps=steps)
     for it in range(g["x_out"].shape[0]):
-        x, u, st, qi = util.oracle_rti(oracle, spec, wl, x, u)
+        x, u, x0 = _inputs(g, wl, it, closed)
+        x, u, st, qi = util.oracle_rti(oracle, spec, wl, x, u, x0=x0)
         assert np.array_equal(st, g["status"][it])
         assert np.array_equal(qi, g["qp_iter"][it])
         assert util.rel_err(x, g["x_out"][it]) < 1e-11 and util.rel_err(u, g["u_out"][it]) < 1e-11
+
+
+SURVEY_FILES = [f for f in FILES if "s_" in os.path.basename(f)]
+
+
+@pytest.mark.parametrize("f", SURVEY_FILES, ids=[os.path.basename(f)[:-4] for f in SURVEY_FILES])
+def test_kernel_bodies_reproduce_survey_golden_on_the_emulator(emu, f):
+    """The unmodified kernel bodies (tests/emu) on the active-row fixtures: what the GPU test below checks on the device."""
+    from mpc_collisionavoidance_amd import _capi
+    from tests.test_emu_kernels import emu_rti
+    g, wl, steps, closed = _load(f)
+    name, N, K, B = str(g["name"]), int(g["N"]), int(g["K"]), int(g["B"])
+    ocp = usv_models.make_ocp(name, N * float(g["dt"]), N, K)
+    ocp.solver_options.sim_method_num_steps = steps
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    for it in range(g["x_out"].shape[0]):
+        x, u, x0 = _inputs(g, wl, it, closed)
+        r = emu_rti(emu, desc, dict(wl, x0=np.ascontiguousarray(x0)), x, u)
+        assert np.array_equal(r["status"], g["status"][it])
+        ex, eu = util.rel_err(r["x"], g["x_out"][it]), util.rel_err(r["u"], g["u_out"][it])
+        assert ex < _tol(name, closed) and eu < _tol(name, closed), (it, ex, eu)
+        assert np.abs(r["qp_iter"] - g["qp_iter"][it]).max() <= 1
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("f", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
 def test_hip_path_reproduces_golden(f):
     from mpc_collisionavoidance_amd import BatchOcpSolver
-    g, wl = _load(f)
+    g, wl, steps, closed = _load(f)
     name, N, K, B = str(g["name"]), int(g["N"]), int(g["K"]), int(g["B"])
     ocp = usv_models.make_ocp(name, N * float(g["dt"]), N, None if name == "usv_model" else K)
+    ocp.solver_options.sim_method_num_steps = steps
     s = BatchOcpSolver(ocp, B)
     scenario.load_into(s, wl)
     for it in range(g["x_out"].shape[0]):
+        if closed:   # every tick from the fixture's inputs of that tick
+            x, u, x0 = _inputs(g, wl, it, closed)
+            s.set_all("x", x)
+            s.set_all("u", u)
+            s.set("x0", 0, x0)
         st = s.solve()
         assert np.array_equal(st, g["status"][it])
-        # tolerance: 1e-7 relative (north_star allows 1e-5); the HIP path uses the classical Riccati form
-        assert util.rel_err(s.get_all("x"), g["x_out"][it]) < 1e-7
-        assert util.rel_err(s.get_all("u"), g["u_out"][it]) < 1e-7
+        ex, eu = util.rel_err(s.get_all("x"), g["x_out"][it]), util.rel_err(s.get_all("u"), g["u_out"][it])
+        assert ex < _tol(name, closed) and eu < _tol(name, closed), (it, ex, eu)
         assert np.abs(s.get_int("qp_iter") - g["qp_iter"][it]).max() <= 1
     s.close()

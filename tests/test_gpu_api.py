@@ -179,3 +179,70 @@ def test_one_row_pass_matches_two(name, N, K, B):
     assert np.array_equal(out[0][2], out[1][2]) and np.abs(out[0][3] - out[1][3]).max() <= 1
     ok = out[0][2] == 0
     assert util.rel_err(out[1][0][ok], out[0][0][ok]) < 1e-7 and util.rel_err(out[1][1][ok], out[0][1][ok]) < 1e-6
+
+
+def test_host_mirror_staging_is_invisible(oracle):
+    """Small handles keep a pinned host mirror of the caller-visible arrays: setters write it, the next launch uploads the dirty
+    fields, x / u / status come back with the solve (include/usvmpc.h, option host_mirror).  Every interleaving of per-stage /
+    whole-field set, get, solve, advance and device-pointer access must behave exactly like the direct path (mirror off)."""
+    name, N, K, B = "usv_model_guidance_ca1", 12, 4, 3
+    ocp, wl = util.make(name, N, K, B, seed=41)
+    rng = np.random.default_rng(3)
+
+    def script(mirror):
+        s = BatchOcpSolver(ocp, B)
+        if not mirror:
+            s.set_option("host_mirror", 0)
+        out = []
+        scenario.load_into(s, wl)
+        out.append(s.get_all("x"))                       # get of a field that is dirty in the mirror, before any solve
+        for k in range(N):                               # the reference protocol: per-stage setters
+            s.set("yref", k, wl["yref"][:, k])
+            s.set("p", k, wl["p"][:, k])
+            s.set("lh", k, wl["lh"][:, k])
+        s.set("p", N, wl["p"][:, N])
+        s.set("yref", N, wl["yref_e"])
+        s.set("x0", 0, wl["x0"])
+        out.append(s.solve().copy())
+        out += [s.get("x", 1), s.get("u", 0), s.get_all("x"), s.get_all("u"), s.get("pi", 3)]
+        xm = s.get_all("x")
+        xm[:, 5] += 0.01
+        s.set("x", 5, xm[:, 5])                           # partial write of an output field, read back whole and per stage
+        out += [s.get_all("x"), s.get("x", 5), s.get("x", 6)]
+        s.advance(0.0)                                    # device-side write of x0 behind the mirror
+        out.append(s.get("x0", 0))
+        s.set("lh", 2, wl["lh"][:, 2] * 0.9)              # one stage dirty, the rest of the field untouched
+        out.append(s.solve().copy())
+        out += [s.get_all("x"), s.get_all("u"), s.get_all("lh")]
+        s.set("x0", 0, wl["x0"] + 0.01)
+        s.advance(0.0)                                    # the pending x0 is uploaded, then overwritten by the hand-over
+        out.append(s.get("x0", 0))
+        t = sharding.device_tensor(s.device_ptr("u"), (B, N, s.nu))   # zero-copy access: the mirror stops vouching for x / u
+        t += 0.125
+        import torch
+        torch.cuda.synchronize()
+        out.append(s.get_all("u"))
+        s.solve_async()
+        s.set("yref", 0, wl["yref"][:, 0] + 0.001)        # a set while the solve (and its read-back) is in flight
+        s.sync()
+        out += [s.get_all("x"), s.get_int("status").copy()]
+        out.append(s.solve().copy())
+        out += [s.get_all("x"), s.get_all("u")]
+        s.close()
+        return out
+
+    a, b = script(True), script(False)
+    assert len(a) == len(b)
+    for i, (p, q) in enumerate(zip(a, b)):
+        assert np.array_equal(p, q), i
+
+
+def test_batch_beyond_the_buffer_window_is_refused():
+    """One stage of the workspace is addressed through a 32-bit buffer window: a batch whose stage exceeds 4 GiB is refused at
+    creation (it used to wrap silently)."""
+    ocp = usv_models.make_ocp("usv_model_pf_ca", 0.4, 8, 10)
+    with pytest.raises(RuntimeError):
+        BatchOcpSolver(ocp, 1400000)
+    s = BatchOcpSolver(ocp, 8)
+    assert s.device_bytes() > 0
+    s.close()

@@ -196,3 +196,71 @@ def test_full_size_batch_properties(oracle):
     ok = (sto == 0) & (ito < 50) & (a[0][2][:U] == 0)
     assert ok.mean() > 0.95
     assert util.rel_err(a[0][0][:U][ok], xo[ok]) <= TOL and util.rel_err(a[0][1][:U][ok], uo[ok]) <= TOL
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The BASELINE configs on their SURVEY.md 8(d) workloads (dt = 0.05 s, obstacles inside the look-ahead: ACTIVE rows), closed loop
+# without disturbance, every tick compared from identical inputs (the iterate and x0 the device starts the tick from).
+def _run_survey(oracle, name, N, K, B, ticks, min_active, seed=1234, moving=False):
+    from mpc_collisionavoidance_amd import usv_models
+    wl = scenario.make_bench_batch(name, N, K, B, seed=seed, moving=moving)
+    dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
+    ocp = usv_models.make_ocp(name, N * dt, N, K)
+    ocp.solver_options.sim_method_num_steps = steps
+    s = BatchOcpSolver(ocp, B)
+    scenario.load_into(s, wl)
+    if not moving:
+        s.set_option("static_obstacles", 1)
+    spec = oracle.spec(util.MODEL_ID[name], N, N * dt, K, sim_steps=steps)
+    x0 = wl["x0"].copy()
+    slack = max(1, int(0.01 * B))
+    hard = name == "usv_model_pf_ca"
+    n_cmp = n_above = 0
+    act = 0.0
+    for t in range(ticks):
+        xs, us = s.get_all("x"), s.get_all("u")
+        st = s.solve()
+        sto, ito = oracle.rti_batch(spec, xs, us, x0, wl["yref"], wl["yref_e"], wl["p"], wl["lh"], threads=0)
+        xg, ug, qs, qi = s.get_all("x"), s.get_all("u"), s.get_int("qp_status"), s.get_int("qp_iter")
+        assert (st != sto).sum() <= slack, (name, t, np.where(st != sto)[0])
+        conv_g, conv_o = qs == 0, (sto == 0) & (ito < spec.opts.qp_iter_max)
+        assert (conv_g != conv_o).sum() <= slack, (name, t)
+        ok = conv_g & conv_o
+        assert ok.mean() >= 0.97, (name, t, ok.mean())
+        e = np.maximum(util.rel_err_per_instance(xg[ok], xs[ok]), util.rel_err_per_instance(ug[ok], us[ok]))
+        n_cmp += int(ok.sum())
+        n_above += int((e > 1e-5).sum())
+        # soft-row model: every instance inside 1e-7.  Hard-row model (R = 0: DESIGN.md section 2): median, 90 % tight, and
+        # north_star's 1e-5 on all but isolated instances, which profiles/r03_parity_tail.txt classifies one by one
+        if hard:
+            assert np.percentile(e, 50) <= 1e-9 and np.percentile(e, 90) <= 1e-7, (name, t, np.percentile(e, 50), np.percentile(e, 90))
+            assert (e > 1e-5).sum() <= max(1, int(0.002 * B)) and e.max() <= 5e-2, (name, t, int((e > 1e-5).sum()), e.max())
+        else:
+            assert e.max() <= TOL, (name, t, e.max())
+        dit = np.abs(qi - ito)[ok]
+        assert (dit > 0).sum() <= slack and (dit > 1).sum() <= 2, (name, t, dit.max(), (dit > 0).sum())
+        act = float((s.get("obs_tmin", 0)[ok] < 1e-3).mean()) if K else 0.0   # some obstacle row's slack t_l at zero: the row binds
+        s.advance(0.0)
+        s.sync()
+        x0 = s.get("x0", 0)
+    s.close()
+    print("survey parity", dict(model=name, N=N, K=K, B=B, ticks=ticks, compared=n_cmp, frac_above_1e5=n_above / max(1, n_cmp),
+                                active_row_frac=act))
+    assert act >= min_active, (name, act)
+
+
+@pytest.mark.parametrize("name", ["usv_model_pf_ca", "usv_model_guidance_ca1"])
+def test_config1_on_its_survey_workload_full_size(oracle, name):
+    """BASELINE configs[1] at full size: 1024 instances, N=20 (Tf = 1 s), 3 static obstacles."""
+    _run_survey(oracle, name, 20, 3, 1024, ticks=12, min_active=0.5)
+
+
+@pytest.mark.parametrize("name", ["usv_model_pf_ca", "usv_model_guidance_ca1"])
+def test_config2_on_its_survey_workload(oracle, name):
+    """BASELINE configs[2] (batch reduced to what the oracle follows in seconds): N=40 (Tf = 2 s), 10 static obstacles."""
+    _run_survey(oracle, name, 40, 10, 768, ticks=6, min_active=0.5)
+
+
+def test_config4_shape_on_its_survey_workload(oracle):
+    """BASELINE configs[4] shape: N=80 (Tf = 4 s), 20 moving obstacles (per-stage p, two obstacle chunks)."""
+    _run_survey(oracle, "usv_model_pf_ca", 80, 20, 128, ticks=4, min_active=0.4, moving=True)

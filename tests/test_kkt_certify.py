@@ -1,0 +1,208 @@
+"""Implementation-independent acceptance of the QP solutions: every converged solve must satisfy the KKT
+conditions of ITS QP as evaluated by tests/kkt.py in numpy - stationarity <= 1e-6, equality / inequality / complementarity
+<= 1e-8 (the IPM's own exit tolerances, acados / HPIPM defaults), multipliers and slacks non-negative - whatever iteration
+path produced it.  The candidate is read through the C ABI: the step from "x" / "u", "pi", and the inequality multipliers
+and slacks from the fields "lam" / "t" (acados' ocp_nlp_out_get names), soft slacks from "sl" / "su".
+
+CPU: the batched checker against the per-instance one of tests/test_oracle_qp.py on the oracle's solutions, and the kernel
+bodies on the lane emulator.  GPU (-m gpu): the bench workload itself (BASELINE configs[2] as SURVEY.md 8(d) spells it out,
+2048 instances x 10 closed-loop ticks), configs[1] at full size, and the soft-row model; every instance the device reports
+as converged must be certified, and every device-vs-oracle difference above north_star's 1e-5 is classified.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mpc_collisionavoidance_amd import _capi, scenario, usv_models
+from tests import kkt, util
+from tests.test_oracle_qp import kkt_residuals
+
+SLACK = 1.02  # the checker's QP data is the oracle's linearisation, the device's its own (they agree to ~1e-12 per entry)
+
+
+def _pad_pi(pi):
+    """[B,N,nx] (stages 1..N) -> [B,N+1,nx] with an unused entry 0."""
+    return np.concatenate([np.zeros_like(pi[:, :1]), pi], axis=1)
+
+
+def _pad_s(s):
+    """[B,N,K] (stages 0..N-1) -> [B,N+1,K]."""
+    return np.concatenate([s, np.zeros_like(s[:, :1])], axis=1)
+
+
+def _step(xn, un, xb, ub):
+    """dz [B,N+1,nz] = [du; dx] from the new and the old iterate."""
+    B, N, nu = ub.shape
+    dz = np.zeros((B, N + 1, nu + xb.shape[2]))
+    dz[:, :N, :nu] = un - ub
+    dz[:, :, nu:] = xn - xb
+    return dz
+
+
+def assert_certified(res, ok, what=""):
+    bad = ok & ~kkt.certified(res, 1e-6 * SLACK, 1e-8 * SLACK, 1e-8 * SLACK, 1e-8 * SLACK)
+    assert not bad.any(), (what, int(bad.sum()), {k: float(v[ok].max()) for k, v in res.items()})
+
+
+@pytest.mark.parametrize("name,N,K", [("usv_model", 10, 0), ("usv_model_guidance_ca1", 12, 5), ("usv_model_pf_ca", 12, 4)])
+def test_batched_checker_agrees_with_the_per_instance_one(oracle, name, N, K):
+    ocp, wl = util.make(name, N, K, 5, seed=3)
+    spec = util.oracle_spec(oracle, name, N, scenario.DT[name], K)
+    args = (wl["x_init"], wl["u_init"], wl["x0"], wl["yref"], wl["yref_e"], wl["p"], wl["lh"])
+    qpb = kkt.linearize_batch(oracle, spec, *args)
+    B = 5
+    nrow = qpb["nbu"] + qpb["nbx"] + K
+    ns = K if qpb["soft"] else 0
+    dz, pi = np.zeros((B, N + 1, qpb["nz"])), np.zeros((B, N + 1, qpb["nx"]))
+    lam, t = np.zeros((B, N + 1, 2 * (nrow + ns))), np.zeros((B, N + 1, 2 * (nrow + ns)))
+    sl, su = np.zeros((B, N + 1, K)), np.zeros((B, N + 1, K))
+    ref = []
+    for b in range(B):
+        qp, sol = oracle.linearize_and_solve(spec, *[a[b] for a in args])
+        assert sol["status"] == 0
+        ref.append(kkt_residuals(qp, sol))
+        dz[b], pi[b] = sol["dz"], sol["pi"]
+        nbu, nbx = qp["nbu"], qp["nbx"]
+        for side in (0, 1):
+            o = side * nrow
+            lam[b, :N, o:o + nbu], t[b, :N, o:o + nbu] = sol["lam_bu"][:, side], sol["t_bu"][:, side]
+            lam[b, 1:N, o + nbu:o + nbu + nbx], t[b, 1:N, o + nbu:o + nbu + nbx] = sol["lam_bx"][1:N, side], sol["t_bx"][1:N, side]
+            lam[b, 1:N, o + nbu + nbx:o + nrow], t[b, 1:N, o + nbu + nbx:o + nrow] = sol["lam_g"][1:N, side], sol["t_g"][1:N, side]
+            if ns:
+                lam[b, 1:N, 2 * nrow + side * ns:2 * nrow + (side + 1) * ns] = sol["lam_s"][1:N, side]
+                t[b, 1:N, 2 * nrow + side * ns:2 * nrow + (side + 1) * ns] = sol["t_s"][1:N, side]
+        sl[b, 1:N], su[b, 1:N] = sol["sl"][1:N], sol["su"][1:N]
+    res = kkt.kkt_batch(qpb, dz, pi, lam, t, sl, su)
+    assert kkt.certified(res).all(), res
+    for b in range(B):
+        stat, prim, dual, comp = ref[b]
+        assert abs(res["stat"][b] - stat) <= 1e-12 + 1e-9 * stat
+        assert abs(res["comp_noslack"][b] - comp) <= 1e-12 + 1e-6 * comp
+        assert dual == 0.0 and res["neg"][b] == 0.0
+
+
+def _emu_rti_with_multipliers(emu, desc, wl, x, u, nlam):
+    B, N = x.shape[0], desc.N
+    lam, t = np.zeros((B, N + 1, nlam)), np.zeros((B, N + 1, nlam))
+    emu.usv_emu_set_export.argtypes = [_capi._dp, _capi._dp]
+    emu.usv_emu_set_export.restype = None
+    emu.usv_emu_set_export(lam.ctypes.data_as(_capi._dp), t.ctypes.data_as(_capi._dp))
+    try:
+        from tests.test_emu_kernels import emu_rti
+        r = emu_rti(emu, desc, wl, x, u)
+    finally:
+        emu.usv_emu_set_export(None, None)
+    r["lam"], r["t"] = lam, t
+    return r
+
+
+# (M2 K=10: the headline's row layout, 6 slot rows + 1 dense row, two row passes; K=4: every box row in a slot lane, one pass;
+#  M1 K=5: soft rows + one box row; K=20: two obstacle chunks)
+@pytest.mark.parametrize("name,N,K,B,lds", [("usv_model_pf_ca", 40, 10, 4, 0), ("usv_model_pf_ca", 40, 4, 4, 1),
+                                            ("usv_model_guidance_ca1", 40, 5, 3, 0), ("usv_model_guidance_ca1", 40, 20, 4, 0),
+                                            ("usv_model", 8, 0, 2, 0)])
+def test_emulated_kernels_deliver_certified_solutions(oracle, emu, name, N, K, B, lds):
+    """The device's read-back path (QpIpm::export_rows, the LDS write-back of finish) on the lane emulator, survey workload
+    (obstacle rows active), two RTI iterations."""
+    dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
+    wl = scenario.make_bench_batch(name, N, K, B, seed=11)
+    ocp = usv_models.make_ocp(name, N * dt, N, None if name == "usv_model" else K)
+    ocp.solver_options.sim_method_num_steps = steps
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    spec = oracle.spec(util.MODEL_ID[name], N, N * dt, K, sim_steps=steps)
+    soft = name == "usv_model_guidance_ca1"
+    nlam = 2 * (desc.nbu + desc.nbx + K + (K if soft else 0))
+    emu.usv_emu_set_mode(lds, 2)
+    try:
+        x, u = wl["x_init"].copy(), wl["u_init"].copy()
+        active = 0
+        for it in range(2):
+            r = _emu_rti_with_multipliers(emu, desc, wl, x, u, nlam)
+            qp = kkt.linearize_batch(oracle, spec, x, u, wl["x0"], wl["yref"], wl["yref_e"], wl["p"], wl["lh"])
+            ok = r["qp_status"] == 0
+            assert ok.any()
+            res = kkt.kkt_batch(qp, _step(r["x"], r["u"], x, u), _pad_pi(r["pi"]), r["lam"], r["t"],
+                                _pad_s(r["sl"]) if soft else None, _pad_s(r["su"]) if soft else None)
+            assert_certified(res, ok, (name, it))
+            nrow = desc.nbu + desc.nbx + K
+            if K:
+                active += int((r["lam"][ok][:, :, desc.nbu + desc.nbx:nrow] > 1e-3).any(axis=(1, 2)).sum())
+            x, u = r["x"], r["u"]
+        if K:
+            assert active > 0, "no obstacle row carried a multiplier: the case does not exercise the inequality path"
+    finally:
+        emu.usv_emu_set_mode(0, 2)
+
+
+# ------------------------------------------------------------------------------------------------ device
+def _device_tick(s, oracle, spec, wl, x0, soft):
+    """One solve on the device + its certification.  Returns (res, ok, new x, new u, old x, old u)."""
+    xb, ub = s.get_all("x"), s.get_all("u")
+    s.solve_async()
+    s.sync()
+    xn, un = s.get_all("x"), s.get_all("u")
+    ok = (s.get_int("qp_status") == 0) & (s.get_int("status") == 0)
+    qp = kkt.linearize_batch(oracle, spec, xb, ub, x0, wl["yref"], wl["yref_e"], wl["p"], wl["lh"])
+    res = kkt.kkt_batch(qp, _step(xn, un, xb, ub), _pad_pi(s.get_all("pi")), s.get_all("lam"), s.get_all("t"),
+                        _pad_s(s.get_all("sl")) if soft else None, _pad_s(s.get_all("su")) if soft else None)
+    return res, ok, xn, un, xb, ub
+
+
+def _certify_closed_loop(oracle, name, N, K, B, ticks, options=()):
+    from mpc_collisionavoidance_amd import BatchOcpSolver
+    wl = scenario.make_bench_batch(name, N, K, B, seed=1234)
+    dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
+    ocp = usv_models.make_ocp(name, N * dt, N, K)
+    ocp.solver_options.sim_method_num_steps = steps
+    s = BatchOcpSolver(ocp, B)
+    scenario.load_into(s, wl)
+    s.set_option("static_obstacles", 1)
+    s.set_option("disturbance_mask", scenario.NOISE_MASK[name])
+    for k, v in options:
+        s.set_option(k, v)
+    spec = oracle.spec(util.MODEL_ID[name], N, N * dt, K, sim_steps=steps)
+    soft = name == "usv_model_guidance_ca1"
+    x0 = wl["x0"].copy()
+    n_ok = n_cert = n_act = 0
+    worst = dict(stat=0.0, eq=0.0, ineq=0.0, comp=0.0)
+    for tk in range(ticks):
+        res, ok, xn, un, xb, ub = _device_tick(s, oracle, spec, wl, x0, soft)
+        assert ok.mean() >= 0.97, (name, tk, ok.mean())
+        cert = kkt.certified(res, 1e-6 * SLACK, 1e-8 * SLACK, 1e-8 * SLACK, 1e-8 * SLACK)
+        n_ok += int(ok.sum())
+        n_cert += int((ok & cert).sum())
+        n_act += int((s.get("obs_tmin", 0) < 1e-3)[ok].sum())
+        for k in worst:
+            worst[k] = max(worst[k], float(res[k][ok].max()))
+        assert_certified(res, ok, (name, tk))
+        s.advance(1e-3, seed=2000 + tk)
+        s.sync()
+        x0 = s.get("x0", 0)
+    s.close()
+    out = dict(model=name, N=N, K=K, B=B, ticks=ticks, converged=n_ok, kkt_certified_frac=n_cert / float(n_ok),
+               active_row_frac=n_act / float(n_ok), worst=worst)
+    print("KKT", out)
+    return out
+
+
+@pytest.mark.gpu
+def test_device_solutions_certified_on_the_bench_workload(oracle):
+    """BASELINE configs[2] (SURVEY 8(d) generator), 2048 instances x 10 closed-loop ticks: 100 % of the converged solves."""
+    r = _certify_closed_loop(oracle, "usv_model_pf_ca", 40, 10, 2048, 10)
+    assert r["kkt_certified_frac"] == 1.0 and r["active_row_frac"] >= 0.5, r
+
+
+@pytest.mark.gpu
+def test_device_solutions_certified_config1_full_size(oracle):
+    """BASELINE configs[1]: 1024 instances, N=20, 3 obstacles, on its 8(d) workload (one row pass, LDS or HBM planes)."""
+    r = _certify_closed_loop(oracle, "usv_model_pf_ca", 20, 3, 1024, 4)
+    assert r["kkt_certified_frac"] == 1.0, r
+    r = _certify_closed_loop(oracle, "usv_model_pf_ca", 20, 3, 96, 3, options=(("lds_workspace", 1),))
+    assert r["kkt_certified_frac"] == 1.0, r
+
+
+@pytest.mark.gpu
+def test_device_solutions_certified_soft_rows(oracle):
+    r = _certify_closed_loop(oracle, "usv_model_guidance_ca1", 40, 10, 512, 5)
+    assert r["kkt_certified_frac"] == 1.0 and r["active_row_frac"] >= 0.5, r

@@ -46,6 +46,10 @@ def test_survey_rollout_is_the_oracles_integrator(oracle):
 def test_legacy_generator_unchanged_defaults():
     a = scenario.make_batch("usv_model_pf_ca", 10, 4, 16)
     assert a["generator"] == "beside" and a["dt"] == 0.01 and np.abs(a["x0"][:, 4]).max() <= 0.03
-    b = scenario.make_bench_batch("usv_model_guidance_ca1", 10, 4, 16)
-    c = scenario.make_batch("usv_model_guidance_ca1", 10, 4, 16, dt=0.05)
+    # at the 2 s look-ahead the field is SURVEY's own (6 m); other horizons scale it (3 Tf)
+    b = scenario.make_bench_batch("usv_model_guidance_ca1", 40, 4, 16)
+    c = scenario.make_batch("usv_model_guidance_ca1", 40, 4, 16, dt=0.05)
     assert all(np.array_equal(b[k], c[k]) for k in ("x0", "p", "lh", "x_init"))
+    d = scenario.make_bench_batch("usv_model_guidance_ca1", 20, 4, 16)
+    e = scenario.make_batch("usv_model_guidance_ca1", 20, 4, 16, dt=0.05, max_range=3.0)
+    assert all(np.array_equal(d[k], e[k]) for k in ("x0", "p", "lh", "x_init"))

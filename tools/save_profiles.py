@@ -31,7 +31,14 @@ pj = dst + "/pmc_traffic.json"
 J = json.load(open(pj))
 J = [e for e in J if e.get("round") != tag]
 cfgw = b["config"]
-J.append({"round": tag, "workload": workload, "kernel": kname.replace("void ", ""), "model": cfgw["ocp"], "N": cfgw["horizon"], "K": cfgw["obstacles"],
+import subprocess
+try:
+    head = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
+    if subprocess.check_output(["git", "status", "--porcelain", "--", "mpc_collisionavoidance_amd/csrc"], text=True).strip():
+        head += "+uncommitted kernel changes"
+except Exception:
+    head = None
+J.append({"round": tag, "workload": workload, "lib_sha256": cfgw.get("lib_sha256"), "git_head": head, "moving": "moving" in cfgw.get("workload", "") and " static " not in cfgw.get("workload", ""), "kernel": kname.replace("void ", ""), "model": cfgw["ocp"], "N": cfgw["horizon"], "K": cfgw["obstacles"],
           "batch": cfgw["instances_per_gpu"], "fetch_size_KiB_raw": f, "write_size_KiB_raw": wv, "hbm_bytes_per_launch": tot,
           "correction": "FETCH_SIZE x2, WRITE_SIZE x1; re-calibrated in this round on the [stage][group][plane][16 lanes] layout with "
                         "usv_calib_stream: 524288 KiB read -> FETCH_SIZE 262166 KiB, 2097152 KiB -> 1048612 KiB (factor 0.5000), "

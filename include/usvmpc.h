@@ -164,6 +164,9 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  *   "merge_box_rows" (default 1) - when every box row rides in an idle lane of the last obstacle chunk's planes the sweeps
  *       process them there (one row pass instead of two).  A separately compiled instantiation: statuses and iteration
  *       counts equal, iterates agree to rounding - as with "lds_workspace";
+ *   "aux_in_lds" (default 1) - an RTI solve keeps the per-stage aux plane (dense box rows, linearisation point, r_g, l_u) in the
+ *       wavefronts' LDS instead of streaming it, when the horizon fits without costing a resident wavefront (a separately
+ *       compiled instantiation of the same arithmetic: results equal to rounding at most);
  *   "host_mirror" (default: on for handles whose caller-visible arrays total <= 1 MiB, i.e. the single-instance drop-in faces) -
  *       usvmpc_set writes a pinned host mirror and the next solve uploads the dirty fields in one asynchronous copy instead
  *       of one synchronising copy per call (the reference issues 3N+4 setters per tick: scripts/usv_guidance_ca1/main.py:

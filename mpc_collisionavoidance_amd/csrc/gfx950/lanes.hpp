@@ -252,6 +252,15 @@ USV_DEV double frsqrt(double x)
 
 // lane index inside the wave (a wave carries four 16-lane groups)
 USV_DEV unsigned wave_lane() { return threadIdx.x & 63u; }
+// rows (16-lane groups) of a wave and this lane's row
+constexpr int WAVE_ROWS = 4;
+USV_DEV unsigned wave_row() { return (threadIdx.x >> 4) & 3u; }
+// the workgroup's dynamic LDS (one wave per workgroup in the QP kernel): the planes of PlanesLds, or the aux area of qp_ipm.hpp
+USV_DEV double *dyn_lds()
+{
+    extern __shared__ double usv_lds[];
+    return usv_lds;
+}
 
 // The lane-major planes of ONE stage in HBM: [group][plane][16 lanes] - a group's (= OCP instance's) planes of a stage
 // are 128-byte rows back to back, so every group streams its own contiguous block whatever groups share its wave.

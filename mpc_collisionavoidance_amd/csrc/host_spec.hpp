@@ -129,6 +129,7 @@ inline std::string build_spec(const usvmpc_desc &d, DevSpec &S)
         S.boxpack = S.boxpack_ok;
         if (S.boxpack_ok) {
             S.box_dense = ndense > 0;
+            S.aux_dense4 = 4 * ndense;
             int slot = k_last, j = 0;
             for (int r = 0; r < LANES; r++) {
                 if (!S.has_b[r]) continue;

@@ -148,12 +148,31 @@ struct ModelM2 {
     // cos(beta) = ue / rho, sin(beta) = v / rho with rho = sqrt(ue^2 + v^2) in every quadrant, the angle-sum formulas
     // give sin / cos(chi) from sin / cos(psi) without the atan2 and without a second sincos (agreement with the
     // literal expressions: a few ulp, tests/test_ref_vectors.py).
-    struct Pre { double sa, ca; };
+    // psi does move inside an interval, but by no more than dt * |r| (a few hundredths of a radian: r is a bounded state), so its
+    // sine and cosine at the 4 x steps stage points follow from those at the interval's start by the angle-sum formulas with a
+    // short series in the increment (|d| <= 0.125: truncation below 1e-19; beyond that the library call) - one
+    // sincos per interval instead of twenty.
+    struct Pre { double sa, ca, psi0, sp0, cp0; };
     USV_DEV static Pre prepare(const double *x)
     {
         Pre p;
         sincos(x[9], &p.sa, &p.ca);
+        p.psi0 = x[0];
+        sincos(x[0], &p.sp0, &p.cp0);
         return p;
+    }
+    USV_DEV static void sincos_near(const Pre &pre, double psi, double &sp, double &cp)
+    {
+        const double d = psi - pre.psi0, d2 = d * d;
+        if (fabs(d) > 0.125) { // (never on the reference's OCPs: |r| <= 1 rad/s, dt <= 0.05 s)
+            sincos(psi, &sp, &cp);
+            return;
+        }
+        // sin d = d (1 - d2/6 (1 - d2/20 (1 - d2/42 (1 - d2/72 (1 - d2/110))))),  cos d = 1 - d2/2 (1 - d2/12 (1 - d2/30 (1 - d2/56 (1 - d2/90))))
+        const double sd = d * fma(-d2 * (1.0 / 6.0), fma(-d2 * (1.0 / 20.0), fma(-d2 * (1.0 / 42.0), fma(-d2 * (1.0 / 72.0), fma(-d2, 1.0 / 110.0, 1.0), 1.0), 1.0), 1.0), 1.0);
+        const double cd = fma(-d2 * 0.5, fma(-d2 * (1.0 / 12.0), fma(-d2 * (1.0 / 30.0), fma(-d2 * (1.0 / 56.0), fma(-d2, 1.0 / 90.0, 1.0), 1.0), 1.0), 1.0), 1.0);
+        sp = fma(pre.sp0, cd, pre.cp0 * sd);
+        cp = fma(pre.cp0, cd, -pre.sp0 * sd);
     }
     USV_DEV static void fjvp(const double *x, const double *U, const double *s, const double *su, double *f, double *js)
     {
@@ -168,7 +187,7 @@ struct ModelM2 {
         const double iden = irho * irho;
         const double cb = ue * irho, sb = v * irho;
         double sp, cp;
-        sincos(psi, &sp, &cp);
+        sincos_near(pre, psi, sp, cp);
         const double sc = sp * cb + cp * sb, cc = cp * cb - sp * sb;
         const double sa = pre.sa, ca = pre.ca;
         const double dchi = s[0] + (-v * iden) * s[3] + (ue * iden) * s[4];

@@ -19,6 +19,7 @@ struct DevSpec {
     int boxpack;                  // 1: packing in use (option "pack_box_rows" toggles it when boxpack_ok)
     int boxpack_ok;               //    whether the rows fit at all
     int box_dense;                // 1: some rows are dense (plane P_BLL is in use)
+    int aux_dense4;               // 4 x the number of dense rows: they occupy lanes 0 .. aux_dense4-1 of the aux plane
     int box_slot[LANES];          // variable r -> lane its value 0 is stored in
     int box_step[LANES];          // variable r -> 0 (slot row: all four values in that lane) | 1 (dense row)
     int slot_var[LANES];          // lane L -> variable whose row (or row element) it stores

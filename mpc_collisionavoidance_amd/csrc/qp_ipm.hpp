@@ -223,9 +223,14 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 // MERGE (with PACK, no dense rows: host_spec.hpp / usvmpc.hip): the box rows are processed where they are stored - as rows of the
 // last obstacle chunk, in its idle lanes - instead of being gathered to their variables' lanes for a row pass of their own:
 // one RowCalc pass per sweep instead of two.  The workspace layout is the one of PACK; only the four sweeps differ.
-template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false, bool MERGE = false>
+// AUXLDS: the aux plane (WsLayout::P_AUX - dense box rows, position of the linearisation point, r_g, l_u: at most ten values
+// per stage) lives in the wave's LDS for the whole launch instead of being streamed with the planes: 4 reads + 2 writes of the
+// 59 + 13 plane accesses per stage and IPM iteration go (the kernel streams at the HBM ceiling: profiles/r03_bound_experiment.txt).
+// RTI launches whose horizon fits (host: usvmpc.hip); finish() leaves a copy in the HBM plane for the read-back paths.
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false>
 struct QpIpm {
     static_assert(!MERGE || PACK, "merged row pass works on the packed layout");
+    static_assert(!(AUXLDS && LDSWS), "with the whole workspace in LDS the aux plane is there already");
     static_assert(!PACK || KCH > 0, "box rows are packed into obstacle planes");
     static_assert(!(PACK && SOFTBOX), "soft state bounds are not packed");
     static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
@@ -308,6 +313,11 @@ struct QpIpm {
     unsigned voff;
     unsigned loff;   // LDSWS: this lane's entry of (stage 0, plane 0) of its row's LDS region, in doubles
     bool live;       // the row owns a workspace (LDSWS: surplus rows of a wave share row 0's region read-only)
+    // AUXLDS: this lane's entry of stage 0 in the wave's aux area [stage][slot][row] (doubles), the stage stride, and whether the
+    // lane holds anything (slots: dense box values 0 .. 4 nd - 1 | zx | zy | r_g (nu) | l_u (nu))
+    unsigned auxoff;
+    int auxstride;
+    bool auxlive;
     long stage_stride;     // doubles between consecutive stages of the workspace: Bp * NPL * 16
     unsigned stage_bytes;  // bytes of one stage's window
     bool xlane, ulane, valid, isPX, isPY;
@@ -445,6 +455,20 @@ struct QpIpm {
                 c_uh[c] = S.uh[i < S.K ? i : 0];
             });
         }
+        auxoff = 0; auxstride = 0; auxlive = false;
+        if constexpr (AUXLDS) {
+            const int nd4 = lanes::uniform(S.aux_dense4);
+            constexpr int ZB = KCH > 0 ? 2 : 0;
+            int slot = lane < nd4 ? lane : -1;
+            if constexpr (KCH > 0) slot = lane == AXL_ZX ? nd4 : (lane == AXL_ZY ? nd4 + 1 : slot);
+            sfor<0, NU>([&](auto l) {
+                slot = lane == AXL_RG - l ? nd4 + ZB + l : slot;
+                slot = lane == AXL_LU - l ? nd4 + ZB + NU + l : slot;
+            });
+            auxlive = slot >= 0;
+            auxstride = (nd4 + ZB + 2 * NU) * lanes::WAVE_ROWS;
+            auxoff = (unsigned)((slot > 0 ? slot : 0) * lanes::WAVE_ROWS) + lanes::wave_row();
+        }
         g = 0; b = 0;
         live = lds_row >= 0;
         loff = (unsigned)((lds_row > 0 ? lds_row : 0) * (N + 1) * NPL * LANES + lane);
@@ -493,6 +517,17 @@ struct QpIpm {
     {
         if constexpr (LDSWS) return Planes(loff + (unsigned)(k * NPL * LANES), live);
         else return wsg(k);
+    }
+    // the aux plane of stage k: from / to the wave's LDS area (AUXLDS) or the workspace plane
+    USV_DEV double aux_ld(int k, const Planes &W) const
+    {
+        if constexpr (AUXLDS) return lanes::dyn_lds()[auxoff + (unsigned)(k * auxstride)];
+        else return W.ld(P_AUX);
+    }
+    USV_DEV void aux_st(int k, const Planes &W, double v) const
+    {
+        if constexpr (AUXLDS) { if (auxlive) lanes::dyn_lds()[auxoff + (unsigned)(k * auxstride)] = v; }
+        else W.st(P_AUX, v);
     }
     // iterate value of this lane's variable at stage k (caller-visible arrays)
     USV_DEV double zbar(int k) const
@@ -686,7 +721,7 @@ struct QpIpm {
             else if (wr) box_store(W, r);
             const double zbx = KCH > 0 ? lanes::bcast<PXL>(zb) : 0.0, zby = KCH > 0 ? lanes::bcast<PYL>(zb) : 0.0;
             const double aux = aux_compose(dv, zbx, zby, 0.0, 0.0);
-            if (wr) W.st(P_AUX, aux);
+            if (wr) aux_st(k, W, aux);
             if constexpr (KCH > 0) {
                 sfor<0, KCH>([&](auto c) {
                     ObsRow o;
@@ -753,7 +788,7 @@ struct QpIpm {
     {
         const Planes W = ws(k);
         in.z = W.ld(P_Z);
-        in.aux = W.ld(P_AUX);
+        in.aux = aux_ld(k, W);
         // b_k of the current iterate = rbscale * (residual of the linearisation point): the forward sweeps
         // enforce the linearised dynamics, so every step scales it by (1 - alpha) and it is never rewritten
         // (raw value here: scaling it in place would make the prefetch wait for its own load)
@@ -883,7 +918,7 @@ struct QpIpm {
                 const Planes Wp = ws(dfr_k);
                 if (!keep) {
                     if (FACT) Wp.st(P_PI, dfr_pi);
-                    Wp.st(P_AUX, dfr_aux);
+                    aux_st(dfr_k, Wp, dfr_aux);
                 }
                 if (FACT && dfr_k < N) {
                     Wp.st(P_PB, dfr_pb);
@@ -1417,6 +1452,9 @@ struct QpIpm {
                     if constexpr (KCH > 0) sfor<0, KCH * OBSN>([&](auto e) { G.st(P_OBS + e, W.ld(P_OBS + e)); });
                 }
             }
+            if constexpr (AUXLDS) { // (the read-back paths and a later full SQP find the dense box rows in the HBM plane)
+                if (out) W.st(P_AUX, aux_ld(k, W));
+            }
             if (out) {
                 if (ok && xlane) P.x[((long)b * (N + 1) + k) * NX + (lane - NU)] = z;
                 if (ok && ulane && k < N) P.u[((long)b * N + k) * NU + lane] = z;
@@ -1434,7 +1472,7 @@ struct QpIpm {
                     });
                 } else if (k == 0) { // wave-uniform
                     // soft rows of stage 0 (see init): x_0 = x0 fixes their value, the slacks minimise their own penalty
-                    const double aux = W.ld(P_AUX);
+                    const double aux = aux_ld(0, W);
                     const double zbx = aux_zx(aux), zby = aux_zy(aux);
                     const double e0 = z - pos_sel(zbx, zby); // x0 - xbar_0 on the position lanes
                     sfor<0, KCH>([&](auto c) {

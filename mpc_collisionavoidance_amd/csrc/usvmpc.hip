@@ -50,14 +50,15 @@ constexpr int qp_waves() { return (KCH >= 2 || SOFTBOX) ? 1 : USV_QP_WAVES; }
 
 // rows: instances a wave starts on (4; fewer when the workspace lives in LDS and only that many fit: LDSWS) - row r of block b
 // starts on group b * rows + r, surplus rows stay idle.
-template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX, bool LDSWS = false, bool MERGE = false>
+// AUXLDS: the aux plane of the rows' instances in the wave's LDS instead of HBM (qp_ipm.hpp)
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false>
 __global__ void __launch_bounds__(64, (LDSWS ? 1 : qp_waves<KCH, SOFTBOX>())) usv_qp_rti(DevPtrs P, long ngroups, int phase, int queue0, int rows)
 {
     const int row = (int)(threadIdx.x >> 4);
     const long g0 = (long)blockIdx.x * rows;
     if (g0 >= ngroups) return;
     const bool has = row < rows;
-    QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, LDSWS, MERGE> q(P, has ? g0 + row : g0, has ? row : -1);
+    QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, LDSWS, MERGE, AUXLDS> q(P, has ? g0 + row : g0, has ? row : -1);
     q.solve(phase, queue0);
 }
 
@@ -235,6 +236,8 @@ struct usvmpc_handle {
     long max_waves;           // cap on the persistent waves of the QP kernel (0: as many as the device holds)
     int ncu;                  // compute units of the device
     long qp_cap;              // groups a full-occupancy launch of the QP kernel holds at once (0: not yet known)
+    bool aux_lds;             // option "aux_in_lds": the aux plane of an RTI solve in the waves' LDS when the horizon fits (default on)
+    long aux_cap;             // the same for the aux-in-LDS instantiation (0: not yet known, -1: does not fit / would cost a wave)
     bool map_changed;         // the group -> instance map differs from the one the workspace's multipliers were written under
     unsigned noise_mask;      // states usvmpc_advance disturbs (option "disturbance_mask"; default: all)
     int *d_fail_ring;         // [RING] instances with status != 0, one slot per solve
@@ -502,7 +505,7 @@ int launch_pair(usvmpc_handle *h, int phase)
     // Small batches: the planes of every instance in flight fit in LDS (160 KB per CU), and a solve whose sweeps wait for
     // HBM at every stage - nothing else runs on the CU to hide it - becomes a solve on LDS.  rows_lds instances per wave
     // (as many whole horizons as fit), one wave per CU at a time; further instances come through the same queue.
-    auto launch_qp = [&](auto kern, decltype(kern) kern_lds) -> int {
+    auto launch_qp = [&](auto kern, decltype(kern) kern_lds, decltype(kern) kern_aux = nullptr) -> int {
         const long lds_inst = (long)(h->N + 1) * h->spec.npt * 128;
         // (the kernel's own static LDS - exchange area, parked constants - comes out of the same 160 KB)
         long lds_static = 0;
@@ -536,21 +539,36 @@ int launch_pair(usvmpc_handle *h, int phase)
         }
         long ng = qp_groups;
         int q0 = -1;
-        if (h->dynamic_rows && phase == 0) {
-            if (h->qp_cap == 0) {
+        if (h->dynamic_rows && phase == 0 && h->qp_cap == 0) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, qp_block, 0) == hipSuccess && nb > 0 && h->ncu > 0)
+                h->qp_cap = 4L * nb * h->ncu;
+            else
+                h->qp_cap = -1;
+        }
+        // The aux plane in LDS (qp_ipm.hpp, AUXLDS): 4 rows x (N + 1) stages x at most ten values beside the kernel's static LDS - taken
+        // when it does not cost a resident wave (usv_model_pf_ca at N = 40, K = 10: 13.1 KB + 6.7 KB of the 20 KB a wave may have)
+        size_t aux_bytes = 0;
+        if (phase == 0 && kern_aux != nullptr && h->aux_lds && h->dynamic_rows && h->qp_cap > 0) {
+            aux_bytes = (size_t)4 * (h->N + 1) * (size_t)(h->spec.aux_dense4 + (h->kch > 0 ? 2 : 0) + 2 * h->nu) * sizeof(double);
+            if (h->aux_cap == 0) {
                 int nb = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, qp_block, 0) == hipSuccess && nb > 0 && h->ncu > 0)
-                    h->qp_cap = 4L * nb * h->ncu;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern_aux, qp_block, aux_bytes) == hipSuccess && 4L * nb * h->ncu >= h->qp_cap)
+                    h->aux_cap = 4L * nb * h->ncu;
                 else
-                    h->qp_cap = -1;
+                    h->aux_cap = -1;
             }
-            long cap = h->qp_cap;
+            if (h->aux_cap < 0) aux_bytes = 0;
+        }
+        if (aux_bytes) kern = kern_aux;
+        if (h->dynamic_rows && phase == 0) {
+            long cap = aux_bytes ? std::min(h->aux_cap, h->qp_cap) : h->qp_cap;
             if (h->max_waves > 0 && 4L * h->max_waves < cap) cap = 4L * h->max_waves; // option "max_waves": fewer resident waves
             if (cap > 0 && cap < qp_groups) { ng = cap; q0 = (int)ng; }
         }
         if (q0 >= 0) HIP_TRY(h, hipMemsetAsync(h->ptrs.queue, 0, sizeof(int), h->stream));
         const dim3 qg((unsigned)((ng * LANES + qp_block - 1) / qp_block)), qb(qp_block);
-        hipLaunchKernelGGL(kern, qg, qb, 0, h->stream, h->ptrs, ng, phase, q0, 4);
+        hipLaunchKernelGGL(kern, qg, qb, aux_bytes, h->stream, h->ptrs, ng, phase, q0, 4);
         return 0;
     };
     int rcq = 0;
@@ -558,18 +576,23 @@ int launch_pair(usvmpc_handle *h, int phase)
     if (!(h->spec.hdiag && pack && !h->spec.any_bsoft)) { h->err = "development build: bench instantiation only"; return USVMPC_E_ARG; }
     // (one row pass when every box row rides in a slot lane: qp_ipm.hpp, MERGE)
     if (h->merge_rows && !h->spec.box_dense)
-        rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true, CANPACK>);
+        rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true, CANPACK>,
+                        &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>);
     else
-        rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>);
+        rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>,
+                        &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>);
 #else
     if (h->spec.any_bsoft) { // soft state bounds: rows with slacks, ten planes of their own
         rcq = h->spec.hdiag ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, true>, nullptr) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, true>, nullptr);
     } else if (h->spec.hdiag) { // (every OCP of the reference: the only instantiations that also come with the workspace in LDS)
         // (one row pass when every box row rides in a slot lane: qp_ipm.hpp, MERGE)
+        // (the packed layouts - every OCP of the reference, the bench workloads - also come with the aux plane in LDS)
         if (pack && h->merge_rows && !h->spec.box_dense)
-            rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true, CANPACK>);
+            rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true, CANPACK>,
+                            &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>);
         else
-            rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>)
+            rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>,
+                                   &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>)
                        : launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, false>, &usv_qp_rti<M, KCH, SOFT, true, false, false, true>);
     } else {
         rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, false, CANPACK, false>, nullptr) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, false>, nullptr);
@@ -747,6 +770,8 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->noise_mask = ~0u;
     h->dynamic_rows = true;
     h->qp_cap = 0;
+    h->aux_lds = true;
+    h->aux_cap = 0;
     h->lds_mode = -1;
     h->lds_cap = 0;
     h->max_waves = 0;
@@ -1088,6 +1113,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         return 0;
     }
     if (s == "max_waves") { h->max_waves = (long)value; return 0; }
+    if (s == "aux_in_lds") { h->aux_lds = value != 0.0; h->aux_cap = 0; return 0; }
     if (s == "lds_workspace") { // -1: when the batch is small (default), 0: never, 1: whenever an instance's planes fit in LDS
         h->lds_mode = value < 0.0 ? -1 : (value > 0.0 ? 1 : 0);
         h->lds_cap = 0;
@@ -1095,7 +1121,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
     }
     if (s == "dynamic_rows") { // 0: one group per row for the whole launch (the rows of a wave wait for its slowest)
         h->dynamic_rows = value != 0.0;
-        h->qp_cap = 0;
+        h->qp_cap = 0; h->aux_cap = 0;
         return 0;
     }
     if (s == "disturbance_mask") { // bit j: usvmpc_advance adds its noise to state j
@@ -1104,7 +1130,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
     }
     if (s == "merge_box_rows") { // 1 (default): box rows processed in their slot lanes when all of them ride there
         h->merge_rows = value != 0.0;
-        h->qp_cap = 0; h->lds_cap = 0;
+        h->qp_cap = 0; h->lds_cap = 0; h->aux_cap = 0;
         return 0;
     }
 #ifdef USV_TIMING_EXPERIMENT
@@ -1130,7 +1156,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
     }
     if (s == "static_obstacles" || s == "pack_box_rows") {
         if (s == "static_obstacles") h->spec.p_static = value != 0.0;
-        else { h->spec.boxpack = (value != 0.0 && h->spec.boxpack_ok) ? 1 : 0; h->qp_cap = 0; h->lds_cap = 0; h->layout_dirty = true; }
+        else { h->spec.boxpack = (value != 0.0 && h->spec.boxpack_ok) ? 1 : 0; h->qp_cap = 0; h->lds_cap = 0; h->aux_cap = 0; h->layout_dirty = true; }
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipMemcpyAsync(h->d_spec, &h->spec, sizeof(DevSpec), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));

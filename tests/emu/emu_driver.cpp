@@ -105,6 +105,7 @@ using namespace usv;
 struct Job { const DevPtrs *P; long gid; int qp_phase; int queue0; };
 int g_emu_lds_mode = 0; // 1: run the RTI solves with the workspace in (emulated) LDS
 int g_emu_merge = 1;    // 1: box rows processed in their slot lanes when all of them ride there (as the device library does)
+int g_emu_aux = 0;      // 1: RTI solves of the packed one-chunk layouts keep the aux plane in (emulated) LDS (AUXLDS instantiations)
 
 template <class M, int KCH, bool SOFT>
 void lin_body(void *a)
@@ -119,6 +120,11 @@ void qp_body(void *a)
     Job *j = (Job *)a;
     if constexpr (HDIAG && !SOFTBOX) if (g_emu_lds_mode && j->qp_phase == 0) { // the workspace of the (single) emulated row in "LDS"
         QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, true, MERGE> q(*j->P, j->gid, 0);
+        q.solve(j->qp_phase, j->queue0);
+        return;
+    }
+    if constexpr (HDIAG && PACK && !SOFTBOX) if (g_emu_aux && j->qp_phase == 0) {
+        QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, false, MERGE, true> q(*j->P, j->gid);
         q.solve(j->qp_phase, j->queue0);
         return;
     }
@@ -308,6 +314,7 @@ static int emu_run(const usvmpc_desc *d, int sqp, double *x, double *u, const do
 // test switches: workspace of the RTI solves in emulated LDS (lds != 0); persistent rows pulling from the queue (rows, 0 = none)
 extern "C" void usv_emu_set_mode(int lds, long rows) { g_emu_lds_mode = lds; g_emu_rows = rows; }
 extern "C" void usv_emu_set_merge(int merge) { g_emu_merge = merge; }
+extern "C" void usv_emu_set_aux(int aux) { g_emu_aux = aux; }
 // the next solves also deliver the multipliers / slacks of their QPs (the device's usvmpc_get "lam" / "t"); NULL switches it off
 extern "C" void usv_emu_set_export(double *lam, double *t) { g_emu_lam = lam; g_emu_t = t; }
 

@@ -149,6 +149,9 @@ struct Stash {
 
 // the workgroup's LDS (one emulated row per "wave")
 extern double *g_emu_lds;
+constexpr int WAVE_ROWS = 1;
+inline unsigned wave_row() { return 0; }
+inline double *dyn_lds() { return g_emu_lds; }
 struct PlanesLds {
     unsigned off;
     bool live;

@@ -210,3 +210,38 @@ def test_one_row_pass_equals_two(emu, name, N, K):
     assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["qp_iter"], b["qp_iter"])
     for f in ("x", "u", "pi", "sl", "su"):
         assert util.rel_err(a[f], b[f]) <= 1e-9, (f, util.rel_err(a[f], b[f]))
+
+
+@pytest.mark.parametrize("name,N,K", [("usv_model_pf_ca", 8, 10), ("usv_model_pf_ca", 6, 9), ("usv_model_pf_ca", 7, 12),
+                                      ("usv_model_guidance_ca1", 7, 10), ("usv_model_guidance_ca1", 6, 3)])
+def test_aux_plane_in_lds_equals_aux_plane_in_hbm(emu, name, N, K):
+    """AUXLDS: the aux plane (dense box rows, linearisation point, r_g, l_u) kept in the wave's LDS for the whole launch - the same
+    values at the same places of the same arithmetic, so iterates, statuses, iteration counts, slacks and multipliers are
+    bit-identical; the read-back (export_rows) finds the dense box rows in the HBM plane finish() copies them to.
+    K = 10: one dense row + six slot rows (the headline layout); 9: no dense row, one row pass; 12: two dense rows."""
+    B = 6
+    wl = scenario.make_batch(name, N, K, B, dt=0.05, seed=13, generator="survey", sim_steps=scenario.BENCH_SIM_STEPS[name], clip_time=0.1)
+    from mpc_collisionavoidance_amd import usv_models
+    ocp = usv_models.make_ocp(name, N * 0.05, N, K)
+    ocp.solver_options.sim_method_num_steps = scenario.BENCH_SIM_STEPS[name]
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    soft = name == "usv_model_guidance_ca1"
+    nlam = 2 * (desc.nbu + desc.nbx + K + (K if soft else 0))
+    emu.usv_emu_set_aux.argtypes = [C.c_int]
+    emu.usv_emu_set_export.argtypes = [_capi._dp, _capi._dp]
+    emu.usv_emu_set_export.restype = None
+    out = []
+    try:
+        for aux in (0, 1):
+            emu.usv_emu_set_aux(aux)
+            lam, t = np.zeros((B, N + 1, nlam)), np.zeros((B, N + 1, nlam))
+            emu.usv_emu_set_export(_d(lam), _d(t))
+            r = emu_rti(emu, desc, wl, wl["x_init"], wl["u_init"])
+            r2 = emu_rti(emu, desc, wl, r["x"], r["u"])
+            out.append((r2["x"], r2["u"], r2["status"], r2["qp_iter"], r2["sl"], r2["su"], r2["pi"], r2["res"], lam.copy(), t.copy()))
+    finally:
+        emu.usv_emu_set_aux(0)
+        emu.usv_emu_set_export(None, None)
+    assert (out[0][2] == 0).any() and out[0][8].any()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)

@@ -9,8 +9,9 @@
       IPM iteration counts, and the iterate with the per-component relative error of tests/util.rel_err.
       usv_model_guidance_ca1: every instance <= 1e-7 (measured ~1e-10).  usv_model_pf_ca, on every tick: median <= 1e-9, at least 90 % of the
       instances <= 1e-7 in states and controls (measured over 25 ticks of 512 instances: median ~1e-12, 97th percentile
-      between 1e-9 and 1.4e-7), every instance that took the same number of IPM iterations <= 1e-3, the odd instance
-      whose path round-off turned elsewhere (seen: 20 against 45 iterations to the same tolerances) <= 5e-2.
+      between 1e-9 and 1.4e-7), every instance <= 1e-5 (north_star) except isolated ones (at most 0.4 % per tick; measured 1e-4 of
+      the solves) which must then carry an independent certificate - the device's point satisfies the KKT conditions of its QP
+      as evaluated by tests/kkt.py - and stay within 5e-3.
       The outliers (up to ~3e-4 on a thrust rate) are this model's conditioning,
       not slack in the kernels: its control weight is R = 0 (scripts/usv_pf_ca/acados_settings.py:93-99), the
       thrust-rate profile is fixed only through the barrier terms, and the QP solution itself is known no better than
@@ -32,7 +33,8 @@ import numpy as np
 import pytest
 
 from mpc_collisionavoidance_amd import BatchOcpSolver, scenario, sharding, usv_models
-from tests import util
+from tests import kkt, util
+from tests.test_kkt_certify import _pad_pi, _pad_s, _step
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-7
@@ -53,9 +55,10 @@ def _closed_loop(oracle, name, N, K, B, ticks, sigma, tol_max, seed=1234):
     xg, ug, x0 = wl["x_init"].copy(), wl["u_init"].copy(), wl["x0"].copy()
     good_f = np.ones(B, dtype=bool)     # free run: converged on both sides in every tick so far
     slack = max(1, int(0.01 * B))       # instances allowed to sit on a threshold (iteration cap / step-length floor)
-    out = dict(fail_g=0, fail_o=0, worst_x=0.0, worst_u=0.0, p90=0.0, p50=0.0, worst_free=0.0)
+    out = dict(fail_g=0, fail_o=0, worst_x=0.0, worst_u=0.0, p90=0.0, p50=0.0, worst_free=0.0, above=0)
     for t in range(ticks):
         xs, us = xg.copy(), ug.copy()   # same-inputs oracle: the device's iterate before this tick
+        xin, uin = xg.copy(), ug.copy()
         s.solve_async()
         s.sync()
         sts, its = oracle.rti_batch(spec, xs, us, x0, *data, threads=8)
@@ -76,9 +79,22 @@ def _closed_loop(oracle, name, N, K, B, ticks, sigma, tol_max, seed=1234):
         assert np.percentile(ex, 90) <= TOL and np.percentile(eu, 90) <= TOL, (name, t, np.percentile(ex, 90), np.percentile(eu, 90))
         assert np.percentile(ex, 50) <= 1e-9 and np.percentile(eu, 50) <= 1e-9, (name, t)
         dit = np.abs(qi - its)[ok]
-        same = dit == 0   # same IPM path; an instance that took another path stops elsewhere in the tolerance ball (3e-2 wide)
-        assert ex[same].max() <= tol_max and eu[same].max() <= tol_max, (name, t, ex[same].max(), eu[same].max())
-        assert ex.max() <= 5e-2 and eu.max() <= 5e-2, (name, t, ex.max(), eu.max())
+        # north_star's 1e-5 on every instance - or, for the isolated instance above it (measured: 2 of 20 442 solves of this
+        # workload, 3.8e-4 and 1.3e-5, profiles/r03_parity_tail.txt: QPs the oracle itself cannot converge to 1e-11, unchanged by an
+        # IEEE-division build of the kernels), an independent certificate: the device's point must satisfy the KKT conditions of
+        # its QP (tests/kkt.py) and stay within 5e-3 of the oracle's
+        e = np.maximum(ex, eu)
+        above = np.where(ok)[0][e > 1e-5]
+        out["above"] += above.size
+        assert e.max() <= (tol_max if tol_max < 1e-5 else 5e-3), (name, t, e.max())
+        assert above.size <= max(1, int(0.004 * B)), (name, t, above.size)
+        if above.size:
+            soft = name == "usv_model_guidance_ca1"
+            qp = kkt.linearize_batch(oracle, spec, xin[above], uin[above], x0[above], *[d[above] for d in data])
+            res = kkt.kkt_batch(qp, _step(xg[above], ug[above], xin[above], uin[above]), _pad_pi(s.get_all("pi")[above]),
+                                s.get_all("lam")[above], s.get_all("t")[above],
+                                _pad_s(s.get_all("sl")[above]) if soft else None, _pad_s(s.get_all("su")[above]) if soft else None)
+            assert kkt.certified(res, 1.02e-6, 1.02e-8, 1.02e-8, 1.02e-8).all(), (name, t, above, res)
         # the same iteration count on all but a handful of instances (an instance whose path round-off moves across a kink
         # can take a very different number of iterations to the same tolerance: seen once in 512 x 25, 20 vs 45)
         assert (dit > 0).sum() <= slack and (dit > 1).sum() <= 2, (name, t, dit.max(), (dit > 0).sum())
@@ -110,7 +126,7 @@ def _closed_loop(oracle, name, N, K, B, ticks, sigma, tol_max, seed=1234):
 
 
 def test_bench_workload_closed_loop_pf_ca(oracle):
-    r = _closed_loop(oracle, "usv_model_pf_ca", 40, 10, 512, ticks=25, sigma=1e-3, tol_max=1e-3)
+    r = _closed_loop(oracle, "usv_model_pf_ca", 40, 10, 512, ticks=25, sigma=1e-3, tol_max=1e-5)
     # failures do not pile up: hard rows make some QPs infeasible for a tick or two, but the count stays small
     assert r["fail_g"] <= 0.01 * 512 * 25 and abs(r["fail_g"] - r["fail_o"]) <= 25, r
 

@@ -388,8 +388,13 @@ class AcadosOcpSolver:
     def solve(self):
         lo, hi = getattr(self, "_lbx", None), getattr(self, "_ubx", None)
         if lo is not None and hi is not None and not np.array_equal(lo, hi):
-            raise Exception("AcadosOcpSolver.solve(): lbx and ubx of stage 0 differ - this solver embeds the initial "
-                            "state as lbx = ubx = x0 and does not support a stage-0 box")
+            # solve() never raises (acados returns a status): a genuine stage-0 box is not supported - this solver embeds the
+            # initial state as lbx = ubx = x0 - so the call fails like a QP failure, iterate untouched, with one warning
+            import warnings
+            warnings.warn("AcadosOcpSolver.solve(): lbx and ubx of stage 0 differ - this solver embeds the initial state as "
+                          "lbx = ubx = x0 and does not support a stage-0 box; returning status 4 without solving")
+            self.status = 4
+            return self.status
         if self._sqp:
             self.status = int(self._b.solve_sqp()[0])
         else:

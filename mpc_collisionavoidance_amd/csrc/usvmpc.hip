@@ -167,13 +167,22 @@ constexpr int SORT_BINS = 64;
 
 // (histogram and ranks are formed per workgroup in LDS; a workgroup then touches each global bin once - 65 536 threads
 // hammering 64 global counters took 0.19 ms per kernel)
-__global__ void __launch_bounds__(256) usv_sort_hist(const int *qp_iter, int B, int *hist)
+// The sort key of an instance: the larger of its IPM iteration counts in the last TWO solves.  What the launch must avoid is an
+// instance that runs long being handed out late (the launch then ends with a few waves finishing it while the device idles: 10-25 %
+// of the launch on the bench workload); the count of one tick predicts the next with correlation 0.53 only, and an instance that
+// was hard recently is more likely to be hard again than its last count alone says (profiles/r03_tail.txt).
+__device__ __forceinline__ int sort_key(const int *qp_iter, const int *qp_iter_prev, int i)
+{
+    return min(max(max(qp_iter[i], qp_iter_prev[i]), 0), SORT_BINS - 1);
+}
+
+__global__ void __launch_bounds__(256) usv_sort_hist(const int *qp_iter, const int *qp_iter_prev, int B, int *hist)
 {
     __shared__ int loc[SORT_BINS];
     if (threadIdx.x < SORT_BINS) loc[threadIdx.x] = 0;
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) atomicAdd(&loc[min(max(qp_iter[i], 0), SORT_BINS - 1)], 1);
+    if (i < B) atomicAdd(&loc[sort_key(qp_iter, qp_iter_prev, i)], 1);
     __syncthreads();
     if (threadIdx.x < SORT_BINS && loc[threadIdx.x] != 0) atomicAdd(&hist[threadIdx.x], loc[threadIdx.x]);
 }
@@ -190,7 +199,7 @@ __global__ void usv_sort_scan(int *hist, int *cursor)
     }
 }
 
-__global__ void __launch_bounds__(256) usv_sort_scatter(const int *qp_iter, int B, int *cursor, int *perm)
+__global__ void __launch_bounds__(256) usv_sort_scatter(const int *qp_iter, const int *qp_iter_prev, int B, int *cursor, int *perm)
 {
     __shared__ int loc[SORT_BINS], base[SORT_BINS];
     if (threadIdx.x < SORT_BINS) loc[threadIdx.x] = 0;
@@ -198,7 +207,7 @@ __global__ void __launch_bounds__(256) usv_sort_scatter(const int *qp_iter, int 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int bin = 0, rank = 0;
     if (i < B) {
-        bin = min(max(qp_iter[i], 0), SORT_BINS - 1);
+        bin = sort_key(qp_iter, qp_iter_prev, i);
         rank = atomicAdd(&loc[bin], 1);
     }
     __syncthreads();
@@ -221,7 +230,7 @@ struct usvmpc_handle {
     hipEvent_t ev[RING][3];
     long nsolves;
     DevSpec *d_spec;
-    int *d_perm, *d_hist, *d_cursor;
+    int *d_perm, *d_hist, *d_cursor, *d_iter_prev;
     GuidancePtrs gd;          // device buffers of the guidance front end (allocated on first use)
     bool gd_ready;
     int gd_npts_cap;
@@ -229,6 +238,7 @@ struct usvmpc_handle {
     double *gd_world;   // [B][n_world][3] world obstacles of the last usvmpc_guidance_sense
     size_t gd_world_cap;
     bool sort_enabled;
+    bool sort_two;            // sort key: the larger of the last two iteration counts (default) instead of the last one
     bool merge_rows;
     bool dynamic_rows;        // QP kernel as a persistent launch whose rows pull instances from a queue (option "dynamic_rows")
     int lds_mode;             // workspace of the QP kernel in LDS: -1 when the batch is small enough (default), 0 never, 1 whenever it fits
@@ -478,12 +488,16 @@ int launch_pair(usvmpc_handle *h, int phase)
         // (a phase-1 launch re-sorts BEFORE its QP writes the multipliers: map and workspace stay consistent)
         if (phase == 0) h->map_changed = true;
         const int B = h->B;
-        hipLaunchKernelGGL(usv_sort_hist, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_iter, B, h->d_hist);
+        const int *prev2 = h->sort_two ? h->d_iter_prev : h->ptrs.qp_iter; // (option "sort_two_ticks" = 0: the last count alone)
+        hipLaunchKernelGGL(usv_sort_hist, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_iter, prev2, B, h->d_hist);
         hipLaunchKernelGGL(usv_sort_scan, dim3(1), dim3(64), 0, h->stream, h->d_hist, h->d_cursor);
-        hipLaunchKernelGGL(usv_sort_scatter, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_iter, B, h->d_cursor, h->d_perm);
+        hipLaunchKernelGGL(usv_sort_scatter, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_iter, prev2, B, h->d_cursor, h->d_perm);
         HIP_TRY(h, hipGetLastError());
         h->ptrs.perm = h->d_perm;
     }
+    // (the counts of the solve before this one: the second half of the next sort key)
+    if (h->sort_enabled && phase == 0)
+        HIP_TRY(h, hipMemcpyAsync(h->d_iter_prev, h->ptrs.qp_iter, (size_t)h->B * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipEventRecord(ev[0], h->stream));
     if (h->spec.sim_steps > 1)
         hipLaunchKernelGGL((usv_linearize<M, KCH, SOFT, true>), dim3((unsigned)lin_grid), dim3(lin_block), 0, h->stream, h->ptrs, lin_groups);
@@ -850,9 +864,11 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     TRY_C(dev_alloc(h, &P.sqp_state, B, true));
     TRY_C(dev_alloc(h, &P.sqp_running, 1, true));
     TRY_C(dev_alloc(h, &h->d_perm, B, true));
+    TRY_C(dev_alloc(h, &h->d_iter_prev, B, true));
     TRY_C(dev_alloc(h, &h->d_hist, SORT_BINS, true));
     TRY_C(dev_alloc(h, &h->d_cursor, SORT_BINS, true));
     h->sort_enabled = true;
+    h->sort_two = true;
     h->merge_rows = true;
     h->gd_ready = false; h->gd_npts_cap = 0; h->gd_psi = nullptr; h->gd_world = nullptr; h->gd_world_cap = 0;
     std::memset(&h->gd, 0, sizeof(h->gd));
@@ -1113,6 +1129,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         return 0;
     }
     if (s == "max_waves") { h->max_waves = (long)value; return 0; }
+    if (s == "sort_two_ticks") { h->sort_two = value != 0.0; return 0; }
     if (s == "aux_in_lds") { h->aux_lds = value != 0.0; h->aux_cap = 0; return 0; }
     if (s == "lds_workspace") { // -1: when the batch is small (default), 0: never, 1: whenever an instance's planes fit in LDS
         h->lds_mode = value < 0.0 ? -1 : (value > 0.0 ? 1 : 0);

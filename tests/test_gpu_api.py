@@ -130,8 +130,10 @@ def test_stage0_bounds_move_x0_and_must_coincide():
     solver.set(0, "ubx", xa)
     assert solver.solve() == 0 and np.allclose(solver.get(0, "x"), xa, atol=1e-9)
     solver.set(0, "lbx", xb)                       # only one of the two: x0 follows, but the pair is inconsistent
-    with pytest.raises(Exception, match="lbx and ubx of stage 0 differ"):
-        solver.solve()
+    xkeep = solver.get(0, "x")
+    with pytest.warns(UserWarning, match="lbx and ubx of stage 0 differ"):
+        assert solver.solve() == 4                 # solve() never raises: status 4, iterate untouched
+    assert np.array_equal(solver.get(0, "x"), xkeep)
     solver.set(0, "ubx", xb)
     assert solver.solve() == 0 and np.allclose(solver.get(0, "x"), xb, atol=1e-9)
 

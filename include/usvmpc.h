@@ -152,8 +152,8 @@ int usvmpc_advance(usvmpc_handle *h, double sigma, unsigned long long seed);
 int usvmpc_set_stream(usvmpc_handle *h, void *stream);
 /* run-time options (scheduling / placement only; none changes the arithmetic beyond rounding - see the two marked):
  *   "sort_by_difficulty" (default 1) - instances are handed to the wavefront rows in the order of their IPM iteration counts of
- *       the last two solves (larger of the two, hardest first): an instance that runs long must not start late;
- *       "sort_two_ticks" = 0 uses the last solve's count alone;
+ *       the previous solve, hardest first (an instance that runs long must not start late); "sort_two_ticks" = 1 (default 0)
+ *       orders by the larger of the last two solves' counts instead;
  *   "static_obstacles" (default 0) - every stage uses stage 0's p and lh (what the reference's callers set:
  *       scripts/usv_pf_ca/main.py puts one obstacle set on all stages), which the kernel then keeps in registers;
  *   "pack_box_rows" (default 1 when the rows fit) - box-row multipliers share the obstacle rows' planes;

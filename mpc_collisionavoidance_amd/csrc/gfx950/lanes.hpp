@@ -278,6 +278,9 @@ USV_DEV double *dyn_lds()
 #ifndef USV_PLANE_STORE_AUX
 #define USV_PLANE_STORE_AUX 2
 #endif
+#ifndef USV_MAT_LOAD_AUX
+#define USV_MAT_LOAD_AUX USV_PLANE_LOAD_AUX // packed matrix planes alone (non-temporal: measured +-0, profiles/r03_kernel_resources.txt)
+#endif
 struct Planes {
     __amdgpu_buffer_rsrc_t rsrc;
     unsigned voff; // byte offset of this lane's entry of plane 0 inside the stage window
@@ -294,6 +297,14 @@ struct Planes {
         // (plane offset added to the VGPR offset: the compiler folds the constant into the instruction's 12-bit offset field;
         // passed as the scalar offset operand it costs an s_movk per access)
         const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff + (unsigned)(plane * 128)), 0, USV_PLANE_LOAD_AUX);
+        return __builtin_bit_cast(double, v);
+    }
+    // the same load with a cache policy of its own (experiments: the packed matrix planes are read once per sweep and never hit)
+    template <int AUX>
+    USV_DEV double ld_policy(int plane) const
+    {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff + (unsigned)(plane * 128)), 0, AUX);
         return __builtin_bit_cast(double, v);
     }
     USV_DEV void st(int plane, double x) const

@@ -35,7 +35,11 @@ struct Dof3 {
         const double Xu = fast ? 64.55 : -25.0;
         const double Xuu = fast ? -70.92 : 0.0;
         const double au = fabs(u), av = fabs(v), ar = fabs(r);
-        const double sp = sqrt(u * u + v * v);
+        // sqrt(u^2 + v^2) and its reciprocal from one rsq estimate + Newton steps (lanes::frsqrt) instead of an IEEE square root
+        // and an IEEE division: ~70 instructions less per evaluation, twenty evaluations per interval
+        const double q2 = u * u + v * v;
+        const double isp = lanes::frsqrt(q2); // inf / NaN at u = v = 0, as the CasADi expression's derivative
+        const double sp = q2 > 0.0 ? q2 * isp : 0.0;
         const double Nr = -0.52 * sp;
         const double idu = 1.0 / (m - Xud), idv = 1.0 / (m - Yvd), idr = 1.0 / (Iz - Nrd);
         const double Tu = Tp + c * Ts;
@@ -49,7 +53,6 @@ struct Dof3 {
         js[1] = (-(m - Xud) * r * su + (2.0 * (CY + Yvv) * av + Yvr * ar) * sv +
                  (-(m - Xud) * u + Yvr * sgn(r) * v) * sr) * idv;
         {
-            const double isp = 1.0 / sp; // inf at u=v=0 -> NaN, as the CasADi expression
             const double dNu = -0.52 * u * isp, dNv = -0.52 * v * isp;
             js[2] = ((2.0 * Yvd * v + a * r - Xud * r + dNu * r) * su +
                      (2.0 * Yvd * u + dNv * r + Nrv * sgn(v) * r) * sv +
@@ -183,7 +186,7 @@ struct ModelM2 {
         const double psi = x[0], u = x[3], v = x[4], r = x[5];
         const double ue = u + .001;
         const double r2 = ue * ue + v * v;
-        const double irho = 1.0 / sqrt(r2);
+        const double irho = lanes::frsqrt(r2);
         const double iden = irho * irho;
         const double cb = ue * irho, sb = v * irho;
         double sp, cp;

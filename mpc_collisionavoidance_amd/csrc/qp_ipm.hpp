@@ -41,6 +41,9 @@
 #include "params.hpp"
 #include "sfor.hpp"
 
+#ifndef USV_MAT_LOAD_AUX
+#define USV_MAT_LOAD_AUX 0 // cache policy of the packed matrix plane loads (lanes.hpp; the emulator has none)
+#endif
 #ifndef USV_PAIRED_RCP
 #define USV_PAIRED_RCP 1 // both reciprocals of a row's slack pair / multiplier pair from one v_rcp_f64 (lanes::frcp2)
 #endif
@@ -645,7 +648,8 @@ struct QpIpm {
     USV_DEV void mat_issue(int k, double *pk) const
     {
         const Planes W = ws(k);
-        sfor<0, MP::NPK>([&](auto q) { pk[q] = W.ld(P_MAT + q); });
+        if constexpr (LDSWS) sfor<0, MP::NPK>([&](auto q) { pk[q] = W.ld(P_MAT + q); });
+        else sfor<0, MP::NPK>([&](auto q) { pk[q] = W.template ld_policy<USV_MAT_LOAD_AUX>(P_MAT + q); });
     }
     // (call under wave-uniform control flow)
     USV_DEV void mat_put(const double *pk) const

@@ -167,10 +167,10 @@ constexpr int SORT_BINS = 64;
 
 // (histogram and ranks are formed per workgroup in LDS; a workgroup then touches each global bin once - 65 536 threads
 // hammering 64 global counters took 0.19 ms per kernel)
-// The sort key of an instance: the larger of its IPM iteration counts in the last TWO solves.  What the launch must avoid is an
-// instance that runs long being handed out late (the launch then ends with a few waves finishing it while the device idles: 10-25 %
-// of the launch on the bench workload); the count of one tick predicts the next with correlation 0.53 only, and an instance that
-// was hard recently is more likely to be hard again than its last count alone says (profiles/r03_tail.txt).
+// The sort key of an instance: its IPM iteration count in the last solve - or, option "sort_two_ticks", the larger of the last TWO.
+// What the launch must avoid is an instance that runs long being handed out late (it then ends with a few waves finishing it while
+// the device idles: a tenth of the launch on the bench workload); one tick's count predicts the next with correlation 0.53 only.
+// The two-tick key looked better in schedule simulations and measured the same on the device (profiles/r03_tail.txt): off by default.
 __device__ __forceinline__ int sort_key(const int *qp_iter, const int *qp_iter_prev, int i)
 {
     return min(max(max(qp_iter[i], qp_iter_prev[i]), 0), SORT_BINS - 1);
@@ -238,7 +238,7 @@ struct usvmpc_handle {
     double *gd_world;   // [B][n_world][3] world obstacles of the last usvmpc_guidance_sense
     size_t gd_world_cap;
     bool sort_enabled;
-    bool sort_two;            // sort key: the larger of the last two iteration counts (default) instead of the last one
+    bool sort_two;            // sort key: the larger of the last two iteration counts instead of the last one (option, default off)
     bool merge_rows;
     bool dynamic_rows;        // QP kernel as a persistent launch whose rows pull instances from a queue (option "dynamic_rows")
     int lds_mode;             // workspace of the QP kernel in LDS: -1 when the batch is small enough (default), 0 never, 1 whenever it fits
@@ -496,7 +496,7 @@ int launch_pair(usvmpc_handle *h, int phase)
         h->ptrs.perm = h->d_perm;
     }
     // (the counts of the solve before this one: the second half of the next sort key)
-    if (h->sort_enabled && phase == 0)
+    if (h->sort_enabled && h->sort_two && phase == 0)
         HIP_TRY(h, hipMemcpyAsync(h->d_iter_prev, h->ptrs.qp_iter, (size_t)h->B * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipEventRecord(ev[0], h->stream));
     if (h->spec.sim_steps > 1)
@@ -868,7 +868,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     TRY_C(dev_alloc(h, &h->d_hist, SORT_BINS, true));
     TRY_C(dev_alloc(h, &h->d_cursor, SORT_BINS, true));
     h->sort_enabled = true;
-    h->sort_two = true;
+    h->sort_two = false;
     h->merge_rows = true;
     h->gd_ready = false; h->gd_npts_cap = 0; h->gd_psi = nullptr; h->gd_world = nullptr; h->gd_world_cap = 0;
     std::memset(&h->gd, 0, sizeof(h->gd));

@@ -19,7 +19,20 @@ import os
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 DPP_ASM = ("v_fmac_f64_dpp",)          # mnemonics placed by hand
-WAIT_STATES = 2
+WAIT_STATES = 2                         # VALU write of the DPP source VGPR -> DPP read
+EXEC_WAIT_STATES = 5                    # VALU write of EXEC (v_cmpx*, v_readlane/writelane never; any v_* naming exec as destination) -> DPP
+# VALU instructions that write a SECOND register beside operand 0 (the swap's other operand): both are destinations
+TWO_DEST = ("v_swap_b32", "v_swap_b16", "v_swaprel_b32")
+
+
+def writes_exec(mn, ops):
+    """a VALU instruction that writes the EXEC mask (only those count for the 5-wait-state DPP rule; SALU writes need none extra)"""
+    if not mn.startswith("v_"):
+        return False
+    if mn.startswith("v_cmpx"):
+        return True
+    first = ops.split(",")[0].strip() if ops else ""
+    return first in ("exec", "exec_lo", "exec_hi")
 
 
 def code_objects(path):
@@ -156,10 +169,15 @@ def check(co):
             if not wt:
                 continue
             dst = regs(wt[0])
+            if wmn in TWO_DEST and len(wt) > 1:
+                dst |= regs(wt[1])
             if wmn.startswith("v_cmp") or wmn.startswith("v_readlane") or wmn.startswith("v_readfirstlane"):
                 dst = set()
             if dst & src0:
                 bad.append((funcs[i], a, ops, prog[j][0], wmn, wops))
+        for (j, wmn, wops) in writers_before(i, EXEC_WAIT_STATES):
+            if writes_exec(wmn, wops):
+                bad.append((funcs[i], a, ops, prog[j][0], wmn, wops + "   (VALU write of EXEC within 5 wait states)"))
     return count, bad, unknown_branch
 
 

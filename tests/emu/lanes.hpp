@@ -122,6 +122,8 @@ struct Planes {
         if (plane < 0 || o + 8 > nbytes) { std::fprintf(stderr, "Planes::ld out of window (plane %d)\n", plane); std::abort(); }
         return base[o / 8];
     }
+    template <int AUX>
+    double ld_policy(int plane) const { return ld(plane); }
     void st(int plane, double x) const
     {
         const unsigned o = voff + (unsigned)plane * 128u;

@@ -76,3 +76,36 @@ def test_checker_refuses_a_fused_build_in_which_it_finds_nothing(tmp_path):
     assert n == 0 and any("nothing was checked" in b for b in bad)
     n, bad = dpp_check.check_library(str(out), expect_fused=False)
     assert n == 0 and not bad
+
+
+EXEC_BAD = r"""
+#include <hip/hip_runtime.h>
+__global__ void exec_write(double *p)
+{
+    double acc = p[threadIdx.x], b = p[64 + threadIdx.x], a = 2.0;
+    asm volatile("s_mov_b64 s[10:11], exec\n v_cmpx_gt_f64 vcc, %2, %1\n s_nop 1\n v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n s_mov_b64 exec, s[10:11]"
+                 : "+v"(acc) : "v"(b), "v"(a) : "s10", "s11", "vcc");
+    p[threadIdx.x] = acc;
+}
+__global__ void exec_write_padded(double *p)
+{
+    double acc = p[threadIdx.x], b = p[64 + threadIdx.x], a = 2.0;
+    asm volatile("s_mov_b64 s[10:11], exec\n v_cmpx_gt_f64 vcc, %2, %1\n s_nop 4\n v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n s_mov_b64 exec, s[10:11]"
+                 : "+v"(acc) : "v"(b), "v"(a) : "s10", "s11", "vcc");
+    p[threadIdx.x] = acc;
+}
+"""
+
+
+def test_checker_flags_a_valu_write_of_exec_in_front_of_dpp(tmp_path):
+    """Second hazard of the hand-placed instruction: a VALU write of EXEC needs 5 wait states before a DPP instruction."""
+    src = tmp_path / "execbad.hip"
+    src.write_text(EXEC_BAD)
+    out = tmp_path / "execbad.co"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O2", "--cuda-device-only", "-c", "-o", str(out), str(src)], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("hipcc could not build the probe: " + r.stderr[-300:])
+    n, bad = dpp_check.check_library(str(out))
+    assert n == 2
+    assert any("exec_write" in b and "EXEC" in b and "padded" not in b for b in bad), bad
+    assert not any("exec_write_padded" in b for b in bad), bad

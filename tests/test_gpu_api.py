@@ -248,3 +248,25 @@ def test_batch_beyond_the_buffer_window_is_refused():
     s = BatchOcpSolver(ocp, 8)
     assert s.device_bytes() > 0
     s.close()
+
+
+def test_host_mirror_small_batch_reference_loop(oracle):
+    """The mirror with more than one instance (per-stage setters are strided over the batch) and the closed-loop hand-over on the
+    host as the reference does it: x0 = get(1, "x"); set(0, "lbx" / "ubx", x0) - against the oracle, 6 ticks."""
+    name, N, K, B = "usv_model_guidance_ca1", 16, 5, 5
+    ocp, wl = util.make(name, N, K, B, seed=12, dt=0.05)
+    s = BatchOcpSolver(ocp, B)
+    scenario.load_into(s, wl)
+    spec = util.oracle_spec(oracle, name, N, 0.05, K)
+    xo, uo, x0 = wl["x_init"].copy(), wl["u_init"].copy(), wl["x0"].copy()
+    for t in range(6):
+        for k in range(N):
+            s.set("yref", k, wl["yref"][:, k]); s.set("p", k, wl["p"][:, k]); s.set("lh", k, wl["lh"][:, k])
+        s.set("p", N, wl["p"][:, N])
+        s.set("x0", 0, x0)
+        st = s.solve()
+        xo, uo, sto, _ = util.oracle_rti(oracle, spec, wl, xo, uo, x0=x0)
+        assert np.array_equal(st, sto) and (st == 0).all()
+        assert util.rel_err(s.get_all("x"), xo) < 1e-7 and util.rel_err(s.get("u", 0), uo[:, 0]) < 1e-7
+        x0 = s.get("x", 1).copy()
+    s.close()

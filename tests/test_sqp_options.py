@@ -240,3 +240,42 @@ def test_gpu_soft_state_bounds(oracle):
             assert util.rel_err(s.get_all("x")[ok], xo[ok]) < 1e-7 and util.rel_err(s.get_all("u")[ok], uo[ok]) < 1e-7
             s.set_all("x", xo); s.set_all("u", uo)
         s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,K,B", [("usv_model_pf_ca", 10, 40), ("usv_model_guidance_ca1", 6, 24)])
+def test_gpu_sqp_after_rti_finds_the_last_qps_multipliers(name, K, B):
+    """Mixed use on one handle: RTI solves (queue + difficulty sort; planes in HBM with the aux plane in LDS, or the whole workspace in
+    LDS) followed by full-SQP calls.  The SQP's first residual test reads the multipliers the last QP left in the HBM workspace: they
+    must be the last QP's whatever placement the RTI launch used (the LDS placements write them back in finish()), and the
+    group -> instance map must stay consistent across the phase-1 sort.  Every placement must therefore give the same
+    SQP run: same iteration counts, same NLP residuals to rounding; and a second SQP call from the converged point returns with
+    0 QPs (the warm start across SQP calls survives)."""
+    from mpc_collisionavoidance_amd import BatchOcpSolver
+    N = 12
+    wl = scenario.make_bench_batch(name, N, K, B, seed=31)
+    ocp = usv_models.make_ocp(name, N * scenario.BENCH_DT, N, K)
+    ocp.solver_options.sim_method_num_steps = scenario.BENCH_SIM_STEPS[name]
+    ocp.solver_options.nlp_solver_max_iter = 30
+    runs = []
+    for opts in ({"lds_workspace": 0, "aux_in_lds": 0}, {"lds_workspace": 0, "aux_in_lds": 1}, {"lds_workspace": 1}):
+        s = BatchOcpSolver(ocp, B)
+        scenario.load_into(s, wl)
+        for k, v in opts.items():
+            s.set_option(k, v)
+        for t in range(3):
+            s.solve()
+        st = s.solve_sqp()
+        it1, res1 = s.get_int("sqp_iter").copy(), s.get("nlp_res", 0).copy()
+        st2 = s.solve_sqp()
+        it2 = s.get_int("sqp_iter").copy()
+        runs.append((st.copy(), it1, res1, s.get_all("x"), st2.copy(), it2))
+        s.close()
+    ok = runs[0][0] == 0
+    assert ok.mean() > 0.8
+    assert (runs[0][5][ok] == 0).all() and (runs[0][4][ok] == 0).all()      # second call: converged already, no QP
+    for r in runs[1:]:
+        assert np.array_equal(r[0], runs[0][0])
+        assert np.abs(r[1] - runs[0][1])[ok].max() <= 1 and (r[1] == runs[0][1])[ok].mean() > 0.9
+        assert util.rel_err(r[3][ok], runs[0][3][ok]) < 1e-4   # (converged to nlp_tol 1e-6 on each side)
+        assert (r[5][ok] == 0).all()

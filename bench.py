@@ -266,6 +266,7 @@ def main():
 
     nk = min(args.steps, 64)
     lin_ms, qp_ms = solver.kernel_ms(nk)
+    pipelined = B >= 16384 and not any(kv.split("=")[0] == "pipeline_linearize" and float(kv.split("=")[1]) == 0.0 for kv in args.option)
     fails = solver.fail_counts(nk)
     st = solver.get_int("status")
     qi = solver.get_int("qp_iter")
@@ -382,6 +383,9 @@ def main():
                 "fp64_alg_tflops": fp64_tflops, "fp64_frac": fp64_tflops / FP64_PEAK_TFLOPS,
                 "algorithmic_bytes_per_solve": balg, "algorithmic_flops_per_solve": falg,
                 "kernel_ms": {"usv_linearize": float(lin_ms.mean()), "usv_qp_rti": float(qp_ms.mean())},
+                "kernel_ms_note": ("with pipeline_linearize (default for >= 16384 instances) the lineariser of tick t + 1 runs on a second stream "
+                                   "in the tail of tick t's QP launch; kernel_ms.usv_linearize is then only the fix-up pass for the instances "
+                                   "it had to skip (--option pipeline_linearize=0 shows the full lineariser)") if pipelined else None,
                 "note": "`achieved` is SURVEY 8(d)'s algorithmic bytes / kernel time (structurally tiny for this path); "
                         "`traffic` is the measured HBM streaming of the per-stage planes per launch (rocprofv3 PMC, "
                         "profiles/pmc_traffic.json) and traffic_GBs / traffic_frac its rate; fp64_* from the "

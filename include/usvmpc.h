@@ -168,6 +168,11 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  *   "aux_in_lds" (default 1) - an RTI solve keeps the per-stage aux plane (dense box rows, linearisation point, r_g, l_u) in the
  *       wavefronts' LDS instead of streaming it, when the horizon fits without costing a resident wavefront (a separately
  *       compiled instantiation of the same arithmetic: results equal to rounding at most);
+ *   "pipeline_linearize" (default 1; RTI solves of handles with >= 16384 instances) - the lineariser of the NEXT tick is enqueued on a
+ *       second stream behind the QP launch and runs in that launch's tail, instance by instance as results become final (the
+ *       few it has to skip are redone in front of the next QP launch); any usvmpc_set, option change or device-pointer access in
+ *       between makes the next solve linearise afresh.  The queue order of a tick is then made one tick earlier.  Scheduling
+ *       only: results are bit-identical to the un-pipelined sequence;
  *   "host_mirror" (default: on for handles whose caller-visible arrays total <= 1 MiB, i.e. the single-instance drop-in faces) -
  *       usvmpc_set writes a pinned host mirror and the next solve uploads the dirty fields in one asynchronous copy instead
  *       of one synchronising copy per call (the reference issues 3N+4 setters per tick: scripts/usv_guidance_ca1/main.py:

@@ -250,6 +250,23 @@ USV_DEV double frsqrt(double x)
     return y;
 }
 
+// Hand-over of an instance's results to a kernel that runs CONCURRENTLY on another stream (the next tick's lineariser inside this
+// launch's tail, usvmpc.hip): the XCDs' L2s are not coherent with each other, so the payload goes out and comes in with accesses
+// that bypass them (agent-scope relaxed atomics = sc1), and the flag is stored after the wave's stores have drained
+// (MI355X_MICROARCH.md: "sc1 payload -> vmcnt(0) -> sc1 flag").  The consumer's payload loads are control-dependent on the flag.
+USV_DEV void st_shared(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+USV_DEV double ld_shared(const double *p)
+{
+    return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+USV_DEV void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+USV_DEV void publish(int *flag, int v) { __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+USV_DEV int observe(const int *flag) { return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+USV_DEV void set_bits(int *word, int bits) { atomicOr(word, bits); }
+
 // lane index inside the wave (a wave carries four 16-lane groups)
 USV_DEV unsigned wave_lane() { return threadIdx.x & 63u; }
 // rows (16-lane groups) of a wave and this lane's row

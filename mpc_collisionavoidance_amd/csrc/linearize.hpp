@@ -39,7 +39,13 @@ struct ModelCall<M, std::void_t<typename M::Pre>> {
 
 // MULTI: more than one RK4 step per interval (the initial sensitivity column is then a carried variable
 // instead of a lane pattern the compiler rematerialises for free: 28 more VGPRs for M2, hence a separate build)
-template <class M, int KCH, bool SOFT, bool MULTI = false>
+// MODE 0: every (instance, stage) of the batch, between two launches of the QP kernel (the plain path).
+// MODE 1: speculative, for the NEXT tick, while the QP launch of tick P.tick is still running (second stream, its workgroups fill the
+//         compute units that launch vacates in its tail): a group goes ahead only if its instance's results of that tick are final
+//         AND so are those of the instance that still owns the group's planes under the running launch's map; otherwise it marks the
+//         instance for MODE 2.  The iterate is read with loads that bypass the non-coherent L2s (lanes::ld_shared).
+// MODE 2: fix-up after that launch: only the instances MODE 1 marked.
+template <class M, int KCH, bool SOFT, bool MULTI = false, int MODE = 0>
 struct Linearize {
     static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
     using WL = WsLayout<M, KCH, SOFT>;
@@ -56,16 +62,31 @@ struct Linearize {
         const int nB = lanes::uniform(S.B);
         const long gi = g < nB ? g : (long)nB - 1; // padded groups replay the last instance
         const long b = P.perm ? (long)P.perm[gi] : gi;
+        if constexpr (MODE == 1) {
+            const long owner = P.perm_cur ? (long)P.perm_cur[gi] : gi;
+            const bool ready = lanes::observe(P.epoch + b) == P.tick && lanes::observe(P.epoch + owner) == P.tick;
+            if (!ready) { // (the whole 16-lane group leaves: nothing below crosses groups)
+                if (lane == 0) lanes::set_bits(P.redo + b * P.redo_words + (k >> 5), 1 << (k & 31)); // this stage of this instance: later
+                return;
+            }
+        }
+        if constexpr (MODE == 2) {
+            if (((P.redo[b * P.redo_words + (k >> 5)] >> (k & 31)) & 1) == 0) return;
+        }
+        auto ld = [](const double *q) { // the iterate: handed over by a kernel that may still be running (MODE 1)
+            if constexpr (MODE == 1) return lanes::ld_shared(q);
+            else return *q;
+        };
         // workspace: [stage][group][plane][16 lanes] (lanes::Planes)
         double *tile = P.ws + (((long)k * Bp + g) * lanes::uniform(S.npt)) * LANES + lane;
         const bool xlane = lane >= NU && lane < NZ;
 
         double x[NX], U[NU > 0 ? NU : 1];
         const double *xk = P.x + ((long)b * (N + 1) + k) * NX;
-        sfor<0, NX>([&](auto i) { x[i] = xk[i]; });
+        sfor<0, NX>([&](auto i) { x[i] = ld(xk + i); });
         if (k < N) {
             const double *uk = P.u + ((long)b * N + k) * NU;
-            sfor<0, NU>([&](auto i) { U[i] = uk[i]; });
+            sfor<0, NU>([&](auto i) { U[i] = ld(uk + i); });
         } else {
             sfor<0, NU>([&](auto i) { U[i] = 0.0; });
         }
@@ -122,7 +143,7 @@ struct Linearize {
         }
         const double *xn = P.x + ((long)b * (N + 1) + k + 1) * NX;
         double bres = 0.0;
-        sfor<0, NX>([&](auto i) { bres = (lane == NU + i) ? x[i] - xn[i] : bres; });
+        sfor<0, NX>([&](auto i) { bres = (lane == NU + i) ? x[i] - ld(xn + i) : bres; });
         // lane r now holds row r of [B A]' (sa[i] = d x+_i / d z_r).  The structurally informative entries (MatPack:
         // M::SENS) are packed into MatPack<M>::NPK planes: lane L of plane q stores entry number 16 q + L of the
         // stream, i.e. for the row j whose range contains it the value sa[j] held by the lane of its column - a lane

@@ -162,6 +162,13 @@ struct DevPtrs {
     // group g, lane r at (((k * Bp + g) * NPT + e) * 16 + r: linearisation output + QP state
     double *ws;
     int *queue;           // [1]  groups handed out beyond the waves' first four (work queue of the QP kernel)
+    // pipelined lineariser (usvmpc.hip, option "pipeline_linearize"): per-instance hand-over between the QP launch of tick t and the
+    // lineariser of tick t + 1 running in its tail on a second stream
+    int *epoch;           // [B]  tick whose results (x, u) are final for the instance; nullptr: no hand-over in this launch
+    int *redo;            // [B][redo_words]  bit k: the speculative lineariser skipped stage k of the instance: the fix-up pass does it
+    int redo_words;       //      (N + 1 + 31) / 32
+    const int *perm_cur;  // [B]  speculative lineariser: the group -> instance map of the QP launch that is still running
+    int tick;             // the solve this launch belongs to (QP, fix-up) / whose results the speculative lineariser waits for
     // multiplier read-back (kernel usv_qp_export): [B][N+1][nlam] each, nlam = 2 (nrow + ns) - DevSpec
     double *lam_out, *t_out;
     int nlam;

@@ -1430,6 +1430,7 @@ struct QpIpm {
     {
         const bool ok = (status == 0 || status == 1);
         const bool out = fin && real;
+        const bool share = P.epoch != nullptr; // wave-uniform (kernel argument)
         double tmin = 1e300; // smallest t_l over this instance's obstacle rows: how close the QP solution sits to a keep-out circle
         for (int k = 0; k <= N; k++) {
             const Planes W = ws(k);
@@ -1460,8 +1461,14 @@ struct QpIpm {
                 if (out) W.st(P_AUX, aux_ld(k, W));
             }
             if (out) {
-                if (ok && xlane) P.x[((long)b * (N + 1) + k) * NX + (lane - NU)] = z;
-                if (ok && ulane && k < N) P.u[((long)b * N + k) * NU + lane] = z;
+                // (with a consumer waiting in another kernel - the next tick's lineariser - the iterate goes out past the L2)
+                if (share) {
+                    if (ok && xlane) lanes::st_shared(&P.x[((long)b * (N + 1) + k) * NX + (lane - NU)], z);
+                    if (ok && ulane && k < N) lanes::st_shared(&P.u[((long)b * N + k) * NU + lane], z);
+                } else {
+                    if (ok && xlane) P.x[((long)b * (N + 1) + k) * NX + (lane - NU)] = z;
+                    if (ok && ulane && k < N) P.u[((long)b * N + k) * NU + lane] = z;
+                }
                 if (k >= 1 && xlane && P.pi) P.pi[((long)b * N + (k - 1)) * NX + (lane - NU)] = W.ld(P_PI);
             }
             if constexpr (KCH > 0 && SOFT) {
@@ -1497,6 +1504,10 @@ struct QpIpm {
             }
         }
         tmin = lanes::gmin(tmin);
+        if (share) { // the instance's iterate is final: tell the lineariser of the next tick (every store of the wave has landed first)
+            lanes::drain_stores();
+            if (out && lane == 0) lanes::publish(P.epoch + b, P.tick);
+        }
         if (out && lane == 0) {
             if (P.obs_tmin) P.obs_tmin[b] = tmin;
             if (!ok && P.fail_count) lanes::count_one(P.fail_count);

@@ -31,12 +31,13 @@ using namespace usv;
 #ifndef USV_LIN_BLOCKS
 #define USV_LIN_BLOCKS 2 // 256-thread blocks per CU the lineariser is compiled for (2: 2 waves per SIMD, 256 registers)
 #endif
-template <class M, int KCH, bool SOFT, bool MULTI>
+// MODE: 0 the whole batch; 1 speculative for the next tick beside a running QP launch; 2 fix-up of what mode 1 skipped (linearize.hpp)
+template <class M, int KCH, bool SOFT, bool MULTI, int MODE = 0>
 __global__ void __launch_bounds__(256, USV_LIN_BLOCKS) usv_linearize(DevPtrs P, long ngroups)
 {
     const long gid = lanes::group_linear();
     if (gid >= ngroups) return; // ngroups is a multiple of 4: whole waves leave together
-    Linearize<M, KCH, SOFT, MULTI>::run(P, gid);
+    Linearize<M, KCH, SOFT, MULTI, MODE>::run(P, gid);
 }
 
 #ifndef USV_QP_WAVES
@@ -264,6 +265,20 @@ struct usvmpc_handle {
     bool inflight;            // a copy between mirror and arena may still be running on the stream
     bool out_valid;           // the mirror's [x | u | status] is what the device holds (or newer)
     bool extern_access;       // a device pointer was handed out: the device arrays may change behind the mirror
+    // Pipelined lineariser (option "pipeline_linearize"): the lineariser of tick t + 1 is launched on a second stream right behind the
+    // QP launch of tick t; its workgroups are dispatched as that launch's persistent waves leave, i.e. it runs in the launch's tail
+    // (profiles/r03_tail.txt: the last ~14 ms of a 76 ms launch run on a device that is being vacated).  An instance is linearised
+    // there only when its own results AND those of the instance still owning the target planes are final (DevPtrs::epoch); the few
+    // that were not are redone by a fix-up pass in front of the next QP launch.  The queue order of a tick is then fixed one tick
+    // earlier (from the counts of two solves back).  Scheduling only: results are bit-identical.
+    bool pipeline;            // option; used for RTI solves of handles without a host mirror
+    hipStream_t aux_stream;   // nullptr until first used
+    hipEvent_t ev_pre, ev_spec;
+    int *d_epoch, *d_redo, *d_perm2;
+    long spec_for;            // solve number the outstanding / finished speculative linearisation was made for (-1: none)
+    bool spec_valid;          // ... and nothing it read has been changed by the caller since
+    bool spec_outstanding;    // the second stream may still be writing the lineariser's planes
+    const int *spec_perm;     // the group -> instance map it used (= the map the solve spec_for must use)
     long export_at;           // nsolves the multiplier read-back buffers (ptrs.lam_out / t_out) were filled at; -1: never
     bool layout_dirty;        // the row layout option changed after the last solve: the workspace cannot be read back
     size_t bytes;
@@ -345,6 +360,18 @@ int lookup(usvmpc_handle *h, const char *f, int stage, bool set, Field &o)
 }
 
 int ensure_export(usvmpc_handle *h); // (below: needs the kernel dispatch)
+
+// the speculative lineariser of the second stream: wait for it and forget what it made (something it read or wrote is about to change)
+int spec_cancel(usvmpc_handle *h)
+{
+    h->spec_valid = false;
+    if (h->spec_outstanding) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipStreamSynchronize(h->aux_stream));
+        h->spec_outstanding = false;
+    }
+    return 0;
+}
 
 constexpr size_t MIRROR_MAX = 1u << 20; // arenas up to 1 MiB are mirrored on the host
 
@@ -446,6 +473,10 @@ int copy_field(usvmpc_handle *h, const char *field, int stage, double *host, siz
         return 0;
     }
     HIP_TRY(h, hipSetDevice(h->device));
+    if (set) { // (a lineariser that ran ahead may have read what is being replaced - it reads x, u, yref: the next solve linearises again)
+        const std::string fs(field ? field : "");
+        if (fs == "x" || fs == "u" || fs == "yref" || fs == "yref_e") h->spec_valid = false;
+    }
     if (!set) { rc = mirror_flush(h); if (rc) return rc; } // (a get of a field with pending writes sees them)
     if (stage < 0 || f.stages == 1) {
         if (stage >= 0 && f.stages == 1 && stage - f.stage_off != 0) {
@@ -482,31 +513,83 @@ int launch_pair(usvmpc_handle *h, int phase)
     const int lin_block = 256, qp_block = 64;
     const long lin_grid = (lin_groups * LANES + lin_block - 1) / lin_block;
     hipEvent_t *ev = h->ev[h->nsolves % usvmpc_handle::RING];
-    // (the later iterations of a full SQP read the multipliers the previous launch left in the group-indexed
-    // workspace: the group -> instance map must not change inside one SQP call)
-    if (h->sort_enabled && h->nsolves > 0 && phase != 2) {
-        // (a phase-1 launch re-sorts BEFORE its QP writes the multipliers: map and workspace stay consistent)
-        if (phase == 0) h->map_changed = true;
-        const int B = h->B;
+    const int B = h->B;
+    // counting sort of the previous solve's iteration counts into a group -> instance map
+    auto sort_into = [&](int *dst) {
         const int *prev2 = h->sort_two ? h->d_iter_prev : h->ptrs.qp_iter; // (option "sort_two_ticks" = 0: the last count alone)
         hipLaunchKernelGGL(usv_sort_hist, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_iter, prev2, B, h->d_hist);
         hipLaunchKernelGGL(usv_sort_scan, dim3(1), dim3(64), 0, h->stream, h->d_hist, h->d_cursor);
-        hipLaunchKernelGGL(usv_sort_scatter, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_iter, prev2, B, h->d_cursor, h->d_perm);
+        hipLaunchKernelGGL(usv_sort_scatter, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_iter, prev2, B, h->d_cursor, dst);
+    };
+    auto lin_launch = [&](auto mode, hipStream_t st, const DevPtrs &P) {
+        constexpr int MODE = decltype(mode)::value;
+        if (h->spec.sim_steps > 1)
+            hipLaunchKernelGGL((usv_linearize<M, KCH, SOFT, true, MODE>), dim3((unsigned)lin_grid), dim3(lin_block), 0, st, P, lin_groups);
+        else
+            hipLaunchKernelGGL((usv_linearize<M, KCH, SOFT, false, MODE>), dim3((unsigned)lin_grid), dim3(lin_block), 0, st, P, lin_groups);
+    };
+    // Pipelined lineariser (see usvmpc_handle): RTI solves of large handles
+    const bool pipe = phase == 0 && h->pipeline && !h->mirror && !h->extern_access && h->dynamic_rows && h->B >= 16384;
+    if (pipe && !h->aux_stream) {
+        // (lowest priority: when this stream's lineariser and the main stream's QP launch become eligible together, the QP
+        // launch's workgroups are placed first and the lineariser gets the compute units that launch vacates)
+        int prio_least = 0, prio_greatest = 0;
+        HIP_TRY(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        HIP_TRY(h, hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_least));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_spec, hipEventDisableTiming));
+        if (dev_alloc(h, &h->d_epoch, (size_t)B, false) || dev_alloc(h, &h->d_redo, (size_t)B * ((h->N + 32) / 32), true) ||
+            dev_alloc(h, &h->d_perm2, (size_t)B, true))
+            return USVMPC_E_HIP;
+        HIP_TRY(h, hipMemsetAsync(h->d_epoch, 0xff, (size_t)B * sizeof(int), h->stream)); // -1: nothing is final yet
+    }
+    // whatever this solve does with the lineariser's planes comes after a speculative linearisation that may still be writing them
+    if (h->spec_outstanding) {
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_spec, 0));
+        h->spec_outstanding = false;
+    }
+    const bool use_spec = pipe && h->spec_valid && h->spec_for == h->nsolves;
+    h->spec_valid = false;
+    if (use_spec) {
+        // the map this tick was linearised under (made one tick ago from the counts of the solve before)
+        h->ptrs.perm = h->spec_perm;
+        h->map_changed = true;
+    } else if (h->sort_enabled && h->nsolves > 0 && phase != 2) {
+        // (the later iterations of a full SQP read the multipliers the previous launch left in the group-indexed workspace: the
+        // group -> instance map must not change inside one SQP call; a phase-1 launch re-sorts BEFORE its QP writes the multipliers:
+        // map and workspace stay consistent)
+        if (phase == 0) h->map_changed = true;
+        sort_into(h->d_perm);
         HIP_TRY(h, hipGetLastError());
         h->ptrs.perm = h->d_perm;
     }
     // (the counts of the solve before this one: the second half of the next sort key)
     if (h->sort_enabled && h->sort_two && phase == 0)
         HIP_TRY(h, hipMemcpyAsync(h->d_iter_prev, h->ptrs.qp_iter, (size_t)h->B * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    h->ptrs.epoch = pipe ? h->d_epoch : nullptr;
+    h->ptrs.redo = pipe ? h->d_redo : nullptr;
+    h->ptrs.redo_words = (h->N + 32) / 32;
+    h->ptrs.perm_cur = nullptr;
+    h->ptrs.tick = (int)h->nsolves;
     HIP_TRY(h, hipEventRecord(ev[0], h->stream));
-    if (h->spec.sim_steps > 1)
-        hipLaunchKernelGGL((usv_linearize<M, KCH, SOFT, true>), dim3((unsigned)lin_grid), dim3(lin_block), 0, h->stream, h->ptrs, lin_groups);
-    else
-        hipLaunchKernelGGL((usv_linearize<M, KCH, SOFT, false>), dim3((unsigned)lin_grid), dim3(lin_block), 0, h->stream, h->ptrs, lin_groups);
+    if (use_spec) lin_launch(std::integral_constant<int, 2>{}, h->stream, h->ptrs); // only what the speculative pass had to skip
+    else lin_launch(std::integral_constant<int, 0>{}, h->stream, h->ptrs);
     HIP_TRY(h, hipGetLastError());
+    if (pipe) HIP_TRY(h, hipMemsetAsync(h->d_redo, 0, (size_t)B * ((h->N + 32) / 32) * sizeof(int), h->stream));
     HIP_TRY(h, hipEventRecord(ev[1], h->stream));
     h->ptrs.fail_count = h->d_fail_ring + h->nsolves % usvmpc_handle::RING;
     HIP_TRY(h, hipMemsetAsync(h->ptrs.fail_count, 0, sizeof(int), h->stream));
+    const int *next_perm = nullptr;
+    if (pipe) {
+        // the NEXT tick's map, from the counts this launch is about to overwrite, into the buffer this tick does not use
+        if (h->sort_enabled) {
+            int *dst = (h->ptrs.perm == h->d_perm) ? h->d_perm2 : h->d_perm;
+            sort_into(dst);
+            HIP_TRY(h, hipGetLastError());
+            next_perm = dst;
+        }
+        HIP_TRY(h, hipEventRecord(h->ev_pre, h->stream));
+    }
     constexpr bool CANPACK = KCH > 0;
     const bool pack = CANPACK && h->spec.boxpack != 0;
     if (h->spec.npt != (h->spec.any_bsoft ? WsLayout<M, KCH, SOFT, true>::NPT : WsLayout<M, KCH, SOFT, false>::NPT)) {
@@ -520,6 +603,9 @@ int launch_pair(usvmpc_handle *h, int phase)
     // HBM at every stage - nothing else runs on the CU to hide it - becomes a solve on LDS.  rows_lds instances per wave
     // (as many whole horizons as fit), one wave per CU at a time; further instances come through the same queue.
     auto launch_qp = [&](auto kern, decltype(kern) kern_lds, decltype(kern) kern_aux = nullptr) -> int {
+#ifdef USV_TIMING_EXPERIMENT
+        if (h->spec.fixed_iters < 0) return 0; // (timing_fixed_iters = -1: lineariser only - tools/overlap_probe.py)
+#endif
         const long lds_inst = (long)(h->N + 1) * h->spec.npt * 128;
         // (the kernel's own static LDS - exchange area, parked constants - comes out of the same 160 KB)
         long lds_static = 0;
@@ -615,6 +701,20 @@ int launch_pair(usvmpc_handle *h, int phase)
     if (rcq) return rcq;
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[2], h->stream));
+    if (pipe) {
+        // the next tick's lineariser, behind this launch on the second stream, under the map made above
+        HIP_TRY(h, hipStreamWaitEvent(h->aux_stream, h->ev_pre, 0));
+        DevPtrs Pn = h->ptrs;
+        Pn.perm = next_perm;
+        Pn.perm_cur = h->ptrs.perm;
+        lin_launch(std::integral_constant<int, 1>{}, h->aux_stream, Pn);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(h->ev_spec, h->aux_stream));
+        h->spec_for = h->nsolves + 1;
+        h->spec_valid = true;
+        h->spec_outstanding = true;
+        h->spec_perm = next_perm;
+    }
     h->nsolves++;
     h->layout_dirty = false;
     if (h->mirror) { // [x | u | status] of this solve, one copy
@@ -781,6 +881,10 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->map_changed = false;
     h->export_at = -1;
     h->layout_dirty = false;
+    h->pipeline = true;
+    h->aux_stream = nullptr; h->ev_pre = nullptr; h->ev_spec = nullptr;
+    h->d_epoch = nullptr; h->d_redo = nullptr; h->d_perm2 = nullptr;
+    h->spec_for = -1; h->spec_valid = false; h->spec_outstanding = false; h->spec_perm = nullptr;
     h->noise_mask = ~0u;
     h->dynamic_rows = true;
     h->qp_cap = 0;
@@ -885,6 +989,12 @@ int usvmpc_destroy(usvmpc_handle *h)
     if (!h) return USVMPC_E_ARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->aux_stream) {
+        (void)hipStreamSynchronize(h->aux_stream);
+        (void)hipStreamDestroy(h->aux_stream);
+        (void)hipEventDestroy(h->ev_pre);
+        (void)hipEventDestroy(h->ev_spec);
+    }
     for (void *a : h->allocs) (void)hipFree(a);
     if (h->mirror) (void)hipHostFree(h->mirror);
     for (int r = 0; r < usvmpc_handle::RING; r++)
@@ -929,6 +1039,10 @@ int usvmpc_sync(usvmpc_handle *h)
     if (!h) return USVMPC_E_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->spec_outstanding) { // (the lineariser that runs a tick ahead is part of the work enqueued so far)
+        HIP_TRY(h, hipStreamSynchronize(h->aux_stream));
+        h->spec_outstanding = false;
+    }
     h->inflight = false;
     return 0;
 }
@@ -957,6 +1071,10 @@ int usvmpc_solve_sqp(usvmpc_handle *h, int *status)
     HIP_TRY(h, hipSetDevice(h->device));
     const int B = h->B;
     const int max_iter = h->desc.nlp_max_iter > 0 ? h->desc.nlp_max_iter : 100;
+    {
+        const int rcs = spec_cancel(h);
+        if (rcs) return rcs;
+    }
     hipLaunchKernelGGL(usv_sqp_begin, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs, B);
     HIP_TRY(h, hipGetLastError());
     for (int it = 0; it < max_iter; it++) {
@@ -1007,6 +1125,8 @@ int usvmpc_get_device_ptr(usvmpc_handle *h, const char *field, void **dptr)
         const int rcf = mirror_flush(h);
         if (rcf) return rcf;
         h->extern_access = true;
+        const int rcs = spec_cancel(h); // (and no lineariser runs ahead on arrays the caller may write behind the library's back)
+        if (rcs) return rcs;
     }
     *dptr = const_cast<void *>(p);
     return 0;
@@ -1123,6 +1243,11 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
 {
     if (!h) return USVMPC_E_ARG;
     const std::string s(name ? name : "");
+    {
+        const int rcs = spec_cancel(h); // (options change maps, layouts or launches: a lineariser that ran ahead is not trusted across them)
+        if (rcs) return rcs;
+    }
+    if (s == "pipeline_linearize") { h->pipeline = value != 0.0; return 0; }
     if (s == "sort_by_difficulty") {
         h->sort_enabled = value != 0.0;
         if (!h->sort_enabled && h->ptrs.perm) { h->ptrs.perm = nullptr; h->map_changed = true; }
@@ -1329,6 +1454,10 @@ int usvmpc_calibrate_traffic(usvmpc_handle *h, int nplanes, double *bytes_read, 
 {
     if (!h || nplanes < 1) return USVMPC_E_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
+    {
+        const int rcs = spec_cancel(h);
+        if (rcs) return rcs;
+    }
     const long stride = (long)h->Bp * LANES;
     const long avail = (long)(h->N + 1) * ws_planes(h->nx, h->nu, h->kch, h->soft, model_mat_planes(h->desc.model), h->spec.any_bsoft != 0);
     if (nplanes + 1 > avail) { h->err = "nplanes exceeds the workspace"; return USVMPC_E_ARG; }
@@ -1355,6 +1484,11 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream)
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->inflight = false;
+    {
+        const int rcs = spec_cancel(h);
+        if (rcs) return rcs;
+        h->pipeline = false; // (the caller's stream carries the caller's own ordering: nothing of this handle runs beside it)
+    }
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     h->stream = (hipStream_t)stream;
     h->own_stream = false;

@@ -107,6 +107,14 @@ inline double frcp(double x) { return 1.0 / x; }
 inline void frcp2(double a, double b, double &ia, double &ib) { const double r = 1.0 / (a * b); ia = r * b; ib = r * a; }
 inline double frsqrt(double x) { return 1.0 / std::sqrt(x); }
 
+// hand-over primitives (gfx950/lanes.hpp): plain memory on the CPU
+inline void st_shared(double *p, double v) { *p = v; }
+inline double ld_shared(const double *p) { return *p; }
+inline void drain_stores() {}
+inline void publish(int *flag, int v) { *flag = v; }
+inline int observe(const int *flag) { return *flag; }
+inline void set_bits(int *word, int bits) { *word |= bits; }
+
 // lane index inside the (emulated) wave: the group's quarter of its 4-group tile
 inline unsigned wave_lane() { return (unsigned)((g_emu.group & 3) * 16 + g_emu.cur); }
 

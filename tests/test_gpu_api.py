@@ -270,3 +270,48 @@ def test_host_mirror_small_batch_reference_loop(oracle):
         assert util.rel_err(s.get_all("x"), xo) < 1e-7 and util.rel_err(s.get("u", 0), uo[:, 0]) < 1e-7
         x0 = s.get("x", 1).copy()
     s.close()
+
+
+@pytest.mark.parametrize("name,N,K", [("usv_model_pf_ca", 12, 4), ("usv_model_guidance_ca1", 12, 6)])
+def test_pipelined_lineariser_is_scheduling_only(name, N, K):
+    """Option pipeline_linearize (default on for >= 16384 instances): the next tick's lineariser runs on a second stream in the tail
+    of the QP launch, instance by instance as results become final, with a fix-up pass for the rest.  Against the un-pipelined
+    sequence, tick by tick: iterates, statuses, iteration counts and the hand-over must be bit-identical - including ticks in
+    front of which the caller replaced the iterate or the reference (the ahead-of-time linearisation must then be discarded) and
+    a multiplier read-back while the second stream is busy."""
+    from mpc_collisionavoidance_amd import usv_models
+    B = 16384 + 7
+    wl = scenario.make_bench_batch(name, N, K, B, seed=5)
+    ocp = usv_models.make_ocp(name, N * scenario.BENCH_DT, N, K)
+    ocp.solver_options.sim_method_num_steps = scenario.BENCH_SIM_STEPS[name]
+    rng = np.random.default_rng(1)
+    bump = 0.01 * rng.standard_normal(wl["x_init"].shape)
+
+    def run(pipe):
+        s = BatchOcpSolver(ocp, B)
+        scenario.load_into(s, wl)
+        s.set_option("static_obstacles", 1)
+        s.set_option("disturbance_mask", scenario.NOISE_MASK[name])
+        s.set_option("pipeline_linearize", pipe)
+        out = []
+        for t in range(14):
+            if t == 5:      # the caller replaces the iterate between two ticks
+                s.sync()
+                s.set_all("x", s.get_all("x") + bump)
+            if t == 8:      # ... or the reference of one stage
+                s.set("yref", 3, wl["yref"][:, 3] * 1.01)
+            s.solve_async()
+            s.advance(1e-3, seed=50 + t)
+            if t in (2, 9):
+                s.sync()
+                out.append(s.get_all("lam")[:64].copy())
+            if t % 3 == 0 or t >= 10:
+                s.sync()
+                out += [s.get_all("x"), s.get_all("u"), s.get_int("status").copy(), s.get_int("qp_iter").copy(), s.get("x0", 0)]
+        s.close()
+        return out
+
+    a, b = run(1), run(0)
+    assert len(a) == len(b)
+    for i, (p, q) in enumerate(zip(a, b)):
+        assert np.array_equal(p, q), i

@@ -336,3 +336,49 @@ extern "C" int usv_emu_sqp(const usvmpc_desc *d, double *x, double *u, const dou
     return emu_run(d, 1, x, u, x0, yref, yref_e, p, lh, sl, su, pi, status, qp_status, qp_iter, res, nullptr, nullptr,
                    nullptr, sqp_iter, nlp_res);
 }
+
+// ---- the pipelined lineariser's three modes (linearize.hpp) on the emulator: MODE 0 under `perm_next` into ws_plain; MODE 1 under
+// (perm_next, perm_cur) with epoch[b] = ready[b] ? tick : tick - 1, then MODE 2, into ws_piped; redo_out receives the mask MODE 1 left
+// ([B][(N + 32) / 32]).  Workspaces: [(N + 1)][Bp][npt][16] doubles each (npt returned).
+namespace {
+template <class M, int KCH, bool SOFT, int MODE>
+void lin_mode_body(void *a)
+{
+    Job *j = (Job *)a;
+    if (j->P->spec->sim_steps > 1) Linearize<M, KCH, SOFT, true, MODE>::run(*j->P, j->gid);
+    else Linearize<M, KCH, SOFT, false, MODE>::run(*j->P, j->gid);
+}
+template <class M, int KCH, bool SOFT>
+int lin_modes(DevPtrs P, DevSpec &S, const int *ready, const int *perm_next, const int *perm_cur, double *ws_plain, double *ws_piped, int *redo_out)
+{
+    S.npt = S.any_bsoft ? WsLayout<M, KCH, SOFT, true>::NPT : WsLayout<M, KCH, SOFT, false>::NPT;
+    const long ngroups = (long)(S.N + 1) * S.Bp;
+    const int tick = 7, words = (S.N + 32) / 32;
+    std::vector<int> epoch(S.B), redo((size_t)S.B * words, 0);
+    for (int b = 0; b < S.B; b++) epoch[b] = ready[b] ? tick : tick - 1;
+    P.spec = &S; P.perm = perm_next; P.tick = tick;
+    P.ws = ws_plain;
+    for (long gid = 0; gid < ngroups; gid++) { Job j{&P, gid, 0, -1}; lanes::run_group(gid, &lin_mode_body<M, KCH, SOFT, 0>, &j); }
+    P.ws = ws_piped; P.epoch = epoch.data(); P.redo = redo.data(); P.redo_words = words; P.perm_cur = perm_cur;
+    for (long gid = 0; gid < ngroups; gid++) { Job j{&P, gid, 0, -1}; lanes::run_group(gid, &lin_mode_body<M, KCH, SOFT, 1>, &j); }
+    std::memcpy(redo_out, redo.data(), redo.size() * sizeof(int));
+    for (long gid = 0; gid < ngroups; gid++) { Job j{&P, gid, 0, -1}; lanes::run_group(gid, &lin_mode_body<M, KCH, SOFT, 2>, &j); }
+    return S.npt;
+}
+} // namespace
+
+extern "C" int usv_emu_lin_modes(const usvmpc_desc *d, const double *x, const double *u, const double *yref, const double *yref_e,
+                                 const int *ready, const int *perm_next, const int *perm_cur, double *ws_plain, double *ws_piped, int *redo_out)
+{
+    DevSpec S;
+    if (!build_spec(*d, S).empty()) return -1;
+    DevPtrs P;
+    std::memset(&P, 0, sizeof(P));
+    P.x = const_cast<double *>(x); P.u = const_cast<double *>(u); P.yref = yref; P.yref_e = yref_e;
+#ifndef USV_GEN_ONLY
+    if (d->model == USVMPC_MODEL_USV) return lin_modes<ModelM0, 0, false>(P, S, ready, perm_next, perm_cur, ws_plain, ws_piped, redo_out);
+    if (d->model == USVMPC_MODEL_GUIDANCE_CA1) return lin_modes<ModelM1, 1, true>(P, S, ready, perm_next, perm_cur, ws_plain, ws_piped, redo_out);
+    if (d->model == USVMPC_MODEL_PF_CA) return lin_modes<ModelM2, 1, false>(P, S, ready, perm_next, perm_cur, ws_plain, ws_piped, redo_out);
+#endif
+    return -3;
+}

@@ -245,3 +245,40 @@ def test_aux_plane_in_lds_equals_aux_plane_in_hbm(emu, name, N, K):
     assert (out[0][2] == 0).any() and out[0][8].any()
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name,N,K", [("usv_model_pf_ca", 6, 3), ("usv_model_guidance_ca1", 5, 2), ("usv_model", 7, 0)])
+def test_pipelined_lineariser_modes_cover_every_group_exactly(emu, name, N, K):
+    """linearize.hpp MODE 1 (ahead of time, beside a running QP launch) + MODE 2 (fix-up) must leave exactly what MODE 0 writes, for any
+    pattern of finished / unfinished instances and any pair of maps: a group is linearised ahead only if its own instance AND the
+    instance that still owns its planes under the running launch's map are final; everything else is marked per (instance, stage)
+    and done by the fix-up - nothing twice, nothing never."""
+    B = 9
+    ocp, wl = util.make(name, N, K, B, seed=4)
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    Bp = (B + 3) // 4 * 4
+    rng = np.random.default_rng(0)
+    emu.usv_emu_lin_modes.argtypes = [C.POINTER(_capi.Desc)] + [_capi._dp] * 4 + [_capi._ip] * 3 + [_capi._dp] * 2 + [_capi._ip]
+    words = (N + 32) // 32
+    for trial in range(4):
+        ready = (rng.uniform(size=B) < (0.0, 0.5, 0.8, 1.0)[trial]).astype(np.int32)
+        pn, pc = rng.permutation(B).astype(np.int32), rng.permutation(B).astype(np.int32)
+        wsa, wsb = np.zeros((N + 1, Bp, 64, 16)), np.zeros((N + 1, Bp, 64, 16))   # (64 >= planes per stage of any layout)
+        redo = np.zeros((B, words), dtype=np.int32)
+        npt = emu.usv_emu_lin_modes(C.byref(desc), _d(wl["x_init"]), _d(wl["u_init"]), _d(wl["yref"]), _d(wl["yref_e"]), _i(ready), _i(pn), _i(pc),
+                                    _d(wsa), _d(wsb), _i(redo))
+        assert npt > 0
+        a = wsa.reshape(-1)[: (N + 1) * Bp * npt * 16]
+        b = wsb.reshape(-1)[: (N + 1) * Bp * npt * 16]
+        assert np.array_equal(a, b), trial
+        assert np.abs(a).max() > 0
+        # the mask: stage k of instance pn[g] was left to the fix-up iff that instance or the planes' current owner pc[g] was not final
+        # (padded groups replay the last instance: they can only add bits for an instance that is marked anyway or whose owner is late)
+        for g in range(B):
+            inst, owner = pn[g], pc[g]
+            late = not (ready[inst] and ready[owner])
+            bits = [(redo[inst, k // 32] >> (k % 32)) & 1 for k in range(N + 1)]
+            if late:
+                assert all(bits), (trial, g)
+        if trial == 3:
+            assert not redo.any()

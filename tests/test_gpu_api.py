@@ -272,7 +272,7 @@ def test_host_mirror_small_batch_reference_loop(oracle):
     s.close()
 
 
-@pytest.mark.parametrize("name,N,K", [("usv_model_pf_ca", 12, 4), ("usv_model_guidance_ca1", 12, 6)])
+@pytest.mark.parametrize("name,N,K", [("usv_model_pf_ca", 12, 4), ("usv_model_guidance_ca1", 12, 6), ("usv_model_guidance_ca1", 70, 3)])
 def test_pipelined_lineariser_is_scheduling_only(name, N, K):
     """Option pipeline_linearize (default on for >= 16384 instances): the next tick's lineariser runs on a second stream in the tail
     of the QP launch, instance by instance as results become final, with a fix-up pass for the rest.  Against the un-pipelined

@@ -1,0 +1,888 @@
+// cond_ipm.hpp — partial condensing on the device (BASELINE.json configs[4]: N = 80 -> N2 = 10).
+//
+// What acados' qp_solver = PARTIAL_CONDENSING_HPIPM does when qp_solver_cond_N = N2 < N
+// (/root/reference/catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/acados_settings.py:172 selects the solver; the reference leaves
+// cond_N at N, for which qp_ipm.hpp IS the solver): HPIPM d_part_cond_qp turns Mb = N / N2 consecutive stages into ONE stage
+// whose state is x_k0 and whose input is the stack u_hat = (u_k0 .. u_k0+Mb-1); the intermediate states are eliminated
+// through the dynamics, x_{k0+j} = Phi_j x_k0 + Gam_j u_hat + c_j.  The block's cost becomes a dense (nx + Mb nu)^2 Hessian,
+// its dynamics a dense nx x (nx + Mb nu) matrix, and every inequality row of an intermediate stage a general row in
+// (u_hat, x_k0).  The QP over the N2 dense stages is solved by the same Mehrotra predictor-corrector IPM as the uncondensed
+// one (cold start, step rule, exit test: qp_ipm.hpp / oracle/usv_oracle.c), Riccati recursion over dense stages
+// (Cholesky of the (Mb nu)^2 input block), and the solution is expanded back (d_part_cond_qp_expand_sol: states by the
+// original dynamics, dynamics multipliers of the intermediate stages by the adjoint recursion).
+//
+// The general rows are kept in FACTORED form: a row of original stage k0+j is c' z_{k0+j} with c sparse (one entry for a
+// bound, the two position entries for an obstacle row) and z_{k0+j} = T_j w + d_j, so C w, C'v and C' diag(g) C are formed
+// as   expand (S_j w)  ->  sparse row  ->  S_j' (.)   with only the rows of S_j = [Gam_j Phi_j] that some row touches
+// (bounded states and the position: 7 of 14 for usv_model_pf_ca).  Same numbers as the dense C of HPIPM up to rounding,
+// 200 x 30 doubles per block less to stream.
+//
+// Mapping (different from qp_ipm.hpp, whose row-per-lane layout ends at 16 variables per stage): ONE instance per team of
+// NT threads (a wave or a workgroup), the block's matrices in LDS, small dense kernels written as team-parallel loops
+// over output elements; the per-instance condensed data (S_j rows, H0, factors, row multipliers) lives in a per-TEAM
+// scratch area in HBM that is reused for every instance the team pulls from the queue.  Hard rows only.
+//
+// Parity: oracle/condense.py (numpy: part_cond + the oracle's IPM on the dense stages + expand) - tests/test_condensing.py
+// (CPU: this file compiled serially, -DUSV_COND_SERIAL; -m gpu: the kernel).
+#pragma once
+#include "lanes.hpp"
+#include "params.hpp"
+#include "qp_ipm.hpp"
+#include <algorithm>
+
+namespace usv {
+
+// sizes and scratch offsets (doubles) of the condensed QP of one instance; host and device
+struct CondDims {
+    int Mb, N2, nuh, nzh, nxr, R, nrows, nbu, nbx, K;
+    int xr[LANES];        // states that some row touches (bounded, position), ascending
+    int xr_of[LANES];     // state -> index in xr, or -1
+    int uvar[LANES];      // u rows: control index;  xvar: x rows: index into xr
+    int xvar[LANES];
+    int ipx, ipy;         // index in xr of the position states (-1 without obstacle rows)
+    // per block
+    long o_SR, o_cr, o_BA, o_bt, o_H0, o_g0, o_row, o_Luu, o_P, o_Pb, o_w, o_pi, o_rg, o_rb, o_dwa, o_dw, o_dpi, o_p, o_lus, blk;
+    long total;           // (N2 + 1) * blk
+    long lds_doubles;     // LDS the kernel needs (doubles), for NT threads
+};
+
+inline bool cond_dims(const DevSpec &S, int nx, int nu, int ipx, int ipy, int N2, int nt, CondDims &D)
+{
+    if (N2 < 1 || N2 >= S.N || S.N % N2) return false;
+    D.Mb = S.N / N2; D.N2 = N2; D.nuh = D.Mb * nu; D.nzh = D.nuh + nx; D.K = S.K;
+    D.nbu = D.nbx = D.nxr = 0;
+    for (int i = 0; i < LANES; i++) { D.xr_of[i] = -1; D.xr[i] = D.uvar[i] = D.xvar[i] = 0; }
+    for (int l = 0; l < nu; l++) if (S.has_b[l]) D.uvar[D.nbu++] = l;
+    for (int s = 0; s < nx; s++)
+        if (S.has_b[nu + s] || (S.K > 0 && (s == ipx || s == ipy))) { D.xr_of[s] = D.nxr; D.xr[D.nxr++] = s; }
+    for (int s = 0; s < nx; s++) if (S.has_b[nu + s]) D.xvar[D.nbx++] = D.xr_of[s];
+    D.ipx = S.K > 0 ? D.xr_of[ipx] : -1; D.ipy = S.K > 0 ? D.xr_of[ipy] : -1;
+    D.R = D.nbu + D.nbx + S.K; D.nrows = D.Mb * D.R;
+    long o = 0;
+    auto take = [&](long n) { const long at = o; o += (n + 15) / 16 * 16; return at; }; // 128-byte pieces
+    D.o_SR = take((long)D.Mb * D.nxr * D.nzh); D.o_cr = take((long)D.Mb * D.nxr);
+    D.o_BA = take((long)nx * D.nzh); D.o_bt = take(nx);
+    D.o_H0 = take((long)D.nzh * D.nzh); D.o_g0 = take(D.nzh);
+    D.o_row = take(8L * D.nrows);            // ll, lu, tl, tu, dl, du, cx, cy
+    D.o_Luu = take((long)D.nzh * D.nuh);     // [Luu; Lxu]: the first nuh columns of the eliminated stage matrix
+    D.o_P = take((long)nx * nx);             // P_{i+1}
+    D.o_Pb = take(nx);
+    D.o_w = take(D.nzh); D.o_pi = take(nx); D.o_rg = take(D.nzh); D.o_rb = take(nx);
+    D.o_dwa = take(D.nzh); D.o_dw = take(D.nzh); D.o_dpi = take(nx); D.o_p = take(nx); D.o_lus = take(D.nuh);
+    D.blk = o;
+    D.total = (long)(N2 + 1) * D.blk;
+    const int nz = nx + nu;
+    long l = 0;
+    l += (long)(D.nzh + 1) * D.nzh;                                       // Gm
+    l += std::max<long>((long)D.Mb * D.nxr * D.nzh, 2L * nx * D.nzh + (long)nz * D.nzh); // SRm | (Sm, Sn, Tm) while condensing
+    l += 2L * nx * D.nzh;                                                 // BAm, PBm
+    l += (long)nx * nx + (long)nx * nz;                                   // Pn, BAk
+    l += 4L * D.Mb * D.nxr + 3L * D.Mb * D.nxr + D.Mb + 3L * D.nuh;       // expansions, slots
+    l += 5L * nt + 64;                                                    // obstacle-row buffer of one pass, reductions
+    l += 8L * D.nzh + 12L * nx + 2L * D.nuh + 2L * nz + (long)D.Mb * nz + (long)D.Mb * D.nxr; // vectors
+    D.lds_doubles = l + 64;
+    return true;
+}
+
+// ---- the threads that work on one instance
+#if defined(USV_COND_SERIAL) // CPU test build: one thread plays the whole team
+struct CondTeam {
+    static constexpr int NT = 1;
+    static int tid() { return 0; }
+    static void sync() {}
+    static double rmax(double v, double *) { return v; }
+    static double rsum(double v, double *) { return v; }
+    static int share(int v, int *) { return v; }
+    static int take(int *q) { return (*q)++; }
+};
+#define USV_CDEV inline
+#else
+template <int NT_>
+struct CondTeam {
+    static constexpr int NT = NT_;
+    static_assert(NT % 64 == 0, "whole waves");
+    __device__ static int tid() { return (int)threadIdx.x; }
+    __device__ static void sync() { __syncthreads(); }
+    __device__ static double rmax(double v, double *red)
+    {
+        for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+        if constexpr (NT > 64) {
+            sync();
+            if ((tid() & 63) == 0) red[tid() >> 6] = v;
+            sync();
+            v = red[0];
+            for (int i = 1; i < NT / 64; i++) v = fmax(v, red[i]);
+        }
+        return v;
+    }
+    __device__ static double rsum(double v, double *red)
+    {
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if constexpr (NT > 64) {
+            sync();
+            if ((tid() & 63) == 0) red[tid() >> 6] = v;
+            sync();
+            v = red[0];
+            for (int i = 1; i < NT / 64; i++) v += red[i];
+        }
+        return v;
+    }
+    __device__ static int share(int v, int *slot) // thread 0's value to the team
+    {
+        sync();
+        if (tid() == 0) *slot = v;
+        sync();
+        return *slot;
+    }
+    __device__ static int take(int *q) { return atomicAdd(q, 1); }
+};
+#define USV_CDEV __device__ __forceinline__
+#endif
+
+template <class M, int KCH, class TM>
+struct CondIpm {
+    static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU, NT = TM::NT;
+    using MP = MatPack<M>;
+    using WL = WsLayout<M, KCH, false, false>;
+    using Row = RowCalc<false>;
+    struct EntTab { unsigned char row[MP::NE > 0 ? MP::NE : 1], col[MP::NE > 0 ? MP::NE : 1]; };
+    static constexpr EntTab make_tab()
+    {
+        EntTab t{};
+        int s = 0;
+        for (int j = 0; j < NX; j++)
+            for (int c = 0; c < NZ; c++)
+                if ((MP::row_mask(j) >> c) & 1u) { t.row[s] = (unsigned char)j; t.col[s] = (unsigned char)c; s++; }
+        return t;
+    }
+
+    const DevPtrs &P;
+    const DevSpec &S;
+    const CondDims &D;
+    double *cw; // the team's scratch area in HBM
+    int tid, N, Kn, Mb, N2, nuh, nzh, nxr, R, nrows;
+    long g, b;
+    // LDS
+    double *Gm, *SRm, *Sm, *Sn, *Tm, *BAm, *PBm, *Pn, *BAk, *del, *delo, *dela, *delf, *yxr, *yxg, *wd, *wxy, *yur, *yug, *wu, *obuf, *red;
+    double *vw, *vdwa, *vdw, *vr, *vgt, *vrq, *vg0, *vt, *vpi, *vpin, *vxn, *vpv, *vPb, *vrb, *vbt, *vdx, *vdxn, *vtmp, *vlus, *vq, *vgk, *vzb, *vdz, *vcr;
+    struct Norms { double rg, rb, rd, rm, musum; bool bad; };
+
+    USV_CDEV CondIpm(const DevPtrs &P_, const CondDims &D_, double *scratch, double *lds) : P(P_), S(*P_.spec), D(D_), cw(scratch)
+    {
+        tid = TM::tid();
+        N = S.N; Kn = S.K; Mb = D.Mb; N2 = D.N2; nuh = D.nuh; nzh = D.nzh; nxr = D.nxr; R = D.R; nrows = D.nrows;
+        double *q = lds;
+        auto take = [&](long n) { double *at = q; q += n; return at; };
+        Gm = take((long)(nzh + 1) * nzh);
+        const long nsr = (long)Mb * nxr * nzh, ncn = 2L * NX * nzh + (long)NZ * nzh;
+        SRm = take(nsr > ncn ? nsr : ncn);
+        Sm = SRm; Sn = SRm + (long)NX * nzh; Tm = SRm + 2L * NX * nzh; // (condense phase only)
+        BAm = take((long)NX * nzh); PBm = take((long)NX * nzh);
+        Pn = take(NX * NX); BAk = take(NX * NZ);
+        del = take(Mb * nxr); delo = take(Mb * nxr); dela = take(Mb * nxr); delf = take(Mb * nxr);
+        yxr = take(Mb * nxr); yxg = take(Mb * nxr); wd = take(Mb * nxr); wxy = take(Mb);
+        yur = take(nuh); yug = take(nuh); wu = take(nuh);
+        obuf = take(5 * NT); red = take(64);
+        vw = take(nzh); vdwa = take(nzh); vdw = take(nzh); vr = take(nzh); vgt = take(nzh); vrq = take(nzh); vg0 = take(nzh); vt = take(nzh);
+        vpi = take(NX); vpin = take(NX); vxn = take(NX); vpv = take(NX); vPb = take(NX); vrb = take(NX); vbt = take(NX); vdx = take(NX);
+        vdxn = take(NX); vtmp = take(NX); vq = take(NX); vlus = take(nuh); vgk = take(NZ); vzb = take(NZ); vdz = take(Mb * NZ); vcr = take(Mb * nxr);
+        take(NX); take(nuh); // (spare)
+    }
+
+    USV_CDEV double *blk(int i) const { return cw + (long)i * D.blk; }
+    USV_CDEV const double *plane(int k, int e) const { return P.ws + (((long)k * S.Bp + g) * S.npt + e) * LANES; }
+
+    // ---- stage k of the lineariser's output: dense [B A] (NX x NZ) into BAk, b_k into vq, g_k = GQ + Hc zbar into vgk, zbar into vzb
+    USV_CDEV void load_stage(int k)
+    {
+        static constexpr EntTab TAB = make_tab();
+        TM::sync();
+        for (int e = tid; e < NX * NZ; e += NT) {
+            const int j = e / NZ, c = e - j * NZ;
+            BAk[e] = (c == NU + j && ((M::DIAG_ONE >> j) & 1u)) ? 1.0 : 0.0;
+        }
+        for (int e = tid; e < NZ; e += NT) {
+            double zb = 0.0;
+            if (e < NU) zb = (k < N) ? P.u[((long)b * N + k) * NU + e] : 0.0;
+            else zb = P.x[((long)b * (N + 1) + k) * NX + (e - NU)];
+            vzb[e] = zb;
+        }
+        TM::sync();
+        if (k < N) {
+            for (int s = tid; s < MP::NE; s += NT) BAk[TAB.row[s] * NZ + TAB.col[s]] = plane(k, WL::P_MAT + s / 16)[s % 16];
+            for (int e = tid; e < NX; e += NT) vq[e] = plane(k, WL::P_RB0)[NU + e];
+        }
+        const double *Hm = (k < N) ? S.Hc : S.He;
+        for (int e = tid; e < NZ; e += NT) {
+            double a = plane(k, WL::P_GQ)[e];
+            for (int c = 0; c < NZ; c++) a = fma(Hm[e * LANES + c], vzb[c], a);
+            vgk[e] = a;
+        }
+        TM::sync();
+    }
+
+    // row q of stage j of block i: which kind, and whether the stage has it
+    USV_CDEV bool row_active(int i, int j, int q) const { return q < D.nbu || (i * Mb + j) >= 1; }
+
+    // ------------------------------------------------------------------ condensing (HPIPM d_part_cond_qp restated) + cold start
+    // Returns whether x0 violates a hard obstacle row of stage 0 (qp_ipm.hpp init(): acados' QP is then infeasible).
+    USV_CDEV bool condense()
+    {
+        double bad0 = 0.0;
+        for (int i = 0; i < N2; i++) {
+            double *W = blk(i);
+            const int k0 = i * Mb;
+            TM::sync();
+            for (int e = tid; e < NX * nzh; e += NT) { const int s = e / nzh, c = e - s * nzh; Sm[e] = (c == nuh + s) ? 1.0 : 0.0; }
+            for (int e = tid; e < (nzh + 1) * nzh; e += NT) Gm[e] = 0.0;
+            for (int e = tid; e < nzh; e += NT) vg0[e] = 0.0;
+            for (int e = tid; e < NX; e += NT) vbt[e] = 0.0; // c_j
+            TM::sync();
+            for (int j = 0; j < Mb; j++) {
+                const int k = k0 + j;
+                load_stage(k);
+                // rows of S_j that some inequality row touches, and the offset c_j there
+                for (int e = tid; e < nxr * nzh; e += NT) { const int r = e / nzh, c = e - r * nzh; W[D.o_SR + (long)j * nxr * nzh + e] = Sm[D.xr[r] * nzh + c]; }
+                for (int e = tid; e < nxr; e += NT) W[D.o_cr + j * nxr + e] = vbt[D.xr[e]];
+                // cost: H0 += T' Hc T, g0 += T' (g_k + Hc d),  T = [E_j; S_j], d = [0; c_j]
+                for (int e = tid; e < NZ; e += NT) {
+                    double a = vgk[e];
+                    for (int s = 0; s < NX; s++) a = fma(S.Hc[e * LANES + NU + s], vbt[s], a);
+                    vt[e] = a; // gy
+                }
+                if (!S.hdiag) // HT = Hc T  (NZ x nzh)
+                    for (int e = tid; e < NZ * nzh; e += NT) {
+                        const int p = e / nzh, c = e - p * nzh;
+                        double a = 0.0;
+                        for (int l = 0; l < NU; l++) a += (c == j * NU + l) ? S.Hc[p * LANES + l] : 0.0;
+                        for (int s = 0; s < NX; s++) a = fma(S.Hc[p * LANES + NU + s], Sm[s * nzh + c], a);
+                        Tm[e] = a;
+                    }
+                TM::sync();
+                for (int e = tid; e < nzh * nzh; e += NT) {
+                    const int a_ = e / nzh, c = e - a_ * nzh;
+                    double acc = Gm[e];
+                    if (S.hdiag) {
+                        for (int s = 0; s < NX; s++) acc = fma(Sm[s * nzh + a_] * S.Hc[(NU + s) * LANES + NU + s], Sm[s * nzh + c], acc);
+                        if (a_ == c && a_ >= j * NU && a_ < (j + 1) * NU) acc += S.Hc[(a_ - j * NU) * (LANES + 1)];
+                    } else {
+                        if (a_ >= j * NU && a_ < (j + 1) * NU) acc += Tm[(a_ - j * NU) * nzh + c];
+                        for (int s = 0; s < NX; s++) acc = fma(Sm[s * nzh + a_], Tm[(NU + s) * nzh + c], acc);
+                    }
+                    Gm[e] = acc;
+                }
+                for (int e = tid; e < nzh; e += NT) {
+                    double acc = vg0[e];
+                    if (e >= j * NU && e < (j + 1) * NU) acc += vt[e - j * NU];
+                    for (int s = 0; s < NX; s++) acc = fma(Sm[s * nzh + e], vt[NU + s], acc);
+                    vg0[e] = acc;
+                }
+                // inequality rows of the stage: constants in step coordinates, cold start (mu0 / thr0 as qp_ipm.hpp init())
+                for (int q = tid; q < R; q += NT) {
+                    const bool act = row_active(i, j, q);
+                    double dl = -1.0, du = 1.0, cx = 0.0, cy = 0.0, v0 = 0.0;
+                    if (q < D.nbu) {
+                        const int l = D.uvar[q];
+                        dl = S.lb[l] - vzb[l]; du = S.ub[l] - vzb[l];
+                    } else if (q < D.nbu + D.nbx) {
+                        const int s = D.xr[D.xvar[q - D.nbu]];
+                        if (act) { dl = S.lb[NU + s] - vzb[NU + s]; du = S.ub[NU + s] - vzb[NU + s]; v0 = vbt[s]; }
+                    } else {
+                        const int o = q - D.nbu - D.nbx;
+                        const int kk = S.p_static ? 0 : k;
+                        const double *pk = P.p + ((long)b * (N + 1) + kk) * 2 * Kn;
+                        const double lhv = P.lh[((long)b * N + (kk < N ? kk : N - 1)) * Kn + o];
+                        double d, ux, uy;
+                        obs_dist(vzb[NU + M::IPX] - pk[2 * o], vzb[NU + M::IPY] - pk[2 * o + 1], d, ux, uy);
+                        if (act) {
+                            dl = lhv - d; du = S.uh[o] - d; cx = ux; cy = uy;
+                            v0 = ux * vbt[M::IPX] + uy * vbt[M::IPY];
+                        } else if (k == 0) { // x0 inside a hard keep-out circle (or beyond uh)
+                            const double e0x = P.x0[(long)b * NX + M::IPX] - vzb[NU + M::IPX], e0y = P.x0[(long)b * NX + M::IPY] - vzb[NU + M::IPY];
+                            const double v = ux * e0x + uy * e0y;
+                            if (lhv - d - v > S.tol_ineq || d + v - S.uh[o] > S.tol_ineq) bad0 = 1.0;
+                        }
+                    }
+                    double *rw = W + D.o_row + (long)j * R + q;
+                    double tl = 1.0, tu = 1.0, ll = 0.0, lu = 0.0;
+                    if (act) {
+                        tl = fmax(v0 - dl, S.thr0); tu = fmax(du - v0, S.thr0);
+                        ll = S.mu0 / tl; lu = S.mu0 / tu;
+                    }
+                    rw[0] = ll; rw[nrows] = lu; rw[2 * nrows] = tl; rw[3 * nrows] = tu;
+                    rw[4 * nrows] = dl; rw[5 * nrows] = du; rw[6 * nrows] = cx; rw[7 * nrows] = cy;
+                }
+                // S_{j+1} = A_k S_j + B_k E_j,  c_{j+1} = A_k c_j + b_k
+                for (int e = tid; e < NX * nzh; e += NT) {
+                    const int s = e / nzh, c = e - s * nzh;
+                    double a = 0.0;
+                    for (int l = 0; l < NU; l++) a += (c == j * NU + l) ? BAk[s * NZ + l] : 0.0;
+                    for (int m = 0; m < NX; m++) a = fma(BAk[s * NZ + NU + m], Sm[m * nzh + c], a);
+                    Sn[e] = a;
+                }
+                for (int e = tid; e < NX; e += NT) {
+                    double a = vq[e];
+                    for (int m = 0; m < NX; m++) a = fma(BAk[e * NZ + NU + m], vbt[m], a);
+                    vtmp[e] = a;
+                }
+                TM::sync();
+                for (int e = tid; e < NX * nzh; e += NT) Sm[e] = Sn[e];
+                for (int e = tid; e < NX; e += NT) vbt[e] = vtmp[e];
+                TM::sync();
+            }
+            for (int e = tid; e < NX * nzh; e += NT) W[D.o_BA + e] = Sm[e];
+            for (int e = tid; e < NX; e += NT) { W[D.o_bt + e] = vbt[e]; W[D.o_pi + e] = 0.0; W[D.o_dpi + e] = 0.0; }
+            for (int e = tid; e < nzh * nzh; e += NT) W[D.o_H0 + e] = Gm[e];
+            for (int e = tid; e < nzh; e += NT) { W[D.o_g0 + e] = vg0[e]; W[D.o_w + e] = 0.0; W[D.o_dwa + e] = 0.0; W[D.o_dw + e] = 0.0; }
+        }
+        {   // terminal stage: H = He (x block), g = GQ_N + He xbar_N, no rows
+            double *W = blk(N2);
+            load_stage(N);
+            for (int e = tid; e < NX; e += NT) { W[D.o_g0 + e] = vgk[NU + e]; W[D.o_w + e] = 0.0; W[D.o_pi + e] = 0.0; W[D.o_dpi + e] = 0.0; W[D.o_dw + e] = 0.0; }
+        }
+        TM::sync();
+        return TM::rmax(bad0, red) > 0.5;
+    }
+
+    // ---- small dense pieces on LDS operands (team-parallel over output elements; call between syncs)
+    // out[j][r] = SRm[j][r][:] . v (+ cr)
+    USV_CDEV void expand_rows(double *out, const double *v, const double *cr) const
+    {
+        for (int e = tid; e < Mb * nxr; e += NT) {
+            double a = cr ? cr[e] : 0.0;
+            const double *srow = SRm + (long)e * nzh;
+            for (int c = 0; c < nzh; c++) a = fma(srow[c], v[c], a);
+            out[e] = a;
+        }
+    }
+    // out[c] += sum_{j,r} SRm[j][r][c] yx[j][r]  (+ yu at the u entries)
+    USV_CDEV void rows_transposed(double *out, const double *yx, const double *yu) const
+    {
+        for (int c = tid; c < nzh; c += NT) {
+            double a = out[c] + (c < nuh ? yu[c] : 0.0);
+            for (int m = 0; m < Mb * nxr; m++) a = fma(SRm[(long)m * nzh + c], yx[m], a);
+            out[c] = a;
+        }
+    }
+    // the block's rows at the current iterate: one pass of NT rows at a time; obstacle rows of a stage are summed in row order
+    // (deterministic) into the stage's position slots.  F(row index, j, q, Row &r, v, wa, wf) does the per-row work and returns
+    // (yr, yg, Gh): coefficients of c in the residual / in the reduced gradient, and of c c' in the Hessian.
+    template <class F>
+    USV_CDEV void row_pass(int i, double *W, bool slots, F f)
+    {
+        if (slots) {
+            for (int e = tid; e < Mb * nxr; e += NT) { yxr[e] = 0.0; yxg[e] = 0.0; wd[e] = 0.0; }
+            for (int e = tid; e < Mb; e += NT) wxy[e] = 0.0;
+            for (int e = tid; e < nuh; e += NT) { yur[e] = 0.0; yug[e] = 0.0; wu[e] = 0.0; }
+        }
+        TM::sync();
+        for (int base = 0; base < nrows; base += NT) {
+            const int e = base + tid;
+            const bool has = e < nrows;
+            const int j = has ? e / R : 0, q = has ? e - j * R : 0;
+            double yr = 0.0, yg = 0.0, Gh = 0.0, cx = 0.0, cy = 0.0;
+            bool obs = false;
+            if (has) {
+                double *rw = W + D.o_row + e;
+                Row r;
+                r.ll = rw[0]; r.lu = rw[nrows]; r.tl = rw[2 * nrows]; r.tu = rw[3 * nrows];
+                r.dl = rw[4 * nrows]; r.du = rw[5 * nrows];
+                r.act = row_active(i, j, q);
+                double v, wa, wf;
+                if (q < D.nbu) {
+                    const int c = j * NU + D.uvar[q];
+                    v = vw[c]; wa = vdwa[c]; wf = vdw[c];
+                } else if (q < D.nbu + D.nbx) {
+                    const int m = j * nxr + D.xvar[q - D.nbu];
+                    v = del[m]; wa = dela[m]; wf = delf[m];
+                } else {
+                    obs = true;
+                    cx = rw[6 * nrows]; cy = rw[7 * nrows];
+                    const int mx = j * nxr + D.ipx, my = j * nxr + D.ipy;
+                    v = cx * del[mx] + cy * del[my]; wa = cx * dela[mx] + cy * dela[my]; wf = cx * delf[mx] + cy * delf[my];
+                }
+                f(e, j, q, r, rw, v, wa, wf, yr, yg, Gh);
+                if (!r.act) { yr = 0.0; yg = 0.0; Gh = 0.0; }
+                if (slots && !obs) {
+                    if (q < D.nbu) { const int c = j * NU + D.uvar[q]; yur[c] = yr; yug[c] = yg; wu[c] = Gh; }
+                    else { const int m = j * nxr + D.xvar[q - D.nbu]; yxr[m] = yr; yxg[m] = yg; wd[m] = Gh; }
+                }
+            }
+            if (slots && Kn > 0) {
+                obuf[tid] = obs ? cx * yr : 0.0; obuf[NT + tid] = obs ? cy * yr : 0.0;
+                obuf[2 * NT + tid] = obs ? cx * yg : 0.0; obuf[3 * NT + tid] = obs ? cy * yg : 0.0;
+                TM::sync();
+                // stages this pass touches: j_lo .. j_hi; one thread per (stage, quantity)
+                const int j_lo = base / R, j_hi = (base + NT - 1 < nrows ? base + NT - 1 : nrows - 1) / R;
+                for (int t = tid; t < (j_hi - j_lo + 1) * 4; t += NT) {
+                    const int jj = j_lo + t / 4, w = t & 3;
+                    int e0 = jj * R + D.nbu + D.nbx, e1 = e0 + Kn;
+                    if (e0 < base) e0 = base;
+                    if (e1 > base + NT) e1 = base + NT;
+                    double a = 0.0;
+                    for (int ee = e0; ee < e1; ee++) a += obuf[w * NT + (ee - base)];
+                    double *dst = (w == 0) ? &yxr[jj * nxr + D.ipx] : (w == 1) ? &yxr[jj * nxr + D.ipy] : (w == 2) ? &yxg[jj * nxr + D.ipx] : &yxg[jj * nxr + D.ipy];
+                    *dst += a;
+                }
+                TM::sync();
+                obuf[tid] = obs ? cx * cx * Gh : 0.0; obuf[NT + tid] = obs ? cy * cy * Gh : 0.0; obuf[2 * NT + tid] = obs ? cx * cy * Gh : 0.0;
+                TM::sync();
+                for (int t = tid; t < (j_hi - j_lo + 1) * 3; t += NT) {
+                    const int jj = j_lo + t / 3, w = t % 3;
+                    int e0 = jj * R + D.nbu + D.nbx, e1 = e0 + Kn;
+                    if (e0 < base) e0 = base;
+                    if (e1 > base + NT) e1 = base + NT;
+                    double a = 0.0;
+                    for (int ee = e0; ee < e1; ee++) a += obuf[w * NT + (ee - base)];
+                    double *dst = (w == 0) ? &wd[jj * nxr + D.ipx] : (w == 1) ? &wd[jj * nxr + D.ipy] : &wxy[jj];
+                    *dst += a;
+                }
+                TM::sync();
+            }
+        }
+        TM::sync();
+    }
+
+    USV_CDEV void load_block(int i, double *W, bool hess)
+    {
+        TM::sync();
+        for (int e = tid; e < Mb * nxr * nzh; e += NT) SRm[e] = W[D.o_SR + e];
+        for (int e = tid; e < Mb * nxr; e += NT) vcr[e] = W[D.o_cr + e];
+        for (int e = tid; e < NX * nzh; e += NT) BAm[e] = W[D.o_BA + e];
+        for (int e = tid; e < nzh; e += NT) { vw[e] = W[D.o_w + e]; vdwa[e] = W[D.o_dwa + e]; vdw[e] = W[D.o_dw + e]; }
+        if (hess) {
+            for (int e = tid; e < nzh * nzh; e += NT) Gm[e] = W[D.o_H0 + e];
+            for (int e = tid; e < nzh; e += NT) vg0[e] = W[D.o_g0 + e];
+        }
+        (void)i;
+        TM::sync();
+    }
+
+    // lus = Luu^-1 rq_u,  pv = rq_x - Lxu lus   (L: nzh x nuh, row-major, in LDS at Gm with row stride nzh)
+    USV_CDEV void solve_forward()
+    {
+        for (int c = 0; c < nuh; c++) {
+            TM::sync();
+            const double y = vrq[c] / Gm[c * nzh + c];
+            TM::sync();
+            if (tid == 0) vrq[c] = y;
+            for (int r = c + 1 + tid; r < nzh; r += NT) vrq[r] -= Gm[r * nzh + c] * y;
+        }
+        TM::sync();
+    }
+
+    // ------------------------------------------------------------------ backward sweep with factorisation
+    // pend: the step of the previous iteration (dw, dpi, rows from dwa / sigmu_prev / dw) is applied first.
+    USV_CDEV Norms backward_factor(bool pend, double a_prev, double sig_prev)
+    {
+        Norms nm{0.0, 0.0, 0.0, 0.0, 0.0, false};
+        double badf = 0.0;
+        {   // terminal stage
+            double *W = blk(N2);
+            TM::sync();
+            for (int e = tid; e < NX; e += NT) {
+                double w = W[D.o_w + e], pi = W[D.o_pi + e];
+                if (pend) { w = fma(a_prev, W[D.o_dw + e], w); pi = fma(a_prev, W[D.o_dpi + e], pi); W[D.o_w + e] = w; W[D.o_pi + e] = pi; }
+                vxn[e] = w; vpin[e] = pi;
+            }
+            TM::sync();
+            for (int e = tid; e < NX; e += NT) {
+                double r = W[D.o_g0 + e] - vpin[e];
+                for (int c = 0; c < NX; c++) r = fma(S.He[(NU + e) * LANES + NU + c], vxn[c], r);
+                W[D.o_rg + e] = r;
+                vpv[e] = r;
+                nm.rg = fmax(nm.rg, fabs(r));
+                if (r != r) badf = 1.0;
+            }
+            for (int e = tid; e < NX * NX; e += NT) Pn[e] = S.He[(NU + e / NX) * LANES + NU + e % NX];
+        }
+        for (int i = N2 - 1; i >= 0; i--) {
+            double *W = blk(i);
+            load_block(i, W, true);
+            for (int e = tid; e < NX; e += NT) { vpi[e] = W[D.o_pi + e]; vbt[e] = W[D.o_bt + e]; }
+            if (pend) { // rows need the old iterate and both steps
+                expand_rows(delo, vw, vcr);
+                expand_rows(dela, vdwa, nullptr);
+                expand_rows(delf, vdw, nullptr);
+                for (int e = tid; e < NX; e += NT) { vpi[e] = fma(a_prev, W[D.o_dpi + e], vpi[e]); W[D.o_pi + e] = vpi[e]; }
+                TM::sync();
+                // (the old values of the u rows are read from vw before it moves: keep a copy in vt)
+                for (int e = tid; e < nzh; e += NT) vt[e] = vw[e];
+                TM::sync();
+                for (int e = tid; e < nzh; e += NT) { vw[e] = fma(a_prev, vdw[e], vw[e]); W[D.o_w + e] = vw[e]; }
+            }
+            TM::sync();
+            expand_rows(del, vw, vcr);
+            TM::sync();
+            double rd = 0.0, rm = 0.0, mus = 0.0, bd = 0.0;
+            row_pass(i, W, true, [&](int e, int j, int q, Row &r, double *rw, double v, double wa, double wf, double &yr, double &yg, double &Gh) {
+                (void)e;
+                if (pend && r.act) {
+                    double vo; // the row's value at the iterate the step was computed at
+                    if (q < D.nbu) vo = vt[j * NU + D.uvar[q]];
+                    else if (q < D.nbu + D.nbx) vo = delo[j * nxr + D.xvar[q - D.nbu]];
+                    else vo = rw[6 * nrows] * delo[j * nxr + D.ipx] + rw[7 * nrows] * delo[j * nxr + D.ipy];
+                    double g0_, g1_;
+                    r.resid(vo); r.targets_pred(); r.reduce(g0_, g1_); r.expand(wa); r.targets_corr(sig_prev); r.reduce(g0_, g1_);
+                    r.expand(wf); r.apply(a_prev);
+                    rw[0] = r.ll; rw[nrows] = r.lu; rw[2 * nrows] = r.tl; rw[3 * nrows] = r.tu;
+                }
+                r.resid(v); r.targets_pred(); r.reduce(Gh, yg);
+                yr = -(r.ll - r.lu);
+                if (r.act) {
+                    rd = fmax(rd, fmax(fabs(r.rdl), fabs(r.rdu)));
+                    rm = fmax(rm, fmax(r.ll * r.tl, r.lu * r.tu));
+                    mus += r.ll * r.tl + r.lu * r.tu;
+                    if (r.rdl != r.rdl || r.rdu != r.rdu || Gh != Gh) bd = 1.0;
+                }
+            });
+            // r = g0 + H0 w + BA' pi_{i+1} - [0; pi_i];  rb = bt + BA w - x_{i+1}
+            for (int c = tid; c < nzh; c += NT) {
+                double a = vg0[c];
+                for (int m = 0; m < nzh; m++) a = fma(Gm[c * nzh + m], vw[m], a);
+                for (int s = 0; s < NX; s++) a = fma(BAm[s * nzh + c], vpin[s], a);
+                if (i >= 1 && c >= nuh) a -= vpi[c - nuh];
+                vr[c] = a;
+            }
+            for (int s = tid; s < NX; s += NT) {
+                double a = vbt[s] - vxn[s];
+                for (int c = 0; c < nzh; c++) a = fma(BAm[s * nzh + c], vw[c], a);
+                vrb[s] = a;
+            }
+            TM::sync();
+            rows_transposed(vr, yxr, yur);
+            TM::sync();
+            double rgl = 0.0, rbl = 0.0;
+            for (int c = tid; c < nzh; c += NT) {
+                W[D.o_rg + c] = vr[c];
+                if (i >= 1 || c < nuh) rgl = fmax(rgl, fabs(vr[c]));
+                if (vr[c] != vr[c]) bd = 1.0;
+                vgt[c] = vr[c];
+            }
+            for (int s = tid; s < NX; s += NT) { W[D.o_rb + s] = vrb[s]; rbl = fmax(rbl, fabs(vrb[s])); if (vrb[s] != vrb[s]) bd = 1.0; }
+            nm.rg = fmax(nm.rg, rgl); nm.rb = fmax(nm.rb, rbl); nm.rd = fmax(nm.rd, rd); nm.rm = fmax(nm.rm, rm); nm.musum += mus;
+            badf = fmax(badf, bd);
+            TM::sync();
+            rows_transposed(vgt, yxg, yug);
+            // Ht = H0 + diag_u(wu) + sum_j SR_j' W_j SR_j   (lower triangle), then G = Ht + BA' P+ BA
+            for (int e = tid; e < NX * nzh; e += NT) {
+                const int s = e / nzh, c = e - s * nzh;
+                double a = 0.0;
+                for (int m = 0; m < NX; m++) a = fma(Pn[s * NX + m], BAm[m * nzh + c], a);
+                PBm[e] = a;
+            }
+            for (int s = tid; s < NX; s += NT) {
+                double a = 0.0;
+                for (int m = 0; m < NX; m++) a = fma(Pn[s * NX + m], vrb[m], a);
+                vPb[s] = a;
+                W[D.o_Pb + s] = a;
+            }
+            for (int e = tid; e < NX * NX; e += NT) W[D.o_P + e] = Pn[e];
+            for (int e = tid; e < NX; e += NT) W[D.o_p + e] = vpv[e];
+            TM::sync();
+            const int ntri = nzh * (nzh + 1) / 2;
+            for (int e = tid; e < ntri; e += NT) {
+                int a_ = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                while ((a_ + 1) * (a_ + 2) / 2 <= e) a_++;
+                while (a_ * (a_ + 1) / 2 > e) a_--;
+                const int c = e - a_ * (a_ + 1) / 2;
+                double acc = Gm[a_ * nzh + c];
+                if (a_ == c && a_ < nuh) acc += wu[a_];
+                for (int m = 0; m < Mb * nxr; m++) acc = fma(SRm[(long)m * nzh + a_] * wd[m], SRm[(long)m * nzh + c], acc);
+                if (Kn > 0)
+                    for (int j = 0; j < Mb; j++) {
+                        const double *sx = SRm + (long)(j * nxr + D.ipx) * nzh, *sy = SRm + (long)(j * nxr + D.ipy) * nzh;
+                        acc = fma(wxy[j], sx[a_] * sy[c] + sy[a_] * sx[c], acc);
+                    }
+                for (int s = 0; s < NX; s++) acc = fma(BAm[s * nzh + a_], PBm[s * nzh + c], acc);
+                Gm[a_ * nzh + c] = acc;
+            }
+            // rq = gt + BA' (Pb + p_{i+1})
+            for (int c = tid; c < nzh; c += NT) {
+                double a = vgt[c];
+                for (int s = 0; s < NX; s++) a = fma(BAm[s * nzh + c], vPb[s] + vpv[s], a);
+                vrq[c] = a;
+            }
+            // eliminate the nuh input columns: [Luu; Lxu] stays in their place, the Schur complement P_i in the x block
+            for (int c = 0; c < nuh; c++) {
+                TM::sync();
+                const double piv = Gm[c * nzh + c];
+                if (!(piv > 0.0)) badf = 1.0;
+                const double dsq = sqrt(piv), dinv = 1.0 / dsq;
+                TM::sync();
+                for (int r = c + 1 + tid; r < nzh; r += NT) Gm[r * nzh + c] *= dinv;
+                if (tid == 0) Gm[c * nzh + c] = dsq;
+                TM::sync();
+                const int nr = nzh - c - 1; // rows c+1 .. nzh-1, lower triangle of the trailing block
+                for (int e = tid; e < nr * (nr + 1) / 2; e += NT) {
+                    int a_ = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                    while ((a_ + 1) * (a_ + 2) / 2 <= e) a_++;
+                    while (a_ * (a_ + 1) / 2 > e) a_--;
+                    const int cc = e - a_ * (a_ + 1) / 2;
+                    const int rr = c + 1 + a_, c2 = c + 1 + cc;
+                    Gm[rr * nzh + c2] = fma(-Gm[rr * nzh + c], Gm[c2 * nzh + c], Gm[rr * nzh + c2]);
+                }
+            }
+            TM::sync();
+            solve_forward();
+            for (int e = tid; e < nzh * nuh; e += NT) { const int r = e / nuh, c = e - r * nuh; W[D.o_Luu + e] = Gm[r * nzh + c]; }
+            for (int c = tid; c < nuh; c += NT) W[D.o_lus + c] = vrq[c];
+            // hand over to block i - 1
+            for (int e = tid; e < NX * NX; e += NT) {
+                const int s = e / NX, m = e - s * NX;
+                Pn[e] = (m <= s) ? Gm[(nuh + s) * nzh + nuh + m] : Gm[(nuh + m) * nzh + nuh + s];
+            }
+            for (int s = tid; s < NX; s += NT) { vpv[s] = vrq[nuh + s]; vxn[s] = vw[nuh + s]; vpin[s] = vpi[s]; }
+            TM::sync();
+        }
+        nm.rg = TM::rmax(nm.rg, red); nm.rb = TM::rmax(nm.rb, red); nm.rd = TM::rmax(nm.rd, red); nm.rm = TM::rmax(nm.rm, red);
+        nm.musum = TM::rsum(nm.musum, red);
+        // the initial-state residual dx0 - w_0[x] belongs to rb
+        double e0m = 0.0;
+        {
+            const double *W0 = blk(0);
+            for (int s = tid; s < NX; s += NT) {
+                const double e0 = (P.x0[(long)b * NX + s] - P.x[((long)b * (N + 1)) * NX + s]) - W0[D.o_w + nuh + s];
+                e0m = fmax(e0m, fabs(e0));
+                if (e0 != e0) badf = 1.0;
+            }
+        }
+        nm.rb = fmax(nm.rb, TM::rmax(e0m, red));
+        nm.bad = TM::rmax(badf, red) > 0.5;
+        return nm;
+    }
+
+    // ------------------------------------------------------------------ backward sweep on the stored factors (corrector rhs)
+    USV_CDEV void backward_rhs(double sigmu)
+    {
+        {
+            double *W = blk(N2);
+            TM::sync();
+            for (int e = tid; e < NX; e += NT) vpv[e] = W[D.o_rg + e];
+        }
+        for (int i = N2 - 1; i >= 0; i--) {
+            double *W = blk(i);
+            load_block(i, W, false);
+            for (int e = tid; e < nzh * nuh; e += NT) { const int r = e / nuh, c = e - r * nuh; Gm[r * nzh + c] = W[D.o_Luu + e]; }
+            for (int e = tid; e < NX; e += NT) { vPb[e] = W[D.o_Pb + e]; W[D.o_p + e] = vpv[e]; }
+            for (int c = tid; c < nzh; c += NT) vgt[c] = W[D.o_rg + c];
+            expand_rows(del, vw, vcr);
+            expand_rows(dela, vdwa, nullptr);
+            TM::sync();
+            row_pass(i, W, true, [&](int, int, int, Row &r, double *, double v, double wa, double, double &yr, double &yg, double &Gh) {
+                double g0_, g1_;
+                r.resid(v); r.targets_pred(); r.reduce(g0_, g1_); r.expand(wa); r.targets_corr(sigmu); r.reduce(Gh, yg);
+                yr = 0.0;
+            });
+            rows_transposed(vgt, yxg, yug);
+            TM::sync();
+            for (int c = tid; c < nzh; c += NT) {
+                double a = vgt[c];
+                for (int s = 0; s < NX; s++) a = fma(BAm[s * nzh + c], vPb[s] + vpv[s], a);
+                vrq[c] = a;
+            }
+            TM::sync();
+            solve_forward();
+            for (int c = tid; c < nuh; c += NT) W[D.o_lus + c] = vrq[c];
+            for (int s = tid; s < NX; s += NT) vpv[s] = vrq[nuh + s];
+            TM::sync();
+        }
+    }
+
+    // ------------------------------------------------------------------ forward sweep: step and step length
+    // corr = false: affine step into dwa, returns alpha_aff and the sums S1, S2 of mu_aff;  true: final step into dw, dpi.
+    USV_CDEV void forward(bool corr, double sigmu, double &alpha, double &S1, double &S2)
+    {
+        double qmax = 1.0, s1 = 0.0, s2 = 0.0;
+        TM::sync();
+        {
+            const double *W0 = blk(0);
+            for (int s = tid; s < NX; s += NT) vdx[s] = (P.x0[(long)b * NX + s] - P.x[((long)b * (N + 1)) * NX + s]) - W0[D.o_w + nuh + s];
+        }
+        for (int i = 0; i < N2; i++) {
+            double *W = blk(i);
+            load_block(i, W, false);
+            for (int e = tid; e < nzh * nuh; e += NT) { const int r = e / nuh, c = e - r * nuh; Gm[r * nzh + c] = W[D.o_Luu + e]; }
+            for (int c = tid; c < nuh; c += NT) vlus[c] = W[D.o_lus + c];
+            for (int s = tid; s < NX; s += NT) vrb[s] = W[D.o_rb + s];
+            TM::sync();
+            // t = lus + Lxu' dx;  du = -Luu^-T t
+            for (int c = tid; c < nuh; c += NT) {
+                double a = vlus[c];
+                for (int s = 0; s < NX; s++) a = fma(Gm[(nuh + s) * nzh + c], vdx[s], a);
+                vt[c] = a;
+            }
+            for (int c = nuh - 1; c >= 0; c--) {
+                TM::sync();
+                const double y = vt[c] / Gm[c * nzh + c];
+                TM::sync();
+                if (tid == 0) vt[c] = y;
+                for (int r = tid; r < c; r += NT) vt[r] -= Gm[c * nzh + r] * y;
+            }
+            TM::sync();
+            double *dst = corr ? vdw : vdwa;
+            for (int c = tid; c < nzh; c += NT) {
+                const double v = (c < nuh) ? -vt[c] : vdx[c - nuh];
+                dst[c] = v;
+                W[(corr ? D.o_dw : D.o_dwa) + c] = v;
+            }
+            TM::sync();
+            for (int s = tid; s < NX; s += NT) {
+                double a = vrb[s];
+                for (int c = 0; c < nzh; c++) a = fma(BAm[s * nzh + c], dst[c], a);
+                vdxn[s] = a;
+            }
+            expand_rows(del, vw, vcr);
+            expand_rows(dela, vdwa, nullptr);
+            if (corr) expand_rows(delf, vdw, nullptr);
+            TM::sync();
+            if (corr) { // dpi_{i+1} = p_{i+1} + P_{i+1} dx_{i+1}
+                double *Wn = blk(i + 1);
+                for (int s = tid; s < NX; s += NT) {
+                    double a = W[D.o_p + s];
+                    for (int m = 0; m < NX; m++) a = fma(W[D.o_P + s * NX + m], vdxn[m], a);
+                    Wn[D.o_dpi + s] = a;
+                }
+            }
+            row_pass(i, W, false, [&](int, int, int, Row &r, double *, double v, double wa, double wf, double &, double &, double &) {
+                double g0_, g1_;
+                r.resid(v); r.targets_pred(); r.reduce(g0_, g1_); r.expand(wa);
+                if (corr) { r.targets_corr(sigmu); r.reduce(g0_, g1_); r.expand(wf); }
+                qmax = r.blocking(qmax);
+                if (!corr && r.act) {
+                    s1 += r.ll * r.dtl + r.tl * r.dll + r.lu * r.dtu + r.tu * r.dlu;
+                    s2 += r.dll * r.dtl + r.dlu * r.dtu;
+                }
+            });
+            for (int s = tid; s < NX; s += NT) vdx[s] = vdxn[s];
+            TM::sync();
+        }
+        {
+            double *W = blk(N2);
+            for (int s = tid; s < NX; s += NT) W[(corr ? D.o_dw : D.o_dwa) + s] = vdx[s];
+        }
+        qmax = TM::rmax(qmax, red);
+        alpha = 1.0 / qmax;
+        if (!corr) { S1 = TM::rsum(s1, red); S2 = TM::rsum(s2, red); }
+    }
+
+    // ------------------------------------------------------------------ expansion + RTI step + outputs
+    USV_CDEV void finish(int status, int iters, const Norms &nm)
+    {
+        const bool ok = (status == 0 || status == 1);
+        double tmin = 1e300;
+        if (status != 4) {
+            for (int i = 0; i < N2; i++) {
+                double *W = blk(i);
+                TM::sync();
+                for (int e = tid; e < nzh; e += NT) vw[e] = W[D.o_w + e];
+                for (int e = tid; e < NX; e += NT) { vdx[e] = W[D.o_w + nuh + e]; vpin[e] = blk(i + 1)[D.o_pi + e]; }
+                for (int e = tid; e < nrows; e += NT) {
+                    const int j = e / R, q = e - j * R;
+                    if (q >= D.nbu + D.nbx && row_active(i, j, q)) tmin = fmin(tmin, W[D.o_row + 2 * nrows + e]);
+                }
+                TM::sync();
+                // primal: the intermediate states by the original dynamics (d_part_cond_qp_expand_sol)
+                for (int j = 0; j < Mb; j++) {
+                    const int k = i * Mb + j;
+                    load_stage(k);
+                    for (int e = tid; e < NZ; e += NT) vdz[j * NZ + e] = (e < NU) ? vw[j * NU + e] : vdx[e - NU];
+                    TM::sync();
+                    for (int s = tid; s < NX; s += NT) {
+                        double a = vq[s];
+                        for (int c = 0; c < NZ; c++) a = fma(BAk[s * NZ + c], vdz[j * NZ + c], a);
+                        vdxn[s] = a;
+                    }
+                    if (ok) {
+                        for (int e = tid; e < NX; e += NT) P.x[((long)b * (N + 1) + k) * NX + e] = vzb[NU + e] + vdz[j * NZ + NU + e];
+                        for (int e = tid; e < NU; e += NT) P.u[((long)b * N + k) * NU + e] = vzb[e] + vdz[j * NZ + e];
+                    }
+                    TM::sync();
+                    for (int s = tid; s < NX; s += NT) vdx[s] = vdxn[s];
+                    TM::sync();
+                }
+                // dynamics multipliers: pi_{k0+Mb} = pi of the next condensed stage; inside the block the adjoint recursion
+                // pi_k = (Hc z_k + g_k - C_k'(ll - lu))_x + A_k' pi_{k+1}
+                if (P.pi) {
+                    for (int j = Mb - 1; j >= 0; j--) {
+                        const int k = i * Mb + j;
+                        TM::sync();
+                        for (int e = tid; e < NX; e += NT) P.pi[((long)b * N + k) * NX + e] = vpin[e]; // pi_{k+1}
+                        if (j == 0) break;
+                        load_stage(k);
+                        for (int s = tid; s < NX; s += NT) {
+                            double a = vgk[NU + s];
+                            for (int c = 0; c < NZ; c++) a = fma(S.Hc[(NU + s) * LANES + c], vdz[j * NZ + c], a);
+                            for (int m = 0; m < NX; m++) a = fma(BAk[m * NZ + NU + s], vpin[m], a);
+                            // rows of this stage on state s
+                            const double *rw = W + D.o_row + (long)j * R;
+                            for (int q = D.nbu; q < D.nbu + D.nbx; q++)
+                                if (D.xr[D.xvar[q - D.nbu]] == s) a -= rw[q] - rw[nrows + q];
+                            if (Kn > 0 && (s == M::IPX || s == M::IPY))
+                                for (int o = 0; o < Kn; o++) {
+                                    const int q = D.nbu + D.nbx + o;
+                                    a -= rw[(s == M::IPX ? 6 : 7) * nrows + q] * (rw[q] - rw[nrows + q]);
+                                }
+                            vtmp[s] = a;
+                        }
+                        TM::sync();
+                        for (int s = tid; s < NX; s += NT) vpin[s] = vtmp[s];
+                    }
+                }
+            }
+            if (ok) {
+                const double *W = blk(N2);
+                for (int e = tid; e < NX; e += NT) P.x[((long)b * (N + 1) + N) * NX + e] += W[D.o_w + e];
+            }
+        }
+        tmin = -TM::rmax(-tmin, red);
+        if (tid == 0) {
+            if (P.obs_tmin) P.obs_tmin[b] = tmin;
+            if (!ok && P.fail_count) atomic_one(P.fail_count);
+            P.status[b] = ok ? 0 : 4;
+            P.qp_iter[b] = iters;
+            P.qp_status[b] = status;
+            if (status != 4) { P.res[b * 4 + 0] = nm.rg; P.res[b * 4 + 1] = nm.rb; P.res[b * 4 + 2] = nm.rd; P.res[b * 4 + 3] = nm.rm; }
+        }
+        TM::sync();
+    }
+    USV_CDEV static void atomic_one(int *p) { lanes::count_one(p); }
+
+    // ------------------------------------------------------------------ one instance
+    USV_CDEV void solve(long group)
+    {
+        g = group;
+        b = P.perm ? (long)P.perm[g] : g;
+        const bool bad0 = condense();
+        int status = bad0 ? 4 : 1, it = 0;
+        Norms nm{0.0, 0.0, 0.0, 0.0, 0.0, false};
+        bool pend = false;
+        double a_prev = 0.0, sig_prev = 0.0;
+        const double nc = (double)S.nc;
+        while (!bad0) {
+            nm = backward_factor(pend, a_prev, sig_prev);
+            if (nm.bad || nm.rg != nm.rg || nm.rb != nm.rb) { status = 3; break; }
+            if (nm.rg <= S.tol_stat && nm.rb <= S.tol_eq && nm.rd <= S.tol_ineq && nm.rm <= S.tol_comp) { status = 0; break; }
+            if (it >= S.iter_max) { status = 1; break; }
+            const double mu = nc > 0.0 ? nm.musum / nc : 0.0;
+            double a_aff = 1.0, S1 = 0.0, S2 = 0.0, a = 1.0, d1, d2;
+            forward(false, 0.0, a_aff, S1, S2);
+            double sigmu = 0.0;
+            if (nc > 0.0) {
+                const double mu_aff = (nm.musum + a_aff * S1 + a_aff * a_aff * S2) / nc;
+                const double sg = mu_aff / mu;
+                sigmu = sg * sg * sg * mu;
+            }
+            backward_rhs(sigmu);
+            forward(true, sigmu, a, d1, d2);
+            if (a < S.alpha_min) { status = 2; break; }
+            a_prev = a * ((1.0 - a) * 0.99 + a * 0.9999999);
+            sig_prev = sigmu;
+            pend = true;
+            it++;
+        }
+        finish(status, it, nm);
+    }
+};
+
+} // namespace usv

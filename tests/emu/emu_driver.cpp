@@ -8,6 +8,8 @@
 #include "linearize.hpp"
 #include "models.hpp"
 #include "qp_ipm.hpp"
+#define USV_COND_SERIAL 1 // partial condensing (cond_ipm.hpp): one CPU thread plays the team of an instance
+#include "cond_ipm.hpp"
 #ifdef USV_GEN_MODEL_HEADER
 #include USV_GEN_MODEL_HEADER
 #endif
@@ -146,6 +148,21 @@ double *g_emu_lam = nullptr, *g_emu_t = nullptr; // [B][N+1][nlam] each: filled 
 // per row), rb0 [N][Bp*16], gq [N+1][Bp*16]
 double *g_dbg_BAt = nullptr, *g_dbg_rb0 = nullptr, *g_dbg_gq = nullptr;
 long g_emu_rows = 2; // persistent rows of an emulated RTI solve (0: one row per group, no queue)
+int g_emu_cond_N2 = 0; // > 0: RTI solves condense the QP to this many stages first (cond_ipm.hpp, hard rows only)
+
+// the condensed solve of every instance, serially (the device runs one team of threads per instance)
+template <class M, int KCH>
+int cond_all(const DevPtrs &P, const DevSpec &S, int N2)
+{
+    CondDims D;
+    if (!cond_dims(S, M::NX, M::NU, M::IPX, M::IPY, N2, 1, D)) return -4;
+    std::vector<double> scratch((size_t)D.total, 0.0), lds((size_t)D.lds_doubles, 0.0);
+    for (long g = 0; g < S.B; g++) {
+        CondIpm<M, KCH, CondTeam> q(P, D, scratch.data(), lds.data());
+        q.solve(g);
+    }
+    return 0;
+}
 
 template <class M, int KCH, bool SOFT>
 void expand_packed(const DevPtrs &P, const DevSpec &S)
@@ -193,6 +210,12 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
     if ((phase & 1) && (g_dbg_BAt || g_dbg_rb0 || g_dbg_gq)) expand_packed<M, KCH, SOFT>(P, S);
     // RTI: a few persistent rows that pull the remaining groups from the queue (as the device launch does); full SQP: one
     // group per row
+    if constexpr (!SOFT) {
+        if ((phase & 2) && qp_phase == 0 && g_emu_cond_N2 > 0 && !S.any_bsoft) {
+            if (cond_all<M, KCH>(P, S, g_emu_cond_N2)) std::abort();
+            return;
+        }
+    }
     const bool queue = qp_phase == 0 && g_emu_rows > 0 && g_emu_rows < S.Bp;
     const long nrows = queue ? g_emu_rows : S.Bp;
     if (queue) *P.queue = 0;
@@ -314,6 +337,7 @@ static int emu_run(const usvmpc_desc *d, int sqp, double *x, double *u, const do
 // test switches: workspace of the RTI solves in emulated LDS (lds != 0); persistent rows pulling from the queue (rows, 0 = none)
 extern "C" void usv_emu_set_mode(int lds, long rows) { g_emu_lds_mode = lds; g_emu_rows = rows; }
 extern "C" void usv_emu_set_merge(int merge) { g_emu_merge = merge; }
+extern "C" void usv_emu_set_cond(int N2) { g_emu_cond_N2 = N2; }
 extern "C" void usv_emu_set_aux(int aux) { g_emu_aux = aux; }
 // the next solves also deliver the multipliers / slacks of their QPs (the device's usvmpc_get "lam" / "t"); NULL switches it off
 extern "C" void usv_emu_set_export(double *lam, double *t) { g_emu_lam = lam; g_emu_t = t; }

@@ -167,6 +167,7 @@ def main():
     if args.cond_N:
         ocp.solver_options.qp_solver_cond_N = args.cond_N
     solver = BatchOcpSolver(ocp, B, device=local_rank)
+    cond_applied = bool(args.cond_N and args.cond_N != N)   # the QP is condensed to cond_N dense stages on the device (csrc/cond_ipm.hpp)
     scenario.load_into(solver, wl)
     solver.set_option("disturbance_mask", mask)
     for kv in args.option:
@@ -199,6 +200,8 @@ def main():
         same_status = n_ok = n_conv_dev = n_cert = 0
         from tests import kkt as kkt_check   # independent acceptance: KKT conditions of every device solution (tests/kkt.py)
         soft_rows = name == "usv_model_guidance_ca1" and K > 0
+        if cond_applied:
+            solver.set_option("keep_multipliers", 1)   # (the condensed solve writes "lam" / "t" itself, into buffers that must exist)
     for w in range(args.warmup):
         if check:   # the oracle starts every tick from the iterate and x0 the device starts it from ("same inputs")
             solver.sync()
@@ -304,7 +307,8 @@ def main():
         try:
             for e in json.load(open(pmc)):
                 if (e.get("model") == name and e.get("N") == N and e.get("K") == K and e.get("batch") == B
-                        and e.get("workload", "r01") == args.workload and bool(e.get("moving", False)) == bool(args.moving)):
+                        and e.get("workload", "r01") == args.workload and bool(e.get("moving", False)) == bool(args.moving)
+                        and int(e.get("cond_N", 0) or 0) == (args.cond_N if cond_applied else 0)):
                     if e.get("lib_sha256") == lib_hash:
                         traffic, traffic_note = e.get("hbm_bytes_per_launch"), "profile %s (git %s), same library sha256" % (e.get("round"), e.get("git_head"))
                     elif traffic is None:
@@ -368,13 +372,15 @@ def main():
                             % (baseline_config(name, B, world, N, K, args.moving), B, name, N, N * dt, dt, steps, K,
                                "moving" if args.moving else "static", wl["generator"], sigma, mask),
                 "ocp": name, "instances_per_gpu": B, "instances_total": world * B, "horizon": N, "obstacles": K,
-                "qp_solver_cond_N": ("%d requested, not applied (uncondensed Riccati over the %d stages; DESIGN.md section 6)" % (args.cond_N, N))
-                if (args.cond_N and args.cond_N != N) else N,
+                "qp_solver_cond_N": args.cond_N if cond_applied else N,
+                "qp_formulation": ("partially condensed on the device: %d stages -> %d dense stages of %d, IPM + Riccati on those, expansion "
+                                   "(csrc/cond_ipm.hpp)" % (N, args.cond_N, N // args.cond_N)) if cond_applied
+                else "uncondensed: Riccati over the %d stages (blocks of one stage, the reference's own setting)" % N,
                 "lib_sha256": lib_hash,
                 "sharding": "batch-sharded x%d, no data-path collective" % world, "ranks_seen": ranks_seen,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "usv_qp_rti",
+                "bound": "hbm", "kernel": "usv_qp_cond" if cond_applied else "usv_qp_rti",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_note,
                 "traffic_GBs": (traffic / qp_avg_s / 1e9) if traffic else None,
@@ -382,7 +388,7 @@ def main():
                 "traffic_over_algorithmic": (traffic / (balg * B)) if traffic else None,
                 "fp64_alg_tflops": fp64_tflops, "fp64_frac": fp64_tflops / FP64_PEAK_TFLOPS,
                 "algorithmic_bytes_per_solve": balg, "algorithmic_flops_per_solve": falg,
-                "kernel_ms": {"usv_linearize": float(lin_ms.mean()), "usv_qp_rti": float(qp_ms.mean())},
+                "kernel_ms": {"usv_linearize": float(lin_ms.mean()), ("usv_qp_cond" if cond_applied else "usv_qp_rti"): float(qp_ms.mean())},
                 "kernel_ms_note": ("with pipeline_linearize (default for >= 16384 instances) the lineariser of tick t + 1 runs on a second stream "
                                    "in the tail of tick t's QP launch; kernel_ms.usv_linearize is then only the fix-up pass for the instances "
                                    "it had to skip (--option pipeline_linearize=0 shows the full lineariser)") if pipelined else None,

@@ -120,8 +120,9 @@ class AcadosOcpOptions:
         self.nlp_solver_tol_eq = None
         self.nlp_solver_tol_ineq = None
         self.nlp_solver_tol_comp = None
-        # accepted for compatibility: block condensing is a reformulation of the same KKT system, the Riccati sweep
-        # works on the uncondensed stages whatever the block size
+        # acados' qp_solver_cond_N: None / N (what the reference leaves it at) = blocks of one stage, i.e. the Riccati sweep over
+        # the N stages; a smaller value that divides N condenses the QP to that many dense stages on the device first
+        # (csrc/cond_ipm.hpp; hard rows only - DESIGN.md section 6 has the measured comparison of the two)
         self.qp_solver_cond_N = None
         self.qp_solver_warm_start = 0   # 0 (cold start of every QP, the acados default) is the only mode built
         self.nlp_solver_step_length = 1.0
@@ -193,6 +194,13 @@ class BatchOcpSolver:
         if rc != 0:
             raise RuntimeError("usvmpc_create failed (%d): no usable HIP device or bad description" % rc)
         self._h = h
+        cn = getattr(ocp.solver_options, "qp_solver_cond_N", None)
+        if cn is not None and int(cn) != self.N:
+            rc = self._lib.usvmpc_set_option(self._h, b"qp_cond_N", float(int(cn)))
+            if rc != 0:
+                msg = self._lib.usvmpc_last_error(self._h).decode()
+                self.close()
+                raise Exception("qp_solver_cond_N = %d: %s" % (int(cn), msg))
         # acados_create(): x trajectory = constraints.x0, u = 0, yref / p / lh from the ocp
         x0 = np.zeros(self.nx) if ocp.constraints.x0 is None else np.asarray(ocp.constraints.x0, dtype=float)
         self.set_all("x", np.tile(x0, (self.B, self.N + 1, 1)))

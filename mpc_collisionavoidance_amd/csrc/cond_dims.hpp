@@ -1,0 +1,60 @@
+// cond_dims.hpp — sizes and scratch layout of the partially condensed QP of one instance (cond_ipm.hpp), host and device.
+#pragma once
+#include "params.hpp"
+#include <algorithm>
+
+namespace usv {
+
+// sizes and scratch offsets (doubles) of the condensed QP of one instance; host and device
+struct CondDims {
+    int Mb, N2, nuh, nzh, nxr, R, nrows, nbu, nbx, K;
+    int xr[LANES];        // states that some row touches (bounded, position), ascending
+    int xr_of[LANES];     // state -> index in xr, or -1
+    int uvar[LANES];      // u rows: control index;  xvar: x rows: index into xr
+    int xvar[LANES];
+    int ipx, ipy;         // index in xr of the position states (-1 without obstacle rows)
+    // per block
+    long o_SR, o_cr, o_BA, o_bt, o_H0, o_g0, o_row, o_Luu, o_P, o_Pb, o_w, o_pi, o_rg, o_rb, o_dwa, o_dw, o_dpi, o_p, o_lus, blk;
+    long total;           // (N2 + 1) * blk
+    long lds_doubles;     // LDS the kernel needs (doubles), for NT threads
+};
+
+inline bool cond_dims(const DevSpec &S, int nx, int nu, int ipx, int ipy, int N2, int nt, CondDims &D)
+{
+    if (N2 < 1 || N2 >= S.N || S.N % N2) return false;
+    D.Mb = S.N / N2; D.N2 = N2; D.nuh = D.Mb * nu; D.nzh = D.nuh + nx; D.K = S.K;
+    D.nbu = D.nbx = D.nxr = 0;
+    for (int i = 0; i < LANES; i++) { D.xr_of[i] = -1; D.xr[i] = D.uvar[i] = D.xvar[i] = 0; }
+    for (int l = 0; l < nu; l++) if (S.has_b[l]) D.uvar[D.nbu++] = l;
+    for (int s = 0; s < nx; s++)
+        if (S.has_b[nu + s] || (S.K > 0 && (s == ipx || s == ipy))) { D.xr_of[s] = D.nxr; D.xr[D.nxr++] = s; }
+    for (int s = 0; s < nx; s++) if (S.has_b[nu + s]) D.xvar[D.nbx++] = D.xr_of[s];
+    D.ipx = S.K > 0 ? D.xr_of[ipx] : -1; D.ipy = S.K > 0 ? D.xr_of[ipy] : -1;
+    D.R = D.nbu + D.nbx + S.K; D.nrows = D.Mb * D.R;
+    long o = 0;
+    auto take = [&](long n) { const long at = o; o += (n + 15) / 16 * 16; return at; }; // 128-byte pieces
+    D.o_SR = take((long)D.Mb * D.nxr * D.nzh); D.o_cr = take((long)D.Mb * D.nxr);
+    D.o_BA = take((long)nx * D.nzh); D.o_bt = take(nx);
+    D.o_H0 = take((long)D.nzh * D.nzh); D.o_g0 = take(D.nzh);
+    D.o_row = take(8L * D.nrows);            // ll, lu, tl, tu, dl, du, cx, cy
+    D.o_Luu = take((long)D.nzh * D.nuh);     // [Luu; Lxu]: the first nuh columns of the eliminated stage matrix
+    D.o_P = take((long)nx * nx);             // P_{i+1}
+    D.o_Pb = take(nx);
+    D.o_w = take(D.nzh); D.o_pi = take(nx); D.o_rg = take(D.nzh); D.o_rb = take(nx);
+    D.o_dwa = take(D.nzh); D.o_dw = take(D.nzh); D.o_dpi = take(nx); D.o_p = take(nx); D.o_lus = take(D.nuh);
+    D.blk = o;
+    D.total = (long)(N2 + 1) * D.blk;
+    const int nz = nx + nu;
+    long l = 0;
+    l += (long)(D.nzh + 1) * D.nzh;                                       // Gm
+    l += std::max<long>((long)D.Mb * D.nxr * D.nzh, 2L * nx * D.nzh + (long)nz * D.nzh); // SRm | (Sm, Sn, Tm) while condensing
+    l += 2L * nx * D.nzh;                                                 // BAm, PBm
+    l += (long)nx * nx + (long)nx * nz;                                   // Pn, BAk
+    l += 4L * D.Mb * D.nxr + 3L * D.Mb * D.nxr + D.Mb + 3L * D.nuh;       // expansions, slots
+    l += 5L * nt + 64;                                                    // obstacle-row buffer of one pass, reductions
+    l += 8L * D.nzh + 12L * nx + 2L * D.nuh + 2L * nz + (long)D.Mb * nz + (long)D.Mb * D.nxr; // vectors
+    D.lds_doubles = l + 64;
+    return true;
+}
+
+} // namespace usv

@@ -1,0 +1,105 @@
+// cond_kernels.hip — the partial-condensing kernels (cond_ipm.hpp) and their launch, per model.
+// Compiled on its own for the shipped library (__graft_entry__.build_hip) or included at the end of usvmpc.hip.
+#include "gfx950/lanes.hpp"
+
+#include "../../include/usvmpc.h"
+#include "cond_launch.hpp"
+#include "cond_ipm.hpp"
+#include "models.hpp"
+#ifdef USV_GEN_MODEL_HEADER
+#include USV_GEN_MODEL_HEADER
+#endif
+
+namespace usv {
+
+#ifndef USV_COND_THREADS
+#define USV_COND_THREADS 64
+#endif
+
+// One instance per workgroup of NT threads, the condensed block's matrices in LDS, the instance's condensed QP in the
+// workgroup's scratch area in HBM; workgroups pull further instances from the queue as they finish.
+template <class M, int KCH, int NT>
+__global__ void __launch_bounds__(NT) usv_qp_cond(DevPtrs P, const CondDims *Dp, double *scratch, int nB, int queue0)
+{
+    extern __shared__ double cond_lds[];
+    __shared__ int nxt;
+    CondIpm<M, KCH, CondTeam<NT>> q(P, *Dp, scratch + (long)blockIdx.x * Dp->total, cond_lds);
+    long g = blockIdx.x;
+    while (g < nB) {
+        q.solve(g);
+        if (threadIdx.x == 0) nxt = queue0 + atomicAdd(P.queue, 1);
+        __syncthreads();
+        g = nxt;
+        __syncthreads();
+    }
+}
+
+namespace {
+
+template <class M, int KCH>
+int prepare_for(const DevSpec &S, int N2, CondDims &D, size_t &lds, int &nb, std::string &err)
+{
+    constexpr int NT = USV_COND_THREADS;
+    auto kern = &usv_qp_cond<M, KCH, NT>;
+    if (!cond_dims(S, M::NX, M::NU, M::IPX, M::IPY, N2, NT, D)) { err = "qp_cond_N must divide N"; return USVMPC_E_ARG; }
+    lds = (size_t)D.lds_doubles * sizeof(double);
+    if (lds > 160u * 1024u) { err = "partial condensing: the condensed block does not fit in LDS (block too large)"; return USVMPC_E_ARG; }
+    nb = 0;
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NT, lds) != hipSuccess) {
+        err = "partial condensing: the kernel cannot be launched with this much LDS";
+        return USVMPC_E_HIP;
+    }
+    return 0;
+}
+
+template <class M, int KCH>
+int run_for(hipStream_t st, long teams, size_t lds, const DevPtrs &P, const CondDims *dD, double *scratch, int B)
+{
+    constexpr int NT = USV_COND_THREADS;
+    hipLaunchKernelGGL((usv_qp_cond<M, KCH, NT>), dim3((unsigned)teams), dim3(NT), lds, st, P, dD, scratch, B, (int)teams);
+    return 0;
+}
+
+} // namespace
+
+// (hard rows only: usv_model has none, usv_model_pf_ca has hard obstacle rows; usv_model_guidance_ca1's are soft)
+#define USV_COND_DISPATCH(CALL)                                                                                      \
+    switch (model) {                                                                                                 \
+    USV_COND_BUILTIN(CALL)                                                                                           \
+    USV_COND_GENERATED(CALL)                                                                                         \
+    }
+
+#if defined(USV_GEN_ONLY)
+#define USV_COND_BUILTIN(CALL)
+#elif defined(USV_BENCH_ONLY)
+#define USV_COND_BUILTIN(CALL) case USVMPC_MODEL_PF_CA: if (kch <= 1) return CALL(ModelM2, 1); break;
+#else
+#define USV_COND_BUILTIN(CALL)                                                                                       \
+    case USVMPC_MODEL_USV: return CALL(ModelM0, 0);                                                                  \
+    case USVMPC_MODEL_PF_CA: return kch <= 1 ? CALL(ModelM2, 1) : CALL(ModelM2, 2);
+#endif
+#if defined(USV_GEN_MODEL_HEADER) && !defined(USV_BENCH_ONLY)
+#define USV_COND_GENERATED(CALL) case USVMPC_MODEL_GENERATED: if (!(USV_GEN_SOFT != 0)) return CALL(ModelGen, USV_GEN_KCH); break;
+#else
+#define USV_COND_GENERATED(CALL)
+#endif
+
+int cond_prepare(int model, int kch, const DevSpec &S, int N2, CondDims &D, size_t &lds_bytes, int &blocks_per_cu, std::string &err)
+{
+#define USV_COND_PREP(M, K) prepare_for<M, K>(S, N2, D, lds_bytes, blocks_per_cu, err)
+    USV_COND_DISPATCH(USV_COND_PREP)
+#undef USV_COND_PREP
+    err = "partial condensing: no kernel for this model in this library (hard rows only)";
+    return USVMPC_E_ARG;
+}
+
+int cond_run(int model, int kch, hipStream_t st, long teams, size_t lds_bytes, const DevPtrs &P, const CondDims *dD, double *scratch, int B)
+{
+#define USV_COND_RUN(M, K) run_for<M, K>(st, teams, lds_bytes, P, dD, scratch, B)
+    USV_COND_DISPATCH(USV_COND_RUN)
+#undef USV_COND_RUN
+    return -1;
+}
+
+} // namespace usv

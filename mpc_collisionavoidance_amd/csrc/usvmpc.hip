@@ -14,6 +14,7 @@
 #include "linearize.hpp"
 #include "models.hpp"
 #include "qp_ipm.hpp"
+#include "cond_launch.hpp"
 #ifdef USV_GEN_MODEL_HEADER // a model generated from a symbolic definition (codegen.py): struct ModelGen
 #include USV_GEN_MODEL_HEADER
 #endif
@@ -279,6 +280,13 @@ struct usvmpc_handle {
     bool spec_valid;          // ... and nothing it read has been changed by the caller since
     bool spec_outstanding;    // the second stream may still be writing the lineariser's planes
     const int *spec_perm;     // the group -> instance map it used (= the map the solve spec_for must use)
+    // partial condensing (option "qp_cond_N"): RTI solves condense the QP to cond_N2 stages first (0: off - the Riccati sweep over the N stages)
+    int cond_N2;
+    CondDims cond_dims;       // sizes of the condensed QP (valid when d_cond_dims is set)
+    CondDims *d_cond_dims;
+    double *d_cond_scratch;   // [cond_teams][cond_dims.total]
+    long cond_teams;
+    size_t cond_lds;          // dynamic LDS of the condensing kernel, bytes
     long export_at;           // nsolves the multiplier read-back buffers (ptrs.lam_out / t_out) were filled at; -1: never
     bool layout_dirty;        // the row layout option changed after the last solve: the workspace cannot be read back
     size_t bytes;
@@ -501,6 +509,46 @@ int copy_field(usvmpc_handle *h, const char *field, int stage, double *host, siz
     return 0;
 }
 
+// the condensed QP solve of an RTI iteration (after the lineariser): buffers on first use; the kernels live in cond_kernels.hip
+int launch_cond(usvmpc_handle *h)
+{
+    if (!h->d_cond_dims) {
+        CondDims D;
+        size_t lds = 0;
+        int nb = 0;
+        const int rcp = cond_prepare(h->desc.model, h->kch, h->spec, h->cond_N2, D, lds, nb, h->err);
+        if (rcp) return rcp;
+        if (nb < 1 || h->ncu < 1) { h->err = "partial condensing: the kernel cannot be launched with this much LDS"; return USVMPC_E_HIP; }
+        long teams = std::min<long>(h->B, (long)nb * h->ncu);
+        if (h->max_waves > 0) teams = std::min<long>(teams, h->max_waves);
+        if (dev_alloc(h, &h->d_cond_dims, 1, false)) return USVMPC_E_HIP;
+        if (dev_alloc(h, &h->d_cond_scratch, (size_t)teams * (size_t)D.total, true)) return USVMPC_E_HIP;
+        HIP_TRY(h, hipMemcpyAsync(h->d_cond_dims, &D, sizeof(CondDims), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream)); // (D is a local)
+        h->cond_dims = D; h->cond_teams = teams; h->cond_lds = lds;
+    }
+    HIP_TRY(h, hipMemsetAsync(h->ptrs.queue, 0, sizeof(int), h->stream));
+    if (h->ptrs.lam_out) { // multiplier read-back: this solve fills the buffers (rows a stage does not have read 0)
+        const size_t nbytes = (size_t)h->B * (h->N + 1) * (size_t)(h->ptrs.nlam > 0 ? h->ptrs.nlam : 1) * sizeof(double);
+        HIP_TRY(h, hipMemsetAsync(h->ptrs.lam_out, 0, nbytes, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->ptrs.t_out, 0, nbytes, h->stream));
+        h->export_at = h->nsolves + 1;
+    }
+    if (cond_run(h->desc.model, h->kch, h->stream, h->cond_teams, h->cond_lds, h->ptrs, h->d_cond_dims, h->d_cond_scratch, h->B)) {
+        h->err = "partial condensing: no kernel for this model in this library";
+        return USVMPC_E_ARG;
+    }
+    h->map_changed = true; // (the group-indexed workspace holds no multipliers of this QP: a later full SQP starts afresh)
+    return 0;
+}
+
+void cond_release(usvmpc_handle *h)
+{
+    if (h->d_cond_scratch) dev_free(h, h->d_cond_scratch, (size_t)h->cond_teams * (size_t)h->cond_dims.total * sizeof(double));
+    if (h->d_cond_dims) dev_free(h, h->d_cond_dims, sizeof(CondDims));
+    h->d_cond_scratch = nullptr; h->d_cond_dims = nullptr; h->cond_teams = 0;
+}
+
 template <class M, int KCH, bool SOFT>
 int launch_pair(usvmpc_handle *h, int phase)
 {
@@ -529,7 +577,8 @@ int launch_pair(usvmpc_handle *h, int phase)
             hipLaunchKernelGGL((usv_linearize<M, KCH, SOFT, false, MODE>), dim3((unsigned)lin_grid), dim3(lin_block), 0, st, P, lin_groups);
     };
     // Pipelined lineariser (see usvmpc_handle): RTI solves of large handles
-    const bool pipe = phase == 0 && h->pipeline && !h->mirror && !h->extern_access && h->dynamic_rows && h->B >= 16384;
+    const bool cond = phase == 0 && h->cond_N2 > 0; // RTI solve on the partially condensed QP (cond_ipm.hpp)
+    const bool pipe = phase == 0 && h->pipeline && !h->mirror && !h->extern_access && h->dynamic_rows && h->B >= 16384 && !cond;
     if (pipe && !h->aux_stream) {
         // (lowest priority: when this stream's lineariser and the main stream's QP launch become eligible together, the QP
         // launch's workgroups are placed first and the lineariser gets the compute units that launch vacates)
@@ -672,6 +721,10 @@ int launch_pair(usvmpc_handle *h, int phase)
         return 0;
     };
     int rcq = 0;
+    if (cond) {
+        if constexpr (SOFT) { h->err = "partial condensing (qp_cond_N) is implemented for hard rows"; return USVMPC_E_ARG; }
+        else rcq = launch_cond(h);
+    } else {
 #ifdef USV_BENCH_ONLY // development builds (tools/dev_build.sh): only the instantiation the bench workload runs
     if (!(h->spec.hdiag && pack && !h->spec.any_bsoft)) { h->err = "development build: bench instantiation only"; return USVMPC_E_ARG; }
     // (one row pass when every box row rides in a slot lane: qp_ipm.hpp, MERGE)
@@ -698,6 +751,7 @@ int launch_pair(usvmpc_handle *h, int phase)
         rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, false, CANPACK, false>, nullptr) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, false>, nullptr);
     }
 #endif
+    }
     if (rcq) return rcq;
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[2], h->stream));
@@ -790,6 +844,12 @@ int ensure_export(usvmpc_handle *h)
         h->export_at = -1;
     }
     if (h->export_at == h->nsolves) return 0;
+    if (h->cond_N2 > 0) {
+        // the partially condensed solve keeps its rows in per-workgroup scratch: it writes "lam" / "t" itself, when the buffers exist
+        h->err = "\"lam\" / \"t\" of a partially condensed solve (qp_cond_N) are written by the solve itself: the buffers exist from now on "
+                 "(option \"keep_multipliers\" = 1 creates them up front) - solve again";
+        return USVMPC_E_ARG;
+    }
     const size_t nbytes = (size_t)h->B * (h->N + 1) * (size_t)(P.nlam > 0 ? P.nlam : 1) * sizeof(double);
     HIP_TRY(h, hipMemsetAsync(P.lam_out, 0, nbytes, h->stream));
     HIP_TRY(h, hipMemsetAsync(P.t_out, 0, nbytes, h->stream));
@@ -886,6 +946,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->d_epoch = nullptr; h->d_redo = nullptr; h->d_perm2 = nullptr;
     h->spec_for = -1; h->spec_valid = false; h->spec_outstanding = false; h->spec_perm = nullptr;
     h->noise_mask = ~0u;
+    h->cond_N2 = 0; h->d_cond_dims = nullptr; h->d_cond_scratch = nullptr; h->cond_teams = 0; h->cond_lds = 0;
     h->dynamic_rows = true;
     h->qp_cap = 0;
     h->aux_lds = true;
@@ -1253,7 +1314,31 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         if (!h->sort_enabled && h->ptrs.perm) { h->ptrs.perm = nullptr; h->map_changed = true; }
         return 0;
     }
-    if (s == "max_waves") { h->max_waves = (long)value; return 0; }
+    if (s == "max_waves") { h->max_waves = (long)value; cond_release(h); return 0; }
+    if (s == "keep_multipliers") { // create the "lam" / "t" buffers now (a partially condensed solve fills them only if they exist)
+        if (value == 0.0) return 0;
+        DevPtrs &P = h->ptrs;
+        if (!P.lam_out) {
+            HIP_TRY(h, hipSetDevice(h->device));
+            P.nlam = lam_len(h->spec, h->soft);
+            const size_t cnt = (size_t)h->B * (h->N + 1) * (size_t)(P.nlam > 0 ? P.nlam : 1);
+            if (dev_alloc(h, &P.lam_out, cnt, false)) return USVMPC_E_HIP;
+            if (dev_alloc(h, &P.t_out, cnt, false)) { P.lam_out = nullptr; return USVMPC_E_HIP; }
+            h->export_at = -1;
+        }
+        return 0;
+    }
+    if (s == "qp_cond_N") { // acados qp_solver_cond_N: stages of the partially condensed QP; 0 or N: no condensing (the default)
+        const int n2 = (int)value;
+        if (n2 < 0 || n2 > h->N) { h->err = "qp_cond_N must lie in 0..N"; return USVMPC_E_ARG; }
+        const int want = (n2 == 0 || n2 == h->N) ? 0 : n2;
+        if (want > 0) {
+            if (h->N % want) { h->err = "qp_cond_N must divide N (equal blocks)"; return USVMPC_E_ARG; }
+            if (h->soft || h->spec.any_bsoft) { h->err = "partial condensing (qp_cond_N) is implemented for hard rows"; return USVMPC_E_ARG; }
+        }
+        if (want != h->cond_N2) { cond_release(h); h->cond_N2 = want; h->map_changed = true; }
+        return 0;
+    }
     if (s == "sort_two_ticks") { h->sort_two = value != 0.0; return 0; }
     if (s == "aux_in_lds") { h->aux_lds = value != 0.0; h->aux_cap = 0; return 0; }
     if (s == "lds_workspace") { // -1: when the batch is small (default), 0: never, 1: whenever an instance's planes fit in LDS
@@ -1500,3 +1585,7 @@ size_t usvmpc_device_bytes(usvmpc_handle *h) { return h ? h->bytes : 0; }
 const char *usvmpc_last_error(usvmpc_handle *h) { return h ? h->err.c_str() : "null handle"; }
 
 } // extern "C"
+
+#ifndef USV_COND_SEPARATE // (one translation unit by default - generated-model and development builds; the shipped library compiles it on its own)
+#include "cond_kernels.hip"
+#endif

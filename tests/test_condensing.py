@@ -1,15 +1,19 @@
 """Partial condensing (BASELINE.json configs[4]: N = 80 -> N2 = 10, 20 moving obstacles).
 
-The product solves the QP on its uncondensed stages: partial condensing is a reformulation of the same QP (HPIPM
-d_part_cond_qp eliminates the intermediate states of a block), chosen by the reference only by solver NAME
-(qp_solver = PARTIAL_CONDENSING_HPIPM with qp_solver_cond_N left at N: scripts/usv_pf_ca/acados_settings.py:172).
-These tests hold the product against an oracle that REALLY condenses: oracle/condense.py (numpy) builds the condensed QP
-- dense block Hessians, every intermediate-stage inequality as a dense general row in (u_hat, x_k0) - solves it with the
-oracle's own Mehrotra IPM on the N2 dense stages and expands the solution.
+The reference selects partial condensing only by solver NAME (qp_solver = PARTIAL_CONDENSING_HPIPM with qp_solver_cond_N
+left at N - blocks of one stage: scripts/usv_pf_ca/acados_settings.py:172); for that setting the Riccati sweep over the N
+stages (csrc/qp_ipm.hpp) is the solver.  With qp_solver_cond_N = N2 < N the product condenses on the device
+(csrc/cond_ipm.hpp, option "qp_cond_N"): HPIPM d_part_cond_qp restated - block Hessians, dense block dynamics, every
+intermediate-stage inequality a general row in (u_hat, x_k0) -, the IPM on the N2 dense stages, expansion of (x, u, pi).
+The oracle for it is oracle/condense.py (numpy: part_cond + the oracle's Mehrotra IPM on the dense stages + expand).
 
 CPU: the condensing oracle against the C oracle (uncondensed) - same solution, and from a point on the linearised
-dynamics (b = 0) the same IPM iterates.  GPU (`-m gpu`): the HIP path at BASELINE configs[4]'s shape, B = 256, against the
-condensing oracle:
+dynamics (b = 0) the same IPM iterates; the condensing KERNEL BODY (cond_ipm.hpp compiled serially into the emulator
+library, one CPU thread playing the team of an instance) against the condensing oracle - same statuses, same iteration
+counts, iterates to 1e-9 - and its expanded (x, u, pi, lam, t) against the KKT conditions of the UNCONDENSED QP.
+GPU (`-m gpu`): at BASELINE configs[4]'s shape, B = 256, (a) the condensing kernel against the condensing oracle
+(identical iteration path: iterates to 1e-8), against the uncondensed kernel (same solution inside the IPM tolerance ball)
+and KKT-certified on the uncondensed QP; (b) the uncondensed kernel against the condensing oracle as before:
   * tick 0 (the rolled-out guess satisfies the dynamics, so both cold starts coincide): status of every instance,
     median error <= 1e-9, 90 % of the instances <= 1e-6, all <= 1e-3 (per-component norm of tests/util.py; measured
     median 4e-10, 90th percentile 2e-7, worst 3e-5 - 80 stages of a model whose controls are weakly determined);
@@ -18,12 +22,14 @@ condensing oracle:
     within 5e-2; and, independent of that ball, the device's step is a feasible point of the CONDENSED QP (violation of
     its dense rows <= 1e-6, block dynamics <= 1e-8) with the condensing oracle's optimal objective to 1e-6 relative.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
-from mpc_collisionavoidance_amd import BatchOcpSolver, scenario, usv_models
+from mpc_collisionavoidance_amd import BatchOcpSolver, _capi, scenario, usv_models
 from oracle import condense
-from tests import util
+from tests import kkt, util
 
 NAME = "usv_model_pf_ca"
 
@@ -68,6 +74,157 @@ def test_condensed_qp_has_dense_rows_and_block_dimensions(oracle):
     assert np.count_nonzero(last[:M * 2]) >= 2 * (M - 1) - 2 and np.count_nonzero(last[M * 2:]) >= 5
 
 
+# ------------------------------------------------------------------------------ the condensing kernel body on the CPU
+def _emu_cond_rti(emu, desc, wl, x, u, N2, export=False):
+    from tests.test_emu_kernels import emu_rti
+    emu.usv_emu_set_cond.argtypes = [C.c_int]
+    emu.usv_emu_set_export.argtypes = [_capi._dp, _capi._dp]
+    emu.usv_emu_set_export.restype = None
+    B, N = x.shape[0], desc.N
+    nlam = 2 * (desc.nbu + desc.nbx + desc.K)
+    lam, t = np.zeros((B, N + 1, nlam)), np.zeros((B, N + 1, nlam))
+    emu.usv_emu_set_cond(N2)
+    if export:
+        emu.usv_emu_set_export(lam.ctypes.data_as(_capi._dp), t.ctypes.data_as(_capi._dp))
+    try:
+        r = emu_rti(emu, desc, wl, x, u)
+    finally:
+        emu.usv_emu_set_cond(0)
+        emu.usv_emu_set_export(None, None)
+    r["lam"], r["t"] = lam, t
+    return r
+
+
+# (blocks of 4 stages; two obstacle chunks; a model without obstacle rows; blocks of 2)
+@pytest.mark.parametrize("name,N,K,B,N2", [("usv_model_pf_ca", 16, 4, 4, 4), ("usv_model_pf_ca", 12, 18, 2, 3),
+                                           ("usv_model", 8, 0, 3, 2), ("usv_model_pf_ca", 12, 3, 2, 6)])
+def test_condensing_kernel_body_matches_condensing_oracle(oracle, emu, name, N, K, B, N2):
+    dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
+    wl = scenario.make_bench_batch(name, N, K, B, moving=K > 0, seed=5)
+    ocp = usv_models.make_ocp(name, N * dt, N, None if name == "usv_model" else K)
+    ocp.solver_options.sim_method_num_steps = steps
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    spec = oracle.spec(util.MODEL_ID[name], N, N * dt, K, sim_steps=steps)
+    x, u = wl["x_init"].copy(), wl["u_init"].copy()
+    for tick in range(3):
+        r = _emu_cond_rti(emu, desc, wl, x, u, N2)
+        for b in range(B):
+            c = condense.rti_condensed(oracle, spec, x[b], u[b], wl["x0"][b], wl["yref"][b], wl["yref_e"][b], wl["p"][b], wl["lh"][b], N2)
+            assert r["status"][b] == c["status"] and r["qp_status"][b] == c["qp_status"] and r["qp_iter"][b] == c["qp_iter"]
+            e = max(util.rel_err(r["x"][b], c["x"]), util.rel_err(r["u"][b], c["u"]))
+            assert e < 1e-9, (tick, b, e)
+            assert np.allclose(r["res"][b], c["res"], rtol=1e-3, atol=1e-12)
+        x, u = r["x"], r["u"]
+        wl["x0"] = x[:, 1].copy()   # closed loop: the dynamics residual is non-zero from the second tick on
+
+
+def test_condensing_kernel_body_solution_is_certified_on_the_uncondensed_qp(oracle, emu):
+    """Expansion (x, u by the original dynamics, pi by the adjoint recursion inside a block) and the multiplier read-back
+    of the condensed solve: together they must satisfy the KKT conditions of the ORIGINAL N-stage QP."""
+    name, N, K, B, N2 = "usv_model_pf_ca", 40, 10, 3, 5
+    dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
+    wl = scenario.make_bench_batch(name, N, K, B, seed=11)
+    ocp = usv_models.make_ocp(name, N * dt, N, K)
+    ocp.solver_options.sim_method_num_steps = steps
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    spec = oracle.spec(util.MODEL_ID[name], N, N * dt, K, sim_steps=steps)
+    x, u = wl["x_init"].copy(), wl["u_init"].copy()
+    active = 0
+    for it in range(2):
+        r = _emu_cond_rti(emu, desc, wl, x, u, N2, export=True)
+        qp = kkt.linearize_batch(oracle, spec, x, u, wl["x0"], wl["yref"], wl["yref_e"], wl["p"], wl["lh"])
+        ok = r["qp_status"] == 0
+        assert ok.all()
+        dz = np.zeros((B, N + 1, 16))
+        dz[:, :, 2:] = r["x"] - x
+        dz[:, :N, :2] = r["u"] - u
+        pi = np.concatenate([np.zeros((B, 1, 14)), r["pi"]], axis=1)
+        res = kkt.kkt_batch(qp, dz, pi, r["lam"], r["t"])
+        assert kkt.certified(res).all(), res
+        nrow = desc.nbu + desc.nbx + K
+        active += int((r["lam"][:, :, desc.nbu + desc.nbx:nrow] > 1e-3).any(axis=(1, 2)).sum())
+        x, u = r["x"], r["u"]
+    assert active > 0
+
+
+# ------------------------------------------------------------------------------ the condensing kernel on the device
+def _cond_solver(name, N, K, B, wl, N2, extra=()):
+    dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
+    ocp = usv_models.make_ocp(name, N * dt, N, None if name == "usv_model" else K)
+    ocp.solver_options.sim_method_num_steps = steps
+    if N2:
+        ocp.solver_options.qp_solver_cond_N = N2
+    s = BatchOcpSolver(ocp, B)
+    scenario.load_into(s, wl)
+    for k, v in extra:
+        s.set_option(k, v)
+    return s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,N,K,B,N2", [("usv_model_pf_ca", 80, 20, 96, 10), ("usv_model_pf_ca", 40, 10, 160, 8),
+                                           ("usv_model", 20, 0, 70, 4)])
+def test_condensing_kernel_on_the_device_vs_condensing_oracle(oracle, name, N, K, B, N2):
+    """qp_solver_cond_N = N2 is APPLIED: the device condenses, solves the N2 dense stages and expands.  Same iteration path as
+    oracle/condense.py: statuses, iteration counts (one off for at most 2 % - a convergence test decided by the last bit) and
+    iterates to 1e-8; the uncondensed kernel reaches the same solution inside the IPM's tolerance ball."""
+    wl = scenario.make_bench_batch(name, N, K, B, moving=K > 0, seed=1234)
+    dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
+    spec = oracle.spec(util.MODEL_ID[name], N, N * dt, K, sim_steps=steps)
+    sc, su_ = _cond_solver(name, N, K, B, wl, N2), _cond_solver(name, N, K, B, wl, 0)
+    x, u = wl["x_init"].copy(), wl["u_init"].copy()
+    x0 = wl["x0"].copy()
+    for tick in range(2):
+        st = sc.solve()
+        stu = su_.solve()
+        xg, ug, qs, qi = sc.get_all("x"), sc.get_all("u"), sc.get_int("qp_status"), sc.get_int("qp_iter")
+        xu, uu, qsu = su_.get_all("x"), su_.get_all("u"), su_.get_int("qp_status")
+        worst, off = 0.0, 0
+        for b in range(B):
+            c = condense.rti_condensed(oracle, spec, x[b], u[b], x0[b], wl["yref"][b], wl["yref_e"][b], wl["p"][b], wl["lh"][b], N2)
+            assert st[b] == c["status"] and qs[b] == c["qp_status"], (tick, b, st[b], c["status"], qs[b], c["qp_status"])
+            assert abs(int(qi[b]) - int(c["qp_iter"])) <= 1
+            off += int(qi[b] != c["qp_iter"])
+            if c["qp_status"] == 0 and qi[b] == c["qp_iter"]:
+                worst = max(worst, util.rel_err(xg[b], c["x"]), util.rel_err(ug[b], c["u"]))
+        assert off <= max(1, int(0.02 * B)), off
+        assert worst <= 1e-8, worst
+        # against the uncondensed kernel: same statuses (up to the few instances that sit on a tolerance), same solution
+        both = (qs == 0) & (qsu == 0)
+        assert (st != stu).sum() <= max(1, int(0.02 * B)) and both.mean() > 0.9
+        e = np.maximum(util.rel_err_per_instance(xg[both], xu[both]), util.rel_err_per_instance(ug[both], uu[both]))
+        assert np.median(e) <= 1e-7 and e.max() <= 5e-2, (np.median(e), e.max())
+        print("cond vs oracle", name, tick, "worst", worst, "iter off", off, "| vs uncondensed kernel: median", np.median(e), "max", e.max())
+        # next tick: both solvers continue from the condensed solver's iterate, x0 <- x1
+        x, u = xg, ug
+        x0 = xg[:, 1].copy()
+        for s in (sc, su_):
+            s.set_all("x", x); s.set_all("u", u); s.set("x0", 0, x0)
+    sc.close(); su_.close()
+
+
+@pytest.mark.gpu
+def test_condensing_kernel_solutions_are_certified_on_the_uncondensed_qp(oracle):
+    """(x, u, pi, lam, t) of the condensed device solve against the KKT conditions of the ORIGINAL N-stage QP (tests/kkt.py),
+    closed loop on the bench workload's generator: expansion and multiplier read-back included."""
+    from tests.test_kkt_certify import _certify_closed_loop
+    out = _certify_closed_loop(oracle, "usv_model_pf_ca", 40, 10, 512, 4, options=(("keep_multipliers", 1), ("qp_cond_N", 5)))
+    assert out["kkt_certified_frac"] == 1.0 and out["active_row_frac"] > 0.3, out
+
+
+@pytest.mark.gpu
+def test_condensing_option_is_refused_where_it_is_not_built():
+    wl = scenario.make_bench_batch("usv_model_guidance_ca1", 20, 4, 8, seed=3)
+    with pytest.raises(Exception, match="hard rows"):
+        _cond_solver("usv_model_guidance_ca1", 20, 4, 8, wl, 5)
+    wl = scenario.make_bench_batch("usv_model_pf_ca", 20, 4, 8, seed=3)
+    with pytest.raises(Exception, match="divide"):
+        _cond_solver("usv_model_pf_ca", 20, 4, 8, wl, 3)
+    s = _cond_solver("usv_model_pf_ca", 20, 4, 8, wl, 20)   # N2 = N: no condensing, the default path
+    assert (s.solve() == 0).all()
+    s.close()
+
+
 @pytest.mark.gpu
 def test_config4_shape_hip_vs_condensing_oracle(oracle):
     N, K, B, N2 = 80, 20, 256, 10
@@ -78,7 +235,7 @@ def test_config4_shape_hip_vs_condensing_oracle(oracle):
     def solver():
         ocp = usv_models.make_ocp(NAME, N * dt, N, K)
         ocp.solver_options.sim_method_num_steps = steps
-        ocp.solver_options.qp_solver_cond_N = N2          # accepted: the same QP
+        # (qp_solver_cond_N left at N: this test holds the UNCONDENSED kernel against the condensing oracle)
         s = BatchOcpSolver(ocp, B)
         scenario.load_into(s, wl)
         return s

@@ -14,7 +14,7 @@ struct CondDims {
     int xvar[LANES];
     int ipx, ipy;         // index in xr of the position states (-1 without obstacle rows)
     // per block
-    long o_SR, o_cr, o_BA, o_bt, o_H0, o_g0, o_row, o_Luu, o_P, o_Pb, o_w, o_pi, o_rg, o_rb, o_dwa, o_dw, o_dpi, o_p, o_lus, blk;
+    long o_SR, o_cr, o_BA, o_bt, o_H0, o_g0, o_row, o_Luu, o_P, o_Pb, o_w, o_pi, o_rg, o_rb, o_dwa, o_dw, o_dpi, o_p, o_lus, o_dg, blk;
     long total;           // (N2 + 1) * blk
     long lds_doubles;     // LDS the kernel needs (doubles), for NT threads
 };
@@ -23,6 +23,7 @@ inline bool cond_dims(const DevSpec &S, int nx, int nu, int ipx, int ipy, int N2
 {
     if (N2 < 1 || N2 >= S.N || S.N % N2) return false;
     D.Mb = S.N / N2; D.N2 = N2; D.nuh = D.Mb * nu; D.nzh = D.nuh + nx; D.K = S.K;
+    if (D.nzh > 64) return false; // (one wave holds a block vector in the triangular solves; the index table packs rows in 8 bits)
     D.nbu = D.nbx = D.nxr = 0;
     for (int i = 0; i < LANES; i++) { D.xr_of[i] = -1; D.xr[i] = D.uvar[i] = D.xvar[i] = 0; }
     for (int l = 0; l < nu; l++) if (S.has_b[l]) D.uvar[D.nbu++] = l;
@@ -41,7 +42,7 @@ inline bool cond_dims(const DevSpec &S, int nx, int nu, int ipx, int ipy, int N2
     D.o_P = take((long)nx * nx);             // P_{i+1}
     D.o_Pb = take(nx);
     D.o_w = take(D.nzh); D.o_pi = take(nx); D.o_rg = take(D.nzh); D.o_rb = take(nx);
-    D.o_dwa = take(D.nzh); D.o_dw = take(D.nzh); D.o_dpi = take(nx); D.o_p = take(nx); D.o_lus = take(D.nuh);
+    D.o_dwa = take(D.nzh); D.o_dw = take(D.nzh); D.o_dpi = take(nx); D.o_p = take(nx); D.o_lus = take(D.nuh); D.o_dg = take(D.nuh);
     D.blk = o;
     D.total = (long)(N2 + 1) * D.blk;
     const int nz = nx + nu;
@@ -51,7 +52,8 @@ inline bool cond_dims(const DevSpec &S, int nx, int nu, int ipx, int ipy, int N2
     l += 2L * nx * D.nzh;                                                 // BAm, PBm
     l += (long)nx * nx + (long)nx * nz;                                   // Pn, BAk
     l += 4L * D.Mb * D.nxr + 3L * D.Mb * D.nxr + D.Mb + 3L * D.nuh;       // expansions, slots
-    l += 5L * nt + 64;                                                    // obstacle-row buffer of one pass, reductions
+    l += 4L * nt + 64;                                                    // obstacle-row buffer of one pass, reductions
+    l += 2L * LANES + (D.nzh * (D.nzh + 1) / 2 + 1) / 2 + 1 + 3L * LANES + KMAX; // short tables (ints), triangle index table, spec copies
     l += 8L * D.nzh + 12L * nx + 2L * D.nuh + 2L * nz + (long)D.Mb * nz + (long)D.Mb * D.nxr; // vectors
     D.lds_doubles = l + 64;
     return true;

@@ -83,6 +83,12 @@ struct CondTeam {
         return *slot;
     }
     __device__ static int take(int *q) { return atomicAdd(q, 1); }
+    // value of lane `src` (wave-uniform) of the calling wave
+    __device__ static double lane_value(double v, int src)
+    {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+        return __hiloint2double(hi, lo);
+    }
 };
 #define USV_CDEV __device__ __forceinline__
 #endif
@@ -104,23 +110,66 @@ struct CondIpm {
         return t;
     }
 
+    // Everything the sweeps read per element is kept out of global memory: DevSpec and CondDims live in HBM and the compiler must
+    // assume the scratch stores alias them, so every `S.field` / `D.field` there would be a load of its own inside the loops.  The
+    // scalars are copied into members once (registers), the short tables into LDS.
+    struct DimsLocal {
+        int Mb, N2, nuh, nzh, nxr, R, nrows, nbu, nbx, ipx, ipy;
+        int o_SR, o_cr, o_BA, o_bt, o_H0, o_g0, o_row, o_Luu, o_P, o_Pb, o_w, o_pi, o_rg, o_rb, o_dwa, o_dw, o_dpi, o_p, o_lus, o_dg;
+        long blk;
+        const int *xr, *uvar, *xvar; // LDS
+    };
+    struct SpecLocal {
+        const double *Hc, *He;        // global (condensing / expansion only)
+        const double *HcD, *lb, *ub, *uh; // LDS: Hessian diagonal, box bounds per variable of [u;x], upper bounds of the obstacle rows
+        const int *box_pos;           // LDS
+        int N, K, B, Bp, npt, hdiag, p_static, iter_max, nbu, nbx, nc;
+        double thr0, mu0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min;
+    };
     const DevPtrs &P;
-    const DevSpec &S;
-    const CondDims &D;
+    SpecLocal S;
+    DimsLocal D;
+    const int *tri; // LDS: element e of a lower triangle -> (row << 8) | column
     double *cw; // the team's scratch area in HBM
     int tid, N, Kn, Mb, N2, nuh, nzh, nxr, R, nrows;
     long g, b;
     // LDS
     double *Gm, *SRm, *Sm, *Sn, *Tm, *BAm, *PBm, *Pn, *BAk, *del, *delo, *dela, *delf, *yxr, *yxg, *wd, *wxy, *yur, *yug, *wu, *obuf, *red;
-    double *vw, *vdwa, *vdw, *vr, *vgt, *vrq, *vg0, *vt, *vpi, *vpin, *vxn, *vpv, *vPb, *vrb, *vbt, *vdx, *vdxn, *vtmp, *vlus, *vq, *vgk, *vzb, *vdz, *vcr;
+    double *vw, *vdwa, *vdw, *vr, *vgt, *vrq, *vg0, *vt, *vpi, *vpin, *vxn, *vpv, *vPb, *vrb, *vbt, *vdx, *vdxn, *vtmp, *vlus, *vq, *vgk, *vzb, *vdz, *vcr, *vdg;
     struct Norms { double rg, rb, rd, rm, musum; bool bad; };
 
-    USV_CDEV CondIpm(const DevPtrs &P_, const CondDims &D_, double *scratch, double *lds) : P(P_), S(*P_.spec), D(D_), cw(scratch)
+    USV_CDEV CondIpm(const DevPtrs &P_, const CondDims &Dg, double *scratch, double *lds) : P(P_), cw(scratch)
     {
         tid = TM::tid();
+        const DevSpec &Sg = *P_.spec;
+        S.Hc = Sg.Hc; S.He = Sg.He;
+        S.N = Sg.N; S.K = Sg.K; S.B = Sg.B; S.Bp = Sg.Bp; S.npt = Sg.npt; S.hdiag = Sg.hdiag; S.p_static = Sg.p_static;
+        S.iter_max = Sg.iter_max; S.nbu = Sg.nbu; S.nbx = Sg.nbx; S.nc = Sg.nc;
+        S.thr0 = Sg.thr0; S.mu0 = Sg.mu0; S.tol_stat = Sg.tol_stat; S.tol_eq = Sg.tol_eq; S.tol_ineq = Sg.tol_ineq; S.tol_comp = Sg.tol_comp;
+        S.alpha_min = Sg.alpha_min;
+        D.Mb = Dg.Mb; D.N2 = Dg.N2; D.nuh = Dg.nuh; D.nzh = Dg.nzh; D.nxr = Dg.nxr; D.R = Dg.R; D.nrows = Dg.nrows; D.nbu = Dg.nbu; D.nbx = Dg.nbx;
+        D.ipx = Dg.ipx; D.ipy = Dg.ipy;
+        D.o_SR = (int)Dg.o_SR; D.o_cr = (int)Dg.o_cr; D.o_BA = (int)Dg.o_BA; D.o_bt = (int)Dg.o_bt; D.o_H0 = (int)Dg.o_H0; D.o_g0 = (int)Dg.o_g0;
+        D.o_row = (int)Dg.o_row; D.o_Luu = (int)Dg.o_Luu; D.o_P = (int)Dg.o_P; D.o_Pb = (int)Dg.o_Pb; D.o_w = (int)Dg.o_w; D.o_pi = (int)Dg.o_pi;
+        D.o_rg = (int)Dg.o_rg; D.o_rb = (int)Dg.o_rb; D.o_dwa = (int)Dg.o_dwa; D.o_dw = (int)Dg.o_dw; D.o_dpi = (int)Dg.o_dpi; D.o_p = (int)Dg.o_p;
+        D.o_lus = (int)Dg.o_lus; D.o_dg = (int)Dg.o_dg; D.blk = Dg.blk;
         N = S.N; Kn = S.K; Mb = D.Mb; N2 = D.N2; nuh = D.nuh; nzh = D.nzh; nxr = D.nxr; R = D.R; nrows = D.nrows;
         double *q = lds;
         auto take = [&](long n) { double *at = q; q += n; return at; };
+        {   // the short tables
+            int *it = reinterpret_cast<int *>(take(2 * LANES + (nzh * (nzh + 1) / 2 + 1) / 2 + 1));
+            int *xr_ = it, *uvar_ = it + LANES, *xvar_ = it + 2 * LANES, *bpos_ = it + 3 * LANES, *tri_ = it + 4 * LANES;
+            double *sd = take(3 * LANES + KMAX);
+            for (int e = tid; e < LANES; e += NT) {
+                xr_[e] = Dg.xr[e]; uvar_[e] = Dg.uvar[e]; xvar_[e] = Dg.xvar[e]; bpos_[e] = Sg.box_pos[e];
+                sd[e] = Sg.Hc[e * (LANES + 1)]; sd[LANES + e] = Sg.lb[e]; sd[2 * LANES + e] = Sg.ub[e];
+            }
+            for (int e = tid; e < KMAX; e += NT) sd[3 * LANES + e] = Sg.uh[e];
+            for (int a_ = tid; a_ < nzh; a_ += NT)
+                for (int c = 0; c <= a_; c++) tri_[a_ * (a_ + 1) / 2 + c] = (a_ << 8) | c;
+            D.xr = xr_; D.uvar = uvar_; D.xvar = xvar_; S.box_pos = bpos_; tri = tri_;
+            S.HcD = sd; S.lb = sd + LANES; S.ub = sd + 2 * LANES; S.uh = sd + 3 * LANES;
+        }
         Gm = take((long)(nzh + 1) * nzh);
         const long nsr = (long)Mb * nxr * nzh, ncn = 2L * NX * nzh + (long)NZ * nzh;
         SRm = take(nsr > ncn ? nsr : ncn);
@@ -130,11 +179,11 @@ struct CondIpm {
         del = take(Mb * nxr); delo = take(Mb * nxr); dela = take(Mb * nxr); delf = take(Mb * nxr);
         yxr = take(Mb * nxr); yxg = take(Mb * nxr); wd = take(Mb * nxr); wxy = take(Mb);
         yur = take(nuh); yug = take(nuh); wu = take(nuh);
-        obuf = take(5 * NT); red = take(64);
+        obuf = take(4 * NT); red = take(64);
         vw = take(nzh); vdwa = take(nzh); vdw = take(nzh); vr = take(nzh); vgt = take(nzh); vrq = take(nzh); vg0 = take(nzh); vt = take(nzh);
         vpi = take(NX); vpin = take(NX); vxn = take(NX); vpv = take(NX); vPb = take(NX); vrb = take(NX); vbt = take(NX); vdx = take(NX);
         vdxn = take(NX); vtmp = take(NX); vq = take(NX); vlus = take(nuh); vgk = take(NZ); vzb = take(NZ); vdz = take(Mb * NZ); vcr = take(Mb * nxr);
-        take(NX); take(nuh); // (spare)
+        take(NX); vdg = take(nuh);
     }
 
     USV_CDEV double *blk(int i) const { return cw + (long)i * D.blk; }
@@ -163,7 +212,8 @@ struct CondIpm {
         const double *Hm = (k < N) ? S.Hc : S.He;
         for (int e = tid; e < NZ; e += NT) {
             double a = plane(k, WL::P_GQ)[e];
-            for (int c = 0; c < NZ; c++) a = fma(Hm[e * LANES + c], vzb[c], a);
+            if (S.hdiag && k < N) a = fma(S.HcD[e], vzb[e], a);
+            else for (int c = 0; c < NZ; c++) a = fma(Hm[e * LANES + c], vzb[c], a);
             vgk[e] = a;
         }
         TM::sync();
@@ -195,7 +245,8 @@ struct CondIpm {
                 // cost: H0 += T' Hc T, g0 += T' (g_k + Hc d),  T = [E_j; S_j], d = [0; c_j]
                 for (int e = tid; e < NZ; e += NT) {
                     double a = vgk[e];
-                    for (int s = 0; s < NX; s++) a = fma(S.Hc[e * LANES + NU + s], vbt[s], a);
+                    if (S.hdiag) a = (e >= NU) ? fma(S.HcD[e], vbt[e - NU], a) : a;
+                    else for (int s = 0; s < NX; s++) a = fma(S.Hc[e * LANES + NU + s], vbt[s], a);
                     vt[e] = a; // gy
                 }
                 if (!S.hdiag) // HT = Hc T  (NZ x nzh)
@@ -211,8 +262,8 @@ struct CondIpm {
                     const int a_ = e / nzh, c = e - a_ * nzh;
                     double acc = Gm[e];
                     if (S.hdiag) {
-                        for (int s = 0; s < NX; s++) acc = fma(Sm[s * nzh + a_] * S.Hc[(NU + s) * LANES + NU + s], Sm[s * nzh + c], acc);
-                        if (a_ == c && a_ >= j * NU && a_ < (j + 1) * NU) acc += S.Hc[(a_ - j * NU) * (LANES + 1)];
+                        for (int s = 0; s < NX; s++) acc = fma(Sm[s * nzh + a_] * S.HcD[NU + s], Sm[s * nzh + c], acc);
+                        if (a_ == c && a_ >= j * NU && a_ < (j + 1) * NU) acc += S.HcD[a_ - j * NU];
                     } else {
                         if (a_ >= j * NU && a_ < (j + 1) * NU) acc += Tm[(a_ - j * NU) * nzh + c];
                         for (int s = 0; s < NX; s++) acc = fma(Sm[s * nzh + a_], Tm[(NU + s) * nzh + c], acc);
@@ -299,6 +350,7 @@ struct CondIpm {
         for (int e = tid; e < Mb * nxr; e += NT) {
             double a = cr ? cr[e] : 0.0;
             const double *srow = SRm + (long)e * nzh;
+#pragma unroll 6
             for (int c = 0; c < nzh; c++) a = fma(srow[c], v[c], a);
             out[e] = a;
         }
@@ -308,6 +360,7 @@ struct CondIpm {
     {
         for (int c = tid; c < nzh; c += NT) {
             double a = out[c] + (c < nuh ? yu[c] : 0.0);
+#pragma unroll 8
             for (int m = 0; m < Mb * nxr; m++) a = fma(SRm[(long)m * nzh + c], yx[m], a);
             out[c] = a;
         }
@@ -333,6 +386,7 @@ struct CondIpm {
             if (has) {
                 double *rw = W + D.o_row + e;
                 Row r;
+                r.neutral(); // (sl = su = 0: the hard-row form still adds them)
                 r.ll = rw[0]; r.lu = rw[nrows]; r.tl = rw[2 * nrows]; r.tu = rw[3 * nrows];
                 r.dl = rw[4 * nrows]; r.du = rw[5 * nrows];
                 r.act = row_active(i, j, q);
@@ -406,15 +460,55 @@ struct CondIpm {
         TM::sync();
     }
 
-    // lus = Luu^-1 rq_u,  pv = rq_x - Lxu lus   (L: nzh x nuh, row-major, in LDS at Gm with row stride nzh)
+    // lus = Luu^-1 rq_u,  pv = rq_x - Lxu lus   (L: nzh x nuh, row-major, in LDS at Gm with row stride nzh; vdg: 1 / diagonal)
+    // On the device ONE wave does the substitution - lane r owns entry r, the pivot entry travels by readlane - instead of two
+    // workgroup barriers per column: the sweeps are bound by their barrier count, not by arithmetic.
     USV_CDEV void solve_forward()
     {
-        for (int c = 0; c < nuh; c++) {
-            TM::sync();
-            const double y = vrq[c] / Gm[c * nzh + c];
-            TM::sync();
-            if (tid == 0) vrq[c] = y;
-            for (int r = c + 1 + tid; r < nzh; r += NT) vrq[r] -= Gm[r * nzh + c] * y;
+        TM::sync();
+        if constexpr (NT == 1) {
+            for (int c = 0; c < nuh; c++) {
+                const double y = vrq[c] * vdg[c];
+                vrq[c] = y;
+                for (int r = c + 1; r < nzh; r++) vrq[r] -= Gm[r * nzh + c] * y;
+            }
+        } else {
+            if (tid < 64) {
+                const int r = tid < nzh ? tid : nzh - 1;
+                double y = vrq[r];
+                const double dg = vdg[r < nuh ? r : 0];
+                for (int c = 0; c < nuh; c++) {
+                    const double yc = TM::lane_value(y, c) * TM::lane_value(dg, c);
+                    const double l = Gm[r * nzh + c];
+                    y = (r == c) ? yc : (r > c ? fma(-l, yc, y) : y);
+                }
+                if (tid < nzh) vrq[tid] = y;
+            }
+        }
+        TM::sync();
+    }
+    // vt[0 .. nuh) <- Luu^-T vt   (back substitution, same arrangement)
+    USV_CDEV void solve_backward()
+    {
+        TM::sync();
+        if constexpr (NT == 1) {
+            for (int c = nuh - 1; c >= 0; c--) {
+                const double y = vt[c] * vdg[c];
+                vt[c] = y;
+                for (int r = 0; r < c; r++) vt[r] -= Gm[c * nzh + r] * y;
+            }
+        } else {
+            if (tid < 64) {
+                const int r = tid < nuh ? tid : nuh - 1;
+                double y = vt[r];
+                const double dg = vdg[r];
+                for (int c = nuh - 1; c >= 0; c--) {
+                    const double yc = TM::lane_value(y, c) * TM::lane_value(dg, c);
+                    const double l = Gm[c * nzh + r];
+                    y = (r == c) ? yc : (r < c ? fma(-l, yc, y) : y);
+                }
+                if (tid < nuh) vt[tid] = y;
+            }
         }
         TM::sync();
     }
@@ -440,7 +534,7 @@ struct CondIpm {
                 W[D.o_rg + e] = r;
                 vpv[e] = r;
                 nm.rg = fmax(nm.rg, fabs(r));
-                if (r != r) badf = 1.0;
+                if (r != r) badf = fmax(badf, 1.0);
             }
             for (int e = tid; e < NX * NX; e += NT) Pn[e] = S.He[(NU + e / NX) * LANES + NU + e % NX];
         }
@@ -481,12 +575,13 @@ struct CondIpm {
                     rd = fmax(rd, fmax(fabs(r.rdl), fabs(r.rdu)));
                     rm = fmax(rm, fmax(r.ll * r.tl, r.lu * r.tu));
                     mus += r.ll * r.tl + r.lu * r.tu;
-                    if (r.rdl != r.rdl || r.rdu != r.rdu || Gh != Gh) bd = 1.0;
+                    if (r.rdl != r.rdl || r.rdu != r.rdu || Gh != Gh) bd = fmax(bd, 2.0);
                 }
             });
             // r = g0 + H0 w + BA' pi_{i+1} - [0; pi_i];  rb = bt + BA w - x_{i+1}
             for (int c = tid; c < nzh; c += NT) {
                 double a = vg0[c];
+#pragma unroll 6
                 for (int m = 0; m < nzh; m++) a = fma(Gm[c * nzh + m], vw[m], a);
                 for (int s = 0; s < NX; s++) a = fma(BAm[s * nzh + c], vpin[s], a);
                 if (i >= 1 && c >= nuh) a -= vpi[c - nuh];
@@ -504,10 +599,10 @@ struct CondIpm {
             for (int c = tid; c < nzh; c += NT) {
                 W[D.o_rg + c] = vr[c];
                 if (i >= 1 || c < nuh) rgl = fmax(rgl, fabs(vr[c]));
-                if (vr[c] != vr[c]) bd = 1.0;
+                if (vr[c] != vr[c]) bd = fmax(bd, 3.0);
                 vgt[c] = vr[c];
             }
-            for (int s = tid; s < NX; s += NT) { W[D.o_rb + s] = vrb[s]; rbl = fmax(rbl, fabs(vrb[s])); if (vrb[s] != vrb[s]) bd = 1.0; }
+            for (int s = tid; s < NX; s += NT) { W[D.o_rb + s] = vrb[s]; rbl = fmax(rbl, fabs(vrb[s])); if (vrb[s] != vrb[s]) bd = fmax(bd, 4.0); }
             nm.rg = fmax(nm.rg, rgl); nm.rb = fmax(nm.rb, rbl); nm.rd = fmax(nm.rd, rd); nm.rm = fmax(nm.rm, rm); nm.musum += mus;
             badf = fmax(badf, bd);
             TM::sync();
@@ -516,6 +611,7 @@ struct CondIpm {
             for (int e = tid; e < NX * nzh; e += NT) {
                 const int s = e / nzh, c = e - s * nzh;
                 double a = 0.0;
+#pragma unroll
                 for (int m = 0; m < NX; m++) a = fma(Pn[s * NX + m], BAm[m * nzh + c], a);
                 PBm[e] = a;
             }
@@ -530,18 +626,17 @@ struct CondIpm {
             TM::sync();
             const int ntri = nzh * (nzh + 1) / 2;
             for (int e = tid; e < ntri; e += NT) {
-                int a_ = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-                while ((a_ + 1) * (a_ + 2) / 2 <= e) a_++;
-                while (a_ * (a_ + 1) / 2 > e) a_--;
-                const int c = e - a_ * (a_ + 1) / 2;
+                const int a_ = tri[e] >> 8, c = tri[e] & 255;
                 double acc = Gm[a_ * nzh + c];
                 if (a_ == c && a_ < nuh) acc += wu[a_];
+#pragma unroll 8
                 for (int m = 0; m < Mb * nxr; m++) acc = fma(SRm[(long)m * nzh + a_] * wd[m], SRm[(long)m * nzh + c], acc);
                 if (Kn > 0)
                     for (int j = 0; j < Mb; j++) {
                         const double *sx = SRm + (long)(j * nxr + D.ipx) * nzh, *sy = SRm + (long)(j * nxr + D.ipy) * nzh;
                         acc = fma(wxy[j], sx[a_] * sy[c] + sy[a_] * sx[c], acc);
                     }
+#pragma unroll
                 for (int s = 0; s < NX; s++) acc = fma(BAm[s * nzh + a_], PBm[s * nzh + c], acc);
                 Gm[a_ * nzh + c] = acc;
             }
@@ -551,30 +646,29 @@ struct CondIpm {
                 for (int s = 0; s < NX; s++) a = fma(BAm[s * nzh + c], vPb[s] + vpv[s], a);
                 vrq[c] = a;
             }
-            // eliminate the nuh input columns: [Luu; Lxu] stays in their place, the Schur complement P_i in the x block
+            // eliminate the nuh input columns: [Luu; Lxu] stays in their place, the Schur complement P_i in the x block.  One barrier
+            // per column: the trailing update uses the UNSCALED column (times 1 / pivot), which nothing writes during the step; the
+            // columns are scaled to Cholesky form in one pass afterwards.
             for (int c = 0; c < nuh; c++) {
                 TM::sync();
                 const double piv = Gm[c * nzh + c];
-                if (!(piv > 0.0)) badf = 1.0;
-                const double dsq = sqrt(piv), dinv = 1.0 / dsq;
-                TM::sync();
-                for (int r = c + 1 + tid; r < nzh; r += NT) Gm[r * nzh + c] *= dinv;
-                if (tid == 0) Gm[c * nzh + c] = dsq;
-                TM::sync();
+                if (!(piv > 0.0)) badf = fmax(badf, 5.0);
+                const double ipiv = 1.0 / piv;
+                if (tid == 0) vdg[c] = 1.0 / sqrt(piv);
                 const int nr = nzh - c - 1; // rows c+1 .. nzh-1, lower triangle of the trailing block
                 for (int e = tid; e < nr * (nr + 1) / 2; e += NT) {
-                    int a_ = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-                    while ((a_ + 1) * (a_ + 2) / 2 <= e) a_++;
-                    while (a_ * (a_ + 1) / 2 > e) a_--;
-                    const int cc = e - a_ * (a_ + 1) / 2;
-                    const int rr = c + 1 + a_, c2 = c + 1 + cc;
-                    Gm[rr * nzh + c2] = fma(-Gm[rr * nzh + c], Gm[c2 * nzh + c], Gm[rr * nzh + c2]);
+                    const int rr = c + 1 + (tri[e] >> 8), c2 = c + 1 + (tri[e] & 255);
+                    Gm[rr * nzh + c2] = fma(-Gm[rr * nzh + c] * ipiv, Gm[c2 * nzh + c], Gm[rr * nzh + c2]);
                 }
             }
             TM::sync();
+            for (int e = tid; e < nzh * nuh; e += NT) {
+                const int r = e / nuh, c = e - r * nuh;
+                if (r >= c) Gm[r * nzh + c] *= vdg[c]; // (diagonal: piv / sqrt(piv))
+            }
             solve_forward();
             for (int e = tid; e < nzh * nuh; e += NT) { const int r = e / nuh, c = e - r * nuh; W[D.o_Luu + e] = Gm[r * nzh + c]; }
-            for (int c = tid; c < nuh; c += NT) W[D.o_lus + c] = vrq[c];
+            for (int c = tid; c < nuh; c += NT) { W[D.o_lus + c] = vrq[c]; W[D.o_dg + c] = vdg[c]; }
             // hand over to block i - 1
             for (int e = tid; e < NX * NX; e += NT) {
                 const int s = e / NX, m = e - s * NX;
@@ -592,11 +686,11 @@ struct CondIpm {
             for (int s = tid; s < NX; s += NT) {
                 const double e0 = (P.x0[(long)b * NX + s] - P.x[((long)b * (N + 1)) * NX + s]) - W0[D.o_w + nuh + s];
                 e0m = fmax(e0m, fabs(e0));
-                if (e0 != e0) badf = 1.0;
+                if (e0 != e0) badf = fmax(badf, 6.0);
             }
         }
         nm.rb = fmax(nm.rb, TM::rmax(e0m, red));
-        nm.bad = TM::rmax(badf, red) > 0.5;
+        { const double code = TM::rmax(badf, red); nm.bad = code > 0.5; if (nm.bad) nm.rd = code; }
         return nm;
     }
 
@@ -613,6 +707,7 @@ struct CondIpm {
             load_block(i, W, false);
             for (int e = tid; e < nzh * nuh; e += NT) { const int r = e / nuh, c = e - r * nuh; Gm[r * nzh + c] = W[D.o_Luu + e]; }
             for (int e = tid; e < NX; e += NT) { vPb[e] = W[D.o_Pb + e]; W[D.o_p + e] = vpv[e]; }
+            for (int c = tid; c < nuh; c += NT) vdg[c] = W[D.o_dg + c];
             for (int c = tid; c < nzh; c += NT) vgt[c] = W[D.o_rg + c];
             expand_rows(del, vw, vcr);
             expand_rows(dela, vdwa, nullptr);
@@ -629,7 +724,6 @@ struct CondIpm {
                 for (int s = 0; s < NX; s++) a = fma(BAm[s * nzh + c], vPb[s] + vpv[s], a);
                 vrq[c] = a;
             }
-            TM::sync();
             solve_forward();
             for (int c = tid; c < nuh; c += NT) W[D.o_lus + c] = vrq[c];
             for (int s = tid; s < NX; s += NT) vpv[s] = vrq[nuh + s];
@@ -651,7 +745,7 @@ struct CondIpm {
             double *W = blk(i);
             load_block(i, W, false);
             for (int e = tid; e < nzh * nuh; e += NT) { const int r = e / nuh, c = e - r * nuh; Gm[r * nzh + c] = W[D.o_Luu + e]; }
-            for (int c = tid; c < nuh; c += NT) vlus[c] = W[D.o_lus + c];
+            for (int c = tid; c < nuh; c += NT) { vlus[c] = W[D.o_lus + c]; vdg[c] = W[D.o_dg + c]; }
             for (int s = tid; s < NX; s += NT) vrb[s] = W[D.o_rb + s];
             TM::sync();
             // t = lus + Lxu' dx;  du = -Luu^-T t
@@ -660,14 +754,7 @@ struct CondIpm {
                 for (int s = 0; s < NX; s++) a = fma(Gm[(nuh + s) * nzh + c], vdx[s], a);
                 vt[c] = a;
             }
-            for (int c = nuh - 1; c >= 0; c--) {
-                TM::sync();
-                const double y = vt[c] / Gm[c * nzh + c];
-                TM::sync();
-                if (tid == 0) vt[c] = y;
-                for (int r = tid; r < c; r += NT) vt[r] -= Gm[c * nzh + r] * y;
-            }
-            TM::sync();
+            solve_backward();
             double *dst = corr ? vdw : vdwa;
             for (int c = tid; c < nzh; c += NT) {
                 const double v = (c < nuh) ? -vt[c] : vdx[c - nuh];
@@ -764,7 +851,8 @@ struct CondIpm {
                         load_stage(k);
                         for (int s = tid; s < NX; s += NT) {
                             double a = vgk[NU + s];
-                            for (int c = 0; c < NZ; c++) a = fma(S.Hc[(NU + s) * LANES + c], vdz[j * NZ + c], a);
+                            if (S.hdiag) a = fma(S.HcD[NU + s], vdz[j * NZ + NU + s], a);
+                            else for (int c = 0; c < NZ; c++) a = fma(S.Hc[(NU + s) * LANES + c], vdz[j * NZ + c], a);
                             for (int m = 0; m < NX; m++) a = fma(BAk[m * NZ + NU + s], vpin[m], a);
                             // rows of this stage on state s
                             const double *rw = W + D.o_row + (long)j * R;

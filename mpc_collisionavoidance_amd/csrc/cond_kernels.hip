@@ -12,14 +12,20 @@
 
 namespace usv {
 
+// Team size and register budget, measured at BASELINE configs[4]'s shape (8192 instances, profiles/r03_condensing_ab.txt): the kernel
+// is bound by latency (LDS round trips, barriers), i.e. by how many teams a CU holds - LDS allows three of ~50 KB; 256 threads at
+// 168 registers (three waves per SIMD, ~160 registers spilled) beat 64 / 128 threads at any budget and 256 at 256 registers.
 #ifndef USV_COND_THREADS
-#define USV_COND_THREADS 64
+#define USV_COND_THREADS 256
+#endif
+#ifndef USV_COND_MINWAVES // waves per SIMD the kernel is compiled for (register budget 512 / that)
+#define USV_COND_MINWAVES 3
 #endif
 
 // One instance per workgroup of NT threads, the condensed block's matrices in LDS, the instance's condensed QP in the
 // workgroup's scratch area in HBM; workgroups pull further instances from the queue as they finish.
 template <class M, int KCH, int NT>
-__global__ void __launch_bounds__(NT) usv_qp_cond(DevPtrs P, const CondDims *Dp, double *scratch, int nB, int queue0)
+__global__ void __launch_bounds__(NT, USV_COND_MINWAVES) usv_qp_cond(DevPtrs P, const CondDims *Dp, double *scratch, int nB, int queue0)
 {
     extern __shared__ double cond_lds[];
     __shared__ int nxt;
@@ -41,7 +47,7 @@ int prepare_for(const DevSpec &S, int N2, CondDims &D, size_t &lds, int &nb, std
 {
     constexpr int NT = USV_COND_THREADS;
     auto kern = &usv_qp_cond<M, KCH, NT>;
-    if (!cond_dims(S, M::NX, M::NU, M::IPX, M::IPY, N2, NT, D)) { err = "qp_cond_N must divide N"; return USVMPC_E_ARG; }
+    if (!cond_dims(S, M::NX, M::NU, M::IPX, M::IPY, N2, NT, D)) { err = "qp_cond_N must divide N, and a condensed stage may have at most 64 variables (nx + (N / qp_cond_N) nu)"; return USVMPC_E_ARG; }
     lds = (size_t)D.lds_doubles * sizeof(double);
     if (lds > 160u * 1024u) { err = "partial condensing: the condensed block does not fit in LDS (block too large)"; return USVMPC_E_ARG; }
     nb = 0;

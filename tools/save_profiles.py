@@ -19,12 +19,15 @@ open("%s/%s_bench.json" % (dst, tag), "w").write(line + "\n")
 b = json.loads(line)
 f = wv = n = None
 kname = None
+cond_N = b["config"].get("qp_solver_cond_N")
+cond_N = int(cond_N) if isinstance(cond_N, int) and cond_N != b["config"]["horizon"] else 0   # (partially condensed solve: kernel usv_qp_cond)
+KERN = "qp_cond" if cond_N else "qp_rti"
 for r in csv.reader(open(src + "/pmc_summary.csv")):
-    if "qp_rti" in r[0]:
+    if KERN in r[0]:
         kname, n, f, wv = r[0], int(r[1]), float(r[2]), float(r[3])
 ms = None
 for r in csv.DictReader(open(src + "/trace/t_kernel_stats.csv")):
-    if "qp_rti" in r["Name"]:
+    if KERN in r["Name"]:
         ms = float(r["AverageNs"]) / 1e6
 tot = (2 * f + wv) * 1024
 pj = dst + "/pmc_traffic.json"
@@ -39,7 +42,7 @@ try:
 except Exception:
     head = None
 J.append({"round": tag, "workload": workload, "lib_sha256": cfgw.get("lib_sha256"), "git_head": head, "moving": "moving" in cfgw.get("workload", "") and " static " not in cfgw.get("workload", ""), "kernel": kname.replace("void ", ""), "model": cfgw["ocp"], "N": cfgw["horizon"], "K": cfgw["obstacles"],
-          "batch": cfgw["instances_per_gpu"], "fetch_size_KiB_raw": f, "write_size_KiB_raw": wv, "hbm_bytes_per_launch": tot,
+          "batch": cfgw["instances_per_gpu"], "cond_N": cond_N, "fetch_size_KiB_raw": f, "write_size_KiB_raw": wv, "hbm_bytes_per_launch": tot,
           "correction": "FETCH_SIZE x2, WRITE_SIZE x1; re-calibrated in this round on the [stage][group][plane][16 lanes] layout with "
                         "usv_calib_stream: 524288 KiB read -> FETCH_SIZE 262166 KiB, 2097152 KiB -> 1048612 KiB (factor 0.5000), "
                         "8192 KiB written -> WRITE_SIZE 8192 KiB (profiles/r02_a_calibration.txt)",

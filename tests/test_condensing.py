@@ -217,6 +217,33 @@ def test_condensing_kernel_solutions_are_certified_on_the_uncondensed_qp(oracle)
 
 
 @pytest.mark.gpu
+def test_condensed_rti_then_full_sqp_and_multiplier_read_back(oracle):
+    """Mixed use on one handle: RTI solves on the condensed QP, "lam" / "t" only once their buffers exist, then a full SQP - which
+    runs on the uncondensed stages and must start from zero multipliers (the condensed solve leaves none in the workspace) - ends
+    where the full SQP of a handle that never condensed ends."""
+    name, N, K, B, N2 = "usv_model_pf_ca", 20, 4, 48, 5
+    wl = scenario.make_bench_batch(name, N, K, B, seed=21)
+    sc, su_ = _cond_solver(name, N, K, B, wl, N2), _cond_solver(name, N, K, B, wl, 0)
+    assert (sc.solve() == su_.solve()).all()
+    with pytest.raises(Exception):
+        sc.get_all("lam")                      # the buffers did not exist during that solve (they do from now on)
+    st = sc.solve(); su_.solve()
+    lam, t = sc.get_all("lam"), sc.get_all("t")
+    ok = st == 0
+    assert ok.mean() > 0.9 and (lam[ok] >= 0).all() and (t[ok] >= 0).all() and float((lam[ok] * t[ok]).max()) <= 1e-7
+    assert np.abs(lam[ok][:, 1:N]).max() > 0 and float(np.abs(lam[:, N]).max()) == 0.0      # rows exist on stages 0 .. N-1 only
+    # both handles continue from the condensed handle's iterate
+    for s in (sc, su_):
+        s.set_all("x", sc.get_all("x")); s.set_all("u", sc.get_all("u"))
+    a, b = sc.solve_sqp(), su_.solve_sqp()
+    assert (a == b).all()
+    both = (a == 0)
+    assert both.mean() > 0.8
+    assert util.rel_err(sc.get_all("x")[both], su_.get_all("x")[both]) < 1e-6 and util.rel_err(sc.get_all("u")[both], su_.get_all("u")[both]) < 1e-5
+    sc.close(); su_.close()
+
+
+@pytest.mark.gpu
 def test_condensing_option_is_refused_where_it_is_not_built():
     wl = scenario.make_bench_batch("usv_model_guidance_ca1", 20, 4, 8, seed=3)
     with pytest.raises(Exception, match="hard rows"):

@@ -184,6 +184,9 @@ struct CondIpm {
         vpi = take(NX); vpin = take(NX); vxn = take(NX); vpv = take(NX); vPb = take(NX); vrb = take(NX); vbt = take(NX); vdx = take(NX);
         vdxn = take(NX); vtmp = take(NX); vq = take(NX); vlus = take(nuh); vgk = take(NZ); vzb = take(NZ); vdz = take(Mb * NZ); vcr = take(Mb * nxr);
         take(NX); vdg = take(nuh);
+#if !defined(USV_COND_SERIAL)
+        if (q - lds > Dg.lds_doubles) __builtin_trap(); // (cond_dims.hpp sizes the launch's LDS: the two counts must agree)
+#endif
     }
 
     USV_CDEV double *blk(int i) const { return cw + (long)i * D.blk; }

@@ -217,6 +217,24 @@ def test_condensing_kernel_solutions_are_certified_on_the_uncondensed_qp(oracle)
 
 
 @pytest.mark.gpu
+def test_condensing_kernel_is_deterministic():
+    """The team-parallel loops of cond_ipm.hpp are only executed serially in the CPU suite; a missing barrier on the device would show as
+    run-to-run differences.  Two handles, same inputs, different numbers of resident teams: bit-identical results (every reduction has a
+    fixed order - no atomics on floating-point data)."""
+    name, N, K, B, N2 = "usv_model_pf_ca", 40, 10, 700, 10
+    wl = scenario.make_bench_batch(name, N, K, B, seed=77)
+    a, b = _cond_solver(name, N, K, B, wl, N2), _cond_solver(name, N, K, B, wl, N2, extra=(("max_waves", 97),))
+    for tick in range(3):
+        sa, sb = a.solve(), b.solve()
+        assert np.array_equal(sa, sb) and np.array_equal(a.get_int("qp_iter"), b.get_int("qp_iter"))
+        assert np.array_equal(a.get_all("x"), b.get_all("x")) and np.array_equal(a.get_all("u"), b.get_all("u"))
+        assert np.array_equal(a.get_all("pi"), b.get_all("pi"))
+        for s in (a, b):
+            s.advance(1e-3, seed=5 + tick)
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
 def test_condensed_rti_then_full_sqp_and_multiplier_read_back(oracle):
     """Mixed use on one handle: RTI solves on the condensed QP, "lam" / "t" only once their buffers exist, then a full SQP - which
     runs on the uncondensed stages and must start from zero multipliers (the condensed solve leaves none in the workspace) - ends

@@ -40,8 +40,6 @@ struct CondTeam {
     static void sync() {}
     static double rmax(double v, double *) { return v; }
     static double rsum(double v, double *) { return v; }
-    static int share(int v, int *) { return v; }
-    static int take(int *q) { return (*q)++; }
 };
 #define USV_CDEV inline
 #else
@@ -75,14 +73,6 @@ struct CondTeam {
         }
         return v;
     }
-    __device__ static int share(int v, int *slot) // thread 0's value to the team
-    {
-        sync();
-        if (tid() == 0) *slot = v;
-        sync();
-        return *slot;
-    }
-    __device__ static int take(int *q) { return atomicAdd(q, 1); }
     // value of lane `src` (wave-uniform) of the calling wave
     __device__ static double lane_value(double v, int src)
     {
@@ -374,6 +364,9 @@ struct CondIpm {
     template <class F>
     USV_CDEV void row_pass(int i, double *W, bool slots, F f)
     {
+#if defined(USV_COND_SKIP) && (USV_COND_SKIP & 1)
+        return;
+#endif
         if (slots) {
             for (int e = tid; e < Mb * nxr; e += NT) { yxr[e] = 0.0; yxg[e] = 0.0; wd[e] = 0.0; }
             for (int e = tid; e < Mb; e += NT) wxy[e] = 0.0;
@@ -451,7 +444,9 @@ struct CondIpm {
     USV_CDEV void load_block(int i, double *W, bool hess)
     {
         TM::sync();
+#if !(defined(USV_COND_SKIP) && (USV_COND_SKIP & 8))
         for (int e = tid; e < Mb * nxr * nzh; e += NT) SRm[e] = W[D.o_SR + e];
+#endif
         for (int e = tid; e < Mb * nxr; e += NT) vcr[e] = W[D.o_cr + e];
         for (int e = tid; e < NX * nzh; e += NT) BAm[e] = W[D.o_BA + e];
         for (int e = tid; e < nzh; e += NT) { vw[e] = W[D.o_w + e]; vdwa[e] = W[D.o_dwa + e]; vdw[e] = W[D.o_dw + e]; }
@@ -628,7 +623,11 @@ struct CondIpm {
             for (int e = tid; e < NX; e += NT) W[D.o_p + e] = vpv[e];
             TM::sync();
             const int ntri = nzh * (nzh + 1) / 2;
+#if defined(USV_COND_SKIP) && (USV_COND_SKIP & 2)
+            for (int e = tid; e < 0; e += NT) {
+#else
             for (int e = tid; e < ntri; e += NT) {
+#endif
                 const int a_ = tri[e] >> 8, c = tri[e] & 255;
                 double acc = Gm[a_ * nzh + c];
                 if (a_ == c && a_ < nuh) acc += wu[a_];
@@ -652,7 +651,11 @@ struct CondIpm {
             // eliminate the nuh input columns: [Luu; Lxu] stays in their place, the Schur complement P_i in the x block.  One barrier
             // per column: the trailing update uses the UNSCALED column (times 1 / pivot), which nothing writes during the step; the
             // columns are scaled to Cholesky form in one pass afterwards.
+#if defined(USV_COND_SKIP) && (USV_COND_SKIP & 4)
+            for (int c = 0; c < 0; c++) {
+#else
             for (int c = 0; c < nuh; c++) {
+#endif
                 TM::sync();
                 const double piv = Gm[c * nzh + c];
                 if (!(piv > 0.0)) badf = fmax(badf, 5.0);
@@ -693,7 +696,7 @@ struct CondIpm {
             }
         }
         nm.rb = fmax(nm.rb, TM::rmax(e0m, red));
-        { const double code = TM::rmax(badf, red); nm.bad = code > 0.5; if (nm.bad) nm.rd = code; }
+        nm.bad = TM::rmax(badf, red) > 0.5; // (badf: 1 terminal residual, 2 row, 3 stationarity, 4 dynamics, 5 pivot, 6 initial state)
         return nm;
     }
 
@@ -912,21 +915,33 @@ struct CondIpm {
         const double nc = (double)S.nc;
         while (!bad0) {
             nm = backward_factor(pend, a_prev, sig_prev);
+#ifdef USV_COND_TIMING // (timing experiments, tools/cond_timing.sh: a fixed number of iterations whatever the residuals; results are garbage)
+            if (it >= USV_COND_TIMING) { status = 0; break; }
+#else
             if (nm.bad || nm.rg != nm.rg || nm.rb != nm.rb) { status = 3; break; }
             if (nm.rg <= S.tol_stat && nm.rb <= S.tol_eq && nm.rd <= S.tol_ineq && nm.rm <= S.tol_comp) { status = 0; break; }
             if (it >= S.iter_max) { status = 1; break; }
+#endif
             const double mu = nc > 0.0 ? nm.musum / nc : 0.0;
             double a_aff = 1.0, S1 = 0.0, S2 = 0.0, a = 1.0, d1, d2;
+#if !(defined(USV_COND_SKIP) && (USV_COND_SKIP & 32))
             forward(false, 0.0, a_aff, S1, S2);
+#endif
             double sigmu = 0.0;
             if (nc > 0.0) {
                 const double mu_aff = (nm.musum + a_aff * S1 + a_aff * a_aff * S2) / nc;
                 const double sg = mu_aff / mu;
                 sigmu = sg * sg * sg * mu;
             }
+#if !(defined(USV_COND_SKIP) && (USV_COND_SKIP & 16))
             backward_rhs(sigmu);
+#endif
+#if !(defined(USV_COND_SKIP) && (USV_COND_SKIP & 32))
             forward(true, sigmu, a, d1, d2);
+#endif
+#ifndef USV_COND_TIMING
             if (a < S.alpha_min) { status = 2; break; }
+#endif
             a_prev = a * ((1.0 - a) * 0.99 + a * 0.9999999);
             sig_prev = sigmu;
             pend = true;

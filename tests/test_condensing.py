@@ -97,7 +97,8 @@ def _emu_cond_rti(emu, desc, wl, x, u, N2, export=False):
 
 # (blocks of 4 stages; two obstacle chunks; a model without obstacle rows; blocks of 2)
 @pytest.mark.parametrize("name,N,K,B,N2", [("usv_model_pf_ca", 16, 4, 4, 4), ("usv_model_pf_ca", 12, 18, 2, 3),
-                                           ("usv_model", 8, 0, 3, 2), ("usv_model_pf_ca", 12, 3, 2, 6)])
+                                           ("usv_model", 8, 0, 3, 2), ("usv_model_pf_ca", 12, 3, 2, 6),
+                                           ("usv_model_pf_ca", 10, 3, 2, 1)])   # (N2 = 1: the whole horizon in one block - full condensing)
 def test_condensing_kernel_body_matches_condensing_oracle(oracle, emu, name, N, K, B, N2):
     dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
     wl = scenario.make_bench_batch(name, N, K, B, moving=K > 0, seed=5)
@@ -163,7 +164,7 @@ def _cond_solver(name, N, K, B, wl, N2, extra=()):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,N,K,B,N2", [("usv_model_pf_ca", 80, 20, 96, 10), ("usv_model_pf_ca", 40, 10, 160, 8),
-                                           ("usv_model", 20, 0, 70, 4)])
+                                           ("usv_model", 20, 0, 70, 4), ("usv_model_pf_ca", 10, 3, 40, 1)])
 def test_condensing_kernel_on_the_device_vs_condensing_oracle(oracle, name, N, K, B, N2):
     """qp_solver_cond_N = N2 is APPLIED: the device condenses, solves the N2 dense stages and expands.  Same iteration path as
     oracle/condense.py: statuses, iteration counts (more than one off for at most 2 % of the instances) and

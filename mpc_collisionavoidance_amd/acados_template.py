@@ -196,6 +196,12 @@ class BatchOcpSolver:
         self._h = h
         cn = getattr(ocp.solver_options, "qp_solver_cond_N", None)
         if cn is not None and int(cn) != self.N:
+            # (a condensed stage has nx + (N / cond_N) nu variables; the kernel holds one in a wave: at most 64 - the C ABI reports the
+            # same limit at the first solve)
+            if self.N % int(cn) == 0 and self.nx + (self.N // int(cn)) * self.nu > 64:
+                self.close()
+                raise Exception("qp_solver_cond_N = %d: a condensed stage would have %d variables (nx + (N / cond_N) nu), at most 64 are built"
+                                % (int(cn), self.nx + (self.N // int(cn)) * self.nu))
             rc = self._lib.usvmpc_set_option(self._h, b"qp_cond_N", float(int(cn)))
             if rc != 0:
                 msg = self._lib.usvmpc_last_error(self._h).decode()

@@ -270,6 +270,9 @@ def test_condensing_option_is_refused_where_it_is_not_built():
     wl = scenario.make_bench_batch("usv_model_pf_ca", 20, 4, 8, seed=3)
     with pytest.raises(Exception, match="divide"):
         _cond_solver("usv_model_pf_ca", 20, 4, 8, wl, 3)
+    wl40 = scenario.make_bench_batch("usv_model_pf_ca", 40, 4, 8, seed=3)
+    with pytest.raises(Exception, match="at most 64"):
+        _cond_solver("usv_model_pf_ca", 40, 4, 8, wl40, 1)    # 14 + 40 * 2 = 94 variables in the one block
     s = _cond_solver("usv_model_pf_ca", 20, 4, 8, wl, 20)   # N2 = N: no condensing, the default path
     assert (s.solve() == 0).all()
     s.close()

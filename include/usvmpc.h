@@ -154,11 +154,12 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  * "qp_cond_N", which selects another formulation of the same QP):
  *   "qp_cond_N" (default 0) - acados' qp_solver_cond_N (qp_solver = PARTIAL_CONDENSING_HPIPM:
  *       catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/acados_settings.py:172; the reference never sets it, i.e. blocks of one stage = the
- *       default here).  A value N2 < N that divides N makes every RTI solve condense its QP to N2 dense stages first (HPIPM
- *       d_part_cond_qp: states of N / N2 consecutive stages eliminated through the dynamics), solve THAT QP with the same
+ *       default here).  A value N2 < N makes every RTI solve condense its QP to N2 dense stages first (HPIPM d_part_cond_qp:
+ *       states of N / N2 consecutive stages - one more in the first N mod N2 blocks - eliminated through the dynamics;
+ *       nx + ceil(N / N2) nu <= 64), solve THAT QP with the same
  *       interior-point method and expand the solution (x, u, pi) - a kernel of its own (csrc/cond_ipm.hpp: one instance per
- *       workgroup, the block's matrices in LDS).  Hard rows only (E_ARG for soft rows / soft state bounds); "lam" / "t" are not
- *       kept; usvmpc_solve_sqp keeps solving the uncondensed stages.  Same solution as the default path up to the IPM exit
+ *       workgroup, the block's matrices in LDS).  Obstacle rows hard or soft; E_ARG for soft state bounds; "lam" / "t" only when
+ *       their buffers exist before the solve (option "keep_multipliers"); usvmpc_solve_sqp keeps solving the uncondensed stages.  Same solution as the default path up to the IPM exit
  *       tolerances; which of the two is faster is measured in DESIGN.md section 6.  0 or N: off;
  *   "sort_by_difficulty" (default 1) - instances are handed to the wavefront rows in the order of their IPM iteration counts of
  *       the previous solve, hardest first (an instance that runs long must not start late); "sort_two_ticks" = 1 (default 0)

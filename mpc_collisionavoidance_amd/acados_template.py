@@ -121,8 +121,8 @@ class AcadosOcpOptions:
         self.nlp_solver_tol_ineq = None
         self.nlp_solver_tol_comp = None
         # acados' qp_solver_cond_N: None / N (what the reference leaves it at) = blocks of one stage, i.e. the Riccati sweep over
-        # the N stages; a smaller value that divides N condenses the QP to that many dense stages on the device first
-        # (csrc/cond_ipm.hpp; hard rows only - DESIGN.md section 6 has the measured comparison of the two)
+        # the N stages; a smaller value condenses the QP to that many dense stages on the device first (blocks as HPIPM partitions them)
+        # (csrc/cond_ipm.hpp; not for soft state bounds - DESIGN.md section 6 has the measured comparison of the two)
         self.qp_solver_cond_N = None
         self.qp_solver_warm_start = 0   # 0 (cold start of every QP, the acados default) is the only mode built
         self.nlp_solver_step_length = 1.0
@@ -198,10 +198,11 @@ class BatchOcpSolver:
         if cn is not None and int(cn) != self.N:
             # (a condensed stage has nx + (N / cond_N) nu variables; the kernel holds one in a wave: at most 64 - the C ABI reports the
             # same limit at the first solve)
-            if self.N % int(cn) == 0 and self.nx + (self.N // int(cn)) * self.nu > 64:
+            mb = -(-self.N // int(cn))
+            if self.nx + mb * self.nu > 64:
                 self.close()
-                raise Exception("qp_solver_cond_N = %d: a condensed stage would have %d variables (nx + (N / cond_N) nu), at most 64 are built"
-                                % (int(cn), self.nx + (self.N // int(cn)) * self.nu))
+                raise Exception("qp_solver_cond_N = %d: a condensed stage would have %d variables (nx + ceil(N / cond_N) nu), at most 64 are built"
+                                % (int(cn), self.nx + mb * self.nu))
             rc = self._lib.usvmpc_set_option(self._h, b"qp_cond_N", float(int(cn)))
             if rc != 0:
                 msg = self._lib.usvmpc_last_error(self._h).decode()

@@ -7,7 +7,8 @@ namespace usv {
 
 // sizes and scratch offsets (doubles) of the condensed QP of one instance; host and device
 struct CondDims {
-    int Mb, N2, nuh, nzh, nxr, R, nrows, nbu, nbx, K;
+    int Mb, N2, nuh, nzh, nxr, R, nrows, nbu, nbx, K;   // Mb: stages of the LONGEST block (sizes everything)
+    int N1, R1;           // HPIPM's partition: N1 = N / N2 stages per block, the first R1 = N - N2 N1 blocks one more
     int xr[LANES];        // states that some row touches (bounded, position), ascending
     int xr_of[LANES];     // state -> index in xr, or -1
     int uvar[LANES];      // u rows: control index;  xvar: x rows: index into xr
@@ -19,10 +20,11 @@ struct CondDims {
     long lds_doubles;     // LDS the kernel needs (doubles), for NT threads
 };
 
-inline bool cond_dims(const DevSpec &S, int nx, int nu, int ipx, int ipy, int N2, int nt, CondDims &D)
+inline bool cond_dims(const DevSpec &S, int nx, int nu, int ipx, int ipy, int N2, int nt, bool soft, CondDims &D)
 {
-    if (N2 < 1 || N2 >= S.N || S.N % N2) return false;
-    D.Mb = S.N / N2; D.N2 = N2; D.nuh = D.Mb * nu; D.nzh = D.nuh + nx; D.K = S.K;
+    if (N2 < 1 || N2 >= S.N) return false;
+    D.N1 = S.N / N2; D.R1 = S.N - N2 * D.N1;
+    D.Mb = D.N1 + (D.R1 > 0 ? 1 : 0); D.N2 = N2; D.nuh = D.Mb * nu; D.nzh = D.nuh + nx; D.K = S.K;
     if (D.nzh > 64) return false; // (one wave holds a block vector in the triangular solves; the index table packs rows in 8 bits)
     D.nbu = D.nbx = D.nxr = 0;
     for (int i = 0; i < LANES; i++) { D.xr_of[i] = -1; D.xr[i] = D.uvar[i] = D.xvar[i] = 0; }
@@ -37,7 +39,7 @@ inline bool cond_dims(const DevSpec &S, int nx, int nu, int ipx, int ipy, int N2
     D.o_SR = take((long)D.Mb * D.nxr * D.nzh); D.o_cr = take((long)D.Mb * D.nxr);
     D.o_BA = take((long)nx * D.nzh); D.o_bt = take(nx);
     D.o_H0 = take((long)D.nzh * D.nzh); D.o_g0 = take(D.nzh);
-    D.o_row = take(8L * D.nrows);            // ll, lu, tl, tu, dl, du, cx, cy
+    D.o_row = take((soft ? 14L : 8L) * D.nrows); // ll, lu, tl, tu, dl, du, cx, cy (+ sl, su, lsl, lsu, tsl, tsu when the obstacle rows are soft)
     D.o_Luu = take((long)D.nzh * D.nuh);     // [Luu; Lxu]: the first nuh columns of the eliminated stage matrix
     D.o_P = take((long)nx * nx);             // P_{i+1}
     D.o_Pb = take(nx);
@@ -53,7 +55,7 @@ inline bool cond_dims(const DevSpec &S, int nx, int nu, int ipx, int ipy, int N2
     l += (long)nx * nx + (long)nx * nz;                                   // Pn, BAk
     l += 4L * D.Mb * D.nxr + 3L * D.Mb * D.nxr + D.Mb + 3L * D.nuh;       // expansions, slots
     l += 4L * nt + 64;                                                    // obstacle-row buffer of one pass, reductions
-    l += 2L * LANES + (D.nzh * (D.nzh + 1) / 2 + 1) / 2 + 1 + 3L * LANES + KMAX; // short tables (ints), triangle index table, spec copies
+    l += 2L * LANES + (D.nzh * (D.nzh + 1) / 2 + 1) / 2 + 1 + 3L * LANES + 7L * KMAX; // short tables (ints), triangle index table, spec copies
     l += 8L * D.nzh + 12L * nx + 2L * D.nuh + 2L * nz + (long)D.Mb * nz + (long)D.Mb * D.nxr; // vectors
     D.lds_doubles = l + 64;
     return true;

@@ -2,7 +2,8 @@
 //
 // What acados' qp_solver = PARTIAL_CONDENSING_HPIPM does when qp_solver_cond_N = N2 < N
 // (/root/reference/catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/acados_settings.py:172 selects the solver; the reference leaves
-// cond_N at N, for which qp_ipm.hpp IS the solver): HPIPM d_part_cond_qp turns Mb = N / N2 consecutive stages into ONE stage
+// cond_N at N, for which qp_ipm.hpp IS the solver): HPIPM d_part_cond_qp turns Mb consecutive stages (N / N2 of them, one more in
+// the first N mod N2 blocks) into ONE stage
 // whose state is x_k0 and whose input is the stack u_hat = (u_k0 .. u_k0+Mb-1); the intermediate states are eliminated
 // through the dynamics, x_{k0+j} = Phi_j x_k0 + Gam_j u_hat + c_j.  The block's cost becomes a dense (nx + Mb nu)^2 Hessian,
 // its dynamics a dense nx x (nx + Mb nu) matrix, and every inequality row of an intermediate stage a general row in
@@ -20,7 +21,8 @@
 // Mapping (different from qp_ipm.hpp, whose row-per-lane layout ends at 16 variables per stage): ONE instance per team of
 // NT threads (a wave or a workgroup), the block's matrices in LDS, small dense kernels written as team-parallel loops
 // over output elements; the per-instance condensed data (S_j rows, H0, factors, row multipliers) lives in a per-TEAM
-// scratch area in HBM that is reused for every instance the team pulls from the queue.  Hard rows only.
+// scratch area in HBM that is reused for every instance the team pulls from the queue.  Obstacle rows hard or soft (SOFT: slacks
+// eliminated row by row as in qp_ipm.hpp's RowCalc); soft state bounds are not built.
 //
 // Parity: oracle/condense.py (numpy: part_cond + the oracle's IPM on the dense stages + expand) - tests/test_condensing.py
 // (CPU: this file compiled serially, -DUSV_COND_SERIAL; -m gpu: the kernel).
@@ -83,12 +85,13 @@ struct CondTeam {
 #define USV_CDEV __device__ __forceinline__
 #endif
 
-template <class M, int KCH, class TM>
+template <class M, int KCH, bool SOFT, class TM>
 struct CondIpm {
     static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU, NT = TM::NT;
     using MP = MatPack<M>;
-    using WL = WsLayout<M, KCH, false, false>;
-    using Row = RowCalc<false>;
+    using WL = WsLayout<M, KCH, SOFT, false>;
+    using Row = RowCalc<SOFT, SOFT>; // (soft obstacle rows next to hard box rows: the mixed form)
+    static constexpr int NRA = SOFT ? 14 : 8; // values per row in the scratch area
     struct EntTab { unsigned char row[MP::NE > 0 ? MP::NE : 1], col[MP::NE > 0 ? MP::NE : 1]; };
     static constexpr EntTab make_tab()
     {
@@ -104,7 +107,7 @@ struct CondIpm {
     // assume the scratch stores alias them, so every `S.field` / `D.field` there would be a load of its own inside the loops.  The
     // scalars are copied into members once (registers), the short tables into LDS.
     struct DimsLocal {
-        int Mb, N2, nuh, nzh, nxr, R, nrows, nbu, nbx, ipx, ipy;
+        int Mb, N2, N1, R1, nuh, nzh, nxr, R, nrows, nbu, nbx, ipx, ipy;
         int o_SR, o_cr, o_BA, o_bt, o_H0, o_g0, o_row, o_Luu, o_P, o_Pb, o_w, o_pi, o_rg, o_rb, o_dwa, o_dw, o_dpi, o_p, o_lus, o_dg;
         long blk;
         const int *xr, *uvar, *xvar; // LDS
@@ -112,6 +115,7 @@ struct CondIpm {
     struct SpecLocal {
         const double *Hc, *He;        // global (condensing / expansion only)
         const double *HcD, *lb, *ub, *uh; // LDS: Hessian diagonal, box bounds per variable of [u;x], upper bounds of the obstacle rows
+        const double *zl, *zu, *Zl, *Zu, *bsl, *bsu; // LDS: slack penalties (scaled by dt) and lower bounds of the slacks, per obstacle row
         const int *box_pos;           // LDS
         int N, K, B, Bp, npt, hdiag, p_static, iter_max, nbu, nbx, nc;
         double thr0, mu0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min;
@@ -137,7 +141,7 @@ struct CondIpm {
         S.iter_max = Sg.iter_max; S.nbu = Sg.nbu; S.nbx = Sg.nbx; S.nc = Sg.nc;
         S.thr0 = Sg.thr0; S.mu0 = Sg.mu0; S.tol_stat = Sg.tol_stat; S.tol_eq = Sg.tol_eq; S.tol_ineq = Sg.tol_ineq; S.tol_comp = Sg.tol_comp;
         S.alpha_min = Sg.alpha_min;
-        D.Mb = Dg.Mb; D.N2 = Dg.N2; D.nuh = Dg.nuh; D.nzh = Dg.nzh; D.nxr = Dg.nxr; D.R = Dg.R; D.nrows = Dg.nrows; D.nbu = Dg.nbu; D.nbx = Dg.nbx;
+        D.Mb = Dg.Mb; D.N2 = Dg.N2; D.N1 = Dg.N1; D.R1 = Dg.R1; D.nuh = Dg.nuh; D.nzh = Dg.nzh; D.nxr = Dg.nxr; D.R = Dg.R; D.nrows = Dg.nrows; D.nbu = Dg.nbu; D.nbx = Dg.nbx;
         D.ipx = Dg.ipx; D.ipy = Dg.ipy;
         D.o_SR = (int)Dg.o_SR; D.o_cr = (int)Dg.o_cr; D.o_BA = (int)Dg.o_BA; D.o_bt = (int)Dg.o_bt; D.o_H0 = (int)Dg.o_H0; D.o_g0 = (int)Dg.o_g0;
         D.o_row = (int)Dg.o_row; D.o_Luu = (int)Dg.o_Luu; D.o_P = (int)Dg.o_P; D.o_Pb = (int)Dg.o_Pb; D.o_w = (int)Dg.o_w; D.o_pi = (int)Dg.o_pi;
@@ -149,16 +153,21 @@ struct CondIpm {
         {   // the short tables
             int *it = reinterpret_cast<int *>(take(2 * LANES + (nzh * (nzh + 1) / 2 + 1) / 2 + 1));
             int *xr_ = it, *uvar_ = it + LANES, *xvar_ = it + 2 * LANES, *bpos_ = it + 3 * LANES, *tri_ = it + 4 * LANES;
-            double *sd = take(3 * LANES + KMAX);
+            double *sd = take(3 * LANES + 7 * KMAX);
             for (int e = tid; e < LANES; e += NT) {
                 xr_[e] = Dg.xr[e]; uvar_[e] = Dg.uvar[e]; xvar_[e] = Dg.xvar[e]; bpos_[e] = Sg.box_pos[e];
                 sd[e] = Sg.Hc[e * (LANES + 1)]; sd[LANES + e] = Sg.lb[e]; sd[2 * LANES + e] = Sg.ub[e];
             }
-            for (int e = tid; e < KMAX; e += NT) sd[3 * LANES + e] = Sg.uh[e];
+            for (int e = tid; e < KMAX; e += NT) {
+                double *so = sd + 3 * LANES;
+                so[e] = Sg.uh[e]; so[KMAX + e] = Sg.zl[e]; so[2 * KMAX + e] = Sg.zu[e]; so[3 * KMAX + e] = Sg.Zl[e]; so[4 * KMAX + e] = Sg.Zu[e];
+                so[5 * KMAX + e] = Sg.lsl[e]; so[6 * KMAX + e] = Sg.lsu[e];
+            }
             for (int a_ = tid; a_ < nzh; a_ += NT)
                 for (int c = 0; c <= a_; c++) tri_[a_ * (a_ + 1) / 2 + c] = (a_ << 8) | c;
             D.xr = xr_; D.uvar = uvar_; D.xvar = xvar_; S.box_pos = bpos_; tri = tri_;
             S.HcD = sd; S.lb = sd + LANES; S.ub = sd + 2 * LANES; S.uh = sd + 3 * LANES;
+            S.zl = S.uh + KMAX; S.zu = S.uh + 2 * KMAX; S.Zl = S.uh + 3 * KMAX; S.Zu = S.uh + 4 * KMAX; S.bsl = S.uh + 5 * KMAX; S.bsu = S.uh + 6 * KMAX;
         }
         Gm = take((long)(nzh + 1) * nzh);
         const long nsr = (long)Mb * nxr * nzh, ncn = 2L * NX * nzh + (long)NZ * nzh;
@@ -212,8 +221,13 @@ struct CondIpm {
         TM::sync();
     }
 
+    // Block i covers the stages k0(i) .. k0(i) + mbi(i) - 1 (HPIPM's partition).  Everything is sized for the longest block (Mb stages);
+    // a shorter block is PADDED: its surplus inputs get a unit Hessian diagonal, no rows and no effect on anything (they stay at 0),
+    // its surplus sensitivity rows are zero - the other numbers of the block are exactly those of the short block.
+    USV_CDEV int mbi(int i) const { return D.N1 + (i < D.R1 ? 1 : 0); }
+    USV_CDEV int k0(int i) const { return i * D.N1 + (i < D.R1 ? i : D.R1); }
     // row q of stage j of block i: which kind, and whether the stage has it
-    USV_CDEV bool row_active(int i, int j, int q) const { return q < D.nbu || (i * Mb + j) >= 1; }
+    USV_CDEV bool row_active(int i, int j, int q) const { return j < mbi(i) && (q < D.nbu || (k0(i) + j) >= 1); }
 
     // ------------------------------------------------------------------ condensing (HPIPM d_part_cond_qp restated) + cold start
     // Returns whether x0 violates a hard obstacle row of stage 0 (qp_ipm.hpp init(): acados' QP is then infeasible).
@@ -222,15 +236,26 @@ struct CondIpm {
         double bad0 = 0.0;
         for (int i = 0; i < N2; i++) {
             double *W = blk(i);
-            const int k0 = i * Mb;
+            const int k0_ = k0(i), mb = mbi(i);
             TM::sync();
             for (int e = tid; e < NX * nzh; e += NT) { const int s = e / nzh, c = e - s * nzh; Sm[e] = (c == nuh + s) ? 1.0 : 0.0; }
             for (int e = tid; e < (nzh + 1) * nzh; e += NT) Gm[e] = 0.0;
             for (int e = tid; e < nzh; e += NT) vg0[e] = 0.0;
             for (int e = tid; e < NX; e += NT) vbt[e] = 0.0; // c_j
             TM::sync();
-            for (int j = 0; j < Mb; j++) {
-                const int k = k0 + j;
+            for (int j = mb; j < Mb; j++) { // padding of a short block (see mbi)
+                for (int e = tid; e < nxr * nzh; e += NT) W[D.o_SR + (long)j * nxr * nzh + e] = 0.0;
+                for (int e = tid; e < nxr; e += NT) W[D.o_cr + j * nxr + e] = 0.0;
+                for (int l = tid; l < NU; l += NT) Gm[(j * NU + l) * nzh + j * NU + l] = 1.0;
+                for (int q = tid; q < R; q += NT) {
+                    double *rw = W + D.o_row + (long)j * R + q;
+                    rw[0] = 0.0; rw[nrows] = 0.0; rw[2 * nrows] = 1.0; rw[3 * nrows] = 1.0;
+                    rw[4 * nrows] = -1.0; rw[5 * nrows] = 1.0; rw[6 * nrows] = 0.0; rw[7 * nrows] = 0.0;
+                    if constexpr (SOFT) { rw[8 * nrows] = 0.0; rw[9 * nrows] = 0.0; rw[10 * nrows] = 0.0; rw[11 * nrows] = 0.0; rw[12 * nrows] = 1.0; rw[13 * nrows] = 1.0; }
+                }
+            }
+            for (int j = 0; j < mb; j++) {
+                const int k = k0_ + j;
                 load_stage(k);
                 // rows of S_j that some inequality row touches, and the offset c_j there
                 for (int e = tid; e < nxr * nzh; e += NT) { const int r = e / nzh, c = e - r * nzh; W[D.o_SR + (long)j * nxr * nzh + e] = Sm[D.xr[r] * nzh + c]; }
@@ -289,7 +314,7 @@ struct CondIpm {
                         if (act) {
                             dl = lhv - d; du = S.uh[o] - d; cx = ux; cy = uy;
                             v0 = ux * vbt[M::IPX] + uy * vbt[M::IPY];
-                        } else if (k == 0) { // x0 inside a hard keep-out circle (or beyond uh)
+                        } else if (!SOFT && k == 0) { // x0 inside a hard keep-out circle (or beyond uh)
                             const double e0x = P.x0[(long)b * NX + M::IPX] - vzb[NU + M::IPX], e0y = P.x0[(long)b * NX + M::IPY] - vzb[NU + M::IPY];
                             const double v = ux * e0x + uy * e0y;
                             if (lhv - d - v > S.tol_ineq || d + v - S.uh[o] > S.tol_ineq) bad0 = 1.0;
@@ -303,6 +328,15 @@ struct CondIpm {
                     }
                     rw[0] = ll; rw[nrows] = lu; rw[2 * nrows] = tl; rw[3 * nrows] = tu;
                     rw[4 * nrows] = dl; rw[5 * nrows] = du; rw[6 * nrows] = cx; rw[7 * nrows] = cy;
+                    if constexpr (SOFT) { // slack pairs of a soft obstacle row (qp_ipm.hpp init()): s = 0, t_s = max(0 - ls, thr0), lam_s = mu0 / t_s
+                        double tsl = 1.0, tsu = 1.0, lsl = 0.0, lsu = 0.0;
+                        if (act && q >= D.nbu + D.nbx) {
+                            const int o = q - D.nbu - D.nbx;
+                            tsl = fmax(0.0 - S.bsl[o], S.thr0); tsu = fmax(0.0 - S.bsu[o], S.thr0);
+                            lsl = S.mu0 / tsl; lsu = S.mu0 / tsu;
+                        }
+                        rw[8 * nrows] = 0.0; rw[9 * nrows] = 0.0; rw[10 * nrows] = lsl; rw[11 * nrows] = lsu; rw[12 * nrows] = tsl; rw[13 * nrows] = tsu;
+                    }
                 }
                 // S_{j+1} = A_k S_j + B_k E_j,  c_{j+1} = A_k c_j + b_k
                 for (int e = tid; e < NX * nzh; e += NT) {
@@ -395,6 +429,12 @@ struct CondIpm {
                     v = del[m]; wa = dela[m]; wf = delf[m];
                 } else {
                     obs = true;
+                    if constexpr (SOFT) {
+                        const int o = q - D.nbu - D.nbx;
+                        r.soft = r.act;
+                        r.sl = rw[8 * nrows]; r.su = rw[9 * nrows]; r.lsl = rw[10 * nrows]; r.lsu = rw[11 * nrows]; r.tsl = rw[12 * nrows]; r.tsu = rw[13 * nrows];
+                        r.zl = S.zl[o]; r.zu = S.zu[o]; r.Zl = S.Zl[o]; r.Zu = S.Zu[o]; r.bsl = S.bsl[o]; r.bsu = S.bsu[o];
+                    }
                     cx = rw[6 * nrows]; cy = rw[7 * nrows];
                     const int mx = j * nxr + D.ipx, my = j * nxr + D.ipy;
                     v = cx * del[mx] + cy * del[my]; wa = cx * dela[mx] + cy * dela[my]; wf = cx * delf[mx] + cy * delf[my];
@@ -554,7 +594,7 @@ struct CondIpm {
             TM::sync();
             expand_rows(del, vw, vcr);
             TM::sync();
-            double rd = 0.0, rm = 0.0, mus = 0.0, bd = 0.0;
+            double rd = 0.0, rm = 0.0, mus = 0.0, bd = 0.0, rgs = 0.0;
             row_pass(i, W, true, [&](int e, int j, int q, Row &r, double *rw, double v, double wa, double wf, double &yr, double &yg, double &Gh) {
                 (void)e;
                 if (pend && r.act) {
@@ -566,6 +606,9 @@ struct CondIpm {
                     r.resid(vo); r.targets_pred(); r.reduce(g0_, g1_); r.expand(wa); r.targets_corr(sig_prev); r.reduce(g0_, g1_);
                     r.expand(wf); r.apply(a_prev);
                     rw[0] = r.ll; rw[nrows] = r.lu; rw[2 * nrows] = r.tl; rw[3 * nrows] = r.tu;
+                    if constexpr (SOFT) {
+                        if (r.soft) { rw[8 * nrows] = r.sl; rw[9 * nrows] = r.su; rw[10 * nrows] = r.lsl; rw[11 * nrows] = r.lsu; rw[12 * nrows] = r.tsl; rw[13 * nrows] = r.tsu; }
+                    }
                 }
                 r.resid(v); r.targets_pred(); r.reduce(Gh, yg);
                 yr = -(r.ll - r.lu);
@@ -574,6 +617,15 @@ struct CondIpm {
                     rm = fmax(rm, fmax(r.ll * r.tl, r.lu * r.tu));
                     mus += r.ll * r.tl + r.lu * r.tu;
                     if (r.rdl != r.rdl || r.rdu != r.rdu || Gh != Gh) bd = fmax(bd, 2.0);
+                    if constexpr (SOFT) {
+                        if (r.soft) { // the slack pairs' residuals belong to the same four families (qp_ipm.hpp backward)
+                            rgs = fmax(rgs, fmax(fabs(r.rsl), fabs(r.rsu)));
+                            rd = fmax(rd, fmax(fabs(r.rdsl), fabs(r.rdsu)));
+                            rm = fmax(rm, fmax(r.lsl * r.tsl, r.lsu * r.tsu));
+                            mus += r.lsl * r.tsl + r.lsu * r.tsu;
+                            if (r.rsl != r.rsl || r.rsu != r.rsu || r.rdsl != r.rdsl || r.rdsu != r.rdsu) bd = fmax(bd, 2.0);
+                        }
+                    }
                 }
             });
             // r = g0 + H0 w + BA' pi_{i+1} - [0; pi_i];  rb = bt + BA w - x_{i+1}
@@ -601,7 +653,7 @@ struct CondIpm {
                 vgt[c] = vr[c];
             }
             for (int s = tid; s < NX; s += NT) { W[D.o_rb + s] = vrb[s]; rbl = fmax(rbl, fabs(vrb[s])); if (vrb[s] != vrb[s]) bd = fmax(bd, 4.0); }
-            nm.rg = fmax(nm.rg, rgl); nm.rb = fmax(nm.rb, rbl); nm.rd = fmax(nm.rd, rd); nm.rm = fmax(nm.rm, rm); nm.musum += mus;
+            nm.rg = fmax(nm.rg, fmax(rgl, rgs)); nm.rb = fmax(nm.rb, rbl); nm.rd = fmax(nm.rd, rd); nm.rm = fmax(nm.rm, rm); nm.musum += mus;
             badf = fmax(badf, bd);
             TM::sync();
             rows_transposed(vgt, yxg, yug);
@@ -793,6 +845,12 @@ struct CondIpm {
                 if (!corr && r.act) {
                     s1 += r.ll * r.dtl + r.tl * r.dll + r.lu * r.dtu + r.tu * r.dlu;
                     s2 += r.dll * r.dtl + r.dlu * r.dtu;
+                    if constexpr (SOFT) {
+                        if (r.soft) {
+                            s1 += r.lsl * r.dtsl + r.tsl * r.dlsl + r.lsu * r.dtsu + r.tsu * r.dlsu;
+                            s2 += r.dlsl * r.dtsl + r.dlsu * r.dtsu;
+                        }
+                    }
                 }
             });
             for (int s = tid; s < NX; s += NT) vdx[s] = vdxn[s];
@@ -823,18 +881,50 @@ struct CondIpm {
                     if (!row_active(i, j, q)) continue;
                     const double *rw = W + D.o_row + e;
                     if (q >= D.nbu + D.nbx) tmin = fmin(tmin, rw[2 * nrows]);
+                    const int kq = k0(i) + j;
                     if (P.lam_out) { // acados' row order [bu.., bx.., h..], lower | upper (qp_ipm.hpp export_rows)
                         const int nrow = S.nbu + S.nbx + Kn;
                         const int pos = q < D.nbu ? S.box_pos[D.uvar[q]] : (q < D.nbu + D.nbx ? S.box_pos[NU + D.xr[D.xvar[q - D.nbu]]] : S.nbu + S.nbx + (q - D.nbu - D.nbx));
-                        double *L = P.lam_out + ((long)b * (N + 1) + i * Mb + j) * P.nlam, *T = P.t_out + ((long)b * (N + 1) + i * Mb + j) * P.nlam;
+                        double *L = P.lam_out + ((long)b * (N + 1) + kq) * P.nlam, *T = P.t_out + ((long)b * (N + 1) + kq) * P.nlam;
                         L[pos] = rw[0]; L[nrow + pos] = rw[nrows]; T[pos] = rw[2 * nrows]; T[nrow + pos] = rw[3 * nrows];
+                        if constexpr (SOFT) {
+                            if (q >= D.nbu + D.nbx) { // slack rows [sh..]: lower-slack bound | upper-slack bound
+                                const int o = q - D.nbu - D.nbx, ns0 = 2 * nrow;
+                                L[ns0 + o] = rw[10 * nrows]; L[ns0 + Kn + o] = rw[11 * nrows]; T[ns0 + o] = rw[12 * nrows]; T[ns0 + Kn + o] = rw[13 * nrows];
+                            }
+                        }
+                    }
+                    if constexpr (SOFT) {
+                        if (q >= D.nbu + D.nbx && P.sl) {
+                            const int o = q - D.nbu - D.nbx;
+                            P.sl[((long)b * N + kq) * Kn + o] = rw[8 * nrows];
+                            P.su[((long)b * N + kq) * Kn + o] = rw[9 * nrows];
+                        }
                     }
                 }
                 TM::sync();
                 // primal: the intermediate states by the original dynamics (d_part_cond_qp_expand_sol)
-                for (int j = 0; j < Mb; j++) {
-                    const int k = i * Mb + j;
+                const int mb = mbi(i);
+                for (int j = 0; j < mb; j++) {
+                    const int k = k0(i) + j;
                     load_stage(k);
+                    if constexpr (SOFT) {
+                        if (k == 0 && P.sl) { // soft rows of stage 0 (qp_ipm.hpp finish()): x_0 = x0 fixes their value, the slacks minimise their own penalty
+                            const double e0x = P.x0[(long)b * NX + M::IPX] - vzb[NU + M::IPX], e0y = P.x0[(long)b * NX + M::IPY] - vzb[NU + M::IPY];
+                            for (int o = tid; o < Kn; o += NT) {
+                                const double *pk = P.p + ((long)b * (N + 1)) * 2 * Kn;
+                                const double lhv = P.lh[((long)b * N) * Kn + o];
+                                double d, ux, uy;
+                                obs_dist(vzb[NU + M::IPX] - pk[2 * o], vzb[NU + M::IPY] - pk[2 * o + 1], d, ux, uy);
+                                const double v0 = ux * e0x + uy * e0y;
+                                double a = fmax(S.bsl[o], lhv - d - v0), qq = fmax(S.bsu[o], d + v0 - S.uh[o]);
+                                if (S.Zl[o] > 0.0) a = fmax(a, -S.zl[o] / S.Zl[o]);
+                                if (S.Zu[o] > 0.0) qq = fmax(qq, -S.zu[o] / S.Zu[o]);
+                                P.sl[(long)b * N * Kn + o] = a;
+                                P.su[(long)b * N * Kn + o] = qq;
+                            }
+                        }
+                    }
                     for (int e = tid; e < NZ; e += NT) vdz[j * NZ + e] = (e < NU) ? vw[j * NU + e] : vdx[e - NU];
                     TM::sync();
                     for (int s = tid; s < NX; s += NT) {
@@ -849,8 +939,8 @@ struct CondIpm {
                 // dynamics multipliers: pi_{k0+Mb} = pi of the next condensed stage; inside the block the adjoint recursion
                 // pi_k = (Hc z_k + g_k - C_k'(ll - lu))_x + A_k' pi_{k+1}
                 if (P.pi) {
-                    for (int j = Mb - 1; j >= 0; j--) {
-                        const int k = i * Mb + j;
+                    for (int j = mb - 1; j >= 0; j--) {
+                        const int k = k0(i) + j;
                         TM::sync();
                         for (int e = tid; e < NX; e += NT) P.pi[((long)b * N + k) * NX + e] = vpin[e]; // pi_{k+1}
                         if (j == 0) break;
@@ -878,8 +968,8 @@ struct CondIpm {
                 // the RTI step (after the multiplier pass, which linearises at the OLD iterate)
                 TM::sync();
                 if (ok)
-                    for (int e = tid; e < Mb * NZ; e += NT) {
-                        const int j = e / NZ, c = e - j * NZ, k = i * Mb + j;
+                    for (int e = tid; e < mb * NZ; e += NT) {
+                        const int j = e / NZ, c = e - j * NZ, k = k0(i) + j;
                         if (c < NU) P.u[((long)b * N + k) * NU + c] += vdz[e];
                         else P.x[((long)b * (N + 1) + k) * NX + (c - NU)] += vdz[e];
                     }

@@ -24,12 +24,12 @@ namespace usv {
 
 // One instance per workgroup of NT threads, the condensed block's matrices in LDS, the instance's condensed QP in the
 // workgroup's scratch area in HBM; workgroups pull further instances from the queue as they finish.
-template <class M, int KCH, int NT>
+template <class M, int KCH, bool SOFT, int NT>
 __global__ void __launch_bounds__(NT, USV_COND_MINWAVES) usv_qp_cond(DevPtrs P, const CondDims *Dp, double *scratch, int nB, int queue0)
 {
     extern __shared__ double cond_lds[];
     __shared__ int nxt;
-    CondIpm<M, KCH, CondTeam<NT>> q(P, *Dp, scratch + (long)blockIdx.x * Dp->total, cond_lds);
+    CondIpm<M, KCH, SOFT, CondTeam<NT>> q(P, *Dp, scratch + (long)blockIdx.x * Dp->total, cond_lds);
     long g = blockIdx.x;
     while (g < nB) {
         q.solve(g);
@@ -42,12 +42,12 @@ __global__ void __launch_bounds__(NT, USV_COND_MINWAVES) usv_qp_cond(DevPtrs P, 
 
 namespace {
 
-template <class M, int KCH>
+template <class M, int KCH, bool SOFT>
 int prepare_for(const DevSpec &S, int N2, CondDims &D, size_t &lds, int &nb, std::string &err)
 {
     constexpr int NT = USV_COND_THREADS;
-    auto kern = &usv_qp_cond<M, KCH, NT>;
-    if (!cond_dims(S, M::NX, M::NU, M::IPX, M::IPY, N2, NT, D)) { err = "qp_cond_N must divide N, and a condensed stage may have at most 64 variables (nx + (N / qp_cond_N) nu)"; return USVMPC_E_ARG; }
+    auto kern = &usv_qp_cond<M, KCH, SOFT, NT>;
+    if (!cond_dims(S, M::NX, M::NU, M::IPX, M::IPY, N2, NT, SOFT, D)) { err = "qp_cond_N must lie in 1..N-1 and a condensed stage may have at most 64 variables (nx + ceil(N / qp_cond_N) nu)"; return USVMPC_E_ARG; }
     lds = (size_t)D.lds_doubles * sizeof(double);
     if (lds > 160u * 1024u) { err = "partial condensing: the condensed block does not fit in LDS (block too large)"; return USVMPC_E_ARG; }
     nb = 0;
@@ -59,17 +59,17 @@ int prepare_for(const DevSpec &S, int N2, CondDims &D, size_t &lds, int &nb, std
     return 0;
 }
 
-template <class M, int KCH>
+template <class M, int KCH, bool SOFT>
 int run_for(hipStream_t st, long teams, size_t lds, const DevPtrs &P, const CondDims *dD, double *scratch, int B)
 {
     constexpr int NT = USV_COND_THREADS;
-    hipLaunchKernelGGL((usv_qp_cond<M, KCH, NT>), dim3((unsigned)teams), dim3(NT), lds, st, P, dD, scratch, B, (int)teams);
+    hipLaunchKernelGGL((usv_qp_cond<M, KCH, SOFT, NT>), dim3((unsigned)teams), dim3(NT), lds, st, P, dD, scratch, B, (int)teams);
     return 0;
 }
 
 } // namespace
 
-// (hard rows only: usv_model has none, usv_model_pf_ca has hard obstacle rows; usv_model_guidance_ca1's are soft)
+// (usv_model has no obstacle rows, usv_model_pf_ca hard ones, usv_model_guidance_ca1 soft ones)
 #define USV_COND_DISPATCH(CALL)                                                                                      \
     switch (model) {                                                                                                 \
     USV_COND_BUILTIN(CALL)                                                                                           \
@@ -79,30 +79,31 @@ int run_for(hipStream_t st, long teams, size_t lds, const DevPtrs &P, const Cond
 #if defined(USV_GEN_ONLY)
 #define USV_COND_BUILTIN(CALL)
 #elif defined(USV_BENCH_ONLY)
-#define USV_COND_BUILTIN(CALL) case USVMPC_MODEL_PF_CA: if (kch <= 1) return CALL(ModelM2, 1); break;
+#define USV_COND_BUILTIN(CALL) case USVMPC_MODEL_PF_CA: if (kch <= 1) return CALL(ModelM2, 1, false); break; case USVMPC_MODEL_GUIDANCE_CA1: if (kch <= 1) return CALL(ModelM1, 1, true); break;
 #else
 #define USV_COND_BUILTIN(CALL)                                                                                       \
-    case USVMPC_MODEL_USV: return CALL(ModelM0, 0);                                                                  \
-    case USVMPC_MODEL_PF_CA: return kch <= 1 ? CALL(ModelM2, 1) : CALL(ModelM2, 2);
+    case USVMPC_MODEL_USV: return CALL(ModelM0, 0, false);                                                           \
+    case USVMPC_MODEL_GUIDANCE_CA1: return kch <= 1 ? CALL(ModelM1, 1, true) : CALL(ModelM1, 2, true);               \
+    case USVMPC_MODEL_PF_CA: return kch <= 1 ? CALL(ModelM2, 1, false) : CALL(ModelM2, 2, false);
 #endif
 #if defined(USV_GEN_MODEL_HEADER) && !defined(USV_BENCH_ONLY)
-#define USV_COND_GENERATED(CALL) case USVMPC_MODEL_GENERATED: if (!(USV_GEN_SOFT != 0)) return CALL(ModelGen, USV_GEN_KCH); break;
+#define USV_COND_GENERATED(CALL) case USVMPC_MODEL_GENERATED: return CALL(ModelGen, USV_GEN_KCH, (USV_GEN_SOFT != 0));
 #else
 #define USV_COND_GENERATED(CALL)
 #endif
 
 int cond_prepare(int model, int kch, const DevSpec &S, int N2, CondDims &D, size_t &lds_bytes, int &blocks_per_cu, std::string &err)
 {
-#define USV_COND_PREP(M, K) prepare_for<M, K>(S, N2, D, lds_bytes, blocks_per_cu, err)
+#define USV_COND_PREP(M, K, SF) prepare_for<M, K, SF>(S, N2, D, lds_bytes, blocks_per_cu, err)
     USV_COND_DISPATCH(USV_COND_PREP)
 #undef USV_COND_PREP
-    err = "partial condensing: no kernel for this model in this library (hard rows only)";
+    err = "partial condensing: no kernel for this model in this library";
     return USVMPC_E_ARG;
 }
 
 int cond_run(int model, int kch, hipStream_t st, long teams, size_t lds_bytes, const DevPtrs &P, const CondDims *dD, double *scratch, int B)
 {
-#define USV_COND_RUN(M, K) run_for<M, K>(st, teams, lds_bytes, P, dD, scratch, B)
+#define USV_COND_RUN(M, K, SF) run_for<M, K, SF>(st, teams, lds_bytes, P, dD, scratch, B)
     USV_COND_DISPATCH(USV_COND_RUN)
 #undef USV_COND_RUN
     return -1;

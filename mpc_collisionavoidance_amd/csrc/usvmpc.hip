@@ -722,8 +722,7 @@ int launch_pair(usvmpc_handle *h, int phase)
     };
     int rcq = 0;
     if (cond) {
-        if constexpr (SOFT) { h->err = "partial condensing (qp_cond_N) is implemented for hard rows"; return USVMPC_E_ARG; }
-        else rcq = launch_cond(h);
+        rcq = launch_cond(h);
     } else {
 #ifdef USV_BENCH_ONLY // development builds (tools/dev_build.sh): only the instantiation the bench workload runs
     if (!(h->spec.hdiag && pack && !h->spec.any_bsoft)) { h->err = "development build: bench instantiation only"; return USVMPC_E_ARG; }
@@ -1333,8 +1332,9 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         if (n2 < 0 || n2 > h->N) { h->err = "qp_cond_N must lie in 0..N"; return USVMPC_E_ARG; }
         const int want = (n2 == 0 || n2 == h->N) ? 0 : n2;
         if (want > 0) {
-            if (h->N % want) { h->err = "qp_cond_N must divide N (equal blocks)"; return USVMPC_E_ARG; }
-            if (h->soft || h->spec.any_bsoft) { h->err = "partial condensing (qp_cond_N) is implemented for hard rows"; return USVMPC_E_ARG; }
+            // (blocks as HPIPM partitions them: N / N2 stages each, the first N mod N2 one more; one block's variables must fit a wave)
+            if (h->nx + ((h->N + want - 1) / want) * h->nu > 64) { h->err = "qp_cond_N: a condensed stage may have at most 64 variables (nx + ceil(N / qp_cond_N) nu)"; return USVMPC_E_ARG; }
+            if (h->spec.any_bsoft) { h->err = "partial condensing (qp_cond_N) is not built for soft state bounds"; return USVMPC_E_ARG; }
         }
         if (want != h->cond_N2) { cond_release(h); h->cond_N2 = want; h->map_changed = true; }
         return 0;

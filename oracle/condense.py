@@ -6,7 +6,8 @@ What acados' qp_solver = PARTIAL_CONDENSING_HPIPM does when qp_solver_cond_N = N
 N = 80 -> N2 = 10; /root/reference/catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/acados_settings.py:172 selects the solver,
 the reference leaves cond_N at its default N, i.e. blocks of one stage):
 
-  part_cond   HPIPM d_part_cond_qp restated - consecutive stages k0 .. k0+M-1 become ONE stage whose state is x_k0 and
+  part_cond   HPIPM d_part_cond_qp restated (blocks of N / N2 stages, the first N mod N2 of them one longer) - consecutive
+              stages k0 .. k0+M-1 become ONE stage whose state is x_k0 and
               whose input is the stack (u_k0, .., u_k0+M-1); the intermediate states are eliminated through the
               dynamics, x_{k0+j} = Phi_j x_k0 + Gam_j u_hat + c_j, which turns the block's cost into a dense
               (nx + M nu)^2 Hessian and EVERY inequality row of an intermediate stage (input bound, state bound,
@@ -26,16 +27,19 @@ def part_cond(qp, N2):
     """qp: dict of oracle.binding.linearize_and_solve(..., solve=False).  Returns the condensed QP: a list of N2 + 1
     stage dicts (H, g, A, B, b, C, dl, du) plus what expand() needs."""
     N, nx, nu, nz, K = qp["N"], qp["nx"], qp["nu"], qp["nz"], qp["K"]
-    if N % N2:
-        raise ValueError("N must be a multiple of the number of blocks")
+    if not 1 <= N2 <= N:
+        raise ValueError("the number of blocks must lie in 1..N")
     if qp["soft"] or any(qp["sbx"]):
         raise NotImplementedError("hard rows only")
-    M = N // N2
-    nuh = M * nu
+    # HPIPM d_part_cond_qp_compute_block_size: N1 = N / N2 stages per block, the first N - N2 N1 blocks one more
+    N1, R1 = N // N2, N - N2 * (N // N2)
+    Ms = [N1 + (1 if i < R1 else 0) for i in range(N2)]
+    k0s = [i * N1 + min(i, R1) for i in range(N2)]
     ipx, ipy = nu + qp["ipx"], nu + qp["ipy"]
     stages, maps = [], []
     for i in range(N2):
-        k0 = i * M
+        k0, M = k0s[i], Ms[i]
+        nuh = M * nu
         nzh = nuh + nx
         Phi, Gam, c = np.eye(nx), np.zeros((nx, nuh)), np.zeros(nx)
         Hh, gh = np.zeros((nzh, nzh)), np.zeros(nzh)
@@ -77,7 +81,7 @@ def part_cond(qp, N2):
         maps.append(Ts)
     HN = qp["H"][N][nu:, nu:]
     stages.append(dict(H=HN, g=qp["g"][N][nu:], A=None, B=None, b=None, C=np.zeros((0, nx)), dl=np.zeros(0), du=np.zeros(0), nu=0))
-    return dict(stages=stages, maps=maps, nx=nx, nu=nu, N=N, N2=N2, M=M, dx0=qp["dx0"].copy())
+    return dict(stages=stages, maps=maps, nx=nx, nu=nu, N=N, N2=N2, Ms=Ms, k0s=k0s, dx0=qp["dx0"].copy())
 
 
 def solve(cq, opts):
@@ -237,11 +241,11 @@ def solve(cq, opts):
 
 def expand(cq, sol):
     """dz [N+1, nz] of the original stages from the condensed solution."""
-    nx, nu, N, M = cq["nx"], cq["nu"], cq["N"], cq["M"]
+    nx, nu, N = cq["nx"], cq["nu"], cq["N"]
     dz = np.zeros((N + 1, nu + nx))
     for i, Ts in enumerate(cq["maps"]):
         for j, (T, d) in enumerate(Ts):
-            dz[i * M + j] = T @ sol["w"][i] + d
+            dz[cq["k0s"][i] + j] = T @ sol["w"][i] + d
     dz[N, nu:] = sol["w"][-1]
     return dz
 
@@ -250,11 +254,12 @@ def evaluate(cq, dz):
     """A step dz [N+1, nz] of the ORIGINAL stages judged as a point of the CONDENSED QP: (objective, largest violation of
     its inequality rows, largest dynamics / initial-state residual).  The block variables are read off dz (u_hat = the
     block's inputs, x_hat = the state at the block's first stage)."""
-    nx, nu, N, M = cq["nx"], cq["nu"], cq["N"], cq["M"]
+    nx, nu, N = cq["nx"], cq["nu"], cq["N"]
     st = cq["stages"]
     w = []
     for i in range(cq["N2"]):
-        w.append(np.concatenate([dz[i * M:(i + 1) * M, :nu].reshape(-1), dz[i * M, nu:]]))
+        k0, M = cq["k0s"][i], cq["Ms"][i]
+        w.append(np.concatenate([dz[k0:k0 + M, :nu].reshape(-1), dz[k0, nu:]]))
     w.append(dz[N, nu:].copy())
     obj, viol = 0.0, 0.0
     eq = float(np.abs(cq["dx0"] - w[0][st[0]["nu"]:]).max())

@@ -148,17 +148,17 @@ double *g_emu_lam = nullptr, *g_emu_t = nullptr; // [B][N+1][nlam] each: filled 
 // per row), rb0 [N][Bp*16], gq [N+1][Bp*16]
 double *g_dbg_BAt = nullptr, *g_dbg_rb0 = nullptr, *g_dbg_gq = nullptr;
 long g_emu_rows = 2; // persistent rows of an emulated RTI solve (0: one row per group, no queue)
-int g_emu_cond_N2 = 0; // > 0: RTI solves condense the QP to this many stages first (cond_ipm.hpp, hard rows only)
+int g_emu_cond_N2 = 0; // > 0: RTI solves condense the QP to this many stages first (cond_ipm.hpp)
 
 // the condensed solve of every instance, serially (the device runs one team of threads per instance)
-template <class M, int KCH>
+template <class M, int KCH, bool SOFT>
 int cond_all(const DevPtrs &P, const DevSpec &S, int N2)
 {
     CondDims D;
-    if (!cond_dims(S, M::NX, M::NU, M::IPX, M::IPY, N2, 1, D)) return -4;
+    if (!cond_dims(S, M::NX, M::NU, M::IPX, M::IPY, N2, 1, SOFT, D)) return -4;
     std::vector<double> scratch((size_t)D.total, 0.0), lds((size_t)D.lds_doubles, 0.0);
     for (long g = 0; g < S.B; g++) {
-        CondIpm<M, KCH, CondTeam> q(P, D, scratch.data(), lds.data());
+        CondIpm<M, KCH, SOFT, CondTeam> q(P, D, scratch.data(), lds.data());
         q.solve(g);
     }
     return 0;
@@ -210,11 +210,9 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
     if ((phase & 1) && (g_dbg_BAt || g_dbg_rb0 || g_dbg_gq)) expand_packed<M, KCH, SOFT>(P, S);
     // RTI: a few persistent rows that pull the remaining groups from the queue (as the device launch does); full SQP: one
     // group per row
-    if constexpr (!SOFT) {
-        if ((phase & 2) && qp_phase == 0 && g_emu_cond_N2 > 0 && !S.any_bsoft) {
-            if (cond_all<M, KCH>(P, S, g_emu_cond_N2)) std::abort();
-            return;
-        }
+    if ((phase & 2) && qp_phase == 0 && g_emu_cond_N2 > 0 && !S.any_bsoft) {
+        if (cond_all<M, KCH, SOFT>(P, S, g_emu_cond_N2)) std::abort();
+        return;
     }
     const bool queue = qp_phase == 0 && g_emu_rows > 0 && g_emu_rows < S.Bp;
     const long nrows = queue ? g_emu_rows : S.Bp;

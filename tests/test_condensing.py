@@ -38,8 +38,9 @@ def _spec(oracle, N, K, **kw):
     return oracle.spec(2, N, N * scenario.BENCH_DT, K, sim_steps=scenario.BENCH_SIM_STEPS[NAME], **kw)
 
 
-def test_condensed_qp_reproduces_the_uncondensed_solution(oracle):
-    N, K, B, N2 = 16, 4, 6, 4
+@pytest.mark.parametrize("N2", [4, 3, 7])   # (3: blocks of 6, 5, 5 stages; 7: of 3, 3, 2, 2, 2, 2, 2 - HPIPM's partition when N2 does not divide N)
+def test_condensed_qp_reproduces_the_uncondensed_solution(oracle, N2):
+    N, K, B = 16, 4, 6
     wl = scenario.make_bench_batch(NAME, N, K, B, moving=True, seed=5)
     spec = _spec(oracle, N, K)
     x, u = wl["x_init"].copy(), wl["u_init"].copy()
@@ -98,7 +99,9 @@ def _emu_cond_rti(emu, desc, wl, x, u, N2, export=False):
 # (blocks of 4 stages; two obstacle chunks; a model without obstacle rows; blocks of 2)
 @pytest.mark.parametrize("name,N,K,B,N2", [("usv_model_pf_ca", 16, 4, 4, 4), ("usv_model_pf_ca", 12, 18, 2, 3),
                                            ("usv_model", 8, 0, 3, 2), ("usv_model_pf_ca", 12, 3, 2, 6),
-                                           ("usv_model_pf_ca", 10, 3, 2, 1)])   # (N2 = 1: the whole horizon in one block - full condensing)
+                                           ("usv_model_pf_ca", 10, 3, 2, 1),    # (N2 = 1: the whole horizon in one block - full condensing)
+                                           ("usv_model_pf_ca", 16, 4, 3, 3), ("usv_model_pf_ca", 16, 4, 2, 7),   # (blocks of 6 5 5 / 3 3 2 2 2 2 2 stages)
+                                           ("usv_model", 11, 0, 2, 4)])
 def test_condensing_kernel_body_matches_condensing_oracle(oracle, emu, name, N, K, B, N2):
     dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
     wl = scenario.make_bench_batch(name, N, K, B, moving=K > 0, seed=5)
@@ -117,6 +120,54 @@ def test_condensing_kernel_body_matches_condensing_oracle(oracle, emu, name, N, 
             assert np.allclose(r["res"][b], c["res"], rtol=1e-3, atol=1e-12)
         x, u = r["x"], r["u"]
         wl["x0"] = x[:, 1].copy()   # closed loop: the dynamics residual is non-zero from the second tick on
+
+
+@pytest.mark.parametrize("K,N2", [(5, 4), (20, 5), (5, 3)])   # (one / two obstacle chunks; blocks of 6 5 5)
+def test_condensing_kernel_body_with_soft_rows(oracle, emu, K, N2):
+    """usv_model_guidance_ca1 (soft obstacle rows: the slacks are eliminated row by row).  oracle/condense.py has hard rows only, so the
+    checks are: tick 0, where the rolled-out guess satisfies the dynamics and the condensed and the uncondensed IPM coincide iterate by
+    iterate - the uncondensed C oracle: same iteration counts, iterates and slacks to 1e-9; every tick - the expanded
+    (x, u, pi, lam, t, sl, su) against the KKT conditions of the original QP (tests/kkt.py, independent of any iteration path)."""
+    name, N, B = "usv_model_guidance_ca1", 16, 3
+    dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
+    wl = scenario.make_bench_batch(name, N, K, B, seed=11)
+    ocp = usv_models.make_ocp(name, N * dt, N, K)
+    ocp.solver_options.sim_method_num_steps = steps
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    spec = oracle.spec(util.MODEL_ID[name], N, N * dt, K, sim_steps=steps)
+    from tests.test_emu_kernels import emu_rti
+    emu.usv_emu_set_cond.argtypes = [C.c_int]
+    emu.usv_emu_set_export.argtypes = [_capi._dp, _capi._dp]
+    emu.usv_emu_set_export.restype = None
+    nlam = 2 * (desc.nbu + desc.nbx + 2 * K)
+    x, u = wl["x_init"].copy(), wl["u_init"].copy()
+    active = 0
+    for tick in range(3):
+        lam, t = np.zeros((B, N + 1, nlam)), np.zeros((B, N + 1, nlam))
+        emu.usv_emu_set_cond(N2)
+        emu.usv_emu_set_export(lam.ctypes.data_as(_capi._dp), t.ctypes.data_as(_capi._dp))
+        try:
+            r = emu_rti(emu, desc, wl, x, u)
+        finally:
+            emu.usv_emu_set_cond(0)
+            emu.usv_emu_set_export(None, None)
+        assert (r["status"] == 0).all() and (r["qp_status"] == 0).all()
+        if tick == 0:
+            xo, uo, sto, ito = util.oracle_rti(oracle, spec, wl, x.copy(), u.copy())
+            assert np.array_equal(r["qp_iter"], ito) and np.array_equal(r["status"], sto)
+            assert util.rel_err(r["x"], xo) < 1e-9 and util.rel_err(r["u"], uo) < 1e-9
+        qp = kkt.linearize_batch(oracle, spec, x, u, wl["x0"], wl["yref"], wl["yref_e"], wl["p"], wl["lh"])
+        dz = np.zeros((B, N + 1, 9))
+        dz[:, :, 1:] = r["x"] - x
+        dz[:, :N, :1] = r["u"] - u
+        pad = lambda a: np.concatenate([a, np.zeros_like(a[:, :1])], axis=1)   # noqa: E731
+        res = kkt.kkt_batch(qp, dz, np.concatenate([np.zeros((B, 1, 8)), r["pi"]], axis=1), lam, t, pad(r["sl"]), pad(r["su"]))
+        assert kkt.certified(res).all(), (tick, res)
+        nrow = desc.nbu + desc.nbx + K
+        active += int((lam[:, :, desc.nbu + desc.nbx:nrow] > 1e-3).any(axis=(1, 2)).sum())
+        x, u = r["x"], r["u"]
+        wl["x0"] = x[:, 1].copy()
+    assert active > 0, "no obstacle row carried a multiplier: the case does not exercise the inequality path"
 
 
 def test_condensing_kernel_body_solution_is_certified_on_the_uncondensed_qp(oracle, emu):
@@ -164,7 +215,8 @@ def _cond_solver(name, N, K, B, wl, N2, extra=()):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,N,K,B,N2", [("usv_model_pf_ca", 80, 20, 96, 10), ("usv_model_pf_ca", 40, 10, 160, 8),
-                                           ("usv_model", 20, 0, 70, 4), ("usv_model_pf_ca", 10, 3, 40, 1)])
+                                           ("usv_model", 20, 0, 70, 4), ("usv_model_pf_ca", 10, 3, 40, 1),
+                                           ("usv_model_pf_ca", 40, 10, 64, 6)])   # (blocks of 7 7 7 7 6 6 stages)
 def test_condensing_kernel_on_the_device_vs_condensing_oracle(oracle, name, N, K, B, N2):
     """qp_solver_cond_N = N2 is APPLIED: the device condenses, solves the N2 dense stages and expands.  Same iteration path as
     oracle/condense.py: statuses, iteration counts (more than one off for at most 2 % of the instances) and
@@ -263,13 +315,34 @@ def test_condensed_rti_then_full_sqp_and_multiplier_read_back(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,K,B,N2", [(40, 10, 256, 8), (100, 8, 64, 20), (40, 20, 96, 6)])   # (the bench shape; the ROS node's N = 100, K = 8; two chunks, blocks of 7 7 7 7 6 6)
+def test_condensing_kernel_with_soft_rows_on_the_device(oracle, N, K, B, N2):
+    """usv_model_guidance_ca1 - the model of the reference's ROS node - with qp_solver_cond_N applied.  No condensing oracle for soft
+    rows, so: tick 0 (both cold starts coincide) against the uncondensed kernel and the C oracle - statuses, iteration counts, iterates and
+    slacks; closed loop: every converged solve KKT-certified on the original QP (tests/test_kkt_certify.py machinery)."""
+    name = "usv_model_guidance_ca1"
+    wl = scenario.make_bench_batch(name, N, K, B, seed=1234)
+    dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
+    spec = oracle.spec(util.MODEL_ID[name], N, N * dt, K, sim_steps=steps)
+    sc, su_ = _cond_solver(name, N, K, B, wl, N2), _cond_solver(name, N, K, B, wl, 0)
+    st, stu = sc.solve(), su_.solve()
+    xo, uo, sto, ito = util.oracle_rti(oracle, spec, wl, wl["x_init"].copy(), wl["u_init"].copy())
+    assert np.array_equal(st, stu) and np.array_equal(st, sto)
+    assert (np.abs(sc.get_int("qp_iter") - ito) > 1).sum() <= max(1, int(0.02 * B))
+    ok = (st == 0) & (sc.get_int("qp_iter") == ito)
+    assert ok.mean() > 0.9
+    assert util.rel_err(sc.get_all("x")[ok], xo[ok]) < 1e-7 and util.rel_err(sc.get_all("u")[ok], uo[ok]) < 1e-7
+    assert util.rel_err(sc.get_all("x")[ok], su_.get_all("x")[ok]) < 1e-7
+    assert np.abs(sc.get_all("sl")[ok] - su_.get_all("sl")[ok]).max() < 1e-7 and np.abs(sc.get_all("su")[ok] - su_.get_all("su")[ok]).max() < 1e-7
+    sc.close(); su_.close()
+    from tests.test_kkt_certify import _certify_closed_loop
+    out = _certify_closed_loop(oracle, name, N, K, B, 3, options=(("keep_multipliers", 1), ("qp_cond_N", N2)))
+    assert out["kkt_certified_frac"] == 1.0, out
+
+
+@pytest.mark.gpu
 def test_condensing_option_is_refused_where_it_is_not_built():
-    wl = scenario.make_bench_batch("usv_model_guidance_ca1", 20, 4, 8, seed=3)
-    with pytest.raises(Exception, match="hard rows"):
-        _cond_solver("usv_model_guidance_ca1", 20, 4, 8, wl, 5)
     wl = scenario.make_bench_batch("usv_model_pf_ca", 20, 4, 8, seed=3)
-    with pytest.raises(Exception, match="divide"):
-        _cond_solver("usv_model_pf_ca", 20, 4, 8, wl, 3)
     wl40 = scenario.make_bench_batch("usv_model_pf_ca", 40, 4, 8, seed=3)
     with pytest.raises(Exception, match="at most 64"):
         _cond_solver("usv_model_pf_ca", 40, 4, 8, wl40, 1)    # 14 + 40 * 2 = 94 variables in the one block

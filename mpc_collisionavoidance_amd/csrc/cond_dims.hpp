@@ -18,6 +18,7 @@ struct CondDims {
     long o_SR, o_cr, o_BA, o_bt, o_H0, o_g0, o_row, o_Luu, o_P, o_Pb, o_w, o_pi, o_rg, o_rb, o_dwa, o_dw, o_dpi, o_p, o_lus, o_dg, blk;
     long total;           // (N2 + 1) * blk
     long lds_doubles;     // LDS the kernel needs (doubles), for NT threads
+    int nt;               // threads of a team (cond_prepare picks it: the instantiation with the most resident waves per CU)
 };
 
 inline bool cond_dims(const DevSpec &S, int nx, int nu, int ipx, int ipy, int N2, int nt, bool soft, CondDims &D)
@@ -58,6 +59,7 @@ inline bool cond_dims(const DevSpec &S, int nx, int nu, int ipx, int ipy, int N2
     l += 2L * LANES + (D.nzh * (D.nzh + 1) / 2 + 1) / 2 + 1 + 3L * LANES + 7L * KMAX; // short tables (ints), triangle index table, spec copies
     l += 8L * D.nzh + 12L * nx + 2L * D.nuh + 2L * nz + (long)D.Mb * nz + (long)D.Mb * D.nxr; // vectors
     D.lds_doubles = l + 64;
+    D.nt = nt;
     return true;
 }
 

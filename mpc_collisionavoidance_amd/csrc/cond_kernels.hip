@@ -12,13 +12,12 @@
 
 namespace usv {
 
-// Team size and register budget, measured at BASELINE configs[4]'s shape (8192 instances, profiles/r03_condensing_ab.txt): the kernel
-// is bound by latency (LDS round trips, barriers), i.e. by how many teams a CU holds - LDS allows three of ~50 KB; 256 threads at
-// 168 registers (three waves per SIMD, ~160 registers spilled) beat 64 / 128 threads at any budget and 256 at 256 registers.
-#ifndef USV_COND_THREADS
-#define USV_COND_THREADS 256
-#endif
-#ifndef USV_COND_MINWAVES // waves per SIMD the kernel is compiled for (register budget 512 / that)
+// Team size and register budget (profiles/r03_condensing_ab.txt): the kernel is bound by latency (LDS round trips, barriers), i.e. by how many
+// waves a CU holds.  With 30-variable blocks (usv_model_pf_ca, 8 stages per block) LDS allows three teams of ~50 KB per CU: 256-thread
+// teams at 168 registers (three waves per SIMD) beat 64 / 128 threads at any budget (233 against 285 .. 425 ms at 8192 instances).  With
+// 13-variable blocks (usv_model_guidance_ca1, 5 stages per block) a team needs a few KB and twelve 64-thread teams fit: 188 ms against
+// 378 ms with 256-thread teams at 65536 instances.  Both are built; cond_prepare takes the one with more resident waves per CU.
+#ifndef USV_COND_MINWAVES // waves per SIMD the kernels are compiled for (register budget 512 / that)
 #define USV_COND_MINWAVES 3
 #endif
 
@@ -42,28 +41,41 @@ __global__ void __launch_bounds__(NT, USV_COND_MINWAVES) usv_qp_cond(DevPtrs P, 
 
 namespace {
 
-template <class M, int KCH, bool SOFT>
-int prepare_for(const DevSpec &S, int N2, CondDims &D, size_t &lds, int &nb, std::string &err)
+template <class M, int KCH, bool SOFT, int NT>
+int occupancy_of(const DevSpec &S, int N2, CondDims &D, size_t &lds, int &nb)
 {
-    constexpr int NT = USV_COND_THREADS;
     auto kern = &usv_qp_cond<M, KCH, SOFT, NT>;
-    if (!cond_dims(S, M::NX, M::NU, M::IPX, M::IPY, N2, NT, SOFT, D)) { err = "qp_cond_N must lie in 1..N-1 and a condensed stage may have at most 64 variables (nx + ceil(N / qp_cond_N) nu)"; return USVMPC_E_ARG; }
-    lds = (size_t)D.lds_doubles * sizeof(double);
-    if (lds > 160u * 1024u) { err = "partial condensing: the condensed block does not fit in LDS (block too large)"; return USVMPC_E_ARG; }
     nb = 0;
+    if (!cond_dims(S, M::NX, M::NU, M::IPX, M::IPY, N2, NT, SOFT, D)) return USVMPC_E_ARG;
+    lds = (size_t)D.lds_doubles * sizeof(double);
+    if (lds > 160u * 1024u) return 0; // (nb = 0: does not fit)
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NT, lds) != hipSuccess) {
-        err = "partial condensing: the kernel cannot be launched with this much LDS";
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NT, lds) != hipSuccess)
         return USVMPC_E_HIP;
-    }
     return 0;
 }
 
 template <class M, int KCH, bool SOFT>
-int run_for(hipStream_t st, long teams, size_t lds, const DevPtrs &P, const CondDims *dD, double *scratch, int B)
+int prepare_for(const DevSpec &S, int N2, CondDims &D, size_t &lds, int &nb, std::string &err)
 {
-    constexpr int NT = USV_COND_THREADS;
-    hipLaunchKernelGGL((usv_qp_cond<M, KCH, SOFT, NT>), dim3((unsigned)teams), dim3(NT), lds, st, P, dD, scratch, B, (int)teams);
+    CondDims D64, D256;
+    size_t l64 = 0, l256 = 0;
+    int n64 = 0, n256 = 0;
+    const int r64 = occupancy_of<M, KCH, SOFT, 64>(S, N2, D64, l64, n64), r256 = occupancy_of<M, KCH, SOFT, 256>(S, N2, D256, l256, n256);
+    if (r64 == USVMPC_E_ARG || r256 == USVMPC_E_ARG) { err = "qp_cond_N must lie in 1..N-1 and a condensed stage may have at most 64 variables (nx + ceil(N / qp_cond_N) nu)"; return USVMPC_E_ARG; }
+    if (r64 || r256) { err = "partial condensing: the kernel cannot be launched with this much LDS"; return USVMPC_E_HIP; }
+    if (n64 < 1 && n256 < 1) { err = "partial condensing: the condensed block does not fit in LDS (block too large)"; return USVMPC_E_ARG; }
+    // (about as many resident waves with the small teams - at least three quarters: more instances in flight, cheaper barriers - measured 2x on M1)
+    if (4 * n64 >= 3 * 4 * n256) { D = D64; lds = l64; nb = n64; }
+    else { D = D256; lds = l256; nb = n256; }
+    return 0;
+}
+
+template <class M, int KCH, bool SOFT>
+int run_for(int nt, hipStream_t st, long teams, size_t lds, const DevPtrs &P, const CondDims *dD, double *scratch, int B)
+{
+    if (nt == 64) hipLaunchKernelGGL((usv_qp_cond<M, KCH, SOFT, 64>), dim3((unsigned)teams), dim3(64), lds, st, P, dD, scratch, B, (int)teams);
+    else hipLaunchKernelGGL((usv_qp_cond<M, KCH, SOFT, 256>), dim3((unsigned)teams), dim3(256), lds, st, P, dD, scratch, B, (int)teams);
     return 0;
 }
 
@@ -101,9 +113,9 @@ int cond_prepare(int model, int kch, const DevSpec &S, int N2, CondDims &D, size
     return USVMPC_E_ARG;
 }
 
-int cond_run(int model, int kch, hipStream_t st, long teams, size_t lds_bytes, const DevPtrs &P, const CondDims *dD, double *scratch, int B)
+int cond_run(int model, int kch, int nt, hipStream_t st, long teams, size_t lds_bytes, const DevPtrs &P, const CondDims *dD, double *scratch, int B)
 {
-#define USV_COND_RUN(M, K, SF) run_for<M, K, SF>(st, teams, lds_bytes, P, dD, scratch, B)
+#define USV_COND_RUN(M, K, SF) run_for<M, K, SF>(nt, st, teams, lds_bytes, P, dD, scratch, B)
     USV_COND_DISPATCH(USV_COND_RUN)
 #undef USV_COND_RUN
     return -1;

@@ -281,7 +281,7 @@ def test_condensing_kernel_is_deterministic():
         sa, sb = a.solve(), b.solve()
         assert np.array_equal(sa, sb) and np.array_equal(a.get_int("qp_iter"), b.get_int("qp_iter"))
         assert np.array_equal(a.get_all("x"), b.get_all("x")) and np.array_equal(a.get_all("u"), b.get_all("u"))
-        assert np.array_equal(a.get_all("pi"), b.get_all("pi"))
+        assert np.array_equal(a.get_all("pi"), b.get_all("pi"), equal_nan=True)   # (a QP that ended in NaNs leaves NaN multipliers, on both)
         for s in (a, b):
             s.advance(1e-3, seed=5 + tick)
     a.close(); b.close()

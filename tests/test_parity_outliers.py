@@ -1,0 +1,145 @@
+"""The classified device-vs-oracle parity outliers of the bench workload, as a committed fixture (tests/golden/m2_parity_outliers.npz,
+made on an MI355X by tools/outlier_fixture.py: BASELINE configs[2] closed loop, 2048 instances x 10 ticks; every instance above
+north_star's 1e-5, the largest ones below it, and a few ordinary instances - inputs of the solve and BOTH sides' outputs).
+
+What they show (CPU suite):
+* the fixture replays: the oracle (square-root Riccati, its default) reproduces its stored outputs;
+* the gap is the factorisation FORM, not the hardware: the oracle's own classical-Riccati mode (USV_RICCATI_CLASSIC - the form
+  the kernels use) lands on the device's point for the largest outlier (same iteration count, <= 1e-5), and over the set the
+  oracle's two forms differ from EACH OTHER by more than the device differs from the oracle;
+* the kernel bodies on the lane emulator (tests/emu: the same C++ as the device, IEEE division, no fused-multiply-add contraction)
+  take the device's iteration counts on every instance, sit 1000x closer to the device than the oracle on the largest outlier -
+  and differ from the device by 1e-6 .. 5e-5 on every other outlier / near instance (1e-13 on ordinary ones): these QPs amplify
+  rounding by ten orders of magnitude whoever solves them, so bit-for-bit equality of two builds of one source does not exist here.
+GPU suite: the device run again on the fixture's inputs against its own emulator and its stored outputs.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from mpc_collisionavoidance_amd import _capi, scenario, usv_models
+from tests.test_emu_kernels import emu_rti
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIX = os.path.join(ROOT, "tests", "golden", "m2_parity_outliers.npz")
+
+
+def _load():
+    f = np.load(FIX)
+    d = {k: f[k] for k in f.files}
+    d["N"], d["K"], d["steps"], d["dt"] = int(f["N"]), int(f["K"]), int(f["sim_steps"]), float(f["dt"])
+    return d
+
+
+def _err(f, xa, ua, xb, ub):
+    """tests/util.rel_err_per_instance with the component scales of the set's stored oracle outputs"""
+    n = xa.shape[0]
+    sx = np.maximum(1e-2, np.abs(f["x_orc"]).max(axis=(0, 1)))
+    su = np.maximum(1e-2, np.abs(f["u_orc"]).max(axis=(0, 1)))
+    return np.maximum((np.abs(xa - xb) / sx).reshape(n, -1).max(axis=1), (np.abs(ua - ub) / su).reshape(n, -1).max(axis=1))
+
+
+def _oracle(ob, f, **opts):
+    spec = ob.spec(2, f["N"], f["N"] * f["dt"], f["K"], sim_steps=f["steps"], **opts)
+    x, u = f["x_in"].copy(), f["u_in"].copy()
+    st, it = ob.rti_batch(spec, x, u, *[np.ascontiguousarray(f[k]) for k in ("x0", "yref", "yref_e", "p", "lh")], threads=0)
+    return x, u, st, it
+
+
+def _ocp(f):
+    ocp = usv_models.make_ocp("usv_model_pf_ca", f["N"] * f["dt"], f["N"], f["K"])
+    ocp.solver_options.sim_method_num_steps = f["steps"]
+    return ocp
+
+
+def _emu(emu, f):
+    n = f["x_in"].shape[0]
+    desc = _capi.desc_from_ocp(_ocp(f), batch=n)
+    wl = {k: np.ascontiguousarray(f[k]) for k in ("x0", "yref", "yref_e", "p", "lh")}
+    return emu_rti(emu, desc, wl, f["x_in"], f["u_in"])
+
+
+def test_fixture_is_what_it_says():
+    f = _load()
+    kinds = list(f["kind"])
+    assert kinds.count("outlier") >= 1 and kinds.count("near") >= 4 and kinds.count("ordinary") >= 2
+    e = _err(f, f["x_dev"], f["u_dev"], f["x_orc"], f["u_orc"])
+    out = f["kind"] == "outlier"
+    assert (e[out] > 1e-5).all() and (e[~out] <= 1e-5).all()
+    assert e.max() <= 5e-3                              # (the cap of the documented rule, tests/parity_rule.py)
+    assert (e[f["kind"] == "ordinary"] <= 1e-11).all()  # what an ordinary instance looks like
+
+
+def test_oracle_replays_and_the_gap_is_the_factorisation_form(oracle):
+    f = _load()
+    xs, us, sts, its = _oracle(oracle, f)
+    # the stored oracle outputs were computed on the GPU box's host: same sources, possibly other compiler flags
+    assert (sts == 0).all() and np.array_equal(its, f["it_orc"])
+    assert _err(f, xs, us, f["x_orc"], f["u_orc"]).max() <= 1e-9
+    xc, uc, stc, itc = _oracle(oracle, f, riccati=oracle.RICCATI_CLASSIC)
+    # (the classical form in plain C is the less robust of the two: on one of the outlier QPs it stops at the step-length floor -
+    # status 4, iterate untouched - where the square-root form and the device both converge; only outliers may do that)
+    assert (stc[f["kind"] != "outlier"] == 0).all()
+    dev_sqrt = _err(f, f["x_dev"], f["u_dev"], xs, us)
+    dev_cls = _err(f, f["x_dev"], f["u_dev"], xc, uc)
+    cls_sqrt = _err(f, xc, uc, xs, us)
+    print("device vs oracle (sqrt)   ", dev_sqrt)
+    print("device vs oracle (classic)", dev_cls, itc, f["it_dev"])
+    print("oracle classic vs sqrt    ", cls_sqrt)
+    worst = int(np.argmax(dev_sqrt))
+    assert f["kind"][worst] == "outlier"
+    # the largest outlier: the oracle run in the kernels' own Riccati form takes the device's iteration count and lands on the
+    # device's point - three orders of magnitude closer than its square-root form does
+    assert itc[worst] == f["it_dev"][worst] != its[worst]
+    assert dev_cls[worst] <= 1e-5 and dev_cls[worst] <= 1e-2 * dev_sqrt[worst]
+    # and over the set the oracle's two forms differ from each other by MORE than the device differs from the oracle: at this
+    # model's conditioning (control weight R = 0) an iterate that passes the exit test is not determined to 1e-5
+    both = stc == 0
+    assert cls_sqrt[both].max() >= dev_sqrt.max()
+    assert (cls_sqrt > 1e-5).sum() >= (dev_sqrt > 1e-5).sum()
+    # ordinary instances: all three agree to rounding
+    o = f["kind"] == "ordinary"
+    assert dev_sqrt[o].max() <= 1e-11 and dev_cls[o].max() <= 1e-11 and cls_sqrt[o].max() <= 1e-11
+
+
+def test_lane_emulator_reproduces_the_device_on_the_outliers(emu):
+    """Nothing hardware in the gap: the kernels' C++ executed on the CPU (IEEE division and square root instead of the
+    v_rcp / v_rsq + Newton forms, libm instead of the device's sincos, no FMA contraction) gives the device's outputs."""
+    f = _load()
+    r = _emu(emu, f)
+    e = _err(f, r["x"], r["u"], f["x_dev"], f["u_dev"])
+    eo = _err(f, f["x_dev"], f["u_dev"], f["x_orc"], f["u_orc"])
+    print("emulator vs device", e, r["qp_iter"], f["it_dev"])
+    assert (r["qp_status"] == 0).all()
+    assert np.array_equal(r["qp_iter"], f["it_dev"])
+    # the largest outlier (a different factorisation form on the oracle's side): the emulator sits 1000x closer to the device
+    worst = int(np.argmax(eo))
+    assert e[worst] <= 1e-2 * eo[worst], (e, eo)
+    # every other instance of the set is rounding-sensitive in itself: the SAME source differs from the device by 1e-6 .. 5e-5
+    # there (iteration counts equal) - the size of the device-vs-oracle differences on them - and by 1e-13 on ordinary instances:
+    # what amplifies is the QP (control weight R = 0, degenerate hard-row vertices), not an implementation
+    sens = f["kind"] != "ordinary"
+    assert e[sens].max() <= 1e-4 and e[~sens].max() <= 1e-11, e
+    assert np.median(e[sens]) >= 1e-7
+
+
+@pytest.mark.gpu
+def test_device_reproduces_its_stored_outputs_and_its_emulator(emu):
+    from mpc_collisionavoidance_amd import BatchOcpSolver
+    f = _load()
+    n = f["x_in"].shape[0]
+    s = BatchOcpSolver(_ocp(f), n)
+    wl = dict(x_init=f["x_in"], u_init=f["u_in"], **{k: np.ascontiguousarray(f[k]) for k in ("x0", "yref", "yref_e", "p", "lh")})
+    scenario.load_into(s, wl)
+    st = s.solve()
+    xg, ug, qi = s.get_all("x"), s.get_all("u"), s.get_int("qp_iter")
+    s.close()
+    assert (st == 0).all() and np.array_equal(qi, f["it_dev"])
+    # the stored outputs came from a 2048-instance handle (static_obstacles on, sorted queue): scheduling and storage options do
+    # not change a bit, and neither does the batch an instance sits in
+    assert np.array_equal(xg, f["x_dev"]) and np.array_equal(ug, f["u_dev"])
+    r = _emu(emu, f)
+    e = _err(f, r["x"], r["u"], xg, ug)
+    sens = f["kind"] != "ordinary"
+    assert np.array_equal(r["qp_iter"], qi) and e[sens].max() <= 1e-4 and e[~sens].max() <= 1e-11, e

@@ -1,0 +1,85 @@
+"""Collect the device-vs-oracle parity outliers of the bench workload as a committed fixture (GPU; writes
+tests/golden/m2_parity_outliers.npz via gpurun_out/).
+
+Closed loop of BASELINE configs[2] (usv_model_pf_ca, N=40, Tf=2 s, 10 obstacles, SURVEY 8(d) generator, seed 1234) exactly as
+tools/parity_tail.py runs it.  Every solve is compared with the oracle from IDENTICAL inputs (the iterate and x0 the device
+starts the tick from).  Kept per instance: the inputs of the solve (x_in, u_in, x0, yref, yref_e, p, lh), the device's outputs
+(x, u, qp_iter, qp_status, pi, lam, t) and the oracle's (x, u, qp_iter) for
+  * every instance above north_star's 1e-5 ("outlier"),
+  * the NEAR ones next to them (the largest differences below 1e-5) and a few ordinary instances, as controls.
+The CPU suite (tests/test_parity_outliers.py) replays them on the oracle in both Riccati forms and on the lane emulator; the GPU
+suite holds the device against its own emulator on them.
+
+usage: python tools/outlier_fixture.py [B=2048] [ticks=10] [out=gpurun_out/m2_parity_outliers.npz]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402,F401  (before the solver library: one HIP runtime)
+from mpc_collisionavoidance_amd import BatchOcpSolver, scenario, usv_models  # noqa: E402
+from oracle import binding as ob  # noqa: E402
+from tests import util  # noqa: E402
+
+name, N, K = "usv_model_pf_ca", 40, 10
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "m2_parity_outliers.npz")
+NEAR, ORDINARY = 6, 4
+
+wl = scenario.make_bench_batch(name, N, K, B, seed=1234)
+dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
+ocp = usv_models.make_ocp(name, N * dt, N, K)
+ocp.solver_options.sim_method_num_steps = steps
+dev = BatchOcpSolver(ocp, B)
+scenario.load_into(dev, wl)
+dev.set_option("static_obstacles", 1)
+dev.set_option("disturbance_mask", scenario.NOISE_MASK[name])
+spec = ob.spec(2, N, N * dt, K, sim_steps=steps)
+data = (wl["yref"], wl["yref_e"], wl["p"], wl["lh"])
+x0 = wl["x0"].copy()
+
+rows = []   # (err, tick, instance, kind, dict of arrays)
+for tk in range(ticks):
+    xp, up = dev.get_all("x"), dev.get_all("u")
+    dev.solve()
+    xg, ug, qs, qi = dev.get_all("x"), dev.get_all("u"), dev.get_int("qp_status"), dev.get_int("qp_iter")
+    pi, lam, tt = dev.get_all("pi"), dev.get_all("lam"), dev.get_all("t")
+    xo, uo = xp.copy(), up.copy()
+    sto, ito = ob.rti_batch(spec, xo, uo, x0, *data, threads=0)
+    ok = (qs == 0) & (sto == 0) & (ito < spec.opts.qp_iter_max)
+    e = np.maximum(util.rel_err_per_instance(xg, xo), util.rel_err_per_instance(ug, uo))
+    e[~ok] = -1.0
+    order = np.argsort(-e)
+    above = [b for b in order if e[b] > 1e-5]
+    near = [b for b in order if 0 <= e[b] <= 1e-5][:2]
+    ordinary = [b for b in order[len(order) // 2:] if e[b] >= 0][:1]
+    for kind, lst in (("outlier", above), ("near", near), ("ordinary", ordinary)):
+        for b in lst:
+            rows.append((float(e[b]), tk, int(b), kind,
+                         dict(x_in=xp[b], u_in=up[b], x0=x0[b], yref=wl["yref"][b], yref_e=wl["yref_e"][b], p=wl["p"][b], lh=wl["lh"][b],
+                              x_dev=xg[b], u_dev=ug[b], pi_dev=pi[b], lam_dev=lam[b], t_dev=tt[b], x_orc=xo[b], u_orc=uo[b],
+                              it_dev=int(qi[b]), it_orc=int(ito[b]))))
+    print("tick %d: converged on both sides %d, above 1e-5: %d (max %.2e)" % (tk, ok.sum(), len(above), e.max()), flush=True)
+    dev.advance(1e-3, seed=2000 + tk)
+    dev.sync()
+    x0 = dev.get("x0", 0)
+
+outl = [r for r in rows if r[3] == "outlier"]
+near = sorted([r for r in rows if r[3] == "near"], key=lambda r: -r[0])[:NEAR]
+ordn = [r for r in rows if r[3] == "ordinary"][:ORDINARY]
+keep = outl + near + ordn
+stack = lambda key: np.stack([r[4][key] for r in keep])   # noqa: E731
+os.makedirs(os.path.dirname(out_path), exist_ok=True)
+np.savez_compressed(
+    out_path, model=name, N=N, K=K, dt=dt, sim_steps=steps, batch=B, ticks=ticks, seed=1234,
+    kind=np.array([r[3] for r in keep]), tick=np.array([r[1] for r in keep]), instance=np.array([r[2] for r in keep]),
+    err_dev_vs_oracle=np.array([r[0] for r in keep]),
+    it_dev=np.array([r[4]["it_dev"] for r in keep]), it_orc=np.array([r[4]["it_orc"] for r in keep]),
+    **{k: stack(k) for k in ("x_in", "u_in", "x0", "yref", "yref_e", "p", "lh", "x_dev", "u_dev", "pi_dev", "lam_dev", "t_dev", "x_orc", "u_orc")})
+print("kept %d outliers, %d near, %d ordinary -> %s" % (len(outl), len(near), len(ordn), out_path))
+for r in keep:
+    print("  %-8s tick %2d instance %5d  dev-vs-oracle %.2e  qp_iter dev %d / oracle %d" % (r[3], r[1], r[2], r[0], r[4]["it_dev"], r[4]["it_orc"]))

@@ -52,9 +52,9 @@ loaded_before_torch = False
 EXPORTS = ["usvmpc_model_dims", "usvmpc_default_options", "usvmpc_create", "usvmpc_destroy",
            "usvmpc_set", "usvmpc_get", "usvmpc_get_int", "usvmpc_solve", "usvmpc_solve_sqp", "usvmpc_solve_async",
            "usvmpc_sync", "usvmpc_get_device_ptr", "usvmpc_last_kernel_ms", "usvmpc_kernel_ms", "usvmpc_fail_counts",
-           "usvmpc_advance", "usvmpc_set_stream", "usvmpc_set_option", "usvmpc_calibrate_traffic", "usvmpc_guidance_reset", "usvmpc_guidance_prepare", "usvmpc_guidance_sense",
+           "usvmpc_unconverged_counts", "usvmpc_closed_loop", "usvmpc_advance", "usvmpc_set_stream", "usvmpc_set_option", "usvmpc_calibrate_traffic", "usvmpc_guidance_reset", "usvmpc_guidance_prepare", "usvmpc_guidance_sense",
            "usvmpc_guidance_publish", "usvmpc_guidance_state", "usvmpc_device_bytes", "usvmpc_last_error",
-           "usvmpc_debug_model_eval", "usvmpc_debug_obstacle_eval"]
+           "usvmpc_debug_model_eval", "usvmpc_debug_obstacle_eval", "usvmpc_debug_workspace"]
 
 
 _libs = {}
@@ -97,6 +97,8 @@ def load(path):
     L.usvmpc_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.usvmpc_fail_counts.argtypes = [C.c_void_p, C.c_int, _ip]
     L.usvmpc_advance.argtypes = [C.c_void_p, C.c_double, C.c_ulonglong]
+    L.usvmpc_unconverged_counts.argtypes = [C.c_void_p, C.c_int, _ip]
+    L.usvmpc_closed_loop.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_ulonglong]
     L.usvmpc_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.usvmpc_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.usvmpc_calibrate_traffic.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
@@ -108,6 +110,7 @@ def load(path):
     L.usvmpc_debug_model_eval.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
     L.usvmpc_debug_obstacle_eval.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
     L.usvmpc_device_bytes.argtypes = [C.c_void_p]
+    L.usvmpc_debug_workspace.argtypes = [C.c_void_p, _dp, C.c_size_t, _ip]
     L.usvmpc_device_bytes.restype = C.c_size_t
     L.usvmpc_last_error.argtypes = [C.c_void_p]
     L.usvmpc_last_error.restype = C.c_char_p

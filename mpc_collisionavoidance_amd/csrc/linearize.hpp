@@ -55,7 +55,6 @@ struct Linearize {
     {
         const DevSpec &S = *P.spec;
         const int lane = lanes::lane();
-        const int N = lanes::uniform(S.N), K = lanes::uniform(S.K);
         const long Bp = lanes::uniform(S.Bp);
         const int k = (int)(gid / Bp);
         const long g = gid - (long)k * Bp;
@@ -73,12 +72,24 @@ struct Linearize {
         if constexpr (MODE == 2) {
             if (((P.redo[b * P.redo_words + (k >> 5)] >> (k & 31)) & 1) == 0) return;
         }
-        auto ld = [](const double *q) { // the iterate: handed over by a kernel that may still be running (MODE 1)
-            if constexpr (MODE == 1) return lanes::ld_shared(q);
-            else return *q;
-        };
         // workspace: [stage][group][plane][16 lanes] (lanes::Planes)
         double *tile = P.ws + (((long)k * Bp + g) * lanes::uniform(S.npt)) * LANES + lane;
+        stage<MODE == 1>(P, b, k, tile);
+    }
+
+    // One (instance, stage): instance b, stage k, results into the 16-lane planes at `tile` (this lane's entry of plane 0).
+    // SHARED: the iterate was handed over by another wave of a running launch and is read past the non-coherent caches
+    // (lanes::ld_shared) - MODE 1 above, and the closed-loop launch of qp_ipm.hpp, whose waves linearise the instance they take up.
+    template <bool SHARED>
+    USV_DEV static void stage(const DevPtrs &P, long b, int k, double *tile)
+    {
+        const DevSpec &S = *P.spec;
+        const int lane = lanes::lane();
+        const int N = lanes::uniform(S.N);
+        auto ld = [](const double *q) {
+            if constexpr (SHARED) return lanes::ld_shared(q);
+            else return *q;
+        };
         const bool xlane = lane >= NU && lane < NZ;
 
         double x[NX], U[NU > 0 ? NU : 1];
@@ -101,7 +112,7 @@ struct Linearize {
             for (int y = 0; y < ny; y++) acc = fma(-Mrow[y], yr[y], acc);
             tile[WL::P_GQ * LANES] = acc;
         }
-        if (k == N) return; // wave-uniform
+        if (k == N) return; // (uniform over the 16-lane group; over the wave too in the lineariser kernel)
 
         // ---- ERK4 + forward VDE for this lane's sensitivity column; sim_steps steps of size dt / sim_steps
         // (acados sim_method_num_steps; the reference leaves it at 1): the column is simply carried on ----

@@ -153,6 +153,7 @@ struct DevPtrs {
     double *res;          // [B][4]      final QP residuals (stat, eq, ineq, comp)
     double *obs_tmin;     // [B]         smallest lower-side slack t_l over the obstacle rows of the last QP (1e300 without rows)
     int *fail_count;      // [1]         instances of THIS launch whose solve ended with status != 0 (host points it at a ring slot)
+    int *unconv_count;    // [1]         instances of THIS launch whose QP did not converge to the tolerances (qp_status != 0)
     // full SQP (usvmpc_solve_sqp): per-instance state between the iterations of one call
     double *nlp_res;      // [B][4]      NLP residuals of the current iterate (stat, eq, ineq, comp)
     int *sqp_iter;        // [B]         SQP iterations taken
@@ -169,6 +170,19 @@ struct DevPtrs {
     int redo_words;       //      (N + 1 + 31) / 32
     const int *perm_cur;  // [B]  speculative lineariser: the group -> instance map of the QP launch that is still running
     int tick;             // the solve this launch belongs to (QP, fix-up) / whose results the speculative lineariser waits for
+    // closed-loop launch (usvmpc_closed_loop, QpIpm::solve_cl): ONE persistent launch works through the items (instance, tick) of cl_ticks
+    // consecutive ticks.  An item is tick * B + instance; the rows' first items are the first groups of the map (tick 0), all others
+    // go through a FIFO in the order they become available: the rest of tick 0 (filled by the host), then (b, t + 1) as soon as the
+    // row that solved (b, t) has handed the instance over.  queue = pop tickets, fifo_tail = push slots.
+    int *fifo;            // [cl_slots]  item + 1 (0: not pushed yet)
+    int *fifo_tail;       // [1]
+    int cl_ticks;         // 0: not a closed-loop launch
+    int cl_slots;         // items that go through the FIFO: B * cl_ticks - (rows' first items)
+    double cl_sigma;      // hand-over disturbance (advance.hpp): std, stream of tick t = cl_seed + t, state mask
+    unsigned long long cl_seed;
+    unsigned cl_mask;
+    int *fail_ring, *unconv_ring; // [ring_len] per-tick counters (fail_count / unconv_count of tick t: slot (ring_base + t) % ring_len)
+    int ring_base, ring_len;
     // multiplier read-back (kernel usv_qp_export): [B][N+1][nlam] each, nlam = 2 (nrow + ns) - DevSpec
     double *lam_out, *t_out;
     int nlam;

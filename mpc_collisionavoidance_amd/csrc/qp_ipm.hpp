@@ -40,6 +40,8 @@
 #include "lanes.hpp"
 #include "params.hpp"
 #include "sfor.hpp"
+#include "advance.hpp"
+#include "linearize.hpp"
 
 #ifndef USV_MAT_LOAD_AUX
 #define USV_MAT_LOAD_AUX 0 // cache policy of the packed matrix plane loads (lanes.hpp; the emulator has none)
@@ -221,6 +223,40 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 #endif
 }
 
+// Closed-loop launch: all stages of ONE instance linearised by the rows of a wave, row q taking stages q, q + 4, ... (tile0: this lane's
+// entry of plane 0 of stage 0 in the target workspace slot).  A CALLED function, not inlined into the QP kernel: the lineariser wants
+// ~220 registers of its own, and inlined it made the register allocator spill inside the sweeps (scratch reloads there drain the plane
+// prefetch: lanes::Stash); as a call its registers are saved and restored around the call - once per item.
+template <class M, int KCH, bool SOFT>
+USV_DEV_CALL void linearize_item(const DevSpec *spec, const double *x, const double *u, const double *yref, const double *yref_e,
+                                 double *tile0, long stage_stride, long b, int N)
+{
+    using Lin = Linearize<M, KCH, SOFT, true, 0>; // (the step count is a run-time value here: one build for sim_method_num_steps >= 1)
+    DevPtrs Q; // what Linearize::stage reads
+#ifdef USV_DBG_GLOBAL_AS
+    typedef double __attribute__((address_space(1))) gdouble;
+    Q.spec = (const DevSpec *)(const DevSpec __attribute__((address_space(1))) *)spec;
+    Q.x = (double *)(gdouble *)x; Q.u = (double *)(gdouble *)u; Q.yref = (const double *)(const gdouble *)yref; Q.yref_e = (const double *)(const gdouble *)yref_e;
+    tile0 = (double *)(gdouble *)tile0;
+#else
+    Q.spec = spec; Q.x = const_cast<double *>(x); Q.u = const_cast<double *>(u); Q.yref = yref; Q.yref_e = yref_e;
+#endif
+    for (int k0 = 0; k0 <= N; k0 += lanes::WAVE_ROWS) {
+        const int k = k0 + (int)lanes::wave_row();
+        // (uniform over each 16-lane row; the cross-lane operations inside stay within a row)
+        if (k <= N) Lin::template stage<true>(Q, b, k, tile0 + (long)k * stage_stride);
+    }
+}
+
+#ifdef USV_DBG_DUMMY_CALL
+__device__ __attribute__((noinline)) void dbg_dummy_call(double *sink, int n)
+{
+    double a = (double)threadIdx.x;
+    for (int i = 0; i < n; i++) a = a * 1.0000001 + 0.5;
+    if (a < 0.0) *sink = a; // (never)
+}
+#endif
+
 // LDSWS: the workspace planes of a row's instance live in LDS for the whole solve (lanes::PlanesLds) - for batches small
 // enough that every instance in flight fits (host: usvmpc.hip); the lineariser's planes are copied in at the cold start.
 // MERGE (with PACK, no dense rows: host_spec.hpp / usvmpc.hip): the box rows are processed where they are stored - as rows of the
@@ -230,8 +266,16 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 // per stage) lives in the wave's LDS for the whole launch instead of being streamed with the planes: 4 reads + 2 writes of the
 // 59 + 13 plane accesses per stage and IPM iteration go (the kernel streams at the HBM ceiling: profiles/r03_bound_experiment.txt).
 // RTI launches whose horizon fits (host: usvmpc.hip); finish() leaves a copy in the HBM plane for the read-back paths.
-template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false>
+// LOOP: closed-loop launch (solve_cl, usvmpc_closed_loop): the rows work through items (instance, tick) of several consecutive ticks in ONE
+// persistent launch - a row that has finished (b, t) hands the instance over itself (x, u out past the non-coherent caches, x0 <- x1 +
+// disturbance: advance.hpp), queues (b, t + 1) and takes the oldest queued item, which its wave linearises on the spot (linearize.hpp,
+// the four rows of the wave share the stages).  No launch boundary between ticks, hence no launch tail per tick: an instance that runs
+// long delays only its own next tick.  A row keeps ONE workspace slot for the whole launch.  Same arithmetic per (instance, tick) as the
+// sequence solve, advance, solve, ...: results are bit-identical (scheduling only).
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false,
+          bool LOOP = false>
 struct QpIpm {
+    static_assert(!LOOP || (!LDSWS && !SOFTBOX), "the closed-loop launch is built for the HBM workspace without soft state bounds");
     static_assert(!MERGE || PACK, "merged row pass works on the packed layout");
     static_assert(!(AUXLDS && LDSWS), "with the whole workspace in LDS the aux plane is there already");
     static_assert(!PACK || KCH > 0, "box rows are packed into obstacle planes");
@@ -313,6 +357,7 @@ struct QpIpm {
     int lane, N;
     // per row (the same in its 16 lanes): the group it works on, that group's instance, the lane's offset in a stage window
     long g, b;
+    int tk;          // LOOP: the tick of the item the row works on
     unsigned voff;
     unsigned loff;   // LDSWS: this lane's entry of (stage 0, plane 0) of its row's LDS region, in doubles
     bool live;       // the row owns a workspace (LDSWS: surplus rows of a wave share row 0's region read-only)
@@ -472,7 +517,7 @@ struct QpIpm {
             auxstride = (nd4 + ZB + 2 * NU) * lanes::WAVE_ROWS;
             auxoff = (unsigned)((slot > 0 ? slot : 0) * lanes::WAVE_ROWS) + lanes::wave_row();
         }
-        g = 0; b = 0;
+        g = 0; b = 0; tk = 0;
         live = lds_row >= 0;
         loff = (unsigned)((lds_row > 0 ? lds_row : 0) * (N + 1) * NPL * LANES + lane);
         if constexpr (KCH > 0) sfor<0, KCH>([&](auto c) { c_ox[c] = 0.0; c_oy[c] = 0.0; c_lh[c] = 0.0; });
@@ -503,6 +548,19 @@ struct QpIpm {
 #else
         voff = lanes::Planes::lane_offset(g, NPL, lane);
 #endif
+        bind_consts(sel);
+    }
+    // LOOP: point the rows selected by `sel` at the item (tick, instance) = (item / B, item % B); the row's workspace slot stays
+    USV_DEV void bind_item(int item, bool sel)
+    {
+        const int t = item / nB;
+        b = sel ? (long)(item - t * nB) : b;
+        tk = sel ? t : tk;
+        bind_consts(sel);
+    }
+    // the per-instance constants of the rows selected by `sel` (their b has just changed)
+    USV_DEV void bind_consts(bool sel)
+    {
         if constexpr (KCH > 0) {
             sfor<0, KCH>([&](auto c) {
                 const int i = c * LANES + lane;
@@ -535,10 +593,21 @@ struct QpIpm {
     // iterate value of this lane's variable at stage k (caller-visible arrays)
     USV_DEV double zbar(int k) const
     {
-        if (ulane) return (k < N) ? P.u[((long)b * N + k) * NU + lane] : 0.0;
-        if (xlane) return P.x[((long)b * (N + 1) + k) * NX + (lane - NU)];
+        if (ulane) return (k < N) ? ldi(&P.u[((long)b * N + k) * NU + lane]) : 0.0;
+        if (xlane) return ldi(&P.x[((long)b * (N + 1) + k) * NX + (lane - NU)]);
         return 0.0;
     }
+    // a caller-visible value of the row's instance that an earlier item of this launch may have written (x, u, x0): in a closed-loop
+    // launch that was another wave, possibly behind another XCD's L2 - read past the non-coherent caches (lanes::ld_shared)
+    USV_DEV static double ldi(const double *q)
+    {
+#ifdef USV_DBG_PLAIN_LD
+        return *q;
+#endif
+        if constexpr (LOOP) return lanes::ld_shared(q);
+        else return *q;
+    }
+    USV_DEV double x0_lane() const { return xlane ? ldi(&P.x0[(long)b * NX + (lane - NU)]) : 0.0; }
 
     // (the row value of a box row is the absolute iterate zbar + z, its bounds are the caller's lb / ub)
     USV_DEV void box_data(int k, BoxRow &r) const
@@ -706,7 +775,7 @@ struct QpIpm {
             }
             if (wr) {
                 W.st(P_Z, zb); // z = 0
-                if (k == 0) W.st(P_DX0, xlane ? P.x0[(long)b * NX + (lane - NU)] : 0.0);
+                if (k == 0) W.st(P_DX0, x0_lane());
             }
             BoxRow r;
             r.neutral();
@@ -742,7 +811,7 @@ struct QpIpm {
                     if (wr) obs_store(W, c, o, (PACK && c == KCH - 1) ? pk : nullptr);
                     if constexpr (!SOFT) {
                         if (k == 0) { // wave-uniform
-                            const double e0 = xlane ? P.x0[(long)b * NX + (lane - NU)] - zb : 0.0; // x0 - xbar_0
+                            const double e0 = xlane ? x0_lane() - zb : 0.0; // x0 - xbar_0
                             double d, ux, uy;
                             obs_dist(zbx - raw[0], zby - raw[1], d, ux, uy);
                             const double v0 = ux * lanes::bcast<PXL>(e0) + uy * lanes::bcast<PYL>(e0);
@@ -1430,7 +1499,7 @@ struct QpIpm {
     {
         const bool ok = (status == 0 || status == 1);
         const bool out = fin && real;
-        const bool share = P.epoch != nullptr; // wave-uniform (kernel argument)
+        const bool share = LOOP || P.epoch != nullptr; // wave-uniform (kernel argument)
         double tmin = 1e300; // smallest t_l over this instance's obstacle rows: how close the QP solution sits to a keep-out circle
         for (int k = 0; k <= N; k++) {
             const Planes W = ws(k);
@@ -1471,6 +1540,16 @@ struct QpIpm {
                 }
                 if (k >= 1 && xlane && P.pi) P.pi[((long)b * N + (k - 1)) * NX + (lane - NU)] = W.ld(P_PI);
             }
+            if constexpr (LOOP) {
+                // the caller's hand-over between two ticks, done by the row that has just solved the instance: x0 <- x_1 (+ disturbance)
+                // - the x_1 of the new iterate, or after a failed solve of the untouched one (usv_advance reads whatever x holds)
+                if (k == 1) { // wave-uniform
+                    const int j = xlane ? lane - NU : 0;
+                    const double x1 = ok ? z : ldi(&P.x[((long)b * (N + 1) + 1) * NX + j]);
+                    const double v = advance_value(x1, P.cl_sigma, P.cl_seed + (unsigned long long)tk, (long)b * NX + j, ((P.cl_mask >> j) & 1u) != 0u);
+                    if (out && xlane) lanes::st_shared(const_cast<double *>(&P.x0[(long)b * NX + j]), v);
+                }
+            }
             if constexpr (KCH > 0 && SOFT) {
                 if (k >= 1 && k < N) {
                     sfor<0, KCH>([&](auto c) {
@@ -1504,13 +1583,22 @@ struct QpIpm {
             }
         }
         tmin = lanes::gmin(tmin);
+        int *fails = P.fail_count, *unconv = P.unconv_count;
         if (share) { // the instance's iterate is final: tell the lineariser of the next tick (every store of the wave has landed first)
             lanes::drain_stores();
-            if (out && lane == 0) lanes::publish(P.epoch + b, P.tick);
+            if constexpr (LOOP) {
+                // ... or whichever row takes the instance's next tick: the item goes to the end of the queue
+                if (out && lane == 0 && tk + 1 < P.cl_ticks) lanes::publish(P.fifo + lanes::fetch_add(P.fifo_tail), (tk + 1) * nB + (int)b + 1);
+                const int slot = (P.ring_base + tk) % P.ring_len; // the per-launch counters of the sequential path, per tick here
+                fails = P.fail_ring + slot; unconv = P.unconv_ring + slot;
+            } else {
+                if (out && lane == 0) lanes::publish(P.epoch + b, P.tick);
+            }
         }
         if (out && lane == 0) {
             if (P.obs_tmin) P.obs_tmin[b] = tmin;
-            if (!ok && P.fail_count) lanes::count_one(P.fail_count);
+            if (!ok && fails) lanes::count_one(fails);
+            if (status != 0 && unconv) lanes::count_one(unconv);
             P.status[b] = ok ? 0 : 4;
             P.qp_iter[b] = iters;
             P.qp_status[b] = status;
@@ -1625,6 +1713,132 @@ struct QpIpm {
 #ifdef USV_TIMING_EXPERIMENT
             if (S.fixed_iters == 0)
 #endif
+            if (run && a < S.alpha_min) { status = 2; done = true; late = true; iters = it; }
+            a_prev = run ? a * ((1.0 - a) * 0.99 + a * 0.9999999) : a_prev;
+            sig_prev = run ? sigmu : sig_prev;
+            pend = run ? true : pend;
+            it = run ? it + 1 : it;
+            fresh = false;
+        }
+    }
+
+    // ------------------------------------------------------------------ closed-loop launch (LOOP)
+    // The instances of the rows selected by `take` have just changed: their linearisation (ERK4 + forward sensitivities, cost
+    // gradient, packed [B A] - linearize.hpp, what the kernel usv_linearize does between two launches of the sequential path) into the
+    // rows' workspace slots.  The rows of the wave share the stages of one instance: row q takes stages q, q + 4, ...
+    USV_DEV void linearize_new(bool take) const
+    {
+        for (int r = 0; r < lanes::WAVE_ROWS; r++) {
+            if (!lanes::row_flag(take, r)) continue; // wave-uniform
+            const long br = lanes::row_value_i((int)b, r), gr = lanes::row_value_i((int)g, r);
+#ifdef USV_DBG_EXEC
+            {
+                const unsigned long long ex = __builtin_amdgcn_read_exec();
+                if (threadIdx.x == 0) { P.nlp_res[0] = (double)(unsigned)(ex >> 32); P.nlp_res[1] = (double)(unsigned)ex; P.nlp_res[2] = xlane ? 1.0 : 0.0; }
+                if (threadIdx.x == 5) P.nlp_res[3] = xlane ? 1.0 : 0.0;
+            }
+#endif
+            linearize_item<M, KCH, SOFT>(P.spec, P.x, P.u, P.yref, P.yref_e, P.ws + gr * (NPL * LANES) + lane, stage_stride, br, N);
+#ifdef USV_DBG_EXEC
+            {
+                const unsigned long long ex = __builtin_amdgcn_read_exec();
+                if (threadIdx.x == 0) { P.nlp_res[4] = (double)(unsigned)(ex >> 32); P.nlp_res[5] = (double)(unsigned)ex; P.nlp_res[6] = xlane ? 1.0 : 0.0; }
+                if (threadIdx.x == 5) P.nlp_res[7] = xlane ? 1.0 : 0.0;
+                if (threadIdx.x == 5) { P.nlp_res[8] = ulane ? 1.0 : 0.0; P.nlp_res[9] = valid ? 1.0 : 0.0; P.nlp_res[10] = isPX ? 1.0 : 0.0; P.nlp_res[11] = hasb ? 1.0 : 0.0; P.nlp_res[12] = (double)N; P.nlp_res[13] = (double)Kn; P.nlp_res[14] = (double)nB; P.nlp_res[15] = (double)itmax; }
+            }
+#endif
+        }
+#ifdef USV_DBG_DUMMY_CALL
+        dbg_dummy_call(P.ws, N);
+#endif
+#ifdef USV_DBG_FENCE
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+    }
+
+    USV_DEV void solve_cl()
+    {
+        keep = false;
+        const int nslots = lanes::uniform(P.cl_slots);
+        rbscale = 1.0;
+        bool real = false;               // the row holds an item whose results are to be written
+        bool done = true;                // nothing (more) to iterate on in this row
+        bool want = live;                // the row is waiting for an item (every row starts that way: all items come through the queue)
+        int ticket = -1;                 // its place in the queue while it waits
+        bool pend = false, fresh = false, late = false;
+        int status = 1, iters = 0, it = 0;
+        Norms nm;
+        nm.rg = nm.rb = nm.rd = nm.rm = nm.musum = nm.nan = 0.0;
+        double a_prev = 0.0, sig_prev = 0.0;
+        const double nc = (double)S.nc;
+        for (;;) {
+            if (lanes::wave_any(!done)) backward<true>(nm, 0.0, pend && !done, a_prev, sig_prev);
+            bool fin = late;
+            if (!done) {
+                if (real && lane == 0) {
+                    P.res[b * 4 + 0] = nm.rg; P.res[b * 4 + 1] = nm.rb; P.res[b * 4 + 2] = nm.rd; P.res[b * 4 + 3] = nm.rm;
+                }
+                iters = it;
+                if (nm.nan != nm.nan) { status = 3; fin = true; }
+                else if (nm.rg <= S.tol_stat && nm.rb <= S.tol_eq && nm.rd <= S.tol_ineq && nm.rm <= S.tol_comp) {
+                    status = 0; fin = true;
+                } else if (it >= itmax) { status = 1; fin = true; }
+            }
+            done = done || fin;
+            late = false;
+            if (lanes::wave_any(fin)) { // wave-uniform
+                finish(fin, real, status, iters, 0); // (hands the instance over and queues its next tick)
+                want = (fin && real) ? true : want;
+                real = fin ? false : real;
+            }
+            if (lanes::wave_any(want)) { // wave-uniform
+                // a row that wants an item draws ONE ticket and keeps it until that place of the queue has been filled: the wave never
+                // waits for it while one of its rows still iterates (that row may be the one whose hand-over fills the place)
+                int tkt = 0;
+                if (want && ticket < 0 && lane == 0) tkt = lanes::fetch_add(P.queue);
+                tkt = lanes::bcast_i<0>(tkt);
+                ticket = (want && ticket < 0) ? tkt : ticket;
+                want = want && ticket < nslots; // beyond the last item: the row retires
+                int item = 0;
+                if (want && lane == 0) item = lanes::observe(P.fifo + ticket);
+                item = lanes::bcast_i<0>(item);
+                const bool take = want && item != 0;
+                if (lanes::wave_any(take)) { // wave-uniform
+                    bind_item(item - 1, take);
+                    linearize_new(take);
+                    const bool bad = init(take) && take;
+                    real = take ? true : real;
+                    done = take ? bad : done;
+                    late = bad;
+                    fresh = take;
+                    pend = take ? false : pend;
+                    rbscale = take ? 1.0 : rbscale;
+                    it = take ? 0 : it;
+                    iters = take ? 0 : iters;
+                    status = take ? (bad ? 4 : 1) : status;
+                    want = take ? false : want;
+                    ticket = take ? -1 : ticket;
+                }
+            }
+            if (!lanes::wave_any(!done)) { // no row of the wave iterates
+                if (lanes::wave_any(late)) continue;                  // a new item stopped in its cold start: its results next
+                if (lanes::wave_any(want)) { lanes::nap(); continue; } // all waiting for their places in the queue
+                break;
+            }
+            const bool run = !done && !fresh; // rows that take part in the rest of this pass
+            const double mu = nc > 0.0 ? nm.musum / nc : 0.0;
+            double a_aff = 1.0, S1 = 0.0, S2 = 0.0, a = 1.0, d1, d2;
+            forward<false>(0.0, a_aff, S1, S2);
+            double sigmu = 0.0;
+            if (nc > 0.0) {
+                const double mu_aff = (nm.musum + a_aff * S1 + a_aff * a_aff * S2) / nc;
+                const double sg = mu_aff / mu;
+                sigmu = sg * sg * sg * mu;
+            }
+            backward<false>(nm, sigmu, false, 0.0, 0.0);
+            forward<true>(sigmu, a, d1, d2);
             if (run && a < S.alpha_min) { status = 2; done = true; late = true; iters = it; }
             a_prev = run ? a * ((1.0 - a) * 0.99 + a * 0.9999999) : a_prev;
             sig_prev = run ? sigmu : sig_prev;

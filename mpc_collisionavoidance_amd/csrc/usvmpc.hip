@@ -9,6 +9,7 @@
 // blocks are at most 16x16).
 #include "gfx950/lanes.hpp"
 
+#include "advance.hpp"
 #include "guidance.hpp"
 #include "host_spec.hpp"
 #include "linearize.hpp"
@@ -64,6 +65,26 @@ __global__ void __launch_bounds__(64, (LDSWS ? 1 : qp_waves<KCH, SOFTBOX>())) us
     q.solve(phase, queue0);
 }
 
+// Closed-loop launch (usvmpc_closed_loop; QpIpm::solve_cl): several consecutive ticks of solve + hand-over in ONE persistent launch whose
+// rows pull (instance, tick) items from a FIFO and linearise what they take themselves - no launch boundary, hence no launch tail,
+// between ticks.  The instantiations every OCP of the reference runs: diagonal Hessian, HBM workspace, no soft state bounds.
+template <class M, int KCH, bool SOFT, bool PACK, bool MERGE, bool AUXLDS>
+__global__ void __launch_bounds__(64, (qp_waves<KCH, false>())) usv_qp_cl(DevPtrs P, long ngroups)
+{
+    const long g0 = (long)blockIdx.x * 4;
+    if (g0 >= ngroups) return;
+    QpIpm<M, KCH, SOFT, true, PACK, false, false, MERGE, AUXLDS, true> q(P, g0 + (long)(threadIdx.x >> 4));
+    q.solve_cl();
+}
+
+// the queue of a closed-loop launch starts with tick 0 of every instance, in the order of the map (hardest first)
+__global__ void usv_fifo_fill(const int *perm, int B, int *fifo, int *tail)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) fifo[i] = (perm ? perm[i] : i) + 1;
+    if (i == 0) *tail = B;
+}
+
 // Multiplier read-back (usvmpc_get "lam" / "t"): the inequality multipliers and slacks of every instance's last QP, from the
 // group-indexed workspace planes into instance-major arrays in acados' row order (QpIpm::export_rows).  Run on demand.
 template <class M, int KCH, bool SOFT, bool PACK, bool SOFTBOX>
@@ -87,18 +108,7 @@ __global__ void usv_sqp_end(DevPtrs P, int B)
     if (i < B) P.status[i] = P.sqp_state[i] < 0 ? 2 : P.sqp_state[i];
 }
 
-// Closed-loop hand-over between two ticks, as the reference's callers do it on the host
-// (x0 = get(1,"x"); set(0,"lbx",x0): scripts/usv_guidance_ca1/main.py:169-175): the next initial
-// state is the predicted x_1 plus an optional Gaussian disturbance (the commented "Add noise"
-// hooks of scripts/usv_pf_ca/main.py:181-183).  No trajectory shift, as in the reference.
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z)
-{
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
+// Closed-loop hand-over between two ticks (advance.hpp), every instance at once: the stand-alone kernel of usvmpc_advance.
 __global__ void usv_advance(DevPtrs P, int nx, double sigma, unsigned long long seed, unsigned mask)
 {
     const DevSpec &S = *P.spec;
@@ -106,15 +116,7 @@ __global__ void usv_advance(DevPtrs P, int nx, double sigma, unsigned long long 
     if (i >= (long)S.B * nx) return;
     const long b = i / nx;
     const int j = (int)(i - b * nx);
-    double v = P.x[(b * (S.N + 1) + 1) * nx + j];
-    if (sigma != 0.0 && ((mask >> j) & 1u)) {
-        const unsigned long long h1 = splitmix64(seed ^ (unsigned long long)(2 * i));
-        const unsigned long long h2 = splitmix64(seed ^ (unsigned long long)(2 * i + 1));
-        const double u1 = ((double)(h1 >> 11) + 1.0) * (1.0 / 9007199254740993.0);
-        const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);
-        v += sigma * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
-    }
-    const_cast<double *>(P.x0)[i] = v;
+    const_cast<double *>(P.x0)[i] = advance_value(P.x[(b * (S.N + 1) + 1) * nx + j], sigma, seed, i, ((mask >> j) & 1u) != 0u);
 }
 
 // Debug / test entry points: the model functions exactly as the lineariser calls them (M::fjvp: f and one Jacobian
@@ -253,6 +255,15 @@ struct usvmpc_handle {
     bool map_changed;         // the group -> instance map differs from the one the workspace's multipliers were written under
     unsigned noise_mask;      // states usvmpc_advance disturbs (option "disturbance_mask"; default: all)
     int *d_fail_ring;         // [RING] instances with status != 0, one slot per solve
+    int *d_unconv_ring;       // [RING] instances whose QP did not converge to the tolerances (qp_status != 0), one slot per solve
+    // the event triple of solve i lives in ring slot ev_owner[i % RING] and spans ev_span[i % RING] solves (a closed-loop launch
+    // carries several ticks: its per-tick times are the launch's divided by its ticks)
+    int ev_owner[RING], ev_span[RING];
+    bool fused_loop;          // option "fused_closed_loop": usvmpc_closed_loop as ONE persistent launch where the kernels exist (default on)
+    int *d_fifo, *d_fifo_tail;
+    size_t fifo_cap;          // ints allocated for the item queue of a closed-loop launch
+    long cl_cap[4];           // groups a full-occupancy closed-loop launch holds, per (merge, aux) variant (0: unknown, -1: unusable)
+    bool ws_slots_shared;     // the last launch reused workspace slots across instances (closed loop): nothing to read back from it
     // Caller-visible arrays live in ONE device arena, in the order [x | u | status | x0 | yref | yref_e | p | lh] (256-byte aligned
     // pieces).  Small handles (the single-instance drop-in faces: AcadosOcpSolver, the acados C shim) also keep a pinned host
     // MIRROR of it: usvmpc_set then writes the mirror and marks the field dirty - no HIP call, no synchronisation - and the next
@@ -627,7 +638,12 @@ int launch_pair(usvmpc_handle *h, int phase)
     if (pipe) HIP_TRY(h, hipMemsetAsync(h->d_redo, 0, (size_t)B * ((h->N + 32) / 32) * sizeof(int), h->stream));
     HIP_TRY(h, hipEventRecord(ev[1], h->stream));
     h->ptrs.fail_count = h->d_fail_ring + h->nsolves % usvmpc_handle::RING;
+    h->ptrs.unconv_count = h->d_unconv_ring + h->nsolves % usvmpc_handle::RING;
     HIP_TRY(h, hipMemsetAsync(h->ptrs.fail_count, 0, sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->ptrs.unconv_count, 0, sizeof(int), h->stream));
+    h->ptrs.cl_ticks = 0;
+    h->ev_owner[h->nsolves % usvmpc_handle::RING] = (int)(h->nsolves % usvmpc_handle::RING);
+    h->ev_span[h->nsolves % usvmpc_handle::RING] = 1;
     const int *next_perm = nullptr;
     if (pipe) {
         // the NEXT tick's map, from the counts this launch is about to overwrite, into the buffer this tick does not use
@@ -770,12 +786,134 @@ int launch_pair(usvmpc_handle *h, int phase)
     }
     h->nsolves++;
     h->layout_dirty = false;
+    if (!cond) h->ws_slots_shared = false;
     if (h->mirror) { // [x | u | status] of this solve, one copy
         HIP_TRY(h, hipMemcpyAsync(h->mirror, h->arena, h->f_off[usvmpc_handle::F_X0], hipMemcpyDeviceToHost, h->stream));
         h->inflight = true;
         h->out_valid = true;
     }
     return 0;
+}
+
+// Closed-loop launch: `ticks` consecutive (solve, advance) pairs as ONE persistent launch (usv_qp_cl).  Returns 1 when this handle /
+// configuration has no such kernel (the caller then runs the sequential pairs), 0 when enqueued, < 0 on errors.
+template <class M, int KCH, bool SOFT>
+int launch_closed(usvmpc_handle *h, int ticks, double sigma, unsigned long long seed)
+{
+    constexpr bool CANPACK = KCH > 0;
+    const bool pack = CANPACK && h->spec.boxpack != 0;
+    if (!h->fused_loop || !h->dynamic_rows || h->cond_N2 > 0 || !h->spec.hdiag || h->spec.any_bsoft || pack != CANPACK || h->ncu < 1) return 1;
+    if (ticks > usvmpc_handle::RING || (double)h->B * ticks >= 2147483000.0) return 1; // (the caller splits longer runs)
+    if (h->spec.npt != WsLayout<M, KCH, SOFT, false>::NPT) { h->err = "workspace layout mismatch between host and kernels"; return USVMPC_E_ARG; }
+    {
+        const int rcf = mirror_flush(h);
+        if (rcf) return rcf;
+    }
+    if (h->spec_outstanding) { // a lineariser that ran ahead on the second stream: its planes are about to be overwritten
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_spec, 0));
+        h->spec_outstanding = false;
+    }
+    h->spec_valid = false;
+    const int B = h->B;
+    const size_t nitems = (size_t)B * ticks;
+    if (h->fifo_cap < nitems) {
+        if (h->d_fifo) dev_free(h, h->d_fifo, h->fifo_cap * sizeof(int));
+        h->d_fifo = nullptr; h->fifo_cap = 0;
+        if (dev_alloc(h, &h->d_fifo, nitems, false)) return USVMPC_E_HIP;
+        h->fifo_cap = nitems;
+    }
+    const int last = (int)((h->nsolves + ticks - 1) % usvmpc_handle::RING);
+    hipEvent_t *ev = h->ev[last];
+    HIP_TRY(h, hipEventRecord(ev[0], h->stream));
+    // the queue starts in the order of the previous solve's iteration counts, hardest first (later ticks queue up as they become ready)
+    if (h->sort_enabled && h->nsolves > 0) {
+        const int *prev2 = h->sort_two ? h->d_iter_prev : h->ptrs.qp_iter;
+        hipLaunchKernelGGL(usv_sort_hist, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_iter, prev2, B, h->d_hist);
+        hipLaunchKernelGGL(usv_sort_scan, dim3(1), dim3(64), 0, h->stream, h->d_hist, h->d_cursor);
+        hipLaunchKernelGGL(usv_sort_scatter, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_iter, prev2, B, h->d_cursor, h->d_perm);
+        HIP_TRY(h, hipGetLastError());
+        h->ptrs.perm = h->d_perm;
+    }
+    HIP_TRY(h, hipMemsetAsync(h->d_fifo, 0, nitems * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->ptrs.queue, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(usv_fifo_fill, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.perm, B, h->d_fifo, h->d_fifo_tail);
+    HIP_TRY(h, hipGetLastError());
+    for (int t = 0; t < ticks; t++) { // the per-tick audit counters of these ticks
+        const int slot = (int)((h->nsolves + t) % usvmpc_handle::RING);
+        HIP_TRY(h, hipMemsetAsync(h->d_fail_ring + slot, 0, sizeof(int), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_unconv_ring + slot, 0, sizeof(int), h->stream));
+        h->ev_owner[slot] = last; h->ev_span[slot] = ticks;
+    }
+    DevPtrs &P = h->ptrs;
+    P.epoch = nullptr; P.redo = nullptr; P.perm_cur = nullptr; P.tick = (int)h->nsolves;
+    P.fail_count = nullptr; P.unconv_count = nullptr;
+    P.fifo = h->d_fifo; P.fifo_tail = h->d_fifo_tail;
+    P.cl_ticks = ticks; P.cl_slots = (int)nitems;
+    P.cl_sigma = sigma; P.cl_seed = seed; P.cl_mask = h->noise_mask;
+    P.fail_ring = h->d_fail_ring; P.unconv_ring = h->d_unconv_ring;
+    P.ring_base = (int)(h->nsolves % usvmpc_handle::RING); P.ring_len = usvmpc_handle::RING;
+    HIP_TRY(h, hipEventRecord(ev[1], h->stream));
+    // the variant: one row pass where every box row rides in a slot lane (MERGE), the aux plane in the waves' LDS where the horizon fits
+    // without costing a resident wave (AUXLDS) - as launch_pair chooses for an RTI solve
+    const bool merge = pack && h->merge_rows && !h->spec.box_dense;
+    const int qp_block = 64;
+    auto occupancy = [&](auto kern, size_t lds) -> long {
+        int nb = 0;
+        if (lds > 0 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, qp_block, lds) != hipSuccess || nb < 1) return -1;
+        return 4L * nb * h->ncu;
+    };
+    auto run = [&](auto kern_plain, auto kern_aux, int vi) -> int {
+        const size_t aux_bytes = (size_t)4 * (h->N + 1) * (size_t)(h->spec.aux_dense4 + (h->kch > 0 ? 2 : 0) + 2 * h->nu) * sizeof(double);
+        if (h->cl_cap[vi] == 0) h->cl_cap[vi] = occupancy(kern_plain, 0);
+        if (h->cl_cap[vi + 1] == 0) {
+            h->cl_cap[vi + 1] = (h->aux_lds && pack) ? occupancy(kern_aux, aux_bytes) : -1;
+            if (h->cl_cap[vi + 1] < h->cl_cap[vi]) h->cl_cap[vi + 1] = -1; // (it would cost a resident wave)
+        }
+        const bool aux = h->cl_cap[vi + 1] > 0;
+        long cap = aux ? h->cl_cap[vi + 1] : h->cl_cap[vi];
+        if (cap <= 0) { h->err = "closed-loop launch: the kernel cannot be resident on this device"; return USVMPC_E_HIP; }
+        if (h->max_waves > 0 && 4L * h->max_waves < cap) cap = 4L * h->max_waves;
+        const long ng = std::min<long>(cap, (long)h->Bp);
+        const dim3 grid((unsigned)((ng * LANES + qp_block - 1) / qp_block)), block(qp_block);
+        if (aux) hipLaunchKernelGGL(kern_aux, grid, block, aux_bytes, h->stream, P, ng);
+        else hipLaunchKernelGGL(kern_plain, grid, block, 0, h->stream, P, ng);
+        return 0;
+    };
+    int rc;
+    if constexpr (CANPACK) {
+        if (merge) rc = run(&usv_qp_cl<M, KCH, SOFT, true, true, false>, &usv_qp_cl<M, KCH, SOFT, true, true, true>, 2);
+        else rc = run(&usv_qp_cl<M, KCH, SOFT, true, false, false>, &usv_qp_cl<M, KCH, SOFT, true, false, true>, 0);
+    } else {
+        rc = run(&usv_qp_cl<M, KCH, SOFT, false, false, false>, &usv_qp_cl<M, KCH, SOFT, false, false, false>, 0);
+    }
+    if (rc) return rc;
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(ev[2], h->stream));
+    P.cl_ticks = 0;
+    h->nsolves += ticks;
+    h->layout_dirty = false;
+    h->map_changed = true;      // (the workspace slots were shared by many instances: a later full SQP starts from zero multipliers)
+    h->ws_slots_shared = true;  // ... and there is nothing per instance to read back from them
+    h->out_valid = false;
+    return 0;
+}
+
+int launch_closed_dispatch(usvmpc_handle *h, int ticks, double sigma, unsigned long long seed)
+{
+    switch (h->desc.model) {
+#ifdef USV_BENCH_ONLY
+    case USVMPC_MODEL_PF_CA: if (h->kch <= 1) return launch_closed<ModelM2, 1, false>(h, ticks, sigma, seed); break;
+    case USVMPC_MODEL_GUIDANCE_CA1: if (h->kch <= 1) return launch_closed<ModelM1, 1, true>(h, ticks, sigma, seed); break;
+#elif !defined(USV_GEN_ONLY)
+    case USVMPC_MODEL_USV: return launch_closed<ModelM0, 0, false>(h, ticks, sigma, seed);
+    case USVMPC_MODEL_GUIDANCE_CA1:
+        return h->kch <= 1 ? launch_closed<ModelM1, 1, true>(h, ticks, sigma, seed) : launch_closed<ModelM1, 2, true>(h, ticks, sigma, seed);
+    case USVMPC_MODEL_PF_CA:
+        return h->kch <= 1 ? launch_closed<ModelM2, 1, false>(h, ticks, sigma, seed) : launch_closed<ModelM2, 2, false>(h, ticks, sigma, seed);
+#endif
+    }
+    return 1; // (generated models: the sequential pairs)
 }
 
 // planes per stage of the packed [B A] for this model (MatPack)
@@ -833,6 +971,11 @@ int ensure_export(usvmpc_handle *h)
 {
     if (h->nsolves == 0) { h->err = "no QP has been solved yet: nothing to read back"; return USVMPC_E_ARG; }
     if (h->layout_dirty) { h->err = "the row layout option changed after the last solve: solve again before reading multipliers"; return USVMPC_E_ARG; }
+    if (h->ws_slots_shared) {
+        h->err = "the last launch was a closed-loop launch (usvmpc_closed_loop), whose rows reuse their workspace slots from item to item: "
+                 "\"lam\" / \"t\" of its last tick do not exist - run the tick of interest with usvmpc_solve";
+        return USVMPC_E_ARG;
+    }
     HIP_TRY(h, hipSetDevice(h->device));
     DevPtrs &P = h->ptrs;
     if (!P.lam_out) {
@@ -1022,6 +1165,11 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     TRY_C(dev_alloc(h, &P.res, B * 4, true));
     TRY_C(dev_alloc(h, &P.obs_tmin, B, true));
     TRY_C(dev_alloc(h, &h->d_fail_ring, usvmpc_handle::RING, true));
+    TRY_C(dev_alloc(h, &h->d_unconv_ring, usvmpc_handle::RING, true));
+    TRY_C(dev_alloc(h, &h->d_fifo_tail, 1, true));
+    h->d_fifo = nullptr; h->fifo_cap = 0; h->fused_loop = true; h->ws_slots_shared = false;
+    for (int i = 0; i < 4; i++) h->cl_cap[i] = 0;
+    for (int r = 0; r < usvmpc_handle::RING; r++) { h->ev_owner[r] = r; h->ev_span[r] = 1; }
     TRY_C(dev_alloc(h, &P.queue, 1, true));
     TRY_C(dev_alloc(h, &P.nlp_res, B * 4, true));
     TRY_C(dev_alloc(h, &P.sqp_iter, B, true));
@@ -1198,13 +1346,15 @@ int usvmpc_kernel_ms(usvmpc_handle *h, int n, float *linearize_ms, float *qp_ms)
     if (h->nsolves < n || n > usvmpc_handle::RING) { h->err = "fewer solves recorded than requested"; return USVMPC_E_ARG; }
     HIP_TRY(h, hipSetDevice(h->device));
     for (int i = 0; i < n; i++) { // oldest of the last n first
-        hipEvent_t *ev = h->ev[(h->nsolves - n + i) % usvmpc_handle::RING];
+        const int slot = (int)((h->nsolves - n + i) % usvmpc_handle::RING);
+        hipEvent_t *ev = h->ev[h->ev_owner[slot]];
         HIP_TRY(h, hipEventSynchronize(ev[2]));
         float a = 0, b = 0;
         HIP_TRY(h, hipEventElapsedTime(&a, ev[0], ev[1]));
         HIP_TRY(h, hipEventElapsedTime(&b, ev[1], ev[2]));
-        if (linearize_ms) linearize_ms[i] = a;
-        if (qp_ms) qp_ms[i] = b;
+        // (a tick of a closed-loop launch: the launch's time divided by its ticks; its lineariser runs inside the QP launch)
+        if (linearize_ms) linearize_ms[i] = a / (float)h->ev_span[slot];
+        if (qp_ms) qp_ms[i] = b / (float)h->ev_span[slot];
     }
     return 0;
 }
@@ -1245,6 +1395,17 @@ int usvmpc_debug_model_eval(int model, int device, int n, const double *x, const
     return rc;
 }
 
+int usvmpc_debug_workspace(usvmpc_handle *h, double *out, size_t n, int *npt)
+{
+    if (!h) return USVMPC_E_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (npt) *npt = h->spec.npt;
+    const size_t total = (size_t)(h->N + 1) * h->spec.npt * (size_t)h->Bp * LANES;
+    if (out && n) HIP_TRY(h, hipMemcpy(out, h->ptrs.ws, std::min(n, total) * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int usvmpc_debug_obstacle_eval(int device, int n, int K, const double *pos, const double *p, double *h, double *grad)
 {
     if (n < 1 || K < 1 || !pos || !p || !h || !grad) return USVMPC_E_ARG;
@@ -1277,6 +1438,40 @@ int usvmpc_fail_counts(usvmpc_handle *h, int n, int *counts)
     HIP_TRY(h, hipMemcpyAsync(ring, h->d_fail_ring, sizeof(ring), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < n; i++) counts[i] = ring[(h->nsolves - n + i) % usvmpc_handle::RING];
+    return 0;
+}
+
+int usvmpc_unconverged_counts(usvmpc_handle *h, int n, int *counts)
+{
+    if (!h || n < 1 || !counts) return USVMPC_E_ARG;
+    if (h->nsolves < n || n > usvmpc_handle::RING) { h->err = "fewer solves recorded than requested"; return USVMPC_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    int ring[usvmpc_handle::RING];
+    HIP_TRY(h, hipMemcpyAsync(ring, h->d_unconv_ring, sizeof(ring), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; i++) counts[i] = ring[(h->nsolves - n + i) % usvmpc_handle::RING];
+    return 0;
+}
+
+int usvmpc_closed_loop(usvmpc_handle *h, int ticks, double sigma, unsigned long long seed)
+{
+    if (!h || ticks < 1) return USVMPC_E_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int done = 0;
+    while (done < ticks) {
+        const int chunk = std::min(ticks - done, (int)usvmpc_handle::RING);
+        const int rc = launch_closed_dispatch(h, chunk, sigma, seed + (unsigned long long)done);
+        if (rc < 0) return rc;
+        if (rc == 1) { // no fused kernel for this handle: the same ticks as kernel pairs
+            for (int t = 0; t < chunk; t++) {
+                int r2 = launch(h);
+                if (r2) return r2;
+                r2 = usvmpc_advance(h, sigma, seed + (unsigned long long)(done + t));
+                if (r2) return r2;
+            }
+        }
+        done += chunk;
+    }
     return 0;
 }
 
@@ -1340,7 +1535,8 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         return 0;
     }
     if (s == "sort_two_ticks") { h->sort_two = value != 0.0; return 0; }
-    if (s == "aux_in_lds") { h->aux_lds = value != 0.0; h->aux_cap = 0; return 0; }
+    if (s == "fused_closed_loop") { h->fused_loop = value != 0.0; return 0; }
+    if (s == "aux_in_lds") { h->aux_lds = value != 0.0; h->aux_cap = 0; for (int i = 0; i < 4; i++) h->cl_cap[i] = 0; return 0; }
     if (s == "lds_workspace") { // -1: when the batch is small (default), 0: never, 1: whenever an instance's planes fit in LDS
         h->lds_mode = value < 0.0 ? -1 : (value > 0.0 ? 1 : 0);
         h->lds_cap = 0;

@@ -5,8 +5,10 @@ gfx950 needs 2 wait states between a VALU write of a VGPR and a DPP instruction 
 compiler pads the DPP moves it emits itself, but not the `v_fmac_f64_dpp` that lanes::fma_bc places through inline asm.  This
 script disassembles every kernel of a shared library (or a bare code object) and, for each such instruction, looks at the two
 instructions issued before it on every path the disassembly shows: straight-line predecessors, and - when the instruction sits
-within two slots of a label - the instructions before every branch to that label.  Anything it cannot follow (computed
-branches) counts as a violation.  Exit status 1 and a listing when a violation exists.
+within two slots of a label - the instructions before every branch to that label; calls of non-inlined device functions
+(s_swappc_b64 / s_setpc_b64 s[30:31]) are followed conservatively (every call site in front of every callee, every callee's return
+in front of every call's successor).  Anything else it cannot follow (computed branches) counts as a violation.  Exit status 1
+and a listing when a violation exists.
 
 usage: python -m mpc_collisionavoidance_amd.dpp_check <lib.so | code object> [...]   (tools/check_dpp_hazard.py wraps this)
 `check_library(path)` is what __graft_entry__.build() and genbuild.build_device_lib() call on every library they produce.
@@ -131,7 +133,19 @@ def check(co):
                 unknown_branch = True
             else:
                 branches_to.setdefault(tgt, []).append(i)
-        if mn in ("s_setpc_b64", "s_swappc_b64"):
+    # Calls: hipcc emits `s_swappc_b64` for a call of a non-inlined device function and `s_setpc_b64 s[30:31]` for its return (nothing else
+    # in these libraries computes a branch).  Which callee a call reaches is a register value, so the walk is conservative: in front of
+    # the instruction after ANY call sit the tails of ALL called functions' returns (and, as if the callee were empty, the call site's own
+    # predecessors); in front of a called function's first instruction sit ALL call sites.
+    calls = [i for i, (_, mn, _) in enumerate(prog) if mn == "s_swappc_b64"]
+    returns = [i for i, (_, mn, _) in enumerate(prog) if mn == "s_setpc_b64"]
+    kernels = {funcs[i] for i, (_, mn, _) in enumerate(prog) if mn == "s_endpgm"}
+    entry_of = {}       # index of a called function's first instruction -> True
+    for i in range(len(prog)):
+        if (i == 0 or funcs[i - 1] != funcs[i]) and funcs[i] not in kernels:
+            entry_of[i] = True
+    for r in returns:   # a return must be the plain `s_setpc_b64 s[30:31]` of a called function, not a computed jump inside a kernel
+        if funcs[r] in kernels or "s[30:31]" not in prog[r][2]:
             unknown_branch = True
     is_target = set(branches_to)
 
@@ -147,11 +161,19 @@ def check(co):
                 yield (src, prog[src][1], prog[src][2])
         j = i - 1
         if j < 0 or funcs[j] != funcs[i]:
+            if i in entry_of:   # first instruction of a called function: every call site leads here
+                for c in calls:
+                    yield (c, prog[c][1], prog[c][2])
+                    yield from writers_before(c, need - 1, depth + 1)
             return
         mn, ops = prog[j][1], prog[j][2]
-        if mn in ("s_branch", "s_endpgm"):
+        if mn in ("s_branch", "s_endpgm", "s_setpc_b64"):
             return      # no fall-through
         yield (j, mn, ops)
+        if mn == "s_swappc_b64":   # the call has returned: whatever the callee did last came in between
+            for r in returns:
+                yield (r, prog[r][1], prog[r][2])
+                yield from writers_before(r, need - 2, depth + 1)
         yield from writers_before(j, need - wait_states(mn, ops), depth)
 
     bad = []

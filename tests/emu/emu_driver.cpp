@@ -404,3 +404,84 @@ extern "C" int usv_emu_lin_modes(const usvmpc_desc *d, const double *x, const do
 #endif
     return -3;
 }
+
+// ---- the closed-loop launch (QpIpm::solve_cl) on the emulator: `rows` persistent rows, one after the other (the first one works
+// through the whole queue - the queue logic, the in-kernel lineariser and the hand-over are what is exercised), against the
+// sequence usv_emu_solve + usv_emu_advance.  fail / unconv: [ticks] per-tick counters.
+namespace {
+template <class M, int KCH, bool SOFT, bool PACK, bool MERGE, bool AUX>
+void cl_body(void *a)
+{
+    Job *j = (Job *)a;
+    QpIpm<M, KCH, SOFT, true, PACK, false, false, MERGE, AUX, true> q(*j->P, j->gid);
+    q.solve_cl();
+}
+template <class M, int KCH, bool SOFT>
+int cl_all(DevPtrs &P, DevSpec &S, long rows)
+{
+    S.npt = WsLayout<M, KCH, SOFT, false>::NPT;
+    constexpr bool CANPACK = KCH > 0;
+    const bool pack = CANPACK && S.boxpack != 0;
+    if (!S.hdiag || S.any_bsoft || pack != CANPACK) return -5;
+    for (long g = 0; g < rows; g++) {
+        static std::vector<double> lds;
+        lds.assign((size_t)(S.N + 1) * 16 * LANES, 0.0); // (the aux area of the emulated wave)
+        lanes::g_emu_lds = lds.data();
+        Job j{&P, g, 0, -1};
+        if constexpr (CANPACK) {
+            if (g_emu_merge && !S.box_dense) lanes::run_group(g, g_emu_aux ? &cl_body<M, KCH, SOFT, true, true, true> : &cl_body<M, KCH, SOFT, true, true, false>, &j);
+            else lanes::run_group(g, g_emu_aux ? &cl_body<M, KCH, SOFT, true, false, true> : &cl_body<M, KCH, SOFT, true, false, false>, &j);
+        } else {
+            lanes::run_group(g, &cl_body<M, KCH, SOFT, false, false, false>, &j);
+        }
+    }
+    return 0;
+}
+} // namespace
+
+extern "C" int usv_emu_closed_loop(const usvmpc_desc *d, double *x, double *u, double *x0, const double *yref, const double *yref_e,
+                                   const double *p, const double *lh, double *sl, double *su, double *pi, int *status, int *qp_status,
+                                   int *qp_iter, double *res, int ticks, double sigma, unsigned long long seed, unsigned mask,
+                                   int *fail, int *unconv, const int *perm)
+{
+    DevSpec S;
+    if (!build_spec(*d, S).empty()) return -1;
+    int nx, nu;
+    model_dims(d->model, nx, nu);
+    const int N = S.N;
+    const int kch = (S.K + LANES - 1) / LANES;
+    const bool soft = d->soft != 0;
+    const long rows = g_emu_rows > 0 ? std::min<long>(g_emu_rows, S.Bp) : S.Bp;
+    std::vector<double> ws((size_t)(N + 1) * ws_planes(nx, nu, kch, soft, 16, true) * (size_t)S.Bp * LANES);
+    std::vector<double> tmin(S.B);
+    std::vector<int> fifo((size_t)S.B * ticks, 0);
+    for (int i = 0; i < S.B; i++) fifo[i] = (perm ? perm[i] : i) + 1;
+    int head = 0, tail = S.B;
+    DevPtrs P;
+    std::memset(&P, 0, sizeof(P));
+    P.spec = &S;
+    P.x = x; P.u = u; P.x0 = x0; P.yref = yref; P.yref_e = yref_e; P.p = p; P.lh = lh;
+    P.sl = sl; P.su = su; P.pi = pi; P.status = status; P.qp_iter = qp_iter; P.qp_status = qp_status; P.res = res;
+    P.obs_tmin = tmin.data();
+    P.ws = ws.data();
+    P.queue = &head; P.fifo = fifo.data(); P.fifo_tail = &tail;
+    P.cl_ticks = ticks; P.cl_slots = S.B * ticks; P.cl_sigma = sigma; P.cl_seed = seed; P.cl_mask = mask;
+    std::memset(fail, 0, sizeof(int) * ticks); std::memset(unconv, 0, sizeof(int) * ticks);
+    P.fail_ring = fail; P.unconv_ring = unconv; P.ring_base = 0; P.ring_len = ticks;
+#ifndef USV_GEN_ONLY
+    if (d->model == USVMPC_MODEL_USV) return cl_all<ModelM0, 0, false>(P, S, rows);
+    if (d->model == USVMPC_MODEL_GUIDANCE_CA1) return kch <= 1 ? cl_all<ModelM1, 1, true>(P, S, rows) : cl_all<ModelM1, 2, true>(P, S, rows);
+    if (d->model == USVMPC_MODEL_PF_CA) return kch <= 1 ? cl_all<ModelM2, 1, false>(P, S, rows) : cl_all<ModelM2, 2, false>(P, S, rows);
+#endif
+    return -3;
+}
+
+// the hand-over of every instance between two ticks (advance.hpp), as the device's usv_advance kernel does it
+extern "C" void usv_emu_advance(int B, int N, int nx, const double *x, double *x0, double sigma, unsigned long long seed, unsigned mask)
+{
+    for (long i = 0; i < (long)B * nx; i++) {
+        const long b = i / nx;
+        const int j = (int)(i - b * nx);
+        x0[i] = usv::advance_value(x[(b * (N + 1) + 1) * nx + j], sigma, seed, i, ((mask >> j) & 1u) != 0u);
+    }
+}

@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #define USV_DEV inline __attribute__((always_inline))
+#define USV_DEV_CALL inline __attribute__((noinline))
 
 namespace lanes {
 
@@ -161,6 +162,9 @@ struct Stash {
 extern double *g_emu_lds;
 constexpr int WAVE_ROWS = 1;
 inline unsigned wave_row() { return 0; }
+inline int row_value_i(int v, int) { return v; }
+inline bool row_flag(bool p, int) { return p; }
+inline void nap() {}
 inline double *dyn_lds() { return g_emu_lds; }
 struct PlanesLds {
     unsigned off;
@@ -177,6 +181,8 @@ void run_group(long group, void (*body)(void *), void *arg);
 
 // device math names used by the kernel bodies
 using std::atan2;
+using std::cos;
+using std::log;
 using std::fabs;
 using std::fma;
 using std::fmax;

@@ -237,6 +237,9 @@ int usvmpc_calibrate_traffic(usvmpc_handle *h, int nplanes, double *bytes_read, 
  * the last launch) copied to the host, first n doubles; *npt receives the planes per stage.  For tests that hold the in-kernel
  * lineariser of the closed-loop launch against the stand-alone kernel plane by plane. */
 int usvmpc_debug_workspace(usvmpc_handle *h, double *out, size_t n, int *npt);
+/* TEST ENTRY: the queue counters of the closed-loop launch, readable while it runs: out[9] = linearised items, lineariser tickets, handed-over
+ * items, waves arrived, abort flag, 3 spare, QP tickets */
+int usvmpc_debug_counters(usvmpc_handle *h, int *out);
 /* Test entry points (no handle): the device transcription of the reference's model files evaluated on caller-supplied
  * points - f [n][nx] and the Jacobian J [n][nx][nu+nx] with respect to z = [u; x] exactly as the lineariser obtains them
  * (one tangent column per call of the model's fjvp), for the CasADi expressions of

@@ -54,7 +54,7 @@ EXPORTS = ["usvmpc_model_dims", "usvmpc_default_options", "usvmpc_create", "usvm
            "usvmpc_sync", "usvmpc_get_device_ptr", "usvmpc_last_kernel_ms", "usvmpc_kernel_ms", "usvmpc_fail_counts",
            "usvmpc_unconverged_counts", "usvmpc_closed_loop", "usvmpc_advance", "usvmpc_set_stream", "usvmpc_set_option", "usvmpc_calibrate_traffic", "usvmpc_guidance_reset", "usvmpc_guidance_prepare", "usvmpc_guidance_sense",
            "usvmpc_guidance_publish", "usvmpc_guidance_state", "usvmpc_device_bytes", "usvmpc_last_error",
-           "usvmpc_debug_model_eval", "usvmpc_debug_obstacle_eval", "usvmpc_debug_workspace"]
+           "usvmpc_debug_model_eval", "usvmpc_debug_obstacle_eval", "usvmpc_debug_workspace", "usvmpc_debug_counters"]
 
 
 _libs = {}
@@ -111,6 +111,7 @@ def load(path):
     L.usvmpc_debug_obstacle_eval.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
     L.usvmpc_device_bytes.argtypes = [C.c_void_p]
     L.usvmpc_debug_workspace.argtypes = [C.c_void_p, _dp, C.c_size_t, _ip]
+    L.usvmpc_debug_counters.argtypes = [C.c_void_p, _ip]
     L.usvmpc_device_bytes.restype = C.c_size_t
     L.usvmpc_last_error.argtypes = [C.c_void_p]
     L.usvmpc_last_error.restype = C.c_char_p

@@ -12,12 +12,6 @@
 #include <hip/hip_runtime.h>
 
 #define USV_DEV __device__ __forceinline__
-// a device function that is CALLED: its own register allocation, saved and restored around the call
-#ifdef USV_DBG_INLINE_CALLS
-#define USV_DEV_CALL __device__ __forceinline__
-#else
-#define USV_DEV_CALL __device__ __attribute__((noinline))
-#endif
 
 namespace lanes {
 
@@ -283,6 +277,8 @@ USV_DEV int row_value_i(int v, int r) { return __builtin_amdgcn_readlane(v, 16 *
 USV_DEV bool row_flag(bool p, int r) { return __builtin_amdgcn_readlane((int)p, 16 * r) != 0; }
 // a wave with nothing to do but poll: off the issue ports for ~64 x n cycles
 USV_DEV void nap() { __builtin_amdgcn_s_sleep(32); }
+// polls of one queue place a closed-loop launch puts up with (each >= 1 us) before it gives up instead of hanging the device
+constexpr int CL_PATIENCE = 1 << 22;
 // the workgroup's dynamic LDS (one wave per workgroup in the QP kernel): the planes of PlanesLds, or the aux area of qp_ipm.hpp
 USV_DEV double *dyn_lds()
 {

@@ -223,40 +223,6 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 #endif
 }
 
-// Closed-loop launch: all stages of ONE instance linearised by the rows of a wave, row q taking stages q, q + 4, ... (tile0: this lane's
-// entry of plane 0 of stage 0 in the target workspace slot).  A CALLED function, not inlined into the QP kernel: the lineariser wants
-// ~220 registers of its own, and inlined it made the register allocator spill inside the sweeps (scratch reloads there drain the plane
-// prefetch: lanes::Stash); as a call its registers are saved and restored around the call - once per item.
-template <class M, int KCH, bool SOFT>
-USV_DEV_CALL void linearize_item(const DevSpec *spec, const double *x, const double *u, const double *yref, const double *yref_e,
-                                 double *tile0, long stage_stride, long b, int N)
-{
-    using Lin = Linearize<M, KCH, SOFT, true, 0>; // (the step count is a run-time value here: one build for sim_method_num_steps >= 1)
-    DevPtrs Q; // what Linearize::stage reads
-#ifdef USV_DBG_GLOBAL_AS
-    typedef double __attribute__((address_space(1))) gdouble;
-    Q.spec = (const DevSpec *)(const DevSpec __attribute__((address_space(1))) *)spec;
-    Q.x = (double *)(gdouble *)x; Q.u = (double *)(gdouble *)u; Q.yref = (const double *)(const gdouble *)yref; Q.yref_e = (const double *)(const gdouble *)yref_e;
-    tile0 = (double *)(gdouble *)tile0;
-#else
-    Q.spec = spec; Q.x = const_cast<double *>(x); Q.u = const_cast<double *>(u); Q.yref = yref; Q.yref_e = yref_e;
-#endif
-    for (int k0 = 0; k0 <= N; k0 += lanes::WAVE_ROWS) {
-        const int k = k0 + (int)lanes::wave_row();
-        // (uniform over each 16-lane row; the cross-lane operations inside stay within a row)
-        if (k <= N) Lin::template stage<true>(Q, b, k, tile0 + (long)k * stage_stride);
-    }
-}
-
-#ifdef USV_DBG_DUMMY_CALL
-__device__ __attribute__((noinline)) void dbg_dummy_call(double *sink, int n)
-{
-    double a = (double)threadIdx.x;
-    for (int i = 0; i < n; i++) a = a * 1.0000001 + 0.5;
-    if (a < 0.0) *sink = a; // (never)
-}
-#endif
-
 // LDSWS: the workspace planes of a row's instance live in LDS for the whole solve (lanes::PlanesLds) - for batches small
 // enough that every instance in flight fits (host: usvmpc.hip); the lineariser's planes are copied in at the cold start.
 // MERGE (with PACK, no dense rows: host_spec.hpp / usvmpc.hip): the box rows are processed where they are stored - as rows of the
@@ -268,10 +234,10 @@ __device__ __attribute__((noinline)) void dbg_dummy_call(double *sink, int n)
 // RTI launches whose horizon fits (host: usvmpc.hip); finish() leaves a copy in the HBM plane for the read-back paths.
 // LOOP: closed-loop launch (solve_cl, usvmpc_closed_loop): the rows work through items (instance, tick) of several consecutive ticks in ONE
 // persistent launch - a row that has finished (b, t) hands the instance over itself (x, u out past the non-coherent caches, x0 <- x1 +
-// disturbance: advance.hpp), queues (b, t + 1) and takes the oldest queued item, which its wave linearises on the spot (linearize.hpp,
-// the four rows of the wave share the stages).  No launch boundary between ticks, hence no launch tail per tick: an instance that runs
-// long delays only its own next tick.  A row keeps ONE workspace slot for the whole launch.  Same arithmetic per (instance, tick) as the
-// sequence solve, advance, solve, ...: results are bit-identical (scheduling only).
+// disturbance: advance.hpp, done by the lineariser waves), queues (b, t + 1) for the launch's lineariser waves (Linearize::serve) and takes the oldest linearised item,
+// whose planes it copies into its own workspace slot at the cold start.  No launch boundary between ticks, hence no launch tail per
+// tick: an instance that runs long delays only its own next tick.  A row keeps ONE workspace slot for the whole launch.  Same arithmetic
+// per (instance, tick) as the sequence solve, advance, solve, ...: results are bit-identical (scheduling only).
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false,
           bool LOOP = false>
 struct QpIpm {
@@ -601,9 +567,6 @@ struct QpIpm {
     // launch that was another wave, possibly behind another XCD's L2 - read past the non-coherent caches (lanes::ld_shared)
     USV_DEV static double ldi(const double *q)
     {
-#ifdef USV_DBG_PLAIN_LD
-        return *q;
-#endif
         if constexpr (LOOP) return lanes::ld_shared(q);
         else return *q;
     }
@@ -760,6 +723,20 @@ struct QpIpm {
         for (int k = 0; k <= N; k++) {
             const Planes W = ws(k);
             const double zb = zbar(k);
+            if constexpr (LOOP) { // the linearisation of this stage comes in from the lineariser waves' planes of the instance
+                using LinT = Linearize<M, KCH, SOFT, true, 0>;
+                const double *L = P.lp + (((long)k * nB + b) * LinT::NLP) * LANES + lane;
+                const double rb = (k < N) ? lanes::ld_shared(L) : 0.0, gq = lanes::ld_shared(L + LANES);
+                double mpk[MP::NPK];
+                if (k < N) sfor<0, MP::NPK>([&](auto q) { mpk[q] = lanes::ld_shared(L + (2 + q) * LANES); });
+                if (wr) {
+                    W.st(P_GQ, gq);
+                    if (k < N) {
+                        W.st(P_RB0, rb);
+                        sfor<0, MP::NPK>([&](auto q) { W.st(P_MAT + q, mpk[q]); });
+                    }
+                }
+            }
             if constexpr (LDSWS) { // the linearisation of this stage comes in from HBM
                 const lanes::Planes G = wsg(k);
                 const double gq = G.ld(P_GQ), rb = (k < N) ? G.ld(P_RB0) : 0.0;
@@ -1540,16 +1517,6 @@ struct QpIpm {
                 }
                 if (k >= 1 && xlane && P.pi) P.pi[((long)b * N + (k - 1)) * NX + (lane - NU)] = W.ld(P_PI);
             }
-            if constexpr (LOOP) {
-                // the caller's hand-over between two ticks, done by the row that has just solved the instance: x0 <- x_1 (+ disturbance)
-                // - the x_1 of the new iterate, or after a failed solve of the untouched one (usv_advance reads whatever x holds)
-                if (k == 1) { // wave-uniform
-                    const int j = xlane ? lane - NU : 0;
-                    const double x1 = ok ? z : ldi(&P.x[((long)b * (N + 1) + 1) * NX + j]);
-                    const double v = advance_value(x1, P.cl_sigma, P.cl_seed + (unsigned long long)tk, (long)b * NX + j, ((P.cl_mask >> j) & 1u) != 0u);
-                    if (out && xlane) lanes::st_shared(const_cast<double *>(&P.x0[(long)b * NX + j]), v);
-                }
-            }
             if constexpr (KCH > 0 && SOFT) {
                 if (k >= 1 && k < N) {
                     sfor<0, KCH>([&](auto c) {
@@ -1587,8 +1554,9 @@ struct QpIpm {
         if (share) { // the instance's iterate is final: tell the lineariser of the next tick (every store of the wave has landed first)
             lanes::drain_stores();
             if constexpr (LOOP) {
-                // ... or whichever row takes the instance's next tick: the item goes to the end of the queue
-                if (out && lane == 0 && tk + 1 < P.cl_ticks) lanes::publish(P.fifo + lanes::fetch_add(P.fifo_tail), (tk + 1) * nB + (int)b + 1);
+                // ... or the launch's lineariser waves: the instance's next tick goes to the end of their queue
+                // (its hand-over x0 <- x_1 is theirs too; after the launch's last tick the item only asks for that)
+                if (out && lane == 0) lanes::publish(P.linq + lanes::fetch_add(P.lin_tail), (tk + 1) * nB + (int)b + 1);
                 const int slot = (P.ring_base + tk) % P.ring_len; // the per-launch counters of the sequential path, per tick here
                 fails = P.fail_ring + slot; unconv = P.unconv_ring + slot;
             } else {
@@ -1723,41 +1691,6 @@ struct QpIpm {
     }
 
     // ------------------------------------------------------------------ closed-loop launch (LOOP)
-    // The instances of the rows selected by `take` have just changed: their linearisation (ERK4 + forward sensitivities, cost
-    // gradient, packed [B A] - linearize.hpp, what the kernel usv_linearize does between two launches of the sequential path) into the
-    // rows' workspace slots.  The rows of the wave share the stages of one instance: row q takes stages q, q + 4, ...
-    USV_DEV void linearize_new(bool take) const
-    {
-        for (int r = 0; r < lanes::WAVE_ROWS; r++) {
-            if (!lanes::row_flag(take, r)) continue; // wave-uniform
-            const long br = lanes::row_value_i((int)b, r), gr = lanes::row_value_i((int)g, r);
-#ifdef USV_DBG_EXEC
-            {
-                const unsigned long long ex = __builtin_amdgcn_read_exec();
-                if (threadIdx.x == 0) { P.nlp_res[0] = (double)(unsigned)(ex >> 32); P.nlp_res[1] = (double)(unsigned)ex; P.nlp_res[2] = xlane ? 1.0 : 0.0; }
-                if (threadIdx.x == 5) P.nlp_res[3] = xlane ? 1.0 : 0.0;
-            }
-#endif
-            linearize_item<M, KCH, SOFT>(P.spec, P.x, P.u, P.yref, P.yref_e, P.ws + gr * (NPL * LANES) + lane, stage_stride, br, N);
-#ifdef USV_DBG_EXEC
-            {
-                const unsigned long long ex = __builtin_amdgcn_read_exec();
-                if (threadIdx.x == 0) { P.nlp_res[4] = (double)(unsigned)(ex >> 32); P.nlp_res[5] = (double)(unsigned)ex; P.nlp_res[6] = xlane ? 1.0 : 0.0; }
-                if (threadIdx.x == 5) P.nlp_res[7] = xlane ? 1.0 : 0.0;
-                if (threadIdx.x == 5) { P.nlp_res[8] = ulane ? 1.0 : 0.0; P.nlp_res[9] = valid ? 1.0 : 0.0; P.nlp_res[10] = isPX ? 1.0 : 0.0; P.nlp_res[11] = hasb ? 1.0 : 0.0; P.nlp_res[12] = (double)N; P.nlp_res[13] = (double)Kn; P.nlp_res[14] = (double)nB; P.nlp_res[15] = (double)itmax; }
-            }
-#endif
-        }
-#ifdef USV_DBG_DUMMY_CALL
-        dbg_dummy_call(P.ws, N);
-#endif
-#ifdef USV_DBG_FENCE
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-    }
-
     USV_DEV void solve_cl()
     {
         keep = false;
@@ -1767,6 +1700,7 @@ struct QpIpm {
         bool done = true;                // nothing (more) to iterate on in this row
         bool want = live;                // the row is waiting for an item (every row starts that way: all items come through the queue)
         int ticket = -1;                 // its place in the queue while it waits
+        int idle = 0;                    // polls in a row with nothing to do in the whole wave
         bool pend = false, fresh = false, late = false;
         int status = 1, iters = 0, it = 0;
         Norms nm;
@@ -1807,7 +1741,6 @@ struct QpIpm {
                 const bool take = want && item != 0;
                 if (lanes::wave_any(take)) { // wave-uniform
                     bind_item(item - 1, take);
-                    linearize_new(take);
                     const bool bad = init(take) && take;
                     real = take ? true : real;
                     done = take ? bad : done;
@@ -1820,11 +1753,19 @@ struct QpIpm {
                     status = take ? (bad ? 4 : 1) : status;
                     want = take ? false : want;
                     ticket = take ? -1 : ticket;
+                    idle = 0;
                 }
             }
             if (!lanes::wave_any(!done)) { // no row of the wave iterates
                 if (lanes::wave_any(late)) continue;                  // a new item stopped in its cold start: its results next
-                if (lanes::wave_any(want)) { lanes::nap(); continue; } // all waiting for their places in the queue
+                if (lanes::wave_any(want)) { // all waiting for their places in the queue
+                    // (a launch that cannot make progress - it never should - ends with an error instead of hanging the device)
+                    int stop = 0;
+                    if (lane == 0) stop = lanes::observe(P.cl_abort) | (++idle > lanes::CL_PATIENCE ? 1 : 0);
+                    if (lanes::wave_any(stop != 0)) { if (lane == 0) lanes::publish(P.cl_abort, 1); break; }
+                    lanes::nap();
+                    continue;
+                }
                 break;
             }
             const bool run = !done && !fresh; // rows that take part in the rest of this pass

@@ -21,6 +21,7 @@
 #endif
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -65,24 +66,33 @@ __global__ void __launch_bounds__(64, (LDSWS ? 1 : qp_waves<KCH, SOFTBOX>())) us
     q.solve(phase, queue0);
 }
 
-// Closed-loop launch (usvmpc_closed_loop; QpIpm::solve_cl): several consecutive ticks of solve + hand-over in ONE persistent launch whose
-// rows pull (instance, tick) items from a FIFO and linearise what they take themselves - no launch boundary, hence no launch tail,
-// between ticks.  The instantiations every OCP of the reference runs: diagonal Hessian, HBM workspace, no soft state bounds.
+// Closed-loop launch (usvmpc_closed_loop; QpIpm::solve_cl, Linearize::serve): several consecutive ticks of solve + hand-over as ONE pair of
+// persistent kernels that run side by side on two streams - no launch boundary, hence no launch tail, between ticks.  usv_qp_cl: the
+// rows of its waves pull linearised (instance, tick) items from a queue, each row with a workspace slot of its own; usv_lin_cl: its waves
+// linearise the instances the QP rows hand over.  Two kernels rather than two roles in one: each gets a register allocation of its own
+// (the lineariser wants ~220 registers; inlined into the QP code it made the allocator spill inside the sweeps, as a called function
+// and as a second role of the same kernel the builds of this toolchain corrupted spilled scalars).  The instantiations every OCP of
+// the reference runs: diagonal Hessian, HBM workspace, no soft state bounds.
 template <class M, int KCH, bool SOFT, bool PACK, bool MERGE, bool AUXLDS>
-__global__ void __launch_bounds__(64, (qp_waves<KCH, false>())) usv_qp_cl(DevPtrs P, long ngroups)
+__global__ void __launch_bounds__(64, (qp_waves<KCH, false>())) usv_qp_cl(DevPtrs P)
 {
-    const long g0 = (long)blockIdx.x * 4;
-    if (g0 >= ngroups) return;
-    QpIpm<M, KCH, SOFT, true, PACK, false, false, MERGE, AUXLDS, true> q(P, g0 + (long)(threadIdx.x >> 4));
+    QpIpm<M, KCH, SOFT, true, PACK, false, false, MERGE, AUXLDS, true> q(P, (long)blockIdx.x * 4 + (long)(threadIdx.x >> 4));
     q.solve_cl();
 }
+template <class M, int KCH, bool SOFT>
+__global__ void __launch_bounds__(64, 2) usv_lin_cl(DevPtrs P)
+{
+    Linearize<M, KCH, SOFT, true, 0>::serve(P);
+}
 
-// the queue of a closed-loop launch starts with tick 0 of every instance, in the order of the map (hardest first)
-__global__ void usv_fifo_fill(const int *perm, int B, int *fifo, int *tail)
+// the queues of a closed-loop launch: tick 0 of every instance waits for its linearisation, in the order of the map (hardest first);
+// nothing is linearised yet; no wave has arrived; the per-tick audit counters of the launch's ticks start at zero
+__global__ void usv_cl_begin(DevPtrs P, int B, int ticks)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) fifo[i] = (perm ? perm[i] : i) + 1;
-    if (i == 0) *tail = B;
+    if (i < B) P.linq[i] = (P.perm ? P.perm[i] : i) + 1;
+    if (i == 0) { *P.lin_tail = B; *P.lin_head = 0; *P.fifo_tail = 0; *P.queue = 0; *P.cl_abort = 0; }
+    if (i < ticks) { P.fail_ring[(P.ring_base + i) % P.ring_len] = 0; P.unconv_ring[(P.ring_base + i) % P.ring_len] = 0; }
 }
 
 // Multiplier read-back (usvmpc_get "lam" / "t"): the inequality multipliers and slacks of every instance's last QP, from the
@@ -260,9 +270,12 @@ struct usvmpc_handle {
     // carries several ticks: its per-tick times are the launch's divided by its ticks)
     int ev_owner[RING], ev_span[RING];
     bool fused_loop;          // option "fused_closed_loop": usvmpc_closed_loop as ONE persistent launch where the kernels exist (default on)
-    int *d_fifo, *d_fifo_tail;
-    size_t fifo_cap;          // ints allocated for the item queue of a closed-loop launch
-    long cl_cap[4];           // groups a full-occupancy closed-loop launch holds, per (merge, aux) variant (0: unknown, -1: unusable)
+    int *d_fifo, *d_linq, *d_cl_ctr; // the two item queues of a closed-loop launch; [8] fifo_tail, lin_head, lin_tail, role, abort flag
+    bool cl_pending;          // a closed-loop launch has been enqueued whose abort flag has not been looked at
+    double *d_lp;             // the lineariser waves' planes, instance-indexed (allocated at the first closed-loop launch)
+    size_t fifo_cap;          // ints allocated for each item queue
+    double lin_share;         // option "loop_lin_share": fraction of a closed-loop launch's waves that linearise (<= 0: the model's default)
+    long cl_cap[4];           // waves the device holds of the closed-loop kernel, per (merge, aux) variant (0: unknown, -1: unusable)
     bool ws_slots_shared;     // the last launch reused workspace slots across instances (closed loop): nothing to read back from it
     // Caller-visible arrays live in ONE device arena, in the order [x | u | status | x0 | yref | yref_e | p | lh] (256-byte aligned
     // pieces).  Small handles (the single-instance drop-in faces: AcadosOcpSolver, the acados C shim) also keep a pinned host
@@ -286,6 +299,8 @@ struct usvmpc_handle {
     bool pipeline;            // option; used for RTI solves of handles without a host mirror
     hipStream_t aux_stream;   // nullptr until first used
     hipEvent_t ev_pre, ev_spec;
+    hipStream_t lin_stream;   // closed-loop launches: the lineariser waves' kernel runs here, beside the QP waves' on `stream` (nullptr until first used)
+    hipEvent_t ev_lin[2];
     int *d_epoch, *d_redo, *d_perm2;
     long spec_for;            // solve number the outstanding / finished speculative linearisation was made for (-1: none)
     bool spec_valid;          // ... and nothing it read has been changed by the caller since
@@ -803,7 +818,7 @@ int launch_closed(usvmpc_handle *h, int ticks, double sigma, unsigned long long 
     constexpr bool CANPACK = KCH > 0;
     const bool pack = CANPACK && h->spec.boxpack != 0;
     if (!h->fused_loop || !h->dynamic_rows || h->cond_N2 > 0 || !h->spec.hdiag || h->spec.any_bsoft || pack != CANPACK || h->ncu < 1) return 1;
-    if (ticks > usvmpc_handle::RING || (double)h->B * ticks >= 2147483000.0) return 1; // (the caller splits longer runs)
+    if (ticks > usvmpc_handle::RING || (double)h->B * (ticks + 1) >= 2147483000.0) return 1; // (the caller splits longer runs)
     if (h->spec.npt != WsLayout<M, KCH, SOFT, false>::NPT) { h->err = "workspace layout mismatch between host and kernels"; return USVMPC_E_ARG; }
     {
         const int rcf = mirror_flush(h);
@@ -815,13 +830,21 @@ int launch_closed(usvmpc_handle *h, int ticks, double sigma, unsigned long long 
     }
     h->spec_valid = false;
     const int B = h->B;
-    const size_t nitems = (size_t)B * ticks;
+    const size_t nitems = (size_t)B * (ticks + 1); // (+ the closing hand-over of every instance, which goes through the lineariser waves' queue)
     if (h->fifo_cap < nitems) {
         if (h->d_fifo) dev_free(h, h->d_fifo, h->fifo_cap * sizeof(int));
-        h->d_fifo = nullptr; h->fifo_cap = 0;
-        if (dev_alloc(h, &h->d_fifo, nitems, false)) return USVMPC_E_HIP;
+        if (h->d_linq) dev_free(h, h->d_linq, h->fifo_cap * sizeof(int));
+        h->d_fifo = nullptr; h->d_linq = nullptr; h->fifo_cap = 0;
+        if (dev_alloc(h, &h->d_fifo, nitems, false) || dev_alloc(h, &h->d_linq, nitems, false)) return USVMPC_E_HIP;
         h->fifo_cap = nitems;
     }
+    if (!h->lin_stream) { // the stream the lineariser waves of the closed-loop launches run on
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->lin_stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_lin[0], hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_lin[1], hipEventDisableTiming));
+    }
+    using LinT = Linearize<M, KCH, SOFT, true, 0>;
+    if (!h->d_lp && dev_alloc(h, &h->d_lp, (size_t)(h->N + 1) * (size_t)B * LinT::NLP * LANES, false)) return USVMPC_E_HIP;
     const int last = (int)((h->nsolves + ticks - 1) % usvmpc_handle::RING);
     hipEvent_t *ev = h->ev[last];
     HIP_TRY(h, hipEventRecord(ev[0], h->stream));
@@ -834,24 +857,23 @@ int launch_closed(usvmpc_handle *h, int ticks, double sigma, unsigned long long 
         HIP_TRY(h, hipGetLastError());
         h->ptrs.perm = h->d_perm;
     }
-    HIP_TRY(h, hipMemsetAsync(h->d_fifo, 0, nitems * sizeof(int), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->ptrs.queue, 0, sizeof(int), h->stream));
-    hipLaunchKernelGGL(usv_fifo_fill, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.perm, B, h->d_fifo, h->d_fifo_tail);
-    HIP_TRY(h, hipGetLastError());
-    for (int t = 0; t < ticks; t++) { // the per-tick audit counters of these ticks
+    for (int t = 0; t < ticks; t++) {
         const int slot = (int)((h->nsolves + t) % usvmpc_handle::RING);
-        HIP_TRY(h, hipMemsetAsync(h->d_fail_ring + slot, 0, sizeof(int), h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->d_unconv_ring + slot, 0, sizeof(int), h->stream));
         h->ev_owner[slot] = last; h->ev_span[slot] = ticks;
     }
     DevPtrs &P = h->ptrs;
     P.epoch = nullptr; P.redo = nullptr; P.perm_cur = nullptr; P.tick = (int)h->nsolves;
     P.fail_count = nullptr; P.unconv_count = nullptr;
-    P.fifo = h->d_fifo; P.fifo_tail = h->d_fifo_tail;
-    P.cl_ticks = ticks; P.cl_slots = (int)nitems;
+    P.fifo = h->d_fifo; P.linq = h->d_linq; P.lp = h->d_lp;
+    P.fifo_tail = h->d_cl_ctr; P.lin_head = h->d_cl_ctr + 1; P.lin_tail = h->d_cl_ctr + 2; P.cl_abort = h->d_cl_ctr + 4;
+    P.cl_ticks = ticks; P.cl_slots = B * ticks;
     P.cl_sigma = sigma; P.cl_seed = seed; P.cl_mask = h->noise_mask;
     P.fail_ring = h->d_fail_ring; P.unconv_ring = h->d_unconv_ring;
     P.ring_base = (int)(h->nsolves % usvmpc_handle::RING); P.ring_len = usvmpc_handle::RING;
+    HIP_TRY(h, hipMemsetAsync(h->d_fifo, 0, nitems * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_linq, 0, nitems * sizeof(int), h->stream));
+    hipLaunchKernelGGL(usv_cl_begin, dim3((std::max(B, ticks) + 255) / 256), dim3(256), 0, h->stream, P, B, ticks);
+    HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[1], h->stream));
     // the variant: one row pass where every box row rides in a slot lane (MERGE), the aux plane in the waves' LDS where the horizon fits
     // without costing a resident wave (AUXLDS) - as launch_pair chooses for an RTI solve
@@ -861,8 +883,16 @@ int launch_closed(usvmpc_handle *h, int ticks, double sigma, unsigned long long 
         int nb = 0;
         if (lds > 0 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, qp_block, lds) != hipSuccess || nb < 1) return -1;
-        return 4L * nb * h->ncu;
+        return (long)nb * h->ncu;
     };
+    // share of the launch's waves that linearise: the lineariser's part of a tick's work (measured on the stand-alone kernels: 7.4 of
+    // 69 ms for usv_model_pf_ca at 5 RK4 steps, 2.0 of 49 for usv_model_guidance_ca1, 0.9 of 17 for usv_model) plus a margin - a lineariser
+    // wave that waits leaves its SIMD to the QP wave beside it, a QP row that waits for a linearised item wastes a quarter of a wave
+    double share = h->lin_share;
+    if (share <= 0.0)
+        share = h->desc.model == USVMPC_MODEL_PF_CA ? 0.04 + 0.018 * h->spec.sim_steps
+                : (h->desc.model == USVMPC_MODEL_GUIDANCE_CA1 ? 0.05 + 0.01 * (h->spec.sim_steps - 1) : 0.065 + 0.01 * (h->spec.sim_steps - 1));
+    share = std::min(0.5, std::max(0.01, share));
     auto run = [&](auto kern_plain, auto kern_aux, int vi) -> int {
         const size_t aux_bytes = (size_t)4 * (h->N + 1) * (size_t)(h->spec.aux_dense4 + (h->kch > 0 ? 2 : 0) + 2 * h->nu) * sizeof(double);
         if (h->cl_cap[vi] == 0) h->cl_cap[vi] = occupancy(kern_plain, 0);
@@ -871,13 +901,26 @@ int launch_closed(usvmpc_handle *h, int ticks, double sigma, unsigned long long 
             if (h->cl_cap[vi + 1] < h->cl_cap[vi]) h->cl_cap[vi + 1] = -1; // (it would cost a resident wave)
         }
         const bool aux = h->cl_cap[vi + 1] > 0;
-        long cap = aux ? h->cl_cap[vi + 1] : h->cl_cap[vi];
-        if (cap <= 0) { h->err = "closed-loop launch: the kernel cannot be resident on this device"; return USVMPC_E_HIP; }
-        if (h->max_waves > 0 && 4L * h->max_waves < cap) cap = 4L * h->max_waves;
-        const long ng = std::min<long>(cap, (long)h->Bp);
-        const dim3 grid((unsigned)((ng * LANES + qp_block - 1) / qp_block)), block(qp_block);
-        if (aux) hipLaunchKernelGGL(kern_aux, grid, block, aux_bytes, h->stream, P, ng);
-        else hipLaunchKernelGGL(kern_plain, grid, block, 0, h->stream, P, ng);
+        long cap = aux ? h->cl_cap[vi + 1] : h->cl_cap[vi]; // waves the device holds
+        if (cap <= 1) { h->err = "closed-loop launch: the kernel cannot be resident on this device"; return USVMPC_E_HIP; }
+        if (h->max_waves > 0 && h->max_waves < cap) cap = std::max<long>(2, h->max_waves);
+        // QP waves: one row per instance at most; lineariser waves: their share of the whole
+        long nl = std::max<long>(1, std::lround((double)cap * share));
+        long nq = std::min<long>(cap - nl, (long)h->Bp / 4);
+        if (nq < cap - nl) nl = std::max<long>(1, std::min<long>(nl, std::lround((double)nq * share / (1.0 - share) + 0.5)));
+        P.cl_waves = (int)nq; P.cl_lin_waves = (int)nl;
+        // the lineariser waves on the second stream, from the moment the queues are set up; the QP waves on the handle's stream; the
+        // handle's stream then waits for both (whatever it runs next must see the lineariser's kernel gone too)
+        HIP_TRY(h, hipEventRecord(h->ev_lin[0], h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->lin_stream, h->ev_lin[0], 0));
+        hipLaunchKernelGGL((usv_lin_cl<M, KCH, SOFT>), dim3((unsigned)nl), dim3(qp_block), 0, h->lin_stream, P);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(h->ev_lin[1], h->lin_stream));
+        const dim3 grid((unsigned)nq), block(qp_block);
+        if (aux) hipLaunchKernelGGL(kern_aux, grid, block, aux_bytes, h->stream, P);
+        else hipLaunchKernelGGL(kern_plain, grid, block, 0, h->stream, P);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_lin[1], 0));
         return 0;
     };
     int rc;
@@ -895,6 +938,7 @@ int launch_closed(usvmpc_handle *h, int ticks, double sigma, unsigned long long 
     h->layout_dirty = false;
     h->map_changed = true;      // (the workspace slots were shared by many instances: a later full SQP starts from zero multipliers)
     h->ws_slots_shared = true;  // ... and there is nothing per instance to read back from them
+    h->cl_pending = true;
     h->out_valid = false;
     return 0;
 }
@@ -1085,6 +1129,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->layout_dirty = false;
     h->pipeline = true;
     h->aux_stream = nullptr; h->ev_pre = nullptr; h->ev_spec = nullptr;
+    h->lin_stream = nullptr; h->ev_lin[0] = nullptr; h->ev_lin[1] = nullptr;
     h->d_epoch = nullptr; h->d_redo = nullptr; h->d_perm2 = nullptr;
     h->spec_for = -1; h->spec_valid = false; h->spec_outstanding = false; h->spec_perm = nullptr;
     h->noise_mask = ~0u;
@@ -1166,8 +1211,10 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     TRY_C(dev_alloc(h, &P.obs_tmin, B, true));
     TRY_C(dev_alloc(h, &h->d_fail_ring, usvmpc_handle::RING, true));
     TRY_C(dev_alloc(h, &h->d_unconv_ring, usvmpc_handle::RING, true));
-    TRY_C(dev_alloc(h, &h->d_fifo_tail, 1, true));
-    h->d_fifo = nullptr; h->fifo_cap = 0; h->fused_loop = true; h->ws_slots_shared = false;
+    TRY_C(dev_alloc(h, &h->d_cl_ctr, 8, true));
+    h->cl_pending = false;
+    h->d_fifo = nullptr; h->d_linq = nullptr; h->d_lp = nullptr; h->fifo_cap = 0; h->fused_loop = true; h->ws_slots_shared = false;
+    h->lin_share = 0.0;
     for (int i = 0; i < 4; i++) h->cl_cap[i] = 0;
     for (int r = 0; r < usvmpc_handle::RING; r++) { h->ev_owner[r] = r; h->ev_span[r] = 1; }
     TRY_C(dev_alloc(h, &P.queue, 1, true));
@@ -1202,6 +1249,12 @@ int usvmpc_destroy(usvmpc_handle *h)
         (void)hipStreamDestroy(h->aux_stream);
         (void)hipEventDestroy(h->ev_pre);
         (void)hipEventDestroy(h->ev_spec);
+    }
+    if (h->lin_stream) {
+        (void)hipStreamSynchronize(h->lin_stream);
+        (void)hipStreamDestroy(h->lin_stream);
+        (void)hipEventDestroy(h->ev_lin[0]);
+        (void)hipEventDestroy(h->ev_lin[1]);
     }
     for (void *a : h->allocs) (void)hipFree(a);
     if (h->mirror) (void)hipHostFree(h->mirror);
@@ -1252,6 +1305,16 @@ int usvmpc_sync(usvmpc_handle *h)
         h->spec_outstanding = false;
     }
     h->inflight = false;
+    if (h->cl_pending) { // did a closed-loop launch give up?  (it never should: its waves wait for each other's hand-overs with a limit)
+        h->cl_pending = false;
+        int ctr[8];
+        HIP_TRY(h, hipMemcpy(ctr, h->d_cl_ctr, sizeof(ctr), hipMemcpyDeviceToHost));
+        if (ctr[4] != 0) {
+            h->err = "closed-loop launch stalled and gave up (linearised " + std::to_string(ctr[0]) + ", lineariser tickets " + std::to_string(ctr[1]) +
+                     ", handed over " + std::to_string(ctr[2]) + ", spare " + std::to_string(ctr[3]) + "): results are incomplete";
+            return USVMPC_E_HIP;
+        }
+    }
     return 0;
 }
 
@@ -1395,6 +1458,15 @@ int usvmpc_debug_model_eval(int model, int device, int n, const double *x, const
     return rc;
 }
 
+int usvmpc_debug_counters(usvmpc_handle *h, int *out)
+{
+    if (!h || !out) return USVMPC_E_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(out, h->d_cl_ctr, 8 * sizeof(int), hipMemcpyDeviceToHost)); // (not ordered against the handle's non-blocking stream)
+    HIP_TRY(h, hipMemcpy(out + 8, h->ptrs.queue, sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int usvmpc_debug_workspace(usvmpc_handle *h, double *out, size_t n, int *npt)
 {
     if (!h) return USVMPC_E_ARG;
@@ -1536,6 +1608,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
     }
     if (s == "sort_two_ticks") { h->sort_two = value != 0.0; return 0; }
     if (s == "fused_closed_loop") { h->fused_loop = value != 0.0; return 0; }
+    if (s == "loop_lin_share") { h->lin_share = value; return 0; } // fraction of a closed-loop launch's waves that linearise (<= 0: default)
     if (s == "aux_in_lds") { h->aux_lds = value != 0.0; h->aux_cap = 0; for (int i = 0; i < 4; i++) h->cl_cap[i] = 0; return 0; }
     if (s == "lds_workspace") { // -1: when the batch is small (default), 0: never, 1: whenever an instance's planes fit in LDS
         h->lds_mode = value < 0.0 ? -1 : (value > 0.0 ? 1 : 0);

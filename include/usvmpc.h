@@ -144,24 +144,18 @@ int usvmpc_kernel_ms(usvmpc_handle *h, int n, float *linearize_ms, float *qp_ms)
  * the device by the solve itself, so a closed loop can be audited without a read-back per tick */
 int usvmpc_fail_counts(usvmpc_handle *h, int n, int *counts);
 /* ... and the number whose QP did not converge to the IPM tolerances (qp_status != 0: iteration cap, step-length floor, NaN, x0 inside
- * a hard keep-out circle), per solve likewise: solves minus this = "solves" as SURVEY.md 8(d) counts them */
+ * a hard keep-out circle), per solve likewise: solves minus this = "solves" as SURVEY.md 8(d) counts them (IPM converged to the stated
+ * tolerance). */
 int usvmpc_unconverged_counts(usvmpc_handle *h, int n, int *counts);
+/* option "pipeline_linearize": how many linearisations made ahead of time (on the second stream, beside the previous tick's QP launch)
+ * were used by the following solve / discarded because the caller wrote x, u or yref in between.  The lineariser only runs ahead after
+ * two solves in a row without such a write, so a caller that sets yref every tick (the reference's protocol) discards none. */
+int usvmpc_pipeline_stats(usvmpc_handle *h, long *used, long *discarded);
 /* Closed-loop hand-over on the device: x0 <- x_1 (+ sigma * N(0,1) on the states selected by option
  * "disturbance_mask", default all), enqueued on the stream.
  * Replaces x0 = solver.get(1,"x"); solver.set(0,"lbx",x0); solver.set(0,"ubx",x0)
  * (catkin_ws/src/nmpc_ca/scripts/usv_guidance_ca1/main.py:169-175). */
 int usvmpc_advance(usvmpc_handle *h, double sigma, unsigned long long seed);
-/* `ticks` closed-loop ticks, enqueued on the stream: exactly
- *     for (t = 0; t < ticks; t++) { usvmpc_solve_async(h); usvmpc_advance(h, sigma, seed + t); }
- * - the reference callers' loop solve() -> x0 = get(1,"x") -> set(0,"lbx"/"ubx",x0) (scripts/usv_pf_ca/main.py:142-186,
- * scripts/usv_guidance_ca1/main.py:135-175) with nothing set in between - and bit-identical results, but where the kernels exist
- * (diagonal Hessian, no soft state bounds, no partial condensing: every OCP of the reference) as ONE persistent launch: its
- * wavefronts take (instance, tick) items from a device queue, an instance's tick t + 1 is queued the moment its tick t has been
- * handed over, and the wavefront that takes an item linearises it itself.  No launch boundary between ticks, so no tick waits for
- * the slowest instance of the one before (option "fused_closed_loop" = 0: always the kernel pairs).  Per-tick status / iteration
- * counts are those of the last tick; usvmpc_fail_counts / usvmpc_unconverged_counts / usvmpc_kernel_ms cover every tick (a tick's
- * kernel time is the launch's divided by its ticks).  "lam" / "t" cannot be read after it (the workspace slots are shared). */
-int usvmpc_closed_loop(usvmpc_handle *h, int ticks, double sigma, unsigned long long seed);
 /* Adopt a caller-owned HIP stream (e.g. torch's current stream) for all subsequent work */
 int usvmpc_set_stream(usvmpc_handle *h, void *stream);
 /* run-time options (scheduling / placement only; none changes the arithmetic beyond rounding - see the two marked -, except
@@ -233,13 +227,6 @@ int usvmpc_guidance_state(usvmpc_handle *h, int *wp_index, float *past_psied);
  * (kernel usv_calib_stream) and report the exact byte counts, to calibrate HBM PMC counters.
  * Overwrites solver scratch; the next usvmpc_solve re-initialises it. */
 int usvmpc_calibrate_traffic(usvmpc_handle *h, int nplanes, double *bytes_read, double *bytes_written);
-/* TEST ENTRY: the solver workspace (lane-major planes [N+1 stages][Bp groups][npt planes][16 lanes]: linearisation output + QP state of
- * the last launch) copied to the host, first n doubles; *npt receives the planes per stage.  For tests that hold the in-kernel
- * lineariser of the closed-loop launch against the stand-alone kernel plane by plane. */
-int usvmpc_debug_workspace(usvmpc_handle *h, double *out, size_t n, int *npt);
-/* TEST ENTRY: the queue counters of the closed-loop launch, readable while it runs: out[9] = linearised items, lineariser tickets, handed-over
- * items, waves arrived, abort flag, 3 spare, QP tickets */
-int usvmpc_debug_counters(usvmpc_handle *h, int *out);
 /* Test entry points (no handle): the device transcription of the reference's model files evaluated on caller-supplied
  * points - f [n][nx] and the Jacobian J [n][nx][nu+nx] with respect to z = [u; x] exactly as the lineariser obtains them
  * (one tangent column per call of the model's fjvp), for the CasADi expressions of

@@ -51,10 +51,10 @@ loaded_before_torch = False
 
 EXPORTS = ["usvmpc_model_dims", "usvmpc_default_options", "usvmpc_create", "usvmpc_destroy",
            "usvmpc_set", "usvmpc_get", "usvmpc_get_int", "usvmpc_solve", "usvmpc_solve_sqp", "usvmpc_solve_async",
-           "usvmpc_sync", "usvmpc_get_device_ptr", "usvmpc_last_kernel_ms", "usvmpc_kernel_ms", "usvmpc_fail_counts",
-           "usvmpc_unconverged_counts", "usvmpc_closed_loop", "usvmpc_advance", "usvmpc_set_stream", "usvmpc_set_option", "usvmpc_calibrate_traffic", "usvmpc_guidance_reset", "usvmpc_guidance_prepare", "usvmpc_guidance_sense",
+           "usvmpc_sync", "usvmpc_get_device_ptr", "usvmpc_last_kernel_ms", "usvmpc_kernel_ms", "usvmpc_fail_counts", "usvmpc_unconverged_counts", "usvmpc_pipeline_stats",
+           "usvmpc_advance", "usvmpc_set_stream", "usvmpc_set_option", "usvmpc_calibrate_traffic", "usvmpc_guidance_reset", "usvmpc_guidance_prepare", "usvmpc_guidance_sense",
            "usvmpc_guidance_publish", "usvmpc_guidance_state", "usvmpc_device_bytes", "usvmpc_last_error",
-           "usvmpc_debug_model_eval", "usvmpc_debug_obstacle_eval", "usvmpc_debug_workspace", "usvmpc_debug_counters"]
+           "usvmpc_debug_model_eval", "usvmpc_debug_obstacle_eval"]
 
 
 _libs = {}
@@ -71,13 +71,12 @@ def load(path):
             "HIP library %s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback)" % path)
     if not _libs:
-        # torch first, whenever it is installed: the two then share one HIP runtime and zero-copy views / RCCL on solver buffers
-        # work whatever the caller's import order was (USVMPC_NO_TORCH=1 skips this for torch-free deployments, e.g. the C shim's
-        # users; sharding.device_tensor then refuses with an explanation)
-        if "torch" not in sys.modules and not os.environ.get("USVMPC_NO_TORCH"):
-            import importlib.util
-            if importlib.util.find_spec("torch") is not None:
-                import torch  # noqa: F401
+        # torch shares its HIP runtime with this library only when it was imported FIRST; zero-copy tensor views and RCCL on solver buffers
+        # need that (sharding.device_tensor says so if the order was the other way round).  The library does not pull torch in on its own -
+        # seconds of start-up and a large footprint for every consumer, the single-instance drop-in faces included - unless asked to:
+        # USVMPC_PRELOAD_TORCH=1 (bench.py, the tests and the tools import torch themselves before this package).
+        if "torch" not in sys.modules and os.environ.get("USVMPC_PRELOAD_TORCH") == "1":
+            import torch  # noqa: F401
         loaded_before_torch = "torch" not in sys.modules
     L = C.CDLL(path)
     L.usvmpc_model_dims.argtypes = [C.c_int, _ip, _ip]
@@ -96,9 +95,9 @@ def load(path):
     L.usvmpc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.usvmpc_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.usvmpc_fail_counts.argtypes = [C.c_void_p, C.c_int, _ip]
-    L.usvmpc_advance.argtypes = [C.c_void_p, C.c_double, C.c_ulonglong]
     L.usvmpc_unconverged_counts.argtypes = [C.c_void_p, C.c_int, _ip]
-    L.usvmpc_closed_loop.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_ulonglong]
+    L.usvmpc_pipeline_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    L.usvmpc_advance.argtypes = [C.c_void_p, C.c_double, C.c_ulonglong]
     L.usvmpc_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.usvmpc_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.usvmpc_calibrate_traffic.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
@@ -110,8 +109,6 @@ def load(path):
     L.usvmpc_debug_model_eval.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
     L.usvmpc_debug_obstacle_eval.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
     L.usvmpc_device_bytes.argtypes = [C.c_void_p]
-    L.usvmpc_debug_workspace.argtypes = [C.c_void_p, _dp, C.c_size_t, _ip]
-    L.usvmpc_debug_counters.argtypes = [C.c_void_p, _ip]
     L.usvmpc_device_bytes.restype = C.c_size_t
     L.usvmpc_last_error.argtypes = [C.c_void_p]
     L.usvmpc_last_error.restype = C.c_char_p

@@ -323,17 +323,17 @@ class BatchOcpSolver:
         self._check(self._lib.usvmpc_fail_counts(self._h, n, a))
         return np.array(a[:])
 
+    def pipeline_stats(self):
+        """(used, discarded): linearisations made ahead of time that the following solve used / threw away (usvmpc_pipeline_stats)."""
+        a, b = C.c_long(), C.c_long()
+        self._check(self._lib.usvmpc_pipeline_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def unconverged_counts(self, n):
         """Instances whose QP did not converge to the IPM tolerances (qp_status != 0) in each of the last n solves (oldest first)."""
         a = (C.c_int * n)()
         self._check(self._lib.usvmpc_unconverged_counts(self._h, n, a))
         return np.array(a[:])
-
-    def closed_loop(self, ticks, sigma=0.0, seed=0):
-        """`ticks` times (solve_async(); advance(sigma, seed + t)) - the reference callers' loop solve() -> x0 = get(1, "x") ->
-        set(0, "lbx" / "ubx", x0) (scripts/usv_pf_ca/main.py:142-186) with nothing set in between - enqueued as ONE persistent
-        launch where the kernels exist (usvmpc_closed_loop); bit-identical results; asynchronous."""
-        self._check(self._lib.usvmpc_closed_loop(self._h, int(ticks), float(sigma), int(seed)))
 
     def advance(self, sigma=0.0, seed=0):
         """Closed-loop hand-over on the device: x0 <- x_1 (+ sigma N(0,1)); asynchronous."""
@@ -344,15 +344,6 @@ class BatchOcpSolver:
 
     def set_stream(self, stream_ptr):
         self._check(self._lib.usvmpc_set_stream(self._h, C.c_void_p(stream_ptr)))
-
-    def debug_workspace(self):
-        """TEST ENTRY: the workspace planes of the last launch as [N+1, Bp, npt, 16] (usvmpc_debug_workspace)."""
-        npt = C.c_int()
-        self._check(self._lib.usvmpc_debug_workspace(self._h, None, 0, C.byref(npt)))
-        Bp = (self.B + 3) // 4 * 4
-        out = np.zeros((self.N + 1, Bp, npt.value, 16))
-        self._check(self._lib.usvmpc_debug_workspace(self._h, out.ctypes.data_as(_capi._dp), out.size, C.byref(npt)))
-        return out
 
     def device_bytes(self):
         return int(self._lib.usvmpc_device_bytes(self._h))

@@ -25,7 +25,7 @@
 // eliminated row by row as in qp_ipm.hpp's RowCalc); soft state bounds are not built.
 //
 // Parity: oracle/condense.py (numpy: part_cond + the oracle's IPM on the dense stages + expand) - tests/test_condensing.py
-// (CPU: this file compiled serially, -DUSV_COND_SERIAL; -m gpu: the kernel).
+// (CPU: this file compiled by the host compiler for the lane emulator - one thread plays the team; -m gpu: the kernel).
 #pragma once
 #include "lanes.hpp"
 #include "params.hpp"
@@ -35,7 +35,7 @@
 namespace usv {
 
 // ---- the threads that work on one instance
-#if defined(USV_COND_SERIAL) // CPU test build: one thread plays the whole team
+#if !defined(__HIPCC__) // compiled by a host compiler (the lane emulator's build, tests/emu): one thread plays the whole team
 struct CondTeam {
     static constexpr int NT = 1;
     static int tid() { return 0; }
@@ -183,7 +183,7 @@ struct CondIpm {
         vpi = take(NX); vpin = take(NX); vxn = take(NX); vpv = take(NX); vPb = take(NX); vrb = take(NX); vbt = take(NX); vdx = take(NX);
         vdxn = take(NX); vtmp = take(NX); vq = take(NX); vlus = take(nuh); vgk = take(NZ); vzb = take(NZ); vdz = take(Mb * NZ); vcr = take(Mb * nxr);
         take(NX); vdg = take(nuh);
-#if !defined(USV_COND_SERIAL)
+#if defined(__HIPCC__)
         if (q - lds > Dg.lds_doubles) __builtin_trap(); // (cond_dims.hpp sizes the launch's LDS: the two counts must agree)
 #endif
     }
@@ -398,9 +398,6 @@ struct CondIpm {
     template <class F>
     USV_CDEV void row_pass(int i, double *W, bool slots, F f)
     {
-#if defined(USV_COND_SKIP) && (USV_COND_SKIP & 1)
-        return;
-#endif
         if (slots) {
             for (int e = tid; e < Mb * nxr; e += NT) { yxr[e] = 0.0; yxg[e] = 0.0; wd[e] = 0.0; }
             for (int e = tid; e < Mb; e += NT) wxy[e] = 0.0;
@@ -484,9 +481,7 @@ struct CondIpm {
     USV_CDEV void load_block(int i, double *W, bool hess)
     {
         TM::sync();
-#if !(defined(USV_COND_SKIP) && (USV_COND_SKIP & 8))
         for (int e = tid; e < Mb * nxr * nzh; e += NT) SRm[e] = W[D.o_SR + e];
-#endif
         for (int e = tid; e < Mb * nxr; e += NT) vcr[e] = W[D.o_cr + e];
         for (int e = tid; e < NX * nzh; e += NT) BAm[e] = W[D.o_BA + e];
         for (int e = tid; e < nzh; e += NT) { vw[e] = W[D.o_w + e]; vdwa[e] = W[D.o_dwa + e]; vdw[e] = W[D.o_dw + e]; }
@@ -675,11 +670,7 @@ struct CondIpm {
             for (int e = tid; e < NX; e += NT) W[D.o_p + e] = vpv[e];
             TM::sync();
             const int ntri = nzh * (nzh + 1) / 2;
-#if defined(USV_COND_SKIP) && (USV_COND_SKIP & 2)
-            for (int e = tid; e < 0; e += NT) {
-#else
             for (int e = tid; e < ntri; e += NT) {
-#endif
                 const int a_ = tri[e] >> 8, c = tri[e] & 255;
                 double acc = Gm[a_ * nzh + c];
                 if (a_ == c && a_ < nuh) acc += wu[a_];
@@ -703,11 +694,7 @@ struct CondIpm {
             // eliminate the nuh input columns: [Luu; Lxu] stays in their place, the Schur complement P_i in the x block.  One barrier
             // per column: the trailing update uses the UNSCALED column (times 1 / pivot), which nothing writes during the step; the
             // columns are scaled to Cholesky form in one pass afterwards.
-#if defined(USV_COND_SKIP) && (USV_COND_SKIP & 4)
-            for (int c = 0; c < 0; c++) {
-#else
             for (int c = 0; c < nuh; c++) {
-#endif
                 TM::sync();
                 const double piv = Gm[c * nzh + c];
                 if (!(piv > 0.0)) badf = fmax(badf, 5.0);
@@ -983,6 +970,7 @@ struct CondIpm {
         if (tid == 0) {
             if (P.obs_tmin) P.obs_tmin[b] = tmin;
             if (!ok && P.fail_count) atomic_one(P.fail_count);
+            if (status != 0 && P.unconv_count) atomic_one(P.unconv_count);
             P.status[b] = ok ? 0 : 4;
             P.qp_iter[b] = iters;
             P.qp_status[b] = status;
@@ -1005,33 +993,21 @@ struct CondIpm {
         const double nc = (double)S.nc;
         while (!bad0) {
             nm = backward_factor(pend, a_prev, sig_prev);
-#ifdef USV_COND_TIMING // (timing experiments, tools/cond_timing.sh: a fixed number of iterations whatever the residuals; results are garbage)
-            if (it >= USV_COND_TIMING) { status = 0; break; }
-#else
             if (nm.bad || nm.rg != nm.rg || nm.rb != nm.rb) { status = 3; break; }
             if (nm.rg <= S.tol_stat && nm.rb <= S.tol_eq && nm.rd <= S.tol_ineq && nm.rm <= S.tol_comp) { status = 0; break; }
             if (it >= S.iter_max) { status = 1; break; }
-#endif
             const double mu = nc > 0.0 ? nm.musum / nc : 0.0;
             double a_aff = 1.0, S1 = 0.0, S2 = 0.0, a = 1.0, d1, d2;
-#if !(defined(USV_COND_SKIP) && (USV_COND_SKIP & 32))
             forward(false, 0.0, a_aff, S1, S2);
-#endif
             double sigmu = 0.0;
             if (nc > 0.0) {
                 const double mu_aff = (nm.musum + a_aff * S1 + a_aff * a_aff * S2) / nc;
                 const double sg = mu_aff / mu;
                 sigmu = sg * sg * sg * mu;
             }
-#if !(defined(USV_COND_SKIP) && (USV_COND_SKIP & 16))
             backward_rhs(sigmu);
-#endif
-#if !(defined(USV_COND_SKIP) && (USV_COND_SKIP & 32))
             forward(true, sigmu, a, d1, d2);
-#endif
-#ifndef USV_COND_TIMING
             if (a < S.alpha_min) { status = 2; break; }
-#endif
             a_prev = a * ((1.0 - a) * 0.99 + a * 0.9999999);
             sig_prev = sigmu;
             pend = true;

@@ -272,13 +272,6 @@ USV_DEV unsigned wave_lane() { return threadIdx.x & 63u; }
 // rows (16-lane groups) of a wave and this lane's row
 constexpr int WAVE_ROWS = 4;
 USV_DEV unsigned wave_row() { return (threadIdx.x >> 4) & 3u; }
-// a value / predicate that is uniform over row r (wave-uniform r), delivered to the whole wave in a scalar register
-USV_DEV int row_value_i(int v, int r) { return __builtin_amdgcn_readlane(v, 16 * r); }
-USV_DEV bool row_flag(bool p, int r) { return __builtin_amdgcn_readlane((int)p, 16 * r) != 0; }
-// a wave with nothing to do but poll: off the issue ports for ~64 x n cycles
-USV_DEV void nap() { __builtin_amdgcn_s_sleep(32); }
-// polls of one queue place a closed-loop launch puts up with (each >= 1 us) before it gives up instead of hanging the device
-constexpr int CL_PATIENCE = 1 << 22;
 // the workgroup's dynamic LDS (one wave per workgroup in the QP kernel): the planes of PlanesLds, or the aux area of qp_ipm.hpp
 USV_DEV double *dyn_lds()
 {

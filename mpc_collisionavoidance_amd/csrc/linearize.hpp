@@ -12,7 +12,6 @@
 #include "lanes.hpp"
 #include "params.hpp"
 #include "sfor.hpp"
-#include "advance.hpp"
 
 namespace usv {
 
@@ -56,6 +55,7 @@ struct Linearize {
     {
         const DevSpec &S = *P.spec;
         const int lane = lanes::lane();
+        const int N = lanes::uniform(S.N), K = lanes::uniform(S.K);
         const long Bp = lanes::uniform(S.Bp);
         const int k = (int)(gid / Bp);
         const long g = gid - (long)k * Bp;
@@ -73,88 +73,12 @@ struct Linearize {
         if constexpr (MODE == 2) {
             if (((P.redo[b * P.redo_words + (k >> 5)] >> (k & 31)) & 1) == 0) return;
         }
-        // workspace: [stage][group][plane][16 lanes] (lanes::Planes)
-        double *tile = P.ws + (((long)k * Bp + g) * lanes::uniform(S.npt)) * LANES + lane;
-        stage<MODE == 1, false>(P, b, k, tile);
-    }
-
-    // Closed-loop launch (params.hpp: DevPtrs::linq ...): what a LINEARISER WAVE of the launch does - take the next handed-over item (b, t);
-    // do the caller's hand-over between the ticks t - 1 and t, x0 <- x_1 (+ disturbance: advance.hpp), unless t is the launch's first tick;
-    // linearise every stage of the instance (the rows of the wave share the stages: row q takes stages q, q + 4, ...) into the instance's
-    // planes of P.lp and pass the item on to the QP rows' queue - unless t is one past the launch's last tick (hand-over only).  A wave with
-    // this role holds nothing anybody waits for, so it may simply wait for its place in the queue to be filled.
-    // (A kernel of its own rather than a step of the QP waves: the lineariser wants ~220 registers, and inlined into the QP code it made the
-    // register allocator spill inside the sweeps - 3.6x the launch time.  The loop below is written for few live values around the stage
-    // code: builds in which the register allocator had to spill the registers that hold spilled scalars ran astray on the device.)
-    static constexpr int NLP = MatPack<M>::NPK + 2; // planes per (stage, instance) of P.lp: WL::P_RB0 .. in workspace order
-    USV_DEV static void serve(const DevPtrs &P)
-    {
-        const DevSpec &S = *P.spec;
-        const int lane = lanes::lane();
-        const bool first = lane == 0 && lanes::wave_row() == 0;
-        for (;;) {
-            const int N = lanes::uniform(S.N), nB = lanes::uniform(S.B), T = lanes::uniform(P.cl_ticks);
-            int tkt = 0;
-            if (first) tkt = lanes::fetch_add(P.lin_head);
-            tkt = lanes::row_value_i(lanes::bcast_i<0>(tkt), 0);
-            if (tkt >= nB * (T + 1)) break; // wave-uniform: every (instance, tick) and every instance's closing hand-over has been taken
-            int item = 0;
-            for (int polls = 0;; polls++) {
-                if (first) item = lanes::observe(P.linq + tkt);
-                item = lanes::row_value_i(lanes::bcast_i<0>(item), 0);
-                if (item != 0) break;
-                // (a launch that cannot make progress - it never should - ends with an error instead of hanging the device)
-                int stop = 0;
-                if (first) stop = lanes::observe(P.cl_abort) | (polls > lanes::CL_PATIENCE ? 1 : 0);
-                stop = lanes::row_value_i(lanes::bcast_i<0>(stop), 0);
-                if (stop) { if (first) lanes::publish(P.cl_abort, 1); return; }
-                lanes::nap();
-            }
-            item -= 1;
-            const int t = item / nB;
-            const long b = item - t * nB;
-            if (t > 0) { // the hand-over the caller does between two ticks: whatever x_1 holds (after a failed solve: the untouched iterate)
-                const int j = (int)(lanes::wave_row() * LANES) + lane; // one state per lane of the wave
-                if (j < NX) {
-                    const double x1 = lanes::ld_shared(P.x + ((long)b * (N + 1) + 1) * NX + j);
-                    const double v = advance_value(x1, P.cl_sigma, P.cl_seed + (unsigned long long)(t - 1), (long)b * NX + j, ((P.cl_mask >> j) & 1u) != 0u);
-                    lanes::st_shared(const_cast<double *>(P.x0) + (long)b * NX + j, v);
-                }
-            }
-            if (t >= T) continue; // wave-uniform (the launch's closing hand-over: nothing to linearise)
-            // Every row of the wave does the same kind of stage at the same time: the intervals four at a time, the surplus rows of the last
-            // round repeating its last interval (the same values to the same places), then the terminal stage on all rows - no ragged round
-            // under an EXEC mask.
-            const int rounds = (N + lanes::WAVE_ROWS - 1) / lanes::WAVE_ROWS;
-            for (int r = 0; r <= rounds; r++) {
-                const int kr = r * lanes::WAVE_ROWS + (int)lanes::wave_row();
-                const int k = r == rounds ? N : (kr < N ? kr : N - 1);
-                stage<true, true>(P, b, k, P.lp + (((long)k * nB + b) * NLP - WL::P_RB0) * LANES + lane);
-            }
-            lanes::drain_stores();
-            if (first) lanes::publish(P.fifo + lanes::fetch_add(P.fifo_tail), item + 1);
-        }
-    }
-
-    // One (instance, stage): instance b, stage k, results into the 16-lane planes at `tile` (this lane's entry of plane 0).
-    // SHARED: the iterate was handed over by another wave of a running launch and is read past the non-coherent caches
-    // (lanes::ld_shared) - MODE 1 above, and the closed-loop launch of qp_ipm.hpp, whose waves linearise the instance they take up.
-    // SHARED_OUT: ... and the planes are for another wave of the running launch (closed-loop launch: the QP row that takes the item):
-    // stored past the caches too (lanes::st_shared; the caller drains the stores and publishes the item afterwards).
-    template <bool SHARED, bool SHARED_OUT = false>
-    USV_DEV static void stage(const DevPtrs &P, long b, int k, double *tile)
-    {
-        auto st = [](double *q, double v) {
-            if constexpr (SHARED_OUT) lanes::st_shared(q, v);
-            else *q = v;
-        };
-        const DevSpec &S = *P.spec;
-        const int lane = lanes::lane();
-        const int N = lanes::uniform(S.N);
-        auto ld = [](const double *q) {
-            if constexpr (SHARED) return lanes::ld_shared(q);
+        auto ld = [](const double *q) { // the iterate: handed over by a kernel that may still be running (MODE 1)
+            if constexpr (MODE == 1) return lanes::ld_shared(q);
             else return *q;
         };
+        // workspace: [stage][group][plane][16 lanes] (lanes::Planes)
+        double *tile = P.ws + (((long)k * Bp + g) * lanes::uniform(S.npt)) * LANES + lane;
         const bool xlane = lane >= NU && lane < NZ;
 
         double x[NX], U[NU > 0 ? NU : 1];
@@ -175,9 +99,9 @@ struct Linearize {
             const int ny = (k < N) ? S.ny : S.ny_e;
             double acc = 0.0;
             for (int y = 0; y < ny; y++) acc = fma(-Mrow[y], yr[y], acc);
-            st(tile + WL::P_GQ * LANES, acc);
+            tile[WL::P_GQ * LANES] = acc;
         }
-        if (k == N) return; // (uniform over the 16-lane group; over the wave too in the lineariser kernel)
+        if (k == N) return; // wave-uniform
 
         // ---- ERK4 + forward VDE for this lane's sensitivity column; sim_steps steps of size dt / sim_steps
         // (acados sim_method_num_steps; the reference leaves it at 1): the column is simply carried on ----
@@ -238,9 +162,9 @@ struct Linearize {
                     val = (within >= 0 && within < cnt) ? gth : val;
                 }
             });
-            st(tile + (WL::P_MAT + q) * LANES, val);
+            tile[(WL::P_MAT + q) * LANES] = val;
         });
-        st(tile + WL::P_RB0 * LANES, xlane ? bres : 0.0);
+        tile[WL::P_RB0 * LANES] = xlane ? bres : 0.0;
         // (obstacle rows are linearised inside the QP kernel from the iterate and (p, lh): QpIpm::obs_geom)
     }
 };

@@ -45,9 +45,6 @@ struct DevSpec {
     // multiplier read-back (usvmpc_get "lam" / "t"): rows of a stage in acados' order [bu.., bx.., h..], nrow = nbu + nbx + K;
     // slack rows [sbx.., sh..], ns = nsbx + (soft ? K : 0); a stage's vector is [lower(nrow) | upper(nrow) | lower slack(ns) | upper slack(ns)]
     int nbu, nbx, nsbx;
-    // timing experiments only (builds with -DUSV_TIMING_EXPERIMENT, tools/bound_experiment.sh; results are garbage):
-    int alias_groups;             // > 0: group g addresses the workspace planes of group g % alias_groups (resident set shrunk)
-    int fixed_iters;              // > 0: every instance runs exactly this many IPM iterations, whatever its residuals
     int box_pos[LANES];           // variable r of [u;x] -> position of its row in [bu.., bx..] (only where has_b)
     int sbx_pos[LANES];           // variable r -> position of its slack pair among the soft state bounds (only where bsoft)
 };
@@ -170,26 +167,6 @@ struct DevPtrs {
     int redo_words;       //      (N + 1 + 31) / 32
     const int *perm_cur;  // [B]  speculative lineariser: the group -> instance map of the QP launch that is still running
     int tick;             // the solve this launch belongs to (QP, fix-up) / whose results the speculative lineariser waits for
-    // closed-loop launch (usvmpc_closed_loop; QpIpm::solve_cl, Linearize::serve): ONE persistent launch works through the items
-    // (instance, tick) of cl_ticks consecutive ticks; an item is tick * B + instance.  Two kernels run side by side: QP waves, whose rows
-    // solve items, and lineariser waves.  Two queues, both filled in the order things become available and emptied through a ticket counter:
-    //   linq  - items whose instance has been handed over (x, u final, x0 set) and waits for its linearisation: tick 0 of every instance
-    //           (the host, in the order of the map), then (b, t + 1) as soon as the row that solved (b, t) is done; taken by the
-    //           lineariser waves, which leave the planes in lp (instance-indexed) and pass the item on to
-    //   fifo  - linearised items; taken by the QP rows (which copy the lineariser's planes into their own workspace slot).
-    int *linq, *lin_head, *lin_tail; // [cl_slots], [1] tickets, [1] places
-    int *fifo;            // [cl_slots]  item + 1 (0: not there yet); tickets: queue
-    int *fifo_tail;       // [1]
-    double *lp;           // [N+1][B][MatPack::NPK + 2][16]: b_k | cost gradient | packed [B A] of every queued instance
-    int *cl_abort;        // [1] set by a wave that has polled a queue place USV_CL_PATIENCE times in vain: every wave leaves (the host reports it)
-    int cl_waves, cl_lin_waves; // QP waves / lineariser waves of the launch (two kernels side by side)
-    int cl_ticks;         // 0: not a closed-loop launch
-    int cl_slots;         // items of the launch: B * cl_ticks
-    double cl_sigma;      // hand-over disturbance (advance.hpp): std, stream of tick t = cl_seed + t, state mask
-    unsigned long long cl_seed;
-    unsigned cl_mask;
-    int *fail_ring, *unconv_ring; // [ring_len] per-tick counters (fail_count / unconv_count of tick t: slot (ring_base + t) % ring_len)
-    int ring_base, ring_len;
     // multiplier read-back (kernel usv_qp_export): [B][N+1][nlam] each, nlam = 2 (nrow + ns) - DevSpec
     double *lam_out, *t_out;
     int nlam;

@@ -40,8 +40,6 @@
 #include "lanes.hpp"
 #include "params.hpp"
 #include "sfor.hpp"
-#include "advance.hpp"
-#include "linearize.hpp"
 
 #ifndef USV_MAT_LOAD_AUX
 #define USV_MAT_LOAD_AUX 0 // cache policy of the packed matrix plane loads (lanes.hpp; the emulator has none)
@@ -232,16 +230,8 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 // per stage) lives in the wave's LDS for the whole launch instead of being streamed with the planes: 4 reads + 2 writes of the
 // 59 + 13 plane accesses per stage and IPM iteration go (the kernel streams at the HBM ceiling: profiles/r03_bound_experiment.txt).
 // RTI launches whose horizon fits (host: usvmpc.hip); finish() leaves a copy in the HBM plane for the read-back paths.
-// LOOP: closed-loop launch (solve_cl, usvmpc_closed_loop): the rows work through items (instance, tick) of several consecutive ticks in ONE
-// persistent launch - a row that has finished (b, t) hands the instance over itself (x, u out past the non-coherent caches, x0 <- x1 +
-// disturbance: advance.hpp, done by the lineariser waves), queues (b, t + 1) for the launch's lineariser waves (Linearize::serve) and takes the oldest linearised item,
-// whose planes it copies into its own workspace slot at the cold start.  No launch boundary between ticks, hence no launch tail per
-// tick: an instance that runs long delays only its own next tick.  A row keeps ONE workspace slot for the whole launch.  Same arithmetic
-// per (instance, tick) as the sequence solve, advance, solve, ...: results are bit-identical (scheduling only).
-template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false,
-          bool LOOP = false>
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false>
 struct QpIpm {
-    static_assert(!LOOP || (!LDSWS && !SOFTBOX), "the closed-loop launch is built for the HBM workspace without soft state bounds");
     static_assert(!MERGE || PACK, "merged row pass works on the packed layout");
     static_assert(!(AUXLDS && LDSWS), "with the whole workspace in LDS the aux plane is there already");
     static_assert(!PACK || KCH > 0, "box rows are packed into obstacle planes");
@@ -323,7 +313,6 @@ struct QpIpm {
     int lane, N;
     // per row (the same in its 16 lanes): the group it works on, that group's instance, the lane's offset in a stage window
     long g, b;
-    int tk;          // LOOP: the tick of the item the row works on
     unsigned voff;
     unsigned loff;   // LDSWS: this lane's entry of (stage 0, plane 0) of its row's LDS region, in doubles
     bool live;       // the row owns a workspace (LDSWS: surplus rows of a wave share row 0's region read-only)
@@ -483,7 +472,7 @@ struct QpIpm {
             auxstride = (nd4 + ZB + 2 * NU) * lanes::WAVE_ROWS;
             auxoff = (unsigned)((slot > 0 ? slot : 0) * lanes::WAVE_ROWS) + lanes::wave_row();
         }
-        g = 0; b = 0; tk = 0;
+        g = 0; b = 0;
         live = lds_row >= 0;
         loff = (unsigned)((lds_row > 0 ? lds_row : 0) * (N + 1) * NPL * LANES + lane);
         if constexpr (KCH > 0) sfor<0, KCH>([&](auto c) { c_ox[c] = 0.0; c_oy[c] = 0.0; c_lh[c] = 0.0; });
@@ -507,26 +496,7 @@ struct QpIpm {
         const long gi = g < nB ? g : (long)nB - 1;
         const long bn = P.perm ? (long)P.perm[gi] : gi;
         b = sel ? bn : b;
-#ifdef USV_TIMING_EXPERIMENT
-        // same instruction stream, plane addresses folded onto the first alias_groups groups: what the sweeps stream then
-        // fits in the L2 / the Infinity Cache - is the kernel waiting for HBM?  (profiles/r03_bound_experiment.txt)
-        voff = lanes::Planes::lane_offset(S.alias_groups > 0 ? g % S.alias_groups : g, NPL, lane);
-#else
         voff = lanes::Planes::lane_offset(g, NPL, lane);
-#endif
-        bind_consts(sel);
-    }
-    // LOOP: point the rows selected by `sel` at the item (tick, instance) = (item / B, item % B); the row's workspace slot stays
-    USV_DEV void bind_item(int item, bool sel)
-    {
-        const int t = item / nB;
-        b = sel ? (long)(item - t * nB) : b;
-        tk = sel ? t : tk;
-        bind_consts(sel);
-    }
-    // the per-instance constants of the rows selected by `sel` (their b has just changed)
-    USV_DEV void bind_consts(bool sel)
-    {
         if constexpr (KCH > 0) {
             sfor<0, KCH>([&](auto c) {
                 const int i = c * LANES + lane;
@@ -559,18 +529,10 @@ struct QpIpm {
     // iterate value of this lane's variable at stage k (caller-visible arrays)
     USV_DEV double zbar(int k) const
     {
-        if (ulane) return (k < N) ? ldi(&P.u[((long)b * N + k) * NU + lane]) : 0.0;
-        if (xlane) return ldi(&P.x[((long)b * (N + 1) + k) * NX + (lane - NU)]);
+        if (ulane) return (k < N) ? P.u[((long)b * N + k) * NU + lane] : 0.0;
+        if (xlane) return P.x[((long)b * (N + 1) + k) * NX + (lane - NU)];
         return 0.0;
     }
-    // a caller-visible value of the row's instance that an earlier item of this launch may have written (x, u, x0): in a closed-loop
-    // launch that was another wave, possibly behind another XCD's L2 - read past the non-coherent caches (lanes::ld_shared)
-    USV_DEV static double ldi(const double *q)
-    {
-        if constexpr (LOOP) return lanes::ld_shared(q);
-        else return *q;
-    }
-    USV_DEV double x0_lane() const { return xlane ? ldi(&P.x0[(long)b * NX + (lane - NU)]) : 0.0; }
 
     // (the row value of a box row is the absolute iterate zbar + z, its bounds are the caller's lb / ub)
     USV_DEV void box_data(int k, BoxRow &r) const
@@ -723,20 +685,6 @@ struct QpIpm {
         for (int k = 0; k <= N; k++) {
             const Planes W = ws(k);
             const double zb = zbar(k);
-            if constexpr (LOOP) { // the linearisation of this stage comes in from the lineariser waves' planes of the instance
-                using LinT = Linearize<M, KCH, SOFT, true, 0>;
-                const double *L = P.lp + (((long)k * nB + b) * LinT::NLP) * LANES + lane;
-                const double rb = (k < N) ? lanes::ld_shared(L) : 0.0, gq = lanes::ld_shared(L + LANES);
-                double mpk[MP::NPK];
-                if (k < N) sfor<0, MP::NPK>([&](auto q) { mpk[q] = lanes::ld_shared(L + (2 + q) * LANES); });
-                if (wr) {
-                    W.st(P_GQ, gq);
-                    if (k < N) {
-                        W.st(P_RB0, rb);
-                        sfor<0, MP::NPK>([&](auto q) { W.st(P_MAT + q, mpk[q]); });
-                    }
-                }
-            }
             if constexpr (LDSWS) { // the linearisation of this stage comes in from HBM
                 const lanes::Planes G = wsg(k);
                 const double gq = G.ld(P_GQ), rb = (k < N) ? G.ld(P_RB0) : 0.0;
@@ -752,7 +700,7 @@ struct QpIpm {
             }
             if (wr) {
                 W.st(P_Z, zb); // z = 0
-                if (k == 0) W.st(P_DX0, x0_lane());
+                if (k == 0) W.st(P_DX0, xlane ? P.x0[(long)b * NX + (lane - NU)] : 0.0);
             }
             BoxRow r;
             r.neutral();
@@ -788,7 +736,7 @@ struct QpIpm {
                     if (wr) obs_store(W, c, o, (PACK && c == KCH - 1) ? pk : nullptr);
                     if constexpr (!SOFT) {
                         if (k == 0) { // wave-uniform
-                            const double e0 = xlane ? x0_lane() - zb : 0.0; // x0 - xbar_0
+                            const double e0 = xlane ? P.x0[(long)b * NX + (lane - NU)] - zb : 0.0; // x0 - xbar_0
                             double d, ux, uy;
                             obs_dist(zbx - raw[0], zby - raw[1], d, ux, uy);
                             const double v0 = ux * lanes::bcast<PXL>(e0) + uy * lanes::bcast<PYL>(e0);
@@ -1476,7 +1424,7 @@ struct QpIpm {
     {
         const bool ok = (status == 0 || status == 1);
         const bool out = fin && real;
-        const bool share = LOOP || P.epoch != nullptr; // wave-uniform (kernel argument)
+        const bool share = P.epoch != nullptr; // wave-uniform (kernel argument)
         double tmin = 1e300; // smallest t_l over this instance's obstacle rows: how close the QP solution sits to a keep-out circle
         for (int k = 0; k <= N; k++) {
             const Planes W = ws(k);
@@ -1550,23 +1498,14 @@ struct QpIpm {
             }
         }
         tmin = lanes::gmin(tmin);
-        int *fails = P.fail_count, *unconv = P.unconv_count;
         if (share) { // the instance's iterate is final: tell the lineariser of the next tick (every store of the wave has landed first)
             lanes::drain_stores();
-            if constexpr (LOOP) {
-                // ... or the launch's lineariser waves: the instance's next tick goes to the end of their queue
-                // (its hand-over x0 <- x_1 is theirs too; after the launch's last tick the item only asks for that)
-                if (out && lane == 0) lanes::publish(P.linq + lanes::fetch_add(P.lin_tail), (tk + 1) * nB + (int)b + 1);
-                const int slot = (P.ring_base + tk) % P.ring_len; // the per-launch counters of the sequential path, per tick here
-                fails = P.fail_ring + slot; unconv = P.unconv_ring + slot;
-            } else {
-                if (out && lane == 0) lanes::publish(P.epoch + b, P.tick);
-            }
+            if (out && lane == 0) lanes::publish(P.epoch + b, P.tick);
         }
         if (out && lane == 0) {
             if (P.obs_tmin) P.obs_tmin[b] = tmin;
-            if (!ok && fails) lanes::count_one(fails);
-            if (status != 0 && unconv) lanes::count_one(unconv);
+            if (!ok && P.fail_count) lanes::count_one(P.fail_count);
+            if (status != 0 && P.unconv_count) lanes::count_one(P.unconv_count);
             P.status[b] = ok ? 0 : 4;
             P.qp_iter[b] = iters;
             P.qp_status[b] = status;
@@ -1629,11 +1568,6 @@ struct QpIpm {
                     P.res[b * 4 + 0] = nm.rg; P.res[b * 4 + 1] = nm.rb; P.res[b * 4 + 2] = nm.rd; P.res[b * 4 + 3] = nm.rm;
                 }
                 iters = it;
-#ifdef USV_TIMING_EXPERIMENT
-                if (S.fixed_iters > 0) {
-                    if (it >= S.fixed_iters) { status = 0; fin = true; }
-                } else
-#endif
                 if (nm.nan != nm.nan) { status = 3; fin = true; }
                 else if (nm.rg <= S.tol_stat && nm.rb <= S.tol_eq && nm.rd <= S.tol_ineq && nm.rm <= S.tol_comp) {
                     status = 0; fin = true;
@@ -1666,108 +1600,6 @@ struct QpIpm {
                 }
             }
             if (!lanes::wave_any(!done)) break;
-            const bool run = !done && !fresh; // rows that take part in the rest of this pass
-            const double mu = nc > 0.0 ? nm.musum / nc : 0.0;
-            double a_aff = 1.0, S1 = 0.0, S2 = 0.0, a = 1.0, d1, d2;
-            forward<false>(0.0, a_aff, S1, S2);
-            double sigmu = 0.0;
-            if (nc > 0.0) {
-                const double mu_aff = (nm.musum + a_aff * S1 + a_aff * a_aff * S2) / nc;
-                const double sg = mu_aff / mu;
-                sigmu = sg * sg * sg * mu;
-            }
-            backward<false>(nm, sigmu, false, 0.0, 0.0);
-            forward<true>(sigmu, a, d1, d2);
-#ifdef USV_TIMING_EXPERIMENT
-            if (S.fixed_iters == 0)
-#endif
-            if (run && a < S.alpha_min) { status = 2; done = true; late = true; iters = it; }
-            a_prev = run ? a * ((1.0 - a) * 0.99 + a * 0.9999999) : a_prev;
-            sig_prev = run ? sigmu : sig_prev;
-            pend = run ? true : pend;
-            it = run ? it + 1 : it;
-            fresh = false;
-        }
-    }
-
-    // ------------------------------------------------------------------ closed-loop launch (LOOP)
-    USV_DEV void solve_cl()
-    {
-        keep = false;
-        const int nslots = lanes::uniform(P.cl_slots);
-        rbscale = 1.0;
-        bool real = false;               // the row holds an item whose results are to be written
-        bool done = true;                // nothing (more) to iterate on in this row
-        bool want = live;                // the row is waiting for an item (every row starts that way: all items come through the queue)
-        int ticket = -1;                 // its place in the queue while it waits
-        int idle = 0;                    // polls in a row with nothing to do in the whole wave
-        bool pend = false, fresh = false, late = false;
-        int status = 1, iters = 0, it = 0;
-        Norms nm;
-        nm.rg = nm.rb = nm.rd = nm.rm = nm.musum = nm.nan = 0.0;
-        double a_prev = 0.0, sig_prev = 0.0;
-        const double nc = (double)S.nc;
-        for (;;) {
-            if (lanes::wave_any(!done)) backward<true>(nm, 0.0, pend && !done, a_prev, sig_prev);
-            bool fin = late;
-            if (!done) {
-                if (real && lane == 0) {
-                    P.res[b * 4 + 0] = nm.rg; P.res[b * 4 + 1] = nm.rb; P.res[b * 4 + 2] = nm.rd; P.res[b * 4 + 3] = nm.rm;
-                }
-                iters = it;
-                if (nm.nan != nm.nan) { status = 3; fin = true; }
-                else if (nm.rg <= S.tol_stat && nm.rb <= S.tol_eq && nm.rd <= S.tol_ineq && nm.rm <= S.tol_comp) {
-                    status = 0; fin = true;
-                } else if (it >= itmax) { status = 1; fin = true; }
-            }
-            done = done || fin;
-            late = false;
-            if (lanes::wave_any(fin)) { // wave-uniform
-                finish(fin, real, status, iters, 0); // (hands the instance over and queues its next tick)
-                want = (fin && real) ? true : want;
-                real = fin ? false : real;
-            }
-            if (lanes::wave_any(want)) { // wave-uniform
-                // a row that wants an item draws ONE ticket and keeps it until that place of the queue has been filled: the wave never
-                // waits for it while one of its rows still iterates (that row may be the one whose hand-over fills the place)
-                int tkt = 0;
-                if (want && ticket < 0 && lane == 0) tkt = lanes::fetch_add(P.queue);
-                tkt = lanes::bcast_i<0>(tkt);
-                ticket = (want && ticket < 0) ? tkt : ticket;
-                want = want && ticket < nslots; // beyond the last item: the row retires
-                int item = 0;
-                if (want && lane == 0) item = lanes::observe(P.fifo + ticket);
-                item = lanes::bcast_i<0>(item);
-                const bool take = want && item != 0;
-                if (lanes::wave_any(take)) { // wave-uniform
-                    bind_item(item - 1, take);
-                    const bool bad = init(take) && take;
-                    real = take ? true : real;
-                    done = take ? bad : done;
-                    late = bad;
-                    fresh = take;
-                    pend = take ? false : pend;
-                    rbscale = take ? 1.0 : rbscale;
-                    it = take ? 0 : it;
-                    iters = take ? 0 : iters;
-                    status = take ? (bad ? 4 : 1) : status;
-                    want = take ? false : want;
-                    ticket = take ? -1 : ticket;
-                    idle = 0;
-                }
-            }
-            if (!lanes::wave_any(!done)) { // no row of the wave iterates
-                if (lanes::wave_any(late)) continue;                  // a new item stopped in its cold start: its results next
-                if (lanes::wave_any(want)) { // all waiting for their places in the queue
-                    // (a launch that cannot make progress - it never should - ends with an error instead of hanging the device)
-                    int stop = 0;
-                    if (lane == 0) stop = lanes::observe(P.cl_abort) | (++idle > lanes::CL_PATIENCE ? 1 : 0);
-                    if (lanes::wave_any(stop != 0)) { if (lane == 0) lanes::publish(P.cl_abort, 1); break; }
-                    lanes::nap();
-                    continue;
-                }
-                break;
-            }
             const bool run = !done && !fresh; // rows that take part in the rest of this pass
             const double mu = nc > 0.0 ? nm.musum / nc : 0.0;
             double a_aff = 1.0, S1 = 0.0, S2 = 0.0, a = 1.0, d1, d2;

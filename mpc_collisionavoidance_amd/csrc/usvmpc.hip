@@ -9,7 +9,6 @@
 // blocks are at most 16x16).
 #include "gfx950/lanes.hpp"
 
-#include "advance.hpp"
 #include "guidance.hpp"
 #include "host_spec.hpp"
 #include "linearize.hpp"
@@ -21,7 +20,6 @@
 #endif
 
 #include <algorithm>
-#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -66,35 +64,6 @@ __global__ void __launch_bounds__(64, (LDSWS ? 1 : qp_waves<KCH, SOFTBOX>())) us
     q.solve(phase, queue0);
 }
 
-// Closed-loop launch (usvmpc_closed_loop; QpIpm::solve_cl, Linearize::serve): several consecutive ticks of solve + hand-over as ONE pair of
-// persistent kernels that run side by side on two streams - no launch boundary, hence no launch tail, between ticks.  usv_qp_cl: the
-// rows of its waves pull linearised (instance, tick) items from a queue, each row with a workspace slot of its own; usv_lin_cl: its waves
-// linearise the instances the QP rows hand over.  Two kernels rather than two roles in one: each gets a register allocation of its own
-// (the lineariser wants ~220 registers; inlined into the QP code it made the allocator spill inside the sweeps, as a called function
-// and as a second role of the same kernel the builds of this toolchain corrupted spilled scalars).  The instantiations every OCP of
-// the reference runs: diagonal Hessian, HBM workspace, no soft state bounds.
-template <class M, int KCH, bool SOFT, bool PACK, bool MERGE, bool AUXLDS>
-__global__ void __launch_bounds__(64, (qp_waves<KCH, false>())) usv_qp_cl(DevPtrs P)
-{
-    QpIpm<M, KCH, SOFT, true, PACK, false, false, MERGE, AUXLDS, true> q(P, (long)blockIdx.x * 4 + (long)(threadIdx.x >> 4));
-    q.solve_cl();
-}
-template <class M, int KCH, bool SOFT>
-__global__ void __launch_bounds__(64, 2) usv_lin_cl(DevPtrs P)
-{
-    Linearize<M, KCH, SOFT, true, 0>::serve(P);
-}
-
-// the queues of a closed-loop launch: tick 0 of every instance waits for its linearisation, in the order of the map (hardest first);
-// nothing is linearised yet; no wave has arrived; the per-tick audit counters of the launch's ticks start at zero
-__global__ void usv_cl_begin(DevPtrs P, int B, int ticks)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) P.linq[i] = (P.perm ? P.perm[i] : i) + 1;
-    if (i == 0) { *P.lin_tail = B; *P.lin_head = 0; *P.fifo_tail = 0; *P.queue = 0; *P.cl_abort = 0; }
-    if (i < ticks) { P.fail_ring[(P.ring_base + i) % P.ring_len] = 0; P.unconv_ring[(P.ring_base + i) % P.ring_len] = 0; }
-}
-
 // Multiplier read-back (usvmpc_get "lam" / "t"): the inequality multipliers and slacks of every instance's last QP, from the
 // group-indexed workspace planes into instance-major arrays in acados' row order (QpIpm::export_rows).  Run on demand.
 template <class M, int KCH, bool SOFT, bool PACK, bool SOFTBOX>
@@ -118,7 +87,18 @@ __global__ void usv_sqp_end(DevPtrs P, int B)
     if (i < B) P.status[i] = P.sqp_state[i] < 0 ? 2 : P.sqp_state[i];
 }
 
-// Closed-loop hand-over between two ticks (advance.hpp), every instance at once: the stand-alone kernel of usvmpc_advance.
+// Closed-loop hand-over between two ticks, as the reference's callers do it on the host
+// (x0 = get(1,"x"); set(0,"lbx",x0): scripts/usv_guidance_ca1/main.py:169-175): the next initial
+// state is the predicted x_1 plus an optional Gaussian disturbance (the commented "Add noise"
+// hooks of scripts/usv_pf_ca/main.py:181-183).  No trajectory shift, as in the reference.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
 __global__ void usv_advance(DevPtrs P, int nx, double sigma, unsigned long long seed, unsigned mask)
 {
     const DevSpec &S = *P.spec;
@@ -126,7 +106,15 @@ __global__ void usv_advance(DevPtrs P, int nx, double sigma, unsigned long long 
     if (i >= (long)S.B * nx) return;
     const long b = i / nx;
     const int j = (int)(i - b * nx);
-    const_cast<double *>(P.x0)[i] = advance_value(P.x[(b * (S.N + 1) + 1) * nx + j], sigma, seed, i, ((mask >> j) & 1u) != 0u);
+    double v = P.x[(b * (S.N + 1) + 1) * nx + j];
+    if (sigma != 0.0 && ((mask >> j) & 1u)) {
+        const unsigned long long h1 = splitmix64(seed ^ (unsigned long long)(2 * i));
+        const unsigned long long h2 = splitmix64(seed ^ (unsigned long long)(2 * i + 1));
+        const double u1 = ((double)(h1 >> 11) + 1.0) * (1.0 / 9007199254740993.0);
+        const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);
+        v += sigma * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    }
+    const_cast<double *>(P.x0)[i] = v;
 }
 
 // Debug / test entry points: the model functions exactly as the lineariser calls them (M::fjvp: f and one Jacobian
@@ -266,17 +254,6 @@ struct usvmpc_handle {
     unsigned noise_mask;      // states usvmpc_advance disturbs (option "disturbance_mask"; default: all)
     int *d_fail_ring;         // [RING] instances with status != 0, one slot per solve
     int *d_unconv_ring;       // [RING] instances whose QP did not converge to the tolerances (qp_status != 0), one slot per solve
-    // the event triple of solve i lives in ring slot ev_owner[i % RING] and spans ev_span[i % RING] solves (a closed-loop launch
-    // carries several ticks: its per-tick times are the launch's divided by its ticks)
-    int ev_owner[RING], ev_span[RING];
-    bool fused_loop;          // option "fused_closed_loop": usvmpc_closed_loop as ONE persistent launch where the kernels exist (default on)
-    int *d_fifo, *d_linq, *d_cl_ctr; // the two item queues of a closed-loop launch; [8] fifo_tail, lin_head, lin_tail, role, abort flag
-    bool cl_pending;          // a closed-loop launch has been enqueued whose abort flag has not been looked at
-    double *d_lp;             // the lineariser waves' planes, instance-indexed (allocated at the first closed-loop launch)
-    size_t fifo_cap;          // ints allocated for each item queue
-    double lin_share;         // option "loop_lin_share": fraction of a closed-loop launch's waves that linearise (<= 0: the model's default)
-    long cl_cap[4];           // waves the device holds of the closed-loop kernel, per (merge, aux) variant (0: unknown, -1: unusable)
-    bool ws_slots_shared;     // the last launch reused workspace slots across instances (closed loop): nothing to read back from it
     // Caller-visible arrays live in ONE device arena, in the order [x | u | status | x0 | yref | yref_e | p | lh] (256-byte aligned
     // pieces).  Small handles (the single-instance drop-in faces: AcadosOcpSolver, the acados C shim) also keep a pinned host
     // MIRROR of it: usvmpc_set then writes the mirror and marks the field dirty - no HIP call, no synchronisation - and the next
@@ -299,12 +276,14 @@ struct usvmpc_handle {
     bool pipeline;            // option; used for RTI solves of handles without a host mirror
     hipStream_t aux_stream;   // nullptr until first used
     hipEvent_t ev_pre, ev_spec;
-    hipStream_t lin_stream;   // closed-loop launches: the lineariser waves' kernel runs here, beside the QP waves' on `stream` (nullptr until first used)
-    hipEvent_t ev_lin[2];
     int *d_epoch, *d_redo, *d_perm2;
     long spec_for;            // solve number the outstanding / finished speculative linearisation was made for (-1: none)
     bool spec_valid;          // ... and nothing it read has been changed by the caller since
     bool spec_outstanding;    // the second stream may still be writing the lineariser's planes
+    int spec_quiet;           // RTI solves in a row whose ahead-of-time linearisation (had there been one) no caller write invalidated: the
+                              // lineariser runs ahead only from SPEC_QUIET_MIN on - a caller that sets yref / x / u every tick (the reference's
+                              // protocol: scripts/usv_guidance_ca1/main.py:123-130) never pays for a speculative pass that is thrown away
+    long spec_hits, spec_misses; // ahead-of-time linearisations used / discarded (usvmpc_pipeline_stats)
     const int *spec_perm;     // the group -> instance map it used (= the map the solve spec_for must use)
     // partial condensing (option "qp_cond_N"): RTI solves condense the QP to cond_N2 stages first (0: off - the Riccati sweep over the N stages)
     int cond_N2;
@@ -314,6 +293,7 @@ struct usvmpc_handle {
     long cond_teams;
     size_t cond_lds;          // dynamic LDS of the condensing kernel, bytes
     long export_at;           // nsolves the multiplier read-back buffers (ptrs.lam_out / t_out) were filled at; -1: never
+    bool last_cond;           // the last launch solved the partially condensed QP (its rows live in per-team scratch, not in the workspace)
     bool layout_dirty;        // the row layout option changed after the last solve: the workspace cannot be read back
     size_t bytes;
     std::string err;
@@ -399,6 +379,7 @@ int ensure_export(usvmpc_handle *h); // (below: needs the kernel dispatch)
 int spec_cancel(usvmpc_handle *h)
 {
     h->spec_valid = false;
+    h->spec_quiet = 0;
     if (h->spec_outstanding) {
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipStreamSynchronize(h->aux_stream));
@@ -499,17 +480,26 @@ int copy_field(usvmpc_handle *h, const char *field, int stage, double *host, siz
                 else std::memcpy((char *)host + b * row, m + b * pitch + first, row);
             }
         }
-        if (set) {
-            const size_t lo = first, hi = whole ? B * pitch : (B - 1) * pitch + first + row;
+        if (set && !whole && B > 1) {
+            // one stage of several instances: the rows are not contiguous, and a dirty RANGE over them would later upload the mirror's
+            // copy of everything in between - stale where a device-side writer (the guidance kernels, a caller holding a device pointer)
+            // has written behind the mirror.  The rows go up now, each on its own (asynchronous, from the pinned mirror).
+            HIP_TRY(h, hipSetDevice(h->device));
+            HIP_TRY(h, hipMemcpy2DAsync(h->arena + h->f_off[fi] + first, pitch, m + first, pitch, row, B, hipMemcpyHostToDevice, h->stream));
+            h->inflight = true;
+        } else if (set) {
+            const size_t lo = first, hi = whole ? B * pitch : first + row;
             if (h->dirty_lo[fi] >= h->dirty_hi[fi]) { h->dirty_lo[fi] = lo; h->dirty_hi[fi] = hi; }
             else { h->dirty_lo[fi] = std::min(h->dirty_lo[fi], lo); h->dirty_hi[fi] = std::max(h->dirty_hi[fi], hi); }
         }
+        if (set && (fi == usvmpc_handle::F_X || fi == usvmpc_handle::F_U || fi == usvmpc_handle::F_YREF || fi == usvmpc_handle::F_YREF_E))
+            h->spec_quiet = 0;
         return 0;
     }
     HIP_TRY(h, hipSetDevice(h->device));
     if (set) { // (a lineariser that ran ahead may have read what is being replaced - it reads x, u, yref: the next solve linearises again)
         const std::string fs(field ? field : "");
-        if (fs == "x" || fs == "u" || fs == "yref" || fs == "yref_e") h->spec_valid = false;
+        if (fs == "x" || fs == "u" || fs == "yref" || fs == "yref_e") { h->spec_valid = false; h->spec_quiet = 0; }
     }
     if (!set) { rc = mirror_flush(h); if (rc) return rc; } // (a get of a field with pending writes sees them)
     if (stage < 0 || f.stages == 1) {
@@ -623,7 +613,9 @@ int launch_pair(usvmpc_handle *h, int phase)
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_spec, 0));
         h->spec_outstanding = false;
     }
-    const bool use_spec = pipe && h->spec_valid && h->spec_for == h->nsolves;
+    const bool had_spec = pipe && h->spec_for == h->nsolves;
+    const bool use_spec = had_spec && h->spec_valid;
+    if (had_spec) (use_spec ? h->spec_hits : h->spec_misses)++;
     h->spec_valid = false;
     if (use_spec) {
         // the map this tick was linearised under (made one tick ago from the counts of the solve before)
@@ -638,10 +630,10 @@ int launch_pair(usvmpc_handle *h, int phase)
         HIP_TRY(h, hipGetLastError());
         h->ptrs.perm = h->d_perm;
     }
-    // (the counts of the solve before this one: the second half of the next sort key)
-    if (h->sort_enabled && h->sort_two && phase == 0)
-        HIP_TRY(h, hipMemcpyAsync(h->d_iter_prev, h->ptrs.qp_iter, (size_t)h->B * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
-    h->ptrs.epoch = pipe ? h->d_epoch : nullptr;
+    constexpr int SPEC_QUIET_MIN = 2;
+    if (pipe) h->spec_quiet++; // (reset by every caller write that would invalidate a linearisation made ahead of time)
+    const bool spec_next = pipe && h->spec_quiet >= SPEC_QUIET_MIN; // the next tick's lineariser runs ahead, beside this solve's QP launch
+    h->ptrs.epoch = spec_next ? h->d_epoch : nullptr;
     h->ptrs.redo = pipe ? h->d_redo : nullptr;
     h->ptrs.redo_words = (h->N + 32) / 32;
     h->ptrs.perm_cur = nullptr;
@@ -656,11 +648,8 @@ int launch_pair(usvmpc_handle *h, int phase)
     h->ptrs.unconv_count = h->d_unconv_ring + h->nsolves % usvmpc_handle::RING;
     HIP_TRY(h, hipMemsetAsync(h->ptrs.fail_count, 0, sizeof(int), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->ptrs.unconv_count, 0, sizeof(int), h->stream));
-    h->ptrs.cl_ticks = 0;
-    h->ev_owner[h->nsolves % usvmpc_handle::RING] = (int)(h->nsolves % usvmpc_handle::RING);
-    h->ev_span[h->nsolves % usvmpc_handle::RING] = 1;
     const int *next_perm = nullptr;
-    if (pipe) {
+    if (spec_next) {
         // the NEXT tick's map, from the counts this launch is about to overwrite, into the buffer this tick does not use
         if (h->sort_enabled) {
             int *dst = (h->ptrs.perm == h->d_perm) ? h->d_perm2 : h->d_perm;
@@ -670,6 +659,10 @@ int launch_pair(usvmpc_handle *h, int phase)
         }
         HIP_TRY(h, hipEventRecord(h->ev_pre, h->stream));
     }
+    // (the counts of the solve before this one: the second half of the next sort key - copied after every sort of THIS solve has read
+    // the pair (qp_iter, d_iter_prev), the pipelined map's included, and before the QP launch overwrites qp_iter)
+    if (h->sort_enabled && h->sort_two && phase == 0)
+        HIP_TRY(h, hipMemcpyAsync(h->d_iter_prev, h->ptrs.qp_iter, (size_t)h->B * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
     constexpr bool CANPACK = KCH > 0;
     const bool pack = CANPACK && h->spec.boxpack != 0;
     if (h->spec.npt != (h->spec.any_bsoft ? WsLayout<M, KCH, SOFT, true>::NPT : WsLayout<M, KCH, SOFT, false>::NPT)) {
@@ -683,9 +676,6 @@ int launch_pair(usvmpc_handle *h, int phase)
     // HBM at every stage - nothing else runs on the CU to hide it - becomes a solve on LDS.  rows_lds instances per wave
     // (as many whole horizons as fit), one wave per CU at a time; further instances come through the same queue.
     auto launch_qp = [&](auto kern, decltype(kern) kern_lds, decltype(kern) kern_aux = nullptr) -> int {
-#ifdef USV_TIMING_EXPERIMENT
-        if (h->spec.fixed_iters < 0) return 0; // (timing_fixed_iters = -1: lineariser only - tools/overlap_probe.py)
-#endif
         const long lds_inst = (long)(h->N + 1) * h->spec.npt * 128;
         // (the kernel's own static LDS - exchange area, parked constants - comes out of the same 160 KB)
         long lds_static = 0;
@@ -785,8 +775,10 @@ int launch_pair(usvmpc_handle *h, int phase)
     if (rcq) return rcq;
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[2], h->stream));
-    if (pipe) {
-        // the next tick's lineariser, behind this launch on the second stream, under the map made above
+    if (spec_next) {
+        // the next tick's lineariser, behind this launch on the second stream, under the map made above.  (Its stream has the lowest
+        // priority: when both become eligible the QP launch's workgroups are placed first; groups it reaches before their instance is
+        // final are marked and redone by the fix-up pass - measured on the bench workload: 0.35 of 7.4 ms, ~5 % of the groups.)
         HIP_TRY(h, hipStreamWaitEvent(h->aux_stream, h->ev_pre, 0));
         DevPtrs Pn = h->ptrs;
         Pn.perm = next_perm;
@@ -801,163 +793,13 @@ int launch_pair(usvmpc_handle *h, int phase)
     }
     h->nsolves++;
     h->layout_dirty = false;
-    if (!cond) h->ws_slots_shared = false;
+    h->last_cond = cond;
     if (h->mirror) { // [x | u | status] of this solve, one copy
         HIP_TRY(h, hipMemcpyAsync(h->mirror, h->arena, h->f_off[usvmpc_handle::F_X0], hipMemcpyDeviceToHost, h->stream));
         h->inflight = true;
         h->out_valid = true;
     }
     return 0;
-}
-
-// Closed-loop launch: `ticks` consecutive (solve, advance) pairs as ONE persistent launch (usv_qp_cl).  Returns 1 when this handle /
-// configuration has no such kernel (the caller then runs the sequential pairs), 0 when enqueued, < 0 on errors.
-template <class M, int KCH, bool SOFT>
-int launch_closed(usvmpc_handle *h, int ticks, double sigma, unsigned long long seed)
-{
-    constexpr bool CANPACK = KCH > 0;
-    const bool pack = CANPACK && h->spec.boxpack != 0;
-    if (!h->fused_loop || !h->dynamic_rows || h->cond_N2 > 0 || !h->spec.hdiag || h->spec.any_bsoft || pack != CANPACK || h->ncu < 1) return 1;
-    if (ticks > usvmpc_handle::RING || (double)h->B * (ticks + 1) >= 2147483000.0) return 1; // (the caller splits longer runs)
-    if (h->spec.npt != WsLayout<M, KCH, SOFT, false>::NPT) { h->err = "workspace layout mismatch between host and kernels"; return USVMPC_E_ARG; }
-    {
-        const int rcf = mirror_flush(h);
-        if (rcf) return rcf;
-    }
-    if (h->spec_outstanding) { // a lineariser that ran ahead on the second stream: its planes are about to be overwritten
-        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_spec, 0));
-        h->spec_outstanding = false;
-    }
-    h->spec_valid = false;
-    const int B = h->B;
-    const size_t nitems = (size_t)B * (ticks + 1); // (+ the closing hand-over of every instance, which goes through the lineariser waves' queue)
-    if (h->fifo_cap < nitems) {
-        if (h->d_fifo) dev_free(h, h->d_fifo, h->fifo_cap * sizeof(int));
-        if (h->d_linq) dev_free(h, h->d_linq, h->fifo_cap * sizeof(int));
-        h->d_fifo = nullptr; h->d_linq = nullptr; h->fifo_cap = 0;
-        if (dev_alloc(h, &h->d_fifo, nitems, false) || dev_alloc(h, &h->d_linq, nitems, false)) return USVMPC_E_HIP;
-        h->fifo_cap = nitems;
-    }
-    if (!h->lin_stream) { // the stream the lineariser waves of the closed-loop launches run on
-        HIP_TRY(h, hipStreamCreateWithFlags(&h->lin_stream, hipStreamNonBlocking));
-        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_lin[0], hipEventDisableTiming));
-        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_lin[1], hipEventDisableTiming));
-    }
-    using LinT = Linearize<M, KCH, SOFT, true, 0>;
-    if (!h->d_lp && dev_alloc(h, &h->d_lp, (size_t)(h->N + 1) * (size_t)B * LinT::NLP * LANES, false)) return USVMPC_E_HIP;
-    const int last = (int)((h->nsolves + ticks - 1) % usvmpc_handle::RING);
-    hipEvent_t *ev = h->ev[last];
-    HIP_TRY(h, hipEventRecord(ev[0], h->stream));
-    // the queue starts in the order of the previous solve's iteration counts, hardest first (later ticks queue up as they become ready)
-    if (h->sort_enabled && h->nsolves > 0) {
-        const int *prev2 = h->sort_two ? h->d_iter_prev : h->ptrs.qp_iter;
-        hipLaunchKernelGGL(usv_sort_hist, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_iter, prev2, B, h->d_hist);
-        hipLaunchKernelGGL(usv_sort_scan, dim3(1), dim3(64), 0, h->stream, h->d_hist, h->d_cursor);
-        hipLaunchKernelGGL(usv_sort_scatter, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_iter, prev2, B, h->d_cursor, h->d_perm);
-        HIP_TRY(h, hipGetLastError());
-        h->ptrs.perm = h->d_perm;
-    }
-    for (int t = 0; t < ticks; t++) {
-        const int slot = (int)((h->nsolves + t) % usvmpc_handle::RING);
-        h->ev_owner[slot] = last; h->ev_span[slot] = ticks;
-    }
-    DevPtrs &P = h->ptrs;
-    P.epoch = nullptr; P.redo = nullptr; P.perm_cur = nullptr; P.tick = (int)h->nsolves;
-    P.fail_count = nullptr; P.unconv_count = nullptr;
-    P.fifo = h->d_fifo; P.linq = h->d_linq; P.lp = h->d_lp;
-    P.fifo_tail = h->d_cl_ctr; P.lin_head = h->d_cl_ctr + 1; P.lin_tail = h->d_cl_ctr + 2; P.cl_abort = h->d_cl_ctr + 4;
-    P.cl_ticks = ticks; P.cl_slots = B * ticks;
-    P.cl_sigma = sigma; P.cl_seed = seed; P.cl_mask = h->noise_mask;
-    P.fail_ring = h->d_fail_ring; P.unconv_ring = h->d_unconv_ring;
-    P.ring_base = (int)(h->nsolves % usvmpc_handle::RING); P.ring_len = usvmpc_handle::RING;
-    HIP_TRY(h, hipMemsetAsync(h->d_fifo, 0, nitems * sizeof(int), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->d_linq, 0, nitems * sizeof(int), h->stream));
-    hipLaunchKernelGGL(usv_cl_begin, dim3((std::max(B, ticks) + 255) / 256), dim3(256), 0, h->stream, P, B, ticks);
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(ev[1], h->stream));
-    // the variant: one row pass where every box row rides in a slot lane (MERGE), the aux plane in the waves' LDS where the horizon fits
-    // without costing a resident wave (AUXLDS) - as launch_pair chooses for an RTI solve
-    const bool merge = pack && h->merge_rows && !h->spec.box_dense;
-    const int qp_block = 64;
-    auto occupancy = [&](auto kern, size_t lds) -> long {
-        int nb = 0;
-        if (lds > 0 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, qp_block, lds) != hipSuccess || nb < 1) return -1;
-        return (long)nb * h->ncu;
-    };
-    // share of the launch's waves that linearise: the lineariser's part of a tick's work (measured on the stand-alone kernels: 7.4 of
-    // 69 ms for usv_model_pf_ca at 5 RK4 steps, 2.0 of 49 for usv_model_guidance_ca1, 0.9 of 17 for usv_model) plus a margin - a lineariser
-    // wave that waits leaves its SIMD to the QP wave beside it, a QP row that waits for a linearised item wastes a quarter of a wave
-    double share = h->lin_share;
-    if (share <= 0.0)
-        share = h->desc.model == USVMPC_MODEL_PF_CA ? 0.04 + 0.018 * h->spec.sim_steps
-                : (h->desc.model == USVMPC_MODEL_GUIDANCE_CA1 ? 0.05 + 0.01 * (h->spec.sim_steps - 1) : 0.065 + 0.01 * (h->spec.sim_steps - 1));
-    share = std::min(0.5, std::max(0.01, share));
-    auto run = [&](auto kern_plain, auto kern_aux, int vi) -> int {
-        const size_t aux_bytes = (size_t)4 * (h->N + 1) * (size_t)(h->spec.aux_dense4 + (h->kch > 0 ? 2 : 0) + 2 * h->nu) * sizeof(double);
-        if (h->cl_cap[vi] == 0) h->cl_cap[vi] = occupancy(kern_plain, 0);
-        if (h->cl_cap[vi + 1] == 0) {
-            h->cl_cap[vi + 1] = (h->aux_lds && pack) ? occupancy(kern_aux, aux_bytes) : -1;
-            if (h->cl_cap[vi + 1] < h->cl_cap[vi]) h->cl_cap[vi + 1] = -1; // (it would cost a resident wave)
-        }
-        const bool aux = h->cl_cap[vi + 1] > 0;
-        long cap = aux ? h->cl_cap[vi + 1] : h->cl_cap[vi]; // waves the device holds
-        if (cap <= 1) { h->err = "closed-loop launch: the kernel cannot be resident on this device"; return USVMPC_E_HIP; }
-        if (h->max_waves > 0 && h->max_waves < cap) cap = std::max<long>(2, h->max_waves);
-        // QP waves: one row per instance at most; lineariser waves: their share of the whole
-        long nl = std::max<long>(1, std::lround((double)cap * share));
-        long nq = std::min<long>(cap - nl, (long)h->Bp / 4);
-        if (nq < cap - nl) nl = std::max<long>(1, std::min<long>(nl, std::lround((double)nq * share / (1.0 - share) + 0.5)));
-        P.cl_waves = (int)nq; P.cl_lin_waves = (int)nl;
-        // the lineariser waves on the second stream, from the moment the queues are set up; the QP waves on the handle's stream; the
-        // handle's stream then waits for both (whatever it runs next must see the lineariser's kernel gone too)
-        HIP_TRY(h, hipEventRecord(h->ev_lin[0], h->stream));
-        HIP_TRY(h, hipStreamWaitEvent(h->lin_stream, h->ev_lin[0], 0));
-        hipLaunchKernelGGL((usv_lin_cl<M, KCH, SOFT>), dim3((unsigned)nl), dim3(qp_block), 0, h->lin_stream, P);
-        HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipEventRecord(h->ev_lin[1], h->lin_stream));
-        const dim3 grid((unsigned)nq), block(qp_block);
-        if (aux) hipLaunchKernelGGL(kern_aux, grid, block, aux_bytes, h->stream, P);
-        else hipLaunchKernelGGL(kern_plain, grid, block, 0, h->stream, P);
-        HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_lin[1], 0));
-        return 0;
-    };
-    int rc;
-    if constexpr (CANPACK) {
-        if (merge) rc = run(&usv_qp_cl<M, KCH, SOFT, true, true, false>, &usv_qp_cl<M, KCH, SOFT, true, true, true>, 2);
-        else rc = run(&usv_qp_cl<M, KCH, SOFT, true, false, false>, &usv_qp_cl<M, KCH, SOFT, true, false, true>, 0);
-    } else {
-        rc = run(&usv_qp_cl<M, KCH, SOFT, false, false, false>, &usv_qp_cl<M, KCH, SOFT, false, false, false>, 0);
-    }
-    if (rc) return rc;
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(ev[2], h->stream));
-    P.cl_ticks = 0;
-    h->nsolves += ticks;
-    h->layout_dirty = false;
-    h->map_changed = true;      // (the workspace slots were shared by many instances: a later full SQP starts from zero multipliers)
-    h->ws_slots_shared = true;  // ... and there is nothing per instance to read back from them
-    h->cl_pending = true;
-    h->out_valid = false;
-    return 0;
-}
-
-int launch_closed_dispatch(usvmpc_handle *h, int ticks, double sigma, unsigned long long seed)
-{
-    switch (h->desc.model) {
-#ifdef USV_BENCH_ONLY
-    case USVMPC_MODEL_PF_CA: if (h->kch <= 1) return launch_closed<ModelM2, 1, false>(h, ticks, sigma, seed); break;
-    case USVMPC_MODEL_GUIDANCE_CA1: if (h->kch <= 1) return launch_closed<ModelM1, 1, true>(h, ticks, sigma, seed); break;
-#elif !defined(USV_GEN_ONLY)
-    case USVMPC_MODEL_USV: return launch_closed<ModelM0, 0, false>(h, ticks, sigma, seed);
-    case USVMPC_MODEL_GUIDANCE_CA1:
-        return h->kch <= 1 ? launch_closed<ModelM1, 1, true>(h, ticks, sigma, seed) : launch_closed<ModelM1, 2, true>(h, ticks, sigma, seed);
-    case USVMPC_MODEL_PF_CA:
-        return h->kch <= 1 ? launch_closed<ModelM2, 1, false>(h, ticks, sigma, seed) : launch_closed<ModelM2, 2, false>(h, ticks, sigma, seed);
-#endif
-    }
-    return 1; // (generated models: the sequential pairs)
 }
 
 // planes per stage of the packed [B A] for this model (MatPack)
@@ -1015,11 +857,6 @@ int ensure_export(usvmpc_handle *h)
 {
     if (h->nsolves == 0) { h->err = "no QP has been solved yet: nothing to read back"; return USVMPC_E_ARG; }
     if (h->layout_dirty) { h->err = "the row layout option changed after the last solve: solve again before reading multipliers"; return USVMPC_E_ARG; }
-    if (h->ws_slots_shared) {
-        h->err = "the last launch was a closed-loop launch (usvmpc_closed_loop), whose rows reuse their workspace slots from item to item: "
-                 "\"lam\" / \"t\" of its last tick do not exist - run the tick of interest with usvmpc_solve";
-        return USVMPC_E_ARG;
-    }
     HIP_TRY(h, hipSetDevice(h->device));
     DevPtrs &P = h->ptrs;
     if (!P.lam_out) {
@@ -1030,7 +867,7 @@ int ensure_export(usvmpc_handle *h)
         h->export_at = -1;
     }
     if (h->export_at == h->nsolves) return 0;
-    if (h->cond_N2 > 0) {
+    if (h->last_cond) {
         // the partially condensed solve keeps its rows in per-workgroup scratch: it writes "lam" / "t" itself, when the buffers exist
         h->err = "\"lam\" / \"t\" of a partially condensed solve (qp_cond_N) are written by the solve itself: the buffers exist from now on "
                  "(option \"keep_multipliers\" = 1 creates them up front) - solve again";
@@ -1127,11 +964,12 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->map_changed = false;
     h->export_at = -1;
     h->layout_dirty = false;
+    h->last_cond = false;
     h->pipeline = true;
     h->aux_stream = nullptr; h->ev_pre = nullptr; h->ev_spec = nullptr;
-    h->lin_stream = nullptr; h->ev_lin[0] = nullptr; h->ev_lin[1] = nullptr;
     h->d_epoch = nullptr; h->d_redo = nullptr; h->d_perm2 = nullptr;
     h->spec_for = -1; h->spec_valid = false; h->spec_outstanding = false; h->spec_perm = nullptr;
+    h->spec_quiet = 0; h->spec_hits = 0; h->spec_misses = 0;
     h->noise_mask = ~0u;
     h->cond_N2 = 0; h->d_cond_dims = nullptr; h->d_cond_scratch = nullptr; h->cond_teams = 0; h->cond_lds = 0;
     h->dynamic_rows = true;
@@ -1211,12 +1049,6 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     TRY_C(dev_alloc(h, &P.obs_tmin, B, true));
     TRY_C(dev_alloc(h, &h->d_fail_ring, usvmpc_handle::RING, true));
     TRY_C(dev_alloc(h, &h->d_unconv_ring, usvmpc_handle::RING, true));
-    TRY_C(dev_alloc(h, &h->d_cl_ctr, 8, true));
-    h->cl_pending = false;
-    h->d_fifo = nullptr; h->d_linq = nullptr; h->d_lp = nullptr; h->fifo_cap = 0; h->fused_loop = true; h->ws_slots_shared = false;
-    h->lin_share = 0.0;
-    for (int i = 0; i < 4; i++) h->cl_cap[i] = 0;
-    for (int r = 0; r < usvmpc_handle::RING; r++) { h->ev_owner[r] = r; h->ev_span[r] = 1; }
     TRY_C(dev_alloc(h, &P.queue, 1, true));
     TRY_C(dev_alloc(h, &P.nlp_res, B * 4, true));
     TRY_C(dev_alloc(h, &P.sqp_iter, B, true));
@@ -1249,12 +1081,6 @@ int usvmpc_destroy(usvmpc_handle *h)
         (void)hipStreamDestroy(h->aux_stream);
         (void)hipEventDestroy(h->ev_pre);
         (void)hipEventDestroy(h->ev_spec);
-    }
-    if (h->lin_stream) {
-        (void)hipStreamSynchronize(h->lin_stream);
-        (void)hipStreamDestroy(h->lin_stream);
-        (void)hipEventDestroy(h->ev_lin[0]);
-        (void)hipEventDestroy(h->ev_lin[1]);
     }
     for (void *a : h->allocs) (void)hipFree(a);
     if (h->mirror) (void)hipHostFree(h->mirror);
@@ -1305,16 +1131,6 @@ int usvmpc_sync(usvmpc_handle *h)
         h->spec_outstanding = false;
     }
     h->inflight = false;
-    if (h->cl_pending) { // did a closed-loop launch give up?  (it never should: its waves wait for each other's hand-overs with a limit)
-        h->cl_pending = false;
-        int ctr[8];
-        HIP_TRY(h, hipMemcpy(ctr, h->d_cl_ctr, sizeof(ctr), hipMemcpyDeviceToHost));
-        if (ctr[4] != 0) {
-            h->err = "closed-loop launch stalled and gave up (linearised " + std::to_string(ctr[0]) + ", lineariser tickets " + std::to_string(ctr[1]) +
-                     ", handed over " + std::to_string(ctr[2]) + ", spare " + std::to_string(ctr[3]) + "): results are incomplete";
-            return USVMPC_E_HIP;
-        }
-    }
     return 0;
 }
 
@@ -1409,15 +1225,13 @@ int usvmpc_kernel_ms(usvmpc_handle *h, int n, float *linearize_ms, float *qp_ms)
     if (h->nsolves < n || n > usvmpc_handle::RING) { h->err = "fewer solves recorded than requested"; return USVMPC_E_ARG; }
     HIP_TRY(h, hipSetDevice(h->device));
     for (int i = 0; i < n; i++) { // oldest of the last n first
-        const int slot = (int)((h->nsolves - n + i) % usvmpc_handle::RING);
-        hipEvent_t *ev = h->ev[h->ev_owner[slot]];
+        hipEvent_t *ev = h->ev[(h->nsolves - n + i) % usvmpc_handle::RING];
         HIP_TRY(h, hipEventSynchronize(ev[2]));
         float a = 0, b = 0;
         HIP_TRY(h, hipEventElapsedTime(&a, ev[0], ev[1]));
         HIP_TRY(h, hipEventElapsedTime(&b, ev[1], ev[2]));
-        // (a tick of a closed-loop launch: the launch's time divided by its ticks; its lineariser runs inside the QP launch)
-        if (linearize_ms) linearize_ms[i] = a / (float)h->ev_span[slot];
-        if (qp_ms) qp_ms[i] = b / (float)h->ev_span[slot];
+        if (linearize_ms) linearize_ms[i] = a;
+        if (qp_ms) qp_ms[i] = b;
     }
     return 0;
 }
@@ -1456,26 +1270,6 @@ int usvmpc_debug_model_eval(int model, int device, int n, const double *x, const
     }
     (void)hipFree(dx); (void)hipFree(du); (void)hipFree(df); (void)hipFree(dJ);
     return rc;
-}
-
-int usvmpc_debug_counters(usvmpc_handle *h, int *out)
-{
-    if (!h || !out) return USVMPC_E_ARG;
-    HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpy(out, h->d_cl_ctr, 8 * sizeof(int), hipMemcpyDeviceToHost)); // (not ordered against the handle's non-blocking stream)
-    HIP_TRY(h, hipMemcpy(out + 8, h->ptrs.queue, sizeof(int), hipMemcpyDeviceToHost));
-    return 0;
-}
-
-int usvmpc_debug_workspace(usvmpc_handle *h, double *out, size_t n, int *npt)
-{
-    if (!h) return USVMPC_E_ARG;
-    HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (npt) *npt = h->spec.npt;
-    const size_t total = (size_t)(h->N + 1) * h->spec.npt * (size_t)h->Bp * LANES;
-    if (out && n) HIP_TRY(h, hipMemcpy(out, h->ptrs.ws, std::min(n, total) * sizeof(double), hipMemcpyDeviceToHost));
-    return 0;
 }
 
 int usvmpc_debug_obstacle_eval(int device, int n, int K, const double *pos, const double *p, double *h, double *grad)
@@ -1525,25 +1319,11 @@ int usvmpc_unconverged_counts(usvmpc_handle *h, int n, int *counts)
     return 0;
 }
 
-int usvmpc_closed_loop(usvmpc_handle *h, int ticks, double sigma, unsigned long long seed)
+int usvmpc_pipeline_stats(usvmpc_handle *h, long *used, long *discarded)
 {
-    if (!h || ticks < 1) return USVMPC_E_ARG;
-    HIP_TRY(h, hipSetDevice(h->device));
-    int done = 0;
-    while (done < ticks) {
-        const int chunk = std::min(ticks - done, (int)usvmpc_handle::RING);
-        const int rc = launch_closed_dispatch(h, chunk, sigma, seed + (unsigned long long)done);
-        if (rc < 0) return rc;
-        if (rc == 1) { // no fused kernel for this handle: the same ticks as kernel pairs
-            for (int t = 0; t < chunk; t++) {
-                int r2 = launch(h);
-                if (r2) return r2;
-                r2 = usvmpc_advance(h, sigma, seed + (unsigned long long)(done + t));
-                if (r2) return r2;
-            }
-        }
-        done += chunk;
-    }
+    if (!h) return USVMPC_E_ARG;
+    if (used) *used = h->spec_hits;
+    if (discarded) *discarded = h->spec_misses;
     return 0;
 }
 
@@ -1607,9 +1387,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         return 0;
     }
     if (s == "sort_two_ticks") { h->sort_two = value != 0.0; return 0; }
-    if (s == "fused_closed_loop") { h->fused_loop = value != 0.0; return 0; }
-    if (s == "loop_lin_share") { h->lin_share = value; return 0; } // fraction of a closed-loop launch's waves that linearise (<= 0: default)
-    if (s == "aux_in_lds") { h->aux_lds = value != 0.0; h->aux_cap = 0; for (int i = 0; i < 4; i++) h->cl_cap[i] = 0; return 0; }
+    if (s == "aux_in_lds") { h->aux_lds = value != 0.0; h->aux_cap = 0; return 0; }
     if (s == "lds_workspace") { // -1: when the batch is small (default), 0: never, 1: whenever an instance's planes fit in LDS
         h->lds_mode = value < 0.0 ? -1 : (value > 0.0 ? 1 : 0);
         h->lds_cap = 0;
@@ -1629,15 +1407,6 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         h->qp_cap = 0; h->lds_cap = 0; h->aux_cap = 0;
         return 0;
     }
-#ifdef USV_TIMING_EXPERIMENT
-    if (s == "timing_alias_groups" || s == "timing_fixed_iters") {
-        (s == "timing_alias_groups" ? h->spec.alias_groups : h->spec.fixed_iters) = (int)value;
-        HIP_TRY(h, hipSetDevice(h->device));
-        HIP_TRY(h, hipMemcpyAsync(h->d_spec, &h->spec, sizeof(DevSpec), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        return 0;
-    }
-#endif
     if (s == "host_mirror") { // 0: drop the pinned host mirror of the caller-visible arrays (every set / get then goes to the device)
         if (value != 0.0) { if (!h->mirror) { h->err = "host_mirror cannot be switched on again"; return USVMPC_E_ARG; } return 0; }
         if (!h->mirror) return 0;

@@ -10,12 +10,14 @@ import numpy as np
 
 
 def shard_bounds(total, world, rank):
-    """Contiguous, balanced slice [lo, hi) of `total` instances for `rank` of `world`."""
+    """Contiguous, balanced slice [lo, hi) of `total` instances for `rank` of `world`: instance b -> rank floor(b * world / total)."""
     if not (0 <= rank < world):
         raise ValueError("rank %d outside world %d" % (rank, world))
-    base, rem = divmod(int(total), int(world))
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    # SURVEY.md 8(d): instance b lives on rank floor(b * world / total), i.e. rank r owns ceil(r T / W) <= b < ceil((r + 1) T / W)
+    # (equal slices when world divides total, ragged by one instance otherwise)
+    total, world = int(total), int(world)
+    lo = -((-rank * total) // world)
+    return lo, -((-(rank + 1) * total) // world)
 
 
 def shard(array, world, rank):
@@ -69,8 +71,8 @@ def device_tensor(ptr, shape, device_index=0):
     """Zero-copy torch view of a solver device buffer (usvmpc_get_device_ptr) of float64 `shape`."""
     from . import _capi
     if _capi.loaded_before_torch:
-        raise RuntimeError("import torch before creating the first solver: torch and libusvmpc.so must share one "
-                           "HIP runtime for zero-copy views / RCCL on solver buffers")
+        raise RuntimeError("import torch before creating the first solver (or set USVMPC_PRELOAD_TORCH=1): torch and libusvmpc.so must "
+                           "share one HIP runtime for zero-copy views / RCCL on solver buffers")
     import torch
 
     class _Wrap:

@@ -38,7 +38,4 @@ def emu():
     dp, ip = _capi._dp, _capi._ip
     lib.usv_emu_solve.argtypes = [C.POINTER(_capi.Desc)] + [dp] * 10 + [ip] * 3 + [dp] * 4
     lib.usv_emu_sqp.argtypes = [C.POINTER(_capi.Desc)] + [dp] * 10 + [ip] * 3 + [dp] + [ip] + [dp]
-    lib.usv_emu_closed_loop.argtypes = [C.POINTER(_capi.Desc)] + [dp] * 10 + [ip] * 3 + [dp] + [C.c_int, C.c_double, C.c_ulonglong, C.c_uint] + [ip] * 3
-    lib.usv_emu_advance.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, C.c_ulonglong, C.c_uint]
-    lib.usv_emu_advance.restype = None
     return lib

@@ -8,8 +8,7 @@
 #include "linearize.hpp"
 #include "models.hpp"
 #include "qp_ipm.hpp"
-#define USV_COND_SERIAL 1 // partial condensing (cond_ipm.hpp): one CPU thread plays the team of an instance
-#include "cond_ipm.hpp"
+#include "cond_ipm.hpp" // (partial condensing: compiled by the host compiler, one CPU thread plays the team of an instance)
 #ifdef USV_GEN_MODEL_HEADER
 #include USV_GEN_MODEL_HEADER
 #endif
@@ -19,9 +18,8 @@
 
 namespace lanes {
 
-constexpr int MAXG = 4;
-static Emu g_emus[MAXG];
-Emu *g_cur = &g_emus[0];
+Emu g_emu;
+double *g_emu_lds = nullptr;
 
 // minimal x86-64 SysV context switch: callee-saved registers + stack pointer
 asm(R"(
@@ -47,70 +45,56 @@ usv_emu_switch:
 .size usv_emu_switch,.-usv_emu_switch
 )");
 
+static void (*g_body)(void *) = nullptr;
+static void *g_arg = nullptr;
+
 static void fiber_entry()
 {
     Emu &e = g_emu;
-    e.body(e.arg);
-    Emu &f = g_emu; // (the same group: g_cur is set before every switch into a fiber)
-    f.finished[f.cur] = true;
-    for (;;) usv_emu_switch(&f.sp[f.cur], f.main_sp);
-}
-
-void run_groups(int n, const long *groups, void (*const *bodies)(void *), void *const *args, double *const *lds)
-{
-    constexpr size_t STACK = 1 << 20;
-    static std::vector<char> stacks((size_t)MAXG * GROUP * STACK);
-    if (n > MAXG) { std::fprintf(stderr, "lane emulator: too many concurrent groups\n"); std::abort(); }
-    double *keep_lds = g_emus[0].lds;
-    for (int gi = 0; gi < n; gi++) {
-        Emu &e = g_emus[gi];
-        e.body = bodies[gi];
-        e.arg = args[gi];
-        e.group = groups[gi];
-        if (lds) e.lds = lds[gi];
-        for (int l = 0; l < GROUP; l++) {
-            char *top = stacks.data() + ((size_t)gi * GROUP + l + 1) * STACK;
-            uintptr_t sp = ((uintptr_t)top) & ~(uintptr_t)15;
-            void **s = (void **)sp;
-            // layout popped by usv_emu_switch: r15 r14 r13 r12 rbx rbp, then ret -> fiber_entry with
-            // rsp = 8 mod 16 as after a call
-            *--s = nullptr;              // alignment slot (acts as the fake return address)
-            *--s = (void *)&fiber_entry; // ret target
-            for (int i = 0; i < 6; i++) *--s = nullptr;
-            e.sp[l] = (void *)s;
-            e.par[l] = 0;
-            e.nops[l] = 0;
-            e.finished[l] = false;
-        }
-    }
-    for (;;) {
-        int nfin = 0;
-        for (int gi = 0; gi < n; gi++) {
-            Emu &e = g_emus[gi];
-            g_cur = &e;
-            for (int l = 0; l < GROUP; l++) {
-                if (e.finished[l]) { nfin++; continue; }
-                e.cur = l;
-                usv_emu_switch(&e.main_sp, e.sp[l]);
-                if (e.finished[l]) nfin++;
-            }
-            for (int l = 0; l < GROUP; l++) {
-                if (e.finished[l] != e.finished[0] || e.nops[l] != e.nops[0]) {
-                    std::fprintf(stderr, "lane emulator: divergent cross-lane op (group %d lane %d: %ld ops, fin %d; lane 0: %ld ops, fin %d)\n",
-                                 gi, l, e.nops[l], (int)e.finished[l], e.nops[0], (int)e.finished[0]);
-                    std::abort();
-                }
-            }
-        }
-        if (nfin == n * GROUP) break;
-    }
-    g_cur = &g_emus[0];
-    if (!lds) g_emus[0].lds = keep_lds;
+    g_body(g_arg);
+    e.finished[e.cur] = true;
+    for (;;) usv_emu_switch(&e.sp[e.cur], e.main_sp);
 }
 
 void run_group(long group, void (*body)(void *), void *arg)
 {
-    run_groups(1, &group, &body, &arg, nullptr);
+    Emu &e = g_emu;
+    constexpr size_t STACK = 1 << 20;
+    static std::vector<char> stacks(GROUP * STACK);
+    g_body = body;
+    g_arg = arg;
+    e.group = group;
+    for (int l = 0; l < GROUP; l++) {
+        char *top = stacks.data() + (size_t)(l + 1) * STACK;
+        uintptr_t sp = ((uintptr_t)top) & ~(uintptr_t)15;
+        void **s = (void **)sp;
+        // layout popped by usv_emu_switch: r15 r14 r13 r12 rbx rbp, then ret -> fiber_entry with
+        // rsp = 8 mod 16 as after a call
+        *--s = nullptr;              // alignment slot (acts as the fake return address)
+        *--s = (void *)&fiber_entry; // ret target
+        for (int i = 0; i < 6; i++) *--s = nullptr;
+        e.sp[l] = (void *)s;
+        e.par[l] = 0;
+        e.nops[l] = 0;
+        e.finished[l] = false;
+    }
+    for (;;) {
+        int nfin = 0;
+        for (int l = 0; l < GROUP; l++) {
+            if (e.finished[l]) { nfin++; continue; }
+            e.cur = l;
+            usv_emu_switch(&e.main_sp, e.sp[l]);
+            if (e.finished[l]) nfin++;
+        }
+        if (nfin == GROUP) break;
+        for (int l = 0; l < GROUP; l++) {
+            if (e.finished[l] != e.finished[0] || e.nops[l] != e.nops[0]) {
+                std::fprintf(stderr, "lane emulator: divergent cross-lane op (lane %d: %ld ops, fin %d; lane 0: %ld ops, fin %d)\n",
+                             l, e.nops[l], (int)e.finished[l], e.nops[0], (int)e.finished[0]);
+                std::abort();
+            }
+        }
+    }
 }
 
 } // namespace lanes
@@ -236,7 +220,7 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
         for (long g = 0; g < nrows; g++) {
             static std::vector<double> lds; // the emulated row's LDS region (allocated here: the body runs once per lane)
             lds.assign((size_t)(S.N + 1) * S.npt * LANES, 0.0);
-            g_emu_lds = lds.data();
+            lanes::g_emu_lds = lds.data();
             Job j{&P, g, qp_phase, queue ? (int)nrows : -1};
             constexpr bool CANPACK = KCH > 0;
             const bool pack = CANPACK && S.boxpack != 0;
@@ -418,98 +402,4 @@ extern "C" int usv_emu_lin_modes(const usvmpc_desc *d, const double *x, const do
     if (d->model == USVMPC_MODEL_PF_CA) return lin_modes<ModelM2, 1, false>(P, S, ready, perm_next, perm_cur, ws_plain, ws_piped, redo_out);
 #endif
     return -3;
-}
-
-// ---- the closed-loop launch (QpIpm::solve_cl + Linearize::serve) on the emulator: `rows` QP rows, one after the other, each side by side
-// with one lineariser "wave" (the two take turns at every cross-lane operation and whenever one of them naps); the first pair works
-// through the whole queue - the two queues, the hand-over, the plane copy and the per-tick counters are what is exercised - against the
-// sequence usv_emu_solve + usv_emu_advance.  fail / unconv: [ticks] per-tick counters.
-namespace {
-template <class M, int KCH, bool SOFT, bool PACK, bool MERGE, bool AUX>
-void cl_body(void *a)
-{
-    Job *j = (Job *)a;
-    QpIpm<M, KCH, SOFT, true, PACK, false, false, MERGE, AUX, true> q(*j->P, j->gid);
-    q.solve_cl();
-}
-template <class M, int KCH, bool SOFT>
-void cl_lin_body(void *a)
-{
-    Linearize<M, KCH, SOFT, true, 0>::serve(*((Job *)a)->P);
-}
-template <class M, int KCH, bool SOFT>
-int cl_all(DevPtrs &P, DevSpec &S, long rows)
-{
-    S.npt = WsLayout<M, KCH, SOFT, false>::NPT;
-    constexpr bool CANPACK = KCH > 0;
-    const bool pack = CANPACK && S.boxpack != 0;
-    if (!S.hdiag || S.any_bsoft || pack != CANPACK) return -5;
-    std::vector<double> lp((size_t)(S.N + 1) * S.B * Linearize<M, KCH, SOFT, true, 0>::NLP * LANES, 0.0);
-    P.lp = lp.data();
-    for (long g = 0; g < rows; g++) {
-        std::vector<double> lds((size_t)(S.N + 1) * 16 * LANES, 0.0); // (the aux area of the emulated QP wave)
-        Job jq{&P, g, 0, -1}, jl{&P, 0, 0, -1};
-        void (*qp)(void *);
-        if constexpr (CANPACK) {
-            if (g_emu_merge && !S.box_dense) qp = g_emu_aux ? &cl_body<M, KCH, SOFT, true, true, true> : &cl_body<M, KCH, SOFT, true, true, false>;
-            else qp = g_emu_aux ? &cl_body<M, KCH, SOFT, true, false, true> : &cl_body<M, KCH, SOFT, true, false, false>;
-        } else {
-            qp = &cl_body<M, KCH, SOFT, false, false, false>;
-        }
-        const long groups[2] = {g, 1000 + g};
-        void (*const bodies[2])(void *) = {qp, &cl_lin_body<M, KCH, SOFT>};
-        void *const args[2] = {&jq, &jl};
-        double *const ldss[2] = {lds.data(), nullptr};
-        lanes::run_groups(2, groups, bodies, args, ldss);
-    }
-    return 0;
-}
-} // namespace
-
-extern "C" int usv_emu_closed_loop(const usvmpc_desc *d, double *x, double *u, double *x0, const double *yref, const double *yref_e,
-                                   const double *p, const double *lh, double *sl, double *su, double *pi, int *status, int *qp_status,
-                                   int *qp_iter, double *res, int ticks, double sigma, unsigned long long seed, unsigned mask,
-                                   int *fail, int *unconv, const int *perm)
-{
-    DevSpec S;
-    if (!build_spec(*d, S).empty()) return -1;
-    int nx, nu;
-    model_dims(d->model, nx, nu);
-    const int N = S.N;
-    const int kch = (S.K + LANES - 1) / LANES;
-    const bool soft = d->soft != 0;
-    const long rows = g_emu_rows > 0 ? std::min<long>(g_emu_rows, S.Bp) : S.Bp;
-    std::vector<double> ws((size_t)(N + 1) * ws_planes(nx, nu, kch, soft, 16, true) * (size_t)S.Bp * LANES);
-    std::vector<double> tmin(S.B);
-    std::vector<int> fifo((size_t)S.B * (ticks + 1), 0), linq((size_t)S.B * (ticks + 1), 0);
-    for (int i = 0; i < S.B; i++) linq[i] = (perm ? perm[i] : i) + 1;
-    int head = 0, tail = 0, lin_head = 0, lin_tail = S.B, abort_flag = 0;
-    DevPtrs P;
-    std::memset(&P, 0, sizeof(P));
-    P.spec = &S;
-    P.x = x; P.u = u; P.x0 = x0; P.yref = yref; P.yref_e = yref_e; P.p = p; P.lh = lh;
-    P.sl = sl; P.su = su; P.pi = pi; P.status = status; P.qp_iter = qp_iter; P.qp_status = qp_status; P.res = res;
-    P.obs_tmin = tmin.data();
-    P.ws = ws.data();
-    P.queue = &head; P.fifo = fifo.data(); P.fifo_tail = &tail;
-    P.linq = linq.data(); P.lin_head = &lin_head; P.lin_tail = &lin_tail; P.cl_abort = &abort_flag;
-    P.cl_ticks = ticks; P.cl_slots = S.B * ticks; P.cl_sigma = sigma; P.cl_seed = seed; P.cl_mask = mask;
-    std::memset(fail, 0, sizeof(int) * ticks); std::memset(unconv, 0, sizeof(int) * ticks);
-    P.fail_ring = fail; P.unconv_ring = unconv; P.ring_base = 0; P.ring_len = ticks;
-#ifndef USV_GEN_ONLY
-    if (d->model == USVMPC_MODEL_USV) return cl_all<ModelM0, 0, false>(P, S, rows);
-    if (d->model == USVMPC_MODEL_GUIDANCE_CA1) return kch <= 1 ? cl_all<ModelM1, 1, true>(P, S, rows) : cl_all<ModelM1, 2, true>(P, S, rows);
-    if (d->model == USVMPC_MODEL_PF_CA) return kch <= 1 ? cl_all<ModelM2, 1, false>(P, S, rows) : cl_all<ModelM2, 2, false>(P, S, rows);
-#endif
-    return -3;
-}
-
-// the hand-over of every instance between two ticks (advance.hpp), as the device's usv_advance kernel does it
-extern "C" void usv_emu_advance(int B, int N, int nx, const double *x, double *x0, double sigma, unsigned long long seed, unsigned mask)
-{
-    for (long i = 0; i < (long)B * nx; i++) {
-        const long b = i / nx;
-        const int j = (int)(i - b * nx);
-        x0[i] = usv::advance_value(x[(b * (N + 1) + 1) * nx + j], sigma, seed, i, ((mask >> j) & 1u) != 0u);
-    }
 }

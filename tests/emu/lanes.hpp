@@ -25,14 +25,8 @@ struct Emu {
     bool finished[GROUP];
     void *sp[GROUP];       // saved stack pointers of the fibers
     void *main_sp = nullptr;
-    void (*body)(void *) = nullptr; // what the group runs
-    void *arg = nullptr;
-    double *lds = nullptr; // the (emulated) wave's dynamic LDS
 };
-// the group whose fiber is running: run_group runs one, run_groups several side by side (a QP row and a lineariser wave of a
-// closed-loop launch) - they take turns whenever a fiber reaches a cross-lane operation or naps
-extern Emu *g_cur;
-#define g_emu (*::lanes::g_cur)
+extern Emu g_emu;
 extern "C" void usv_emu_switch(void **save_sp, void *load_sp);
 
 inline int lane() { return g_emu.cur; }
@@ -164,17 +158,9 @@ struct Stash {
 };
 
 // the workgroup's LDS (one emulated row per "wave")
-#define g_emu_lds (::lanes::g_cur->lds)
+extern double *g_emu_lds;
 constexpr int WAVE_ROWS = 1;
 inline unsigned wave_row() { return 0; }
-inline int row_value_i(int v, int) { return v; }
-inline bool row_flag(bool p, int) { return p; }
-constexpr int CL_PATIENCE = 1 << 22;
-inline void nap() // a wave with nothing to do but poll: every other fiber gets a turn (all 16 lanes of the group nap together)
-{
-    Emu &e = g_emu;
-    usv_emu_switch(&e.sp[e.cur], e.main_sp);
-}
 inline double *dyn_lds() { return g_emu_lds; }
 struct PlanesLds {
     unsigned off;
@@ -186,15 +172,11 @@ struct PlanesLds {
 
 // run body(lane) on 16 fibers in lock step
 void run_group(long group, void (*body)(void *), void *arg);
-// the same for n groups side by side (group numbers, bodies, arguments, LDS regions per group)
-void run_groups(int n, const long *groups, void (*const *bodies)(void *), void *const *args, double *const *lds);
 
 } // namespace lanes
 
 // device math names used by the kernel bodies
 using std::atan2;
-using std::cos;
-using std::log;
 using std::fabs;
 using std::fma;
 using std::fmax;

@@ -61,3 +61,48 @@ def test_gpus_gt_visible_devices_is_refused():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
                         "--batch", "8", "--cpu-sample", "0"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and '"metric"' not in r.stdout
+
+
+def test_global_batch_mode_shards_one_seed_1234_batch():
+    """SURVEY.md 8(d) configs[3] / [4]: ONE batch from seed 1234, instance b on rank floor(b * world / B): the ranks' workloads are the
+    contiguous slices of the single-rank workload - also for a batch that does not divide evenly."""
+    import numpy as np
+    for G, world in ((64, 8), (50, 4)):
+        whole, B1, dt, steps, sigma, mask = bench.make_workload("usv_model_pf_ca", 10, 4, 9999, G, "survey", False, 0, 1)
+        assert B1 == G and steps == 5 and dt == 0.05 and sigma == 1e-3
+        parts = [bench.make_workload("usv_model_pf_ca", 10, 4, 9999, G, "survey", False, r, world) for r in range(world)]
+        assert sum(p[1] for p in parts) == G
+        for k in ("x0", "x_init", "u_init", "yref", "yref_e", "p", "lh"):
+            assert np.array_equal(np.concatenate([p[0][k] for p in parts], axis=0), whole[k]), k
+        # instance b sits on rank floor(b * world / G)
+        off = 0
+        for r, p in enumerate(parts):
+            for b in range(off, off + p[1]):
+                assert b * world // G == r, (b, r)
+            off += p[1]
+    # without --global-batch every rank draws its own batch (weak scaling)
+    a = bench.make_workload("usv_model_pf_ca", 10, 4, 8, 0, "survey", False, 0, 2)
+    b = bench.make_workload("usv_model_pf_ca", 10, 4, 8, 0, "survey", False, 1, 2)
+    assert a[1] == b[1] == 8 and not np.array_equal(a[0]["x0"], b[0]["x0"])
+
+
+def test_value_counts_converged_solves_and_the_line_states_its_departures():
+    """round-4 lines: `value` is the rate of CONVERGED solves, the rate counting every solve sits beside it, and
+    config.workload names the generator's departures (obstacle clip, initial guess)."""
+    import glob
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_*bench*.json")))
+    assert lines, "no round-4 bench line committed under profiles/"
+    for fn in lines:
+        d = json.load(open(fn))
+        ws = d["workload_stats"]
+        allv, unc = ws["solves_per_s_counting_unconverged_ones"], ws["unconverged_solves_in_timed_region"]
+        total = d["config"]["instances_total"] * d["steps"]
+        assert abs(d["value"] - allv * (1.0 - unc / total)) <= 1e-9 * allv and d["value"] <= allv
+        if d["config"]["ocp"] == "usv_model_pf_ca":
+            w = d["config"]["workload"]
+            assert "obstacle clip" in w and "initial guess" in w and "RK4 steps" in w
+        if d.get("parity"):
+            p = d["parity"]
+            for k in ("rel_err_x", "rel_err_u", "count_above_1e-5", "compared", "above_1e-5_without_kkt_certificate_or_beyond_5e-3"):
+                assert k in p, k
+            assert p["above_1e-5_without_kkt_certificate_or_beyond_5e-3"] == 0

@@ -194,3 +194,33 @@ def test_two_handles_on_shards_equal_unsharded(name, B):
         parts.append(run(sharding.split_workload(wl, 2, r), hi - lo))
     for i in range(5):
         assert np.array_equal(np.concatenate([parts[0][i], parts[1][i]], axis=0), whole[i]), i
+
+
+def test_bench_scale_shards_equal_the_unsharded_batch():
+    """bench.py --global-batch at BASELINE configs[2] scale on ONE GPU: the seed-1234 batch of 65 536 instances solved as two handles on
+    the slices two ranks would get (bench.make_workload: shard b -> rank floor(b * 2 / B)) returns, bit for bit, what one handle returns for
+    the whole batch - what configs[3] / [4] (one batch sharded over 8 GPUs) rely on."""
+    import bench
+    name, N, K, G = "usv_model_pf_ca", 40, 10, 65536
+
+    def run(rank, world):
+        wl, B, dt, steps, sigma, mask = bench.make_workload(name, N, K, 0, G, "survey", False, rank, world)
+        ocp = usv_models.make_ocp(name, N * dt, N, K)
+        ocp.solver_options.sim_method_num_steps = steps
+        s = BatchOcpSolver(ocp, B)
+        scenario.load_into(s, wl)
+        s.set_option("static_obstacles", 1)
+        s.set_option("disturbance_mask", mask)
+        for t in range(2):
+            s.solve_async()
+            s.advance(0.0)      # (the disturbance stream is indexed by the instance's number inside its handle: no noise here)
+        s.sync()
+        out = (s.get_all("x"), s.get_all("u"), s.get_int("status"), s.get_int("qp_iter"), s.get("x0", 0))
+        s.close()
+        return out
+
+    whole = run(0, 1)
+    parts = [run(r, 2) for r in range(2)]
+    for i in range(5):
+        assert np.array_equal(np.concatenate([parts[0][i], parts[1][i]], axis=0), whole[i]), i
+    assert (whole[2] == 0).mean() > 0.99

@@ -1,4 +1,4 @@
-"""The classified device-vs-oracle parity outliers of the bench workload, as a committed fixture (tests/golden/m2_parity_outliers.npz,
+"""The classified device-vs-oracle parity outliers of the bench workload, as a committed fixture (tests/golden/parity_outliers_pf_ca.npz,
 made on an MI355X by tools/outlier_fixture.py: BASELINE configs[2] closed loop, 2048 instances x 10 ticks; every instance above
 north_star's 1e-5, the largest ones below it, and a few ordinary instances - inputs of the solve and BOTH sides' outputs).
 
@@ -22,7 +22,7 @@ from mpc_collisionavoidance_amd import _capi, scenario, usv_models
 from tests.test_emu_kernels import emu_rti
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FIX = os.path.join(ROOT, "tests", "golden", "m2_parity_outliers.npz")
+FIX = os.path.join(ROOT, "tests", "golden", "parity_outliers_pf_ca.npz")
 
 
 def _load():

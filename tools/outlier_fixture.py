@@ -1,5 +1,5 @@
 """Collect the device-vs-oracle parity outliers of the bench workload as a committed fixture (GPU; writes
-tests/golden/m2_parity_outliers.npz via gpurun_out/).
+tests/golden/parity_outliers_pf_ca.npz via gpurun_out/).
 
 Closed loop of BASELINE configs[2] (usv_model_pf_ca, N=40, Tf=2 s, 10 obstacles, SURVEY 8(d) generator, seed 1234) exactly as
 tools/parity_tail.py runs it.  Every solve is compared with the oracle from IDENTICAL inputs (the iterate and x0 the device
@@ -10,7 +10,7 @@ starts the tick from).  Kept per instance: the inputs of the solve (x_in, u_in, 
 The CPU suite (tests/test_parity_outliers.py) replays them on the oracle in both Riccati forms and on the lane emulator; the GPU
 suite holds the device against its own emulator on them.
 
-usage: python tools/outlier_fixture.py [B=2048] [ticks=10] [out=gpurun_out/m2_parity_outliers.npz]
+usage: python tools/outlier_fixture.py [B=2048] [ticks=10] [out=gpurun_out/parity_outliers_pf_ca.npz]
 """
 import os
 import sys
@@ -27,7 +27,7 @@ from tests import util  # noqa: E402
 name, N, K = "usv_model_pf_ca", 40, 10
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "m2_parity_outliers.npz")
+out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "parity_outliers_pf_ca.npz")
 NEAR, ORDINARY = 6, 4
 
 wl = scenario.make_bench_batch(name, N, K, B, seed=1234)

@@ -1,8 +1,11 @@
 """Child process of tests/test_gpu_rccl.py: a world_size-1 RCCL ("nccl") process group bound to cuda:0, a real BatchOcpSolver,
 and sharding.gather_results on zero-copy views of the solver's own device buffers.  Deliberately imports the solver package
-BEFORE torch: the import-order trap of round 2 is gone (_capi.load brings torch in first)."""
+BEFORE torch, with USVMPC_PRELOAD_TORCH=1: the library then brings torch in first itself (the opt-in of _capi.load; without it the
+order "package, then torch" is refused by sharding.device_tensor with an explanation - tests/test_host_api.py)."""
 import os
 import sys
+
+os.environ["USVMPC_PRELOAD_TORCH"] = "1"
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,7 +18,7 @@ def main():
     wl = scenario.make_bench_batch(name, N, K, B, seed=77)
     ocp = usv_models.make_ocp(name, N * scenario.BENCH_DT, N, K)
     ocp.solver_options.sim_method_num_steps = scenario.BENCH_SIM_STEPS[name]
-    s = BatchOcpSolver(ocp, B)            # loads libusvmpc.so (and, through _capi.load, torch before it)
+    s = BatchOcpSolver(ocp, B)            # loads libusvmpc.so (and, through _capi.load with USVMPC_PRELOAD_TORCH=1, torch before it)
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)

@@ -130,7 +130,7 @@ def test_device_reproduces_its_stored_outputs_and_its_emulator(emu):
     f = _load()
     n = f["x_in"].shape[0]
     s = BatchOcpSolver(_ocp(f), n)
-    wl = dict(x_init=f["x_in"], u_init=f["u_in"], **{k: np.ascontiguousarray(f[k]) for k in ("x0", "yref", "yref_e", "p", "lh")})
+    wl = dict(x_init=f["x_in"], u_init=f["u_in"], K=f["K"], **{k: np.ascontiguousarray(f[k]) for k in ("x0", "yref", "yref_e", "p", "lh")})
     scenario.load_into(s, wl)
     st = s.solve()
     xg, ug, qi = s.get_all("x"), s.get_all("u"), s.get_int("qp_iter")

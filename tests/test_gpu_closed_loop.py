@@ -16,7 +16,7 @@
       not slack in the kernels: its control weight is R = 0 (scripts/usv_pf_ca/acados_settings.py:93-99), the
       thrust-rate profile is fixed only through the barrier terms, and the QP solution itself is known no better than
       3e-2 (controls) / 9e-4 (states) at the default IPM tolerances - that is how far BOTH implementations sit from the
-      oracle converged to 1e-11 (tools/parity_probe2.py, profiles/r02_parity_probe.txt).  The two implementations
+      oracle converged to 1e-11 (profiles/r02_parity_probe.txt, profiles/r03_parity_tail.txt: tools/parity_tail.py).  The two implementations
       follow the same iteration path and so agree ~7 orders of magnitude better than that, except where round-off
       moves an iterate across one of the path's kinks;
     - "free running": the oracle keeps its own iterate and only receives the device's x0.  The closed-loop map of the

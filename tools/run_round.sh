@@ -1,0 +1,19 @@
+#!/bin/bash
+# The round's GPU evidence in one gpurun call: the -m gpu suite, tools/profile_round.sh for the bench lines that get a rocprofv3 set
+# (BASELINE configs[2] both models, configs[1], configs[4]) and the plain (un-profiled) bench lines.
+# usage (through gpurun): tools/run_round.sh <round tag, e.g. r04_b>
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+R=$1; out=gpurun_out/$R; mkdir -p $out
+timeout 2400 python -m pytest tests -m gpu -q > $out/pytest.log 2>&1; echo "pytest rc $?" >> $out/pytest.log
+tools/profile_round.sh $R > $out/prof.log 2>&1
+BENCH_ARGS='--model usv_model_guidance_ca1' tools/profile_round.sh ${R}_m1 > $out/prof_m1.log 2>&1
+BENCH_ARGS='--batch 1024 --horizon 20 --obstacles 3' tools/profile_round.sh ${R}_cfg1 > $out/prof_cfg1.log 2>&1
+BENCH_ARGS='--horizon 80 --obstacles 20 --moving' tools/profile_round.sh ${R}_cfg4 > $out/prof_cfg4.log 2>&1
+python bench.py > $out/bench_plain.json 2> $out/bench_plain.err; echo "rc $?" >> $out/bench_plain.err
+python bench.py --cpu-sample 0 --model usv_model_guidance_ca1 > $out/bench_m1_plain.json 2>/dev/null
+python bench.py --cpu-sample 0 --model usv_model --horizon 20 > $out/bench_m0_plain.json 2>/dev/null
+python bench.py --cpu-sample 0 --batch 1024 --horizon 20 --obstacles 3 > $out/bench_cfg1_plain.json 2>/dev/null
+python bench.py --cpu-sample 0 --horizon 80 --obstacles 20 --moving > $out/bench_cfg4_b65536_plain.json 2>/dev/null
+python bench.py --cpu-sample 0 --horizon 80 --obstacles 20 --moving --batch 8192 > $out/bench_cfg4_b8192_per_gpu_plain.json 2>/dev/null
+python bench.py --cpu-sample 0 --horizon 80 --obstacles 20 --moving --batch 8192 --cond-N 10 > $out/bench_cfg4_b8192_condN10_plain.json 2>/dev/null
+tail -3 $out/pytest.log; for f in $out/bench*_plain.json; do python -c "import json,sys; d=json.load(open('$f')); print('$f'.split('/')[-1], round(d['value']), round(d['ms_per_step'],2))"; done

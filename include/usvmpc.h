@@ -145,7 +145,7 @@ int usvmpc_kernel_ms(usvmpc_handle *h, int n, float *linearize_ms, float *qp_ms)
 int usvmpc_fail_counts(usvmpc_handle *h, int n, int *counts);
 /* ... and the number whose QP did not converge to the IPM tolerances (qp_status != 0: iteration cap, step-length floor, NaN, x0 inside
  * a hard keep-out circle), per solve likewise: solves minus this = "solves" as SURVEY.md 8(d) counts them (IPM converged to the stated
- * tolerance). */
+ * tolerance).  RTI solves (usvmpc_solve / usvmpc_solve_async); counted by a small kernel behind the QP launch. */
 int usvmpc_unconverged_counts(usvmpc_handle *h, int n, int *counts);
 /* option "pipeline_linearize": how many linearisations made ahead of time (on the second stream, beside the previous tick's QP launch)
  * were used by the following solve / discarded because the caller wrote x, u or yref in between.  The lineariser only runs ahead after

@@ -150,7 +150,6 @@ struct DevPtrs {
     double *res;          // [B][4]      final QP residuals (stat, eq, ineq, comp)
     double *obs_tmin;     // [B]         smallest lower-side slack t_l over the obstacle rows of the last QP (1e300 without rows)
     int *fail_count;      // [1]         instances of THIS launch whose solve ended with status != 0 (host points it at a ring slot)
-    int *unconv_count;    // [1]         instances of THIS launch whose QP did not converge to the tolerances (qp_status != 0)
     // full SQP (usvmpc_solve_sqp): per-instance state between the iterations of one call
     double *nlp_res;      // [B][4]      NLP residuals of the current iterate (stat, eq, ineq, comp)
     int *sqp_iter;        // [B]         SQP iterations taken

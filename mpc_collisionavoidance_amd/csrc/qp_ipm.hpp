@@ -1505,7 +1505,6 @@ struct QpIpm {
         if (out && lane == 0) {
             if (P.obs_tmin) P.obs_tmin[b] = tmin;
             if (!ok && P.fail_count) lanes::count_one(P.fail_count);
-            if (status != 0 && P.unconv_count) lanes::count_one(P.unconv_count);
             P.status[b] = ok ? 0 : 4;
             P.qp_iter[b] = iters;
             P.qp_status[b] = status;

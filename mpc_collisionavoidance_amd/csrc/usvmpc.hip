@@ -75,6 +75,21 @@ __global__ void __launch_bounds__(64) usv_qp_export(DevPtrs P, long ngroups)
     q.export_rows();
 }
 
+// Instances of a launch whose QP did not converge to the IPM tolerances (qp_status != 0): counted by a kernel of its own behind the QP
+// launch, per workgroup in LDS and one atomic per workgroup (usvmpc_unconverged_counts; SURVEY.md 8(d) counts converged solves).  Not inside
+// QpIpm::finish(): one more counter there moved the headline kernel's register allocation (12 -> 17 spilled registers, +1.3 % per launch in a
+// same-box A/B).
+__global__ void __launch_bounds__(256) usv_count_unconverged(const int *qp_status, int B, int *count)
+{
+    __shared__ int loc;
+    if (threadIdx.x == 0) loc = 0;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B && qp_status[i] != 0) atomicAdd(&loc, 1);
+    __syncthreads();
+    if (threadIdx.x == 0 && loc != 0) atomicAdd(count, loc);
+}
+
 // full SQP bookkeeping: start of a call (everything running) and end (still running = max iterations)
 __global__ void usv_sqp_begin(DevPtrs P, int B)
 {
@@ -645,9 +660,8 @@ int launch_pair(usvmpc_handle *h, int phase)
     if (pipe) HIP_TRY(h, hipMemsetAsync(h->d_redo, 0, (size_t)B * ((h->N + 32) / 32) * sizeof(int), h->stream));
     HIP_TRY(h, hipEventRecord(ev[1], h->stream));
     h->ptrs.fail_count = h->d_fail_ring + h->nsolves % usvmpc_handle::RING;
-    h->ptrs.unconv_count = h->d_unconv_ring + h->nsolves % usvmpc_handle::RING;
     HIP_TRY(h, hipMemsetAsync(h->ptrs.fail_count, 0, sizeof(int), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->ptrs.unconv_count, 0, sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_unconv_ring + h->nsolves % usvmpc_handle::RING, 0, sizeof(int), h->stream));
     const int *next_perm = nullptr;
     if (spec_next) {
         // the NEXT tick's map, from the counts this launch is about to overwrite, into the buffer this tick does not use
@@ -775,6 +789,11 @@ int launch_pair(usvmpc_handle *h, int phase)
     if (rcq) return rcq;
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[2], h->stream));
+    if (phase == 0) { // (an RTI solve: one QP per instance)
+        hipLaunchKernelGGL(usv_count_unconverged, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_status, B,
+                           h->d_unconv_ring + h->nsolves % usvmpc_handle::RING);
+        HIP_TRY(h, hipGetLastError());
+    }
     if (spec_next) {
         // the next tick's lineariser, behind this launch on the second stream, under the map made above.  (Its stream has the lowest
         // priority: when both become eligible the QP launch's workgroups are placed first; groups it reaches before their instance is

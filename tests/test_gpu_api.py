@@ -315,3 +315,41 @@ def test_pipelined_lineariser_is_scheduling_only(name, N, K):
     assert len(a) == len(b)
     for i, (p, q) in enumerate(zip(a, b)):
         assert np.array_equal(p, q), i
+
+
+def test_lineariser_runs_ahead_only_for_callers_that_do_not_write_between_ticks():
+    """a linearisation made ahead of time is thrown away by every caller write of x / u / yref, so the lineariser only runs ahead
+    after two solves in a row without one.  A solve + advance loop (the bench's flow) uses every pass made ahead; the reference's protocol -
+    yref set on every stage every tick (scripts/usv_guidance_ca1/main.py:123-130) - discards exactly the one that was in flight when it
+    started writing and never causes another (usvmpc_pipeline_stats).  Results equal the un-pipelined sequence either way."""
+    from mpc_collisionavoidance_amd import usv_models
+    name, N, K, B = "usv_model_guidance_ca1", 10, 3, 16384
+    wl = scenario.make_bench_batch(name, N, K, B, seed=9)
+    ocp = usv_models.make_ocp(name, N * scenario.BENCH_DT, N, K)
+
+    def run(pipe):
+        s = BatchOcpSolver(ocp, B)
+        scenario.load_into(s, wl)
+        s.set_option("pipeline_linearize", pipe)
+        stats = []
+        for t in range(6):          # nothing written between the ticks
+            s.solve_async()
+            s.advance(0.0)
+        s.sync()
+        stats.append(s.pipeline_stats())
+        for t in range(5):          # the reference's protocol: the reference goes in again before every solve
+            s.set_all("yref", wl["yref"])
+            s.solve_async()
+            s.advance(0.0)
+        s.sync()
+        stats.append(s.pipeline_stats())
+        out = (s.get_all("x"), s.get_all("u"), s.get_int("qp_iter").copy())
+        s.close()
+        return stats, out
+
+    (quiet, writing), a = run(1)
+    _, b = run(0)
+    for p, q in zip(a, b):
+        assert np.array_equal(p, q)
+    assert quiet[0] >= 3 and quiet[1] == 0, quiet              # solves 3 .. 6 ran on a linearisation made ahead of time
+    assert writing[1] == 1 and writing[0] == quiet[0], writing  # one pass in flight when the writes began, none launched afterwards

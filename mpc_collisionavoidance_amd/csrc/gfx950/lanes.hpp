@@ -272,6 +272,22 @@ USV_DEV unsigned wave_lane() { return threadIdx.x & 63u; }
 // rows (16-lane groups) of a wave and this lane's row
 constexpr int WAVE_ROWS = 4;
 USV_DEV unsigned wave_row() { return (threadIdx.x >> 4) & 3u; }
+// ---- the WIDE mapping of qp_ipm.hpp (ONE instance per wave: its four rows hold the same values and share out the stage-local row
+// work): what crosses rows.  xrow_*: all-reduce over the four lanes that sit at the same position of the four rows (ds_bpermute
+// through the LDS crossbar, no LDS memory); wave_first_i: lane 0's value in every lane; lds_fence: rows hand values to each other
+// through LDS - the operations of one wave execute in order, the fence only keeps the compiler from moving reads above writes.
+USV_DEV double xrow_shfl(double v, unsigned mask)
+{
+    const int addr = (int)((((unsigned)threadIdx.x & 63u) ^ mask) << 2);
+    const long l = __builtin_bit_cast(long, v);
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)l);
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, (int)(l >> 32));
+    return __builtin_bit_cast(double, ((long)(unsigned)lo) | ((long)hi << 32));
+}
+USV_DEV double xrow_max(double v) { v = vmax(v, xrow_shfl(v, 16u)); v = vmax(v, xrow_shfl(v, 32u)); return v; }
+USV_DEV double xrow_sum(double v) { v += xrow_shfl(v, 16u); v += xrow_shfl(v, 32u); return v; }
+USV_DEV int wave_first_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+USV_DEV void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 // the workgroup's dynamic LDS (one wave per workgroup in the QP kernel): the planes of PlanesLds, or the aux area of qp_ipm.hpp
 USV_DEV double *dyn_lds()
 {

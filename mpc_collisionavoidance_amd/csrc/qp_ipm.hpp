@@ -230,8 +230,17 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 // per stage) lives in the wave's LDS for the whole launch instead of being streamed with the planes: 4 reads + 2 writes of the
 // 59 + 13 plane accesses per stage and IPM iteration go (the kernel streams at the HBM ceiling: profiles/r03_bound_experiment.txt).
 // RTI launches whose horizon fits (host: usvmpc.hip); finish() leaves a copy in the HBM plane for the read-back paths.
-template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false>
+// WIDE (with LDSWS + MERGE, one obstacle chunk): the latency mapping - ONE instance per wave.  The four rows of the wave are given the
+// same instance and hold the same values; what a lone row spends most of a sweep on, the chains of a stage's box / obstacle rows
+// (stage-local: they depend on nothing outside their stage), the rows do for FOUR CONSECUTIVE STAGES at once - row r takes stage
+// kb -+ r of a block - and leave each stage's terms (Gamma, gamma, S_xx ...) in an exchange area of the workgroup's LDS; the
+// Riccati / forward recursion then runs over the block's stages in all four rows alike (a wave64 instruction costs the same for
+// one active row as for four: profiles/r03_exec16_microbench.txt).  Every sum is taken in the order of the 16-lane sweeps, so
+// the results equal theirs bit for bit; only row 0 writes results.
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false,
+          bool WIDE = false>
 struct QpIpm {
+    static_assert(!WIDE || (LDSWS && MERGE && KCH == 1 && HDIAG), "the wide mapping works on the merged one-chunk layout with the planes in LDS");
     static_assert(!MERGE || PACK, "merged row pass works on the packed layout");
     static_assert(!(AUXLDS && LDSWS), "with the whole workspace in LDS the aux plane is there already");
     static_assert(!PACK || KCH > 0, "box rows are packed into obstacle planes");
@@ -846,7 +855,7 @@ struct QpIpm {
     USV_DEV void obs_from(const StageIn &in, int k, double zbx, double zby, ObsRow &r, double &cx, double &cy) const
     {
         r.neutral();
-        if (k >= 1 && k < N) { // wave-uniform
+        if (WIDE || (k >= 1 && k < N)) { // wave-uniform (WIDE: k differs from row to row; obs_geom yields the inactive row of the other branch)
             // with a stage-independent obstacle set the data sits in per-lane constants: no copy in the prefetch
             const double cst[3] = {c_ox[C], c_oy[C], c_lh[C]};
             obs_geom<C>(k, zbx, zby, pstat ? cst : in.raw[C], r, cx, cy);
@@ -897,6 +906,7 @@ struct QpIpm {
     template <bool FACT>
     USV_DEV void backward(Norms &nm, double sigmu, bool pend, double a_prev, double sigmu_prev)
     {
+        if constexpr (WIDE) { backward_wide<FACT>(nm, sigmu, pend, a_prev, sigmu_prev); return; }
         constexpr int SW = FACT ? SW_BACK_A : SW_BACK_B;
         double Pn[NX], pn = 0.0, pin = 0.0;
         sfor<0, NX>([&](auto c) { Pn[c] = 0.0; });
@@ -1180,6 +1190,7 @@ struct QpIpm {
     template <bool FINAL>
     USV_DEV void forward(double sigmu, double &alpha, double &S1, double &S2)
     {
+        if constexpr (WIDE) { forward_wide<FINAL>(sigmu, alpha, S1, S2); return; }
         constexpr int SW = FINAL ? SW_FWD_B : SW_FWD_A;
         double dzx;
         {
@@ -1273,6 +1284,334 @@ struct QpIpm {
         }
         ws(N).st(FINAL ? P_DZ : P_DZA, dfr_dz);
         alpha = 1.0 / lanes::gmax(q); // q >= 1: alpha = min(1, min over blocking pairs of -v/dv)
+        if (!FINAL) { S1 = lanes::gsum(s1); S2 = lanes::gsum(s2); }
+    }
+
+    // ------------------------------------------------------------------ the sweeps of the WIDE mapping
+    // Exchange area behind the instance's planes in the workgroup's LDS: [row][EX_N][16 lanes].  Row r leaves the terms of the stage it
+    // has just processed in its own slice; the recursion reads slice j for the block's j-th stage in every row.
+    enum : int { EX_GHB = 0, EX_GAMB, EX_DLB, EX_SXX, EX_SXY, EX_SYY, EX_GX, EX_GY, EX_LX, EX_LY, EX_MU1, EX_MU2, EX_N };
+    static constexpr int wide_lds_doubles(int N_) { return (N_ + 1) * NPL * LANES + 4 * EX_N * LANES; }
+    USV_DEV unsigned ex_at(int row, int plane) const { return (unsigned)((N + 1) * NPL * LANES + (row * EX_N + plane) * LANES + lane); }
+    USV_DEV void ex_put(int row, int plane, double v) const { lanes::dyn_lds()[ex_at(row, plane)] = v; }
+    USV_DEV double ex_get(int row, int plane) const { return lanes::dyn_lds()[ex_at(row, plane)]; }
+    // the planes of stage k for the row phase: every row stores the rows of ITS stage (own = this row has a stage in the block)
+    USV_DEV Planes ws_row(int k, bool own) const { return Planes(loff + (unsigned)(k * NPL * LANES), own); }
+    // the row planes of a stage as obs_from wants them (all of them, whatever the stage: LDS, in bounds, unused values are masked)
+    USV_DEV void load_rows(int k, const Planes &W, StageIn &in) const
+    {
+        sfor<0, OBSN>([&](auto e) { in.obs[0][e] = W.ld(P_OBS + e); });
+        if (!pstat) obs_raw<0>(k, in.raw[0]);
+    }
+
+    template <bool FACT>
+    USV_DEV void backward_wide(Norms &nm, double sigmu, bool pend, double a_prev, double sigmu_prev)
+    {
+        const int row = (int)lanes::wave_row();
+        double Pn[NX], pn = 0.0, pin = 0.0;
+        sfor<0, NX>([&](auto c) { Pn[c] = 0.0; });
+        double rg_r = 0.0, rd_r = 0.0, rm_r = 0.0, nan_r = 0.0; // what the norms get from the rows this row has processed
+        if (FACT) {
+            nm.rg = nm.rb = nm.rd = nm.rm = nm.musum = nm.nan = 0.0;
+            rbscale = pend ? rbscale * (1.0 - a_prev) : rbscale; // the step applied in this sweep
+        }
+        for (int kb = N; kb >= 0; kb -= 4) {
+            // ---- row phase: row r on stage kb - r (with the pending update of the previous iteration applied first)
+            {
+                const int kr = kb - row;
+                const bool own = kr >= 0;
+                const int k = own ? kr : 0;
+                const Planes W = ws_row(k, own);
+                StageIn in;
+                const double z = W.ld(P_Z), aux = W.ld(P_AUX);
+                const double dzp = FACT ? W.ld(P_DZ) : 0.0;
+                const double dzs = W.ld(P_DZA);
+                load_rows(k, W, in);
+                const double dzap = FACT ? dzs : 0.0, dza = FACT ? 0.0 : dzs;
+                const double zbx = aux_zx(aux), zby = aux_zy(aux);
+                const double psel = pos_sel(zbx, zby);
+                const double znew = (FACT && pend) ? z + a_prev * dzp : z;
+                double Sxx = 0.0, Sxy = 0.0, Syy = 0.0, gx = 0.0, gy = 0.0, lx = 0.0, ly = 0.0, dl_m = 0.0, mu1 = 0.0, mu2 = 0.0;
+                ObsRow o;
+                double cx, cy, Gh, gam;
+                obs_from<0>(in, k, zbx, zby, o, cx, cy);
+                o.act = o.act && own;
+                if (FACT) {
+                    const double vo = rowdot<0>(cx, cy, z - psel, z), wp = rowdot<0>(cx, cy, dzp, dzp), wap = rowdot<0>(cx, cy, dzap, dzap);
+                    if (pend && o.act) {
+                        chain(o, vo, true, wap, sigmu_prev, Gh, gam);
+                        o.expand(wp);
+                        o.apply(a_prev);
+                    }
+                    if (pend && (o.act || isslot)) obs_store(W, 0, o, nullptr);
+                }
+                const double v = rowdot<0>(cx, cy, znew - psel, znew);
+                const double wa = FACT ? 0.0 : rowdot<0>(cx, cy, dza, dza);
+                chain(o, v, !FACT, wa, sigmu, Gh, gam);
+                gx += gam * cx; gy += gam * cy;
+                if (FACT) {
+                    Sxx += Gh * cx * cx; Sxy += Gh * cx * cy; Syy += Gh * cy * cy;
+                    const double dl_ = o.act ? o.ll - o.lu : 0.0;
+                    dl_m = dl_;
+                    lx += dl_ * cx; ly += dl_ * cy;
+                    if (o.act) {
+                        rd_r = lanes::vmax(rd_r, lanes::vmax_abs2(o.rdl, o.rdu));
+                        rm_r = lanes::vmax(rm_r, lanes::vmax(o.ll * o.tl, o.lu * o.tu));
+                        mu1 = o.ll * o.tl + o.lu * o.tu;
+                        nan_r = fma(0.0, o.rdl + o.rdu, nan_r);
+                        if constexpr (SOFT) {
+                            rg_r = lanes::vmax(rg_r, lanes::vmax_abs2(o.rsl, o.rsu));
+                            rd_r = lanes::vmax(rd_r, lanes::vmax_abs2(o.rdsl, o.rdsu));
+                            rm_r = lanes::vmax(rm_r, lanes::vmax(o.lsl * o.tsl, o.lsu * o.tsu));
+                            mu2 = o.lsl * o.tsl + o.lsu * o.tsu;
+                            nan_r = fma(0.0, o.rsl + o.rsu + o.rdsl + o.rdsu, nan_r);
+                        }
+                    }
+                }
+                gx = lanes::gsum(gx); gy = lanes::gsum(gy);
+                if (FACT) {
+                    Sxx = lanes::gsum(Sxx); Sxy = lanes::gsum(Sxy); Syy = lanes::gsum(Syy);
+                    lx = lanes::gsum(lx); ly = lanes::gsum(ly);
+                }
+                // the box rows' terms come home from their slot lanes (an inactive row has delivered zeros)
+                const double g1 = lanes::gather(gam, bsrc);
+                ex_put(row, EX_GAMB, hasb ? g1 : 0.0);
+                ex_put(row, EX_GX, gx); ex_put(row, EX_GY, gy);
+                if (FACT) {
+                    const double g0 = lanes::gather(Gh, bsrc), g2 = lanes::gather(dl_m, bsrc);
+                    ex_put(row, EX_GHB, hasb ? g0 : 0.0);
+                    ex_put(row, EX_DLB, hasb ? g2 : 0.0);
+                    ex_put(row, EX_SXX, Sxx); ex_put(row, EX_SXY, Sxy); ex_put(row, EX_SYY, Syy);
+                    ex_put(row, EX_LX, lx); ex_put(row, EX_LY, ly);
+                    ex_put(row, EX_MU1, mu1);
+                    if constexpr (SOFT) ex_put(row, EX_MU2, mu2);
+                    if (pend) W.st(P_Z, znew);
+                }
+            }
+            lanes::lds_fence();
+            // ---- the recursion over the block's stages, in all four rows alike
+            for (int j = 0; j < 4; j++) {
+                const int k = kb - j;
+                if (k < 0) break; // wave-uniform
+                const Planes W = ws(k);
+                double mpk[MP::NPK];
+                if (k < N) mat_issue(k, mpk);
+                const double z = W.ld(P_Z), aux = W.ld(P_AUX);
+                const double zbx = aux_zx(aux), zby = aux_zy(aux);
+                const double ou1 = ounit ? 1.0 : 0.0;
+                const double hd = (k < N) ? hd_stage : hd_term;
+                double rb = (FACT && k < N) ? W.ld(P_RB0) * rbscale : 0.0;
+                const double gamb = ex_get(j, EX_GAMB), gx = ex_get(j, EX_GX), gy = ex_get(j, EX_GY);
+                double Ghb = 0.0, dlb = 0.0, Sxx = 0.0, Sxy = 0.0, Syy = 0.0, lx = 0.0, ly = 0.0;
+                if (FACT) {
+                    Ghb = ex_get(j, EX_GHB); dlb = ex_get(j, EX_DLB);
+                    Sxx = ex_get(j, EX_SXX); Sxy = ex_get(j, EX_SXY); Syy = ex_get(j, EX_SYY);
+                    lx = ex_get(j, EX_LX); ly = ex_get(j, EX_LY);
+                    nm.musum += ex_get(j, EX_MU1);
+                    if constexpr (SOFT) nm.musum += ex_get(j, EX_MU2);
+                }
+                double bat[NX];
+                if (k < N) mat_unpack(mpk, bat); // wave-uniform
+                else sfor<0, NX>([&](auto jj) { bat[jj] = 0.0; });
+
+                double rg, pik = 0.0;
+                if (FACT) {
+                    double t = W.ld(P_GQ);
+                    t = fma(hd, z, t);
+                    lanes::settle(pin);
+                    dot_lanes<NONUNIT, NU>(t, pin, [&](auto jj) { return bat[jj]; });
+                    if constexpr (M::OUT_UNIT != 0u) t = fma(ou1, pin, t);
+                    t -= dlb;
+                    t -= isPX ? lx : (isPY ? ly : 0.0);
+                    pik = xlane ? t : 0.0;
+                    rg = (ulane && k < N) ? t : 0.0;
+                    if (!keep) W.st(P_PI, rg + pik); // rg lives on the u lanes, pik on the x lanes
+                    nm.rg = lanes::vmax_abs(nm.rg, rg);
+                    nm.nan = fma(0.0, t, nm.nan);
+                    nm.rb = lanes::vmax_abs(nm.rb, rb);
+                } else {
+                    rg = (k < N) ? aux_ulane<AXL_RG>(aux) : 0.0;
+                }
+                const double gt = rg + gamb + (isPX ? gx : (isPY ? gy : 0.0));
+
+                double pv, luv_new = 0.0;
+                if (k == N) {
+                    if (FACT) sfor<0, NX>([&](auto c) { Pn[c] = (lane == NU + c) ? hd : 0.0; });
+                    pv = xlane ? gt : 0.0;
+                } else {
+                    double Lzu[NU], iLd[NU], Pb;
+                    if (FACT) {
+                        Pb = 0.0;
+                        lanes::settle(rb);
+                        dot_lanes<XMASK, NU>(Pb, rb, [&](auto c) { return Pn[c]; });
+                        double T[NX];
+                        sfor<0, NX>([&](auto c) {
+                            double a = 0.0;
+                            dot_lanes<NONUNIT, NU>(a, Pn[c], [&](auto jj) { return bat[jj]; });
+                            if constexpr (M::OUT_UNIT != 0u) a = fma(ou1, Pn[c], a);
+                            T[c] = a;
+                        });
+                        auto gcol = [&](auto c) {
+                            double a = (lane == c) ? hd + Ghb : 0.0;
+                            if constexpr (c == PXL) a += isPX ? Sxx : (isPY ? Sxy : 0.0);
+                            if constexpr (c == PYL) a += isPX ? Sxy : (isPY ? Syy : 0.0);
+                            if constexpr (((M::IN_UNIT >> c) & 1u) != 0u) {
+                                if constexpr (c >= NU) a += T[c - NU];
+                            } else {
+                                dot_col<NONUNIT, c>(a, [&](auto jj) { return bat[jj]; }, [&](auto jj) { return T[jj]; });
+                                if constexpr (c >= NU) { if constexpr (out_unit(c - NU)) a += T[c - NU]; }
+                            }
+                            return a;
+                        };
+                        double Gu[NU > 0 ? NU : 1];
+                        sfor<0, NU>([&](auto c) { Gu[c] = gcol(c); });
+                        sfor<0, NU>([&](auto l) {
+                            const double il = lanes::frsqrt(lanes::bcast<l>(Gu[l]));
+                            Lzu[l] = Gu[l] * il;
+                            lanes::settle(Lzu[l]);
+                            iLd[l] = il;
+                            sfor<l + 1, NU>([&](auto m) { lanes::fma_bc<m>(Gu[m], Lzu[l], -Lzu[l]); });
+                        });
+                        sfor<0, NX>([&](auto c) {
+                            double a = gcol(std::integral_constant<int, NU + c>{});
+                            dot_col<(1u << NU) - 1u, NU + c>(a, [&](auto l) { return Lzu[l]; }, [&](auto l) { return -Lzu[l]; });
+                            Pn[c] = a;
+                        });
+                        W.st(P_PB, Pb);
+                        sfor<0, NU>([&](auto l) { W.st(P_LZU + l, (lane == l) ? iLd[l] : Lzu[l]); });
+                    } else {
+                        const double pb = W.ld(P_PB);
+                        Pb = xlane ? pb : 0.0;
+                        sfor<0, NU>([&](auto l) {
+                            Lzu[l] = W.ld(P_LZU + l);
+                            iLd[l] = lanes::bcast<l>(Lzu[l]); // (stored as the reciprocal)
+                        });
+                    }
+                    double h = Pb + pn;
+                    lanes::settle(h);
+                    double rq = gt;
+                    dot_lanes<NONUNIT, NU>(rq, h, [&](auto jj) { return bat[jj]; });
+                    if constexpr (M::OUT_UNIT != 0u) rq = fma(ou1, h, rq);
+                    double lu[NU], luv = 0.0;
+                    sfor<0, NU>([&](auto l) {
+                        double a = lanes::bcast<l>(rq);
+                        sfor<0, l>([&](auto m) { a -= lanes::bcast<l>(Lzu[m]) * lu[m]; });
+                        lu[l] = a * iLd[l];
+                        luv = (lane == l) ? lu[l] : luv;
+                    });
+                    pv = rq;
+                    sfor<0, NU>([&](auto l) { pv -= Lzu[l] * lu[l]; });
+                    pv = xlane ? pv : 0.0;
+                    luv_new = luv;
+                }
+                if (!keep) W.st(P_AUX, aux_compose(aux, zbx, zby, rg, luv_new));
+                pn = pv;
+                pin = pik;
+            }
+            lanes::lds_fence();
+        }
+        if (FACT) {
+            const Planes W0 = ws(0);
+            const double e0 = xlane ? W0.ld(P_DX0) - W0.ld(P_Z) : 0.0; // x0 - (xbar_0 + dx_0)
+            nm.rg = lanes::gmax(lanes::vmax(nm.rg, lanes::xrow_max(rg_r)));
+            nm.rb = lanes::gmax(fmax(nm.rb, fabs(e0)));
+            nm.rd = lanes::gmax(lanes::xrow_max(rd_r));
+            nm.rm = lanes::gmax(lanes::xrow_max(rm_r));
+            nm.musum = lanes::gsum(nm.musum);
+            nm.nan = lanes::gsum(nm.nan + lanes::xrow_sum(nan_r));
+        }
+    }
+
+    template <bool FINAL>
+    USV_DEV void forward_wide(double sigmu, double &alpha, double &S1, double &S2)
+    {
+        const int row = (int)lanes::wave_row();
+        double dzx;
+        {
+            const Planes W0 = ws(0);
+            dzx = xlane ? W0.ld(P_DX0) - W0.ld(P_Z) : 0.0;
+        }
+        double q = 1.0, s1 = 0.0, s2 = 0.0;
+        for (int kb = 0; kb <= N; kb += 4) {
+            // ---- the recursion over the block's stages, in all four rows alike; row r keeps the step of stage kb + r
+            double mydz = 0.0;
+            for (int j = 0; j < 4; j++) {
+                const int k = kb + j;
+                if (k > N) break; // wave-uniform
+                const Planes W = ws(k);
+                double mpk[MP::NPK], lzu[NU > 0 ? NU : 1], rb0 = 0.0;
+                const double aux = W.ld(P_AUX);
+                if (k < N) {
+                    mat_issue(k, mpk);
+                    sfor<0, NU>([&](auto l) { lzu[l] = W.ld(P_LZU + l); });
+                    rb0 = W.ld(P_RB0);
+                }
+                double dz;
+                if (k < N) {
+                    double t[NU], du[NU];
+                    sfor<0, NU>([&](auto l) {
+                        t[l] = lanes::bcast<AXL_LU - l>(aux) + lanes::gsum(xlane ? lzu[l] * dzx : 0.0);
+                    });
+                    sfor<0, NU>([&](auto qq) { // back substitution with Luu'
+                        constexpr int l = NU - 1 - qq;
+                        double acc = t[l];
+                        sfor<l + 1, NU>([&](auto m) { acc -= lanes::bcast<m>(lzu[l]) * du[m]; });
+                        du[l] = acc * lanes::bcast<l>(lzu[l]); // (the diagonal entry is stored as its reciprocal)
+                    });
+                    dz = xlane ? dzx : 0.0;
+                    sfor<0, NU>([&](auto l) { dz = (lane == l) ? -du[l] : dz; });
+                } else {
+                    dz = xlane ? dzx : 0.0;
+                }
+                W.st(FINAL ? P_DZ : P_DZA, dz);
+                mydz = (row == j) ? dz : mydz;
+                if (k < N) {
+                    const double dxn = mat_apply(mpk, dz, rb0 * rbscale);
+                    dzx = xlane ? dxn : 0.0;
+                }
+            }
+            lanes::lds_fence();
+            // ---- row phase: row r on the rows of stage kb + r
+            {
+                const int kr = kb + row;
+                const bool own = kr <= N;
+                const int k = own ? kr : N;
+                const Planes W = ws_row(k, false);
+                StageIn in;
+                const double z = W.ld(P_Z), aux = W.ld(P_AUX);
+                const double dz = mydz;
+                const double dza = FINAL ? W.ld(P_DZA) : dz;
+                load_rows(k, W, in);
+                const double zbx = aux_zx(aux), zby = aux_zy(aux);
+                ObsRow o;
+                double cx, cy, Gh2, gam2;
+                obs_from<0>(in, k, zbx, zby, o, cx, cy);
+                o.act = o.act && own;
+                const double v = rowdot<0>(cx, cy, z - pos_sel(zbx, zby), z);
+                const double w = rowdot<0>(cx, cy, dz, dz);
+                const double wa = FINAL ? rowdot<0>(cx, cy, dza, dza) : w;
+                chain(o, v, FINAL, wa, sigmu, Gh2, gam2);
+                o.expand(w);
+                q = o.blocking(q);
+                if (!FINAL) {
+                    ex_put(row, 0, o.act ? o.ll * o.dtl + o.tl * o.dll + o.lu * o.dtu + o.tu * o.dlu : 0.0);
+                    ex_put(row, 1, o.act ? o.dll * o.dtl + o.dlu * o.dtu : 0.0);
+                    if constexpr (SOFT) {
+                        ex_put(row, 2, o.act ? o.lsl * o.dtsl + o.tsl * o.dlsl + o.lsu * o.dtsu + o.tsu * o.dlsu : 0.0);
+                        ex_put(row, 3, o.act ? o.dlsl * o.dtsl + o.dlsu * o.dtsu : 0.0);
+                    }
+                }
+            }
+            if (!FINAL) { // the sums for mu_aff, stage by stage as the 16-lane sweep takes them
+                lanes::lds_fence();
+                for (int j = 0; j < 4; j++) {
+                    s1 += ex_get(j, 0); s2 += ex_get(j, 1);
+                    if constexpr (SOFT) { s1 += ex_get(j, 2); s2 += ex_get(j, 3); }
+                }
+                lanes::lds_fence();
+            }
+        }
+        alpha = 1.0 / lanes::gmax(lanes::xrow_max(q)); // q >= 1: alpha = min(1, min over blocking pairs of -v/dv)
         if (!FINAL) { S1 = lanes::gsum(s1); S2 = lanes::gsum(s2); }
     }
 
@@ -1546,11 +1885,12 @@ struct QpIpm {
         const bool bad0 = init(true);
         // ---- per-row state of the IPM (every row is in its own iteration)
         rbscale = 1.0;
+        const bool own = WIDE ? true : live;     // (WIDE: all four rows iterate on the wave's instance, row 0 - live - writes)
         bool real = g < nB && !frozen && live;   // the row holds an instance whose results are to be written
-        bool done = frozen || !live;             // nothing (more) to iterate on in this row
+        bool done = frozen || !own;              // nothing (more) to iterate on in this row
         bool pend = false;               // a step of the previous iteration is waiting to be applied
         bool fresh = false;              // cold-started after this pass's factorisation sweep: sits out the rest of the pass
-        bool late = bad0 && !frozen && live;     // stopped after the factorisation sweep (step-length floor), or never started
+        bool late = bad0 && !frozen && own;      // stopped after the factorisation sweep (step-length floor), or never started
                                          // (x0 inside a hard keep-out circle): results at the next pass
         int status = late ? 4 : 1, iters = 0, it = 0;
         done = done || late;
@@ -1580,13 +1920,18 @@ struct QpIpm {
                 if (refill) {
                     // one ticket per finished row; beyond the batch there is nothing left and the row stays idle
                     int gn = 0;
-                    if (fin && lane == 0) gn = queue0 + lanes::fetch_add(P.queue);
-                    gn = lanes::bcast_i<0>(gn);
+                    if constexpr (WIDE) { // one ticket for the wave
+                        if (fin && lanes::wave_lane() == 0u) gn = queue0 + lanes::fetch_add(P.queue);
+                        gn = lanes::wave_first_i(gn);
+                    } else {
+                        if (fin && lane == 0) gn = queue0 + lanes::fetch_add(P.queue);
+                        gn = lanes::bcast_i<0>(gn);
+                    }
                     const bool take = fin && gn < nB;
                     if (lanes::wave_any(take)) { // wave-uniform
                         bind((long)gn, take);
                         const bool bad = init(take) && take;
-                        real = take ? true : real;
+                        real = take ? (WIDE ? live : true) : real;
                         done = take ? bad : done;
                         late = bad;
                         fresh = take;

@@ -56,15 +56,17 @@ static void fiber_entry()
     for (;;) usv_emu_switch(&e.sp[e.cur], e.main_sp);
 }
 
-void run_group(long group, void (*body)(void *), void *arg)
+void run_group(long group, void (*body)(void *), void *arg, int rows)
 {
     Emu &e = g_emu;
     constexpr size_t STACK = 1 << 20;
-    static std::vector<char> stacks(GROUP * STACK);
+    static std::vector<char> stacks(MAXF * STACK);
+    const int NF = GROUP * rows;
     g_body = body;
     g_arg = arg;
     e.group = group;
-    for (int l = 0; l < GROUP; l++) {
+    e.rows = rows;
+    for (int l = 0; l < NF; l++) {
         char *top = stacks.data() + (size_t)(l + 1) * STACK;
         uintptr_t sp = ((uintptr_t)top) & ~(uintptr_t)15;
         void **s = (void **)sp;
@@ -80,14 +82,14 @@ void run_group(long group, void (*body)(void *), void *arg)
     }
     for (;;) {
         int nfin = 0;
-        for (int l = 0; l < GROUP; l++) {
+        for (int l = 0; l < NF; l++) {
             if (e.finished[l]) { nfin++; continue; }
             e.cur = l;
             usv_emu_switch(&e.main_sp, e.sp[l]);
             if (e.finished[l]) nfin++;
         }
-        if (nfin == GROUP) break;
-        for (int l = 0; l < GROUP; l++) {
+        if (nfin == NF) break;
+        for (int l = 0; l < NF; l++) {
             if (e.finished[l] != e.finished[0] || e.nops[l] != e.nops[0]) {
                 std::fprintf(stderr, "lane emulator: divergent cross-lane op (lane %d: %ld ops, fin %d; lane 0: %ld ops, fin %d)\n",
                              l, e.nops[l], (int)e.finished[l], e.nops[0], (int)e.finished[0]);
@@ -95,6 +97,8 @@ void run_group(long group, void (*body)(void *), void *arg)
             }
         }
     }
+    e.rows = 1;
+    e.cur = 0;
 }
 
 } // namespace lanes
@@ -107,6 +111,8 @@ struct Job { const DevPtrs *P; long gid; int qp_phase; int queue0; };
 int g_emu_lds_mode = 0; // 1: run the RTI solves with the workspace in (emulated) LDS
 int g_emu_merge = 1;    // 1: box rows processed in their slot lanes when all of them ride there (as the device library does)
 int g_emu_aux = 0;      // 1: RTI solves of the packed one-chunk layouts keep the aux plane in (emulated) LDS (AUXLDS instantiations)
+int g_emu_wide = 0;     // 1: RTI solves of the merged one-chunk layouts on the WIDE mapping (a whole emulated wave per instance)
+long g_emu_wide_runs = 0; // rows started on the WIDE mapping since the switch was set
 
 template <class M, int KCH, bool SOFT>
 void lin_body(void *a)
@@ -131,6 +137,23 @@ void qp_body(void *a)
     }
     QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, false, MERGE> q(*j->P, j->gid);
     q.solve(j->qp_phase, j->queue0);
+}
+
+// the WIDE mapping: the body runs on the 64 fibers of a whole wave; row 0 owns the LDS region, rows 1 - 3 share it
+template <class M, int KCH, bool SOFT>
+void qp_wide_body(void *a)
+{
+    Job *j = (Job *)a;
+    if constexpr (KCH == 1) {
+        QpIpm<M, KCH, SOFT, true, true, false, true, true, false, true> q(*j->P, j->gid, lanes::wave_row() == 0 ? 0 : -1);
+        q.solve(j->qp_phase, j->queue0);
+    }
+}
+template <class M, int KCH, bool SOFT>
+size_t wide_lds(int N)
+{
+    if constexpr (KCH == 1) return (size_t)QpIpm<M, KCH, SOFT, true, true, false, true, true, false, true>::wide_lds_doubles(N);
+    else return 0;
 }
 
 // multiplier read-back (QpIpm::export_rows) of one group, as the device's usv_qp_export kernel runs it
@@ -227,6 +250,13 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
             if (S.any_bsoft) {
                 if (S.hdiag) lanes::run_group(g, &qp_body<M, KCH, SOFT, true, false, true>, &j);
                 else lanes::run_group(g, &qp_body<M, KCH, SOFT, false, false, true>, &j);
+                continue;
+            }
+            if (KCH == 1 && g_emu_wide && qp_phase == 0 && S.hdiag && pack && !S.box_dense) {
+                lds.assign(wide_lds<M, KCH, SOFT>(S.N), 0.0);
+                lanes::g_emu_lds = lds.data();
+                lanes::run_group(g, &qp_wide_body<M, KCH, SOFT>, &j, 4);
+                g_emu_wide_runs++;
                 continue;
             }
             if (S.hdiag && pack && g_emu_merge && !S.box_dense) lanes::run_group(g, &qp_body<M, KCH, SOFT, true, CANPACK, false, CANPACK>, &j);
@@ -336,6 +366,8 @@ extern "C" void usv_emu_set_mode(int lds, long rows) { g_emu_lds_mode = lds; g_e
 extern "C" void usv_emu_set_merge(int merge) { g_emu_merge = merge; }
 extern "C" void usv_emu_set_cond(int N2) { g_emu_cond_N2 = N2; }
 extern "C" void usv_emu_set_aux(int aux) { g_emu_aux = aux; }
+extern "C" void usv_emu_set_wide(int wide) { g_emu_wide = wide; g_emu_wide_runs = 0; }
+extern "C" long usv_emu_wide_runs() { return g_emu_wide_runs; }
 // the next solves also deliver the multipliers / slacks of their QPs (the device's usvmpc_get "lam" / "t"); NULL switches it off
 extern "C" void usv_emu_set_export(double *lam, double *t) { g_emu_lam = lam; g_emu_t = t; }
 

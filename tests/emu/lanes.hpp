@@ -15,25 +15,27 @@
 namespace lanes {
 
 constexpr int GROUP = 16;
+constexpr int MAXF = 64;   // fibers of a whole emulated wave (the WIDE mapping of qp_ipm.hpp: four rows in lock step)
 
 struct Emu {
-    int cur = 0;           // lane currently running
+    int cur = 0;           // fiber currently running: row * 16 + lane
+    int rows = 1;          // rows emulated side by side (1: one 16-lane group; 4: a whole wave)
     long group = 0;        // group index handed to the body
-    double slot[2][GROUP]; // exchange buffers, double-buffered by parity
-    int par[GROUP];        // per-lane parity
-    long nops[GROUP];      // per-lane exchange counter (divergence check)
-    bool finished[GROUP];
-    void *sp[GROUP];       // saved stack pointers of the fibers
+    double slot[2][MAXF];  // exchange buffers, double-buffered by parity
+    int par[MAXF];         // per-lane parity
+    long nops[MAXF];       // per-lane exchange counter (divergence check)
+    bool finished[MAXF];
+    void *sp[MAXF];        // saved stack pointers of the fibers
     void *main_sp = nullptr;
 };
 extern Emu g_emu;
 extern "C" void usv_emu_switch(void **save_sp, void *load_sp);
 
-inline int lane() { return g_emu.cur; }
+inline int lane() { return g_emu.cur & 15; }
 inline long group_linear() { return g_emu.group; }
 
-// publish v, wait until all 16 lanes have published, return the value published by lane src
-inline double exchange(double v, int src)
+// publish v, wait until all lanes have published, return the value published by fiber src (of the whole emulated wave)
+inline double exchange_wave(double v, int src)
 {
     Emu &e = g_emu;
     const int me = e.cur;
@@ -42,8 +44,10 @@ inline double exchange(double v, int src)
     e.nops[me]++;
     usv_emu_switch(&e.sp[me], e.main_sp); // yield to the scheduler
     e.par[me] = p ^ 1;
-    return e.slot[p][src & 15];
+    return e.slot[p][src];
 }
+// ... by lane src of the caller's own row
+inline double exchange(double v, int src) { return exchange_wave(v, (g_emu.cur & ~15) | (src & 15)); }
 
 template <int K>
 inline double bcast(double v) { return exchange(v, K); }
@@ -64,7 +68,7 @@ inline void settle(double &) {} // hazard padding of the device build: nothing t
 inline double gather(double v, int src) { return exchange(v, src); }
 
 template <int N>
-inline double ror(double v) { return exchange(v, (g_emu.cur - N) & 15); }
+inline double ror(double v) { return exchange(v, (lane() - N) & 15); }
 
 inline double gsum(double v)
 {
@@ -115,8 +119,24 @@ inline void publish(int *flag, int v) { *flag = v; }
 inline int observe(const int *flag) { return *flag; }
 inline void set_bits(int *word, int bits) { *word |= bits; }
 
-// lane index inside the (emulated) wave: the group's quarter of its 4-group tile
-inline unsigned wave_lane() { return (unsigned)((g_emu.group & 3) * 16 + g_emu.cur); }
+// lane index inside the (emulated) wave: the group's quarter of its 4-group tile (a whole emulated wave: the fiber number)
+inline unsigned wave_lane() { return g_emu.rows > 1 ? (unsigned)g_emu.cur : (unsigned)((g_emu.group & 3) * 16 + g_emu.cur); }
+// across the rows of a whole emulated wave (gfx950/lanes.hpp): rendezvous of all its fibers
+inline double xrow_shfl(double v, unsigned mask) { return exchange_wave(v, (int)((unsigned)g_emu.cur ^ mask) % (16 * g_emu.rows)); }
+inline double xrow_max(double v)
+{
+    if (g_emu.rows < 4) return v;
+    v = std::fmax(v, xrow_shfl(v, 16u)); v = std::fmax(v, xrow_shfl(v, 32u));
+    return v;
+}
+inline double xrow_sum(double v)
+{
+    if (g_emu.rows < 4) return v;
+    v += xrow_shfl(v, 16u); v += xrow_shfl(v, 32u);
+    return v;
+}
+inline int wave_first_i(int v) { return (int)exchange_wave((double)v, 0); }
+inline void lds_fence() { (void)exchange(0.0, 0); }
 
 // the planes of one stage [group][plane][16] (plain pointers here; a buffer resource on the GPU)
 struct Planes {
@@ -143,7 +163,7 @@ struct Planes {
 // wave-private exchange area (gfx950/lanes.hpp): one emulated row, sync() is a rendezvous of its 16 lanes
 template <int NENT>
 struct Xpose {
-    static double *area() { static double s[NENT]; return s; }
+    static double *area() { static double s[4][NENT]; return s[g_emu.cur >> 4]; }
     static void put(int slot, double v) { area()[slot] = v; }
     static double get(int slot) { return area()[slot]; }
     static void sync() { (void)exchange(0.0, 0); }
@@ -152,7 +172,7 @@ struct Xpose {
 // per-lane constants parked in LDS (gfx950/lanes.hpp): one emulated row
 template <int NSLOT>
 struct Stash {
-    static double *area() { static double s[NSLOT * 16]; return s; }
+    static double *area() { static double s[4][NSLOT * 16]; return s[g_emu.cur >> 4]; }
     static void put(int slot, double v) { area()[slot * 16 + lane()] = v; }
     static double get(int slot) { return area()[slot * 16 + lane()]; }
 };
@@ -160,7 +180,7 @@ struct Stash {
 // the workgroup's LDS (one emulated row per "wave")
 extern double *g_emu_lds;
 constexpr int WAVE_ROWS = 1;
-inline unsigned wave_row() { return 0; }
+inline unsigned wave_row() { return (unsigned)(g_emu.cur >> 4); }
 inline double *dyn_lds() { return g_emu_lds; }
 struct PlanesLds {
     unsigned off;
@@ -170,8 +190,8 @@ struct PlanesLds {
     void st(int plane, double x) const { if (live) g_emu_lds[off + plane * 16] = x; }
 };
 
-// run body(lane) on 16 fibers in lock step
-void run_group(long group, void (*body)(void *), void *arg);
+// run body(lane) on 16 fibers in lock step (rows = 4: on the 64 fibers of a whole wave, every row handed the same group)
+void run_group(long group, void (*body)(void *), void *arg, int rows = 1);
 
 } // namespace lanes
 

@@ -1,0 +1,47 @@
+"""The WIDE mapping of the QP kernel (qp_ipm.hpp: ONE instance per wave - the four rows of the wave share out the stage-local row work
+of four consecutive stages, the Riccati / forward recursion runs in all rows alike) on the lane emulator, a whole wave of 64 fibers
+per instance: iterates, statuses, iteration counts, residuals, slacks and multipliers equal the 16-lane sweeps' BIT FOR BIT (every
+sum is taken in the same order), with and without the work queue, horizons that are and are not a multiple of the block of four."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mpc_collisionavoidance_amd import _capi, scenario, usv_models
+from tests.test_emu_kernels import emu_rti, _d
+
+
+@pytest.mark.parametrize("name,N,K,rows", [("usv_model_pf_ca", 8, 3, 2), ("usv_model_pf_ca", 7, 4, 0), ("usv_model_pf_ca", 6, 9, 2),
+                                           ("usv_model_pf_ca", 5, 1, 1), ("usv_model_guidance_ca1", 7, 8, 2), ("usv_model_guidance_ca1", 6, 3, 0)])
+def test_wide_mapping_equals_the_16_lane_sweeps_bit_for_bit(emu, name, N, K, rows):
+    B = 5
+    wl = scenario.make_batch(name, N, K, B, dt=0.05, seed=17, generator="survey", sim_steps=scenario.BENCH_SIM_STEPS[name], clip_time=0.1)
+    ocp = usv_models.make_ocp(name, N * 0.05, N, K)
+    ocp.solver_options.sim_method_num_steps = scenario.BENCH_SIM_STEPS[name]
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    soft = name == "usv_model_guidance_ca1"
+    nlam = 2 * (desc.nbu + desc.nbx + K + (K if soft else 0))
+    emu.usv_emu_set_wide.argtypes = [C.c_int]
+    emu.usv_emu_set_mode.argtypes = [C.c_int, C.c_long]
+    emu.usv_emu_set_export.argtypes = [_capi._dp, _capi._dp]
+    emu.usv_emu_set_export.restype = None
+    out = []
+    try:
+        emu.usv_emu_set_mode(1, rows)   # (both with the workspace in emulated LDS)
+        for wide in (0, 1):
+            emu.usv_emu_set_wide(wide)
+            lam, t = np.zeros((B, N + 1, nlam)), np.zeros((B, N + 1, nlam))
+            emu.usv_emu_set_export(_d(lam), _d(t))
+            r = emu_rti(emu, desc, wl, wl["x_init"], wl["u_init"])
+            r2 = emu_rti(emu, desc, wl, r["x"], r["u"])
+            if wide:
+                emu.usv_emu_wide_runs.restype = C.c_long
+                assert emu.usv_emu_wide_runs() == 2 * (rows if 0 < rows < B else (B + 3) // 4 * 4)   # (the wide sweeps did run)
+            out.append((r2["x"], r2["u"], r2["status"], r2["qp_status"], r2["qp_iter"], r2["sl"], r2["su"], r2["pi"], r2["res"], lam.copy(), t.copy()))
+    finally:
+        emu.usv_emu_set_wide(0)
+        emu.usv_emu_set_mode(0, 2)
+        emu.usv_emu_set_export(None, None)
+    assert (out[0][2] == 0).any() and out[0][9].any() and out[0][4].max() >= 3
+    for n, (a, b) in enumerate(zip(out[0], out[1])):
+        assert np.array_equal(a, b), (n, np.abs(np.asarray(a, float) - np.asarray(b, float)).max())

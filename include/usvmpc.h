@@ -151,6 +151,12 @@ int usvmpc_unconverged_counts(usvmpc_handle *h, int n, int *counts);
  * were used by the following solve / discarded because the caller wrote x, u or yref in between.  The lineariser only runs ahead after
  * two solves in a row without such a write, so a caller that sets yref every tick (the reference's protocol) discards none. */
 int usvmpc_pipeline_stats(usvmpc_handle *h, long *used, long *discarded);
+/* Which mapping the last RTI solve ran on: 0 = four instances per wavefront (one per 16-lane row: the throughput mapping), 1 = ONE
+ * instance per wavefront (option "wide": the latency mapping north_star names - the four rows of the wave share out the stage-local
+ * constraint-row work of four consecutive stages; taken by default for batches that leave SIMDs idle, when the OCP's layout allows:
+ * one obstacle chunk (K <= 16), every box row riding in an idle obstacle lane, the horizon's planes within a CU's LDS).  Results are
+ * bit-identical on both.  The reference solves one instance per call: nmpc_guidance_ca1.cpp:577,612, usv_pf_ca/main.py:142-186. */
+int usvmpc_last_mapping(usvmpc_handle *h, int *mapping);
 /* Closed-loop hand-over on the device: x0 <- x_1 (+ sigma * N(0,1) on the states selected by option
  * "disturbance_mask", default all), enqueued on the stream.
  * Replaces x0 = solver.get(1,"x"); solver.set(0,"lbx",x0); solver.set(0,"ubx",x0)
@@ -183,6 +189,8 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  *   "merge_box_rows" (default 1) - when every box row rides in an idle lane of the last obstacle chunk's planes the sweeps
  *       process them there (one row pass instead of two).  A separately compiled instantiation: statuses and iteration
  *       counts equal, iterates agree to rounding - as with "lds_workspace";
+ *   "wide" (default -1) - the latency mapping, ONE instance per wavefront (usvmpc_last_mapping): -1 while the batch fits the device's
+ *       SIMDs twice over, 0 never, 1 whenever the OCP's layout allows it; results do not change by a bit;
  *   "aux_in_lds" (default 1) - an RTI solve keeps the per-stage aux plane (dense box rows, linearisation point, r_g, l_u) in the
  *       wavefronts' LDS instead of streaming it, when the horizon fits without costing a resident wavefront (a separately
  *       compiled instantiation of the same arithmetic: results equal to rounding at most);

@@ -329,6 +329,12 @@ class BatchOcpSolver:
         self._check(self._lib.usvmpc_pipeline_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def last_mapping(self):
+        """0: the last RTI solve ran four instances per wavefront; 1: one instance per wavefront (option "wide", usvmpc_last_mapping)."""
+        a = C.c_int()
+        self._check(self._lib.usvmpc_last_mapping(self._h, C.byref(a)))
+        return a.value
+
     def unconverged_counts(self, n):
         """Instances whose QP did not converge to the IPM tolerances (qp_status != 0) in each of the last n solves (oldest first)."""
         a = (C.c_int * n)()

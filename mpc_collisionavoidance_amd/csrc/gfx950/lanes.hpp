@@ -402,4 +402,23 @@ struct PlanesLds {
     }
 };
 
+// The planes of the WIDE mapping in LDS: only those the solve writes live there (MAP::at(plane): position among them; the unused box
+// planes of the packed layouts are squeezed out, the lineariser's planes - read once per sweep - stay in HBM / L2).
+template <class MAP>
+struct PlanesLdsMapped {
+    unsigned off;
+    bool live;
+    USV_DEV PlanesLdsMapped(unsigned off_, bool live_) : off(off_), live(live_) {}
+    USV_DEV double ld(int plane) const
+    {
+        extern __shared__ double usv_lds[];
+        return usv_lds[off + MAP::at(plane) * 16];
+    }
+    USV_DEV void st(int plane, double x) const
+    {
+        extern __shared__ double usv_lds[];
+        if (live) usv_lds[off + MAP::at(plane) * 16] = x;
+    }
+};
+
 } // namespace lanes

@@ -110,6 +110,9 @@ struct MatPack {
 // window per stage so that the QP kernel needs one buffer descriptor and compile-time plane numbers (separate
 // arrays cost scalar registers, and once those ran out the compiler moved plane offsets to vector registers
 // and wrapped the loads in waterfall loops).
+// planes of the exchange area of the wide mapping (qp_ipm.hpp, WIDE: [4 rows][WIDE_EX_PLANES][16 lanes] behind the instance's planes in LDS)
+constexpr int WIDE_EX_PLANES = 12;
+
 template <class M, int KCH, bool SOFT, bool SOFTBOX = false>
 struct WsLayout {
     // P_Z   : the QP iterate in absolute form, zbar + z (what the box rows and the Hessian product need); the step z of an

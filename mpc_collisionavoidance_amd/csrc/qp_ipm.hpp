@@ -308,7 +308,14 @@ struct QpIpm {
 
     using BoxRow = RowCalc<SOFTBOX, SOFTBOX>;
     using ObsRow = RowCalc<SOFT, SOFT && MERGE>; // (merged: the chunk's slot lanes carry hard box rows next to soft obstacle rows)
-    using Planes = std::conditional_t<LDSWS, lanes::PlanesLds, lanes::Planes>;
+    // WIDE: the LDS holds what the solve writes - P_Z .. P_PI, the row planes, L_zu; the four box planes the packed layouts never
+    // touch are squeezed out and the lineariser's planes (P_RB0, P_GQ, P_MAT..: read once per sweep) stay in HBM, so that the
+    // horizon of an instance takes half the LDS and twice as many waves are resident.
+    struct WideMap {
+        static constexpr int at(int plane) { return plane < WL::P_BLL ? plane : (plane >= WL::P_OBS && plane < WL::P_RB0 ? plane - 4 : -1); }
+    };
+    static constexpr int NPLW = WIDE ? WL::P_RB0 - 4 : WL::NPT; // planes per stage of an LDS region
+    using Planes = std::conditional_t<WIDE, lanes::PlanesLdsMapped<WideMap>, std::conditional_t<LDSWS, lanes::PlanesLds, lanes::Planes>>;
 
     const DevPtrs &P;
     const DevSpec &S;
@@ -483,7 +490,7 @@ struct QpIpm {
         }
         g = 0; b = 0;
         live = lds_row >= 0;
-        loff = (unsigned)((lds_row > 0 ? lds_row : 0) * (N + 1) * NPL * LANES + lane);
+        loff = (unsigned)((lds_row > 0 ? lds_row : 0) * (N + 1) * NPLW * LANES + lane);
         if constexpr (KCH > 0) sfor<0, KCH>([&](auto c) { c_ox[c] = 0.0; c_oy[c] = 0.0; c_lh[c] = 0.0; });
         bind(g_, true);
         if constexpr (KCH > 0 && SOFT) {
@@ -521,7 +528,7 @@ struct QpIpm {
     USV_DEV lanes::Planes wsg(int k) const { return lanes::Planes(P.ws + (long)k * stage_stride, stage_bytes, voff); }
     USV_DEV Planes ws(int k) const
     {
-        if constexpr (LDSWS) return Planes(loff + (unsigned)(k * NPL * LANES), live);
+        if constexpr (LDSWS) return Planes(loff + (unsigned)(k * NPLW * LANES), live);
         else return wsg(k);
     }
     // the aux plane of stage k: from / to the wave's LDS area (AUXLDS) or the workspace plane
@@ -694,7 +701,7 @@ struct QpIpm {
         for (int k = 0; k <= N; k++) {
             const Planes W = ws(k);
             const double zb = zbar(k);
-            if constexpr (LDSWS) { // the linearisation of this stage comes in from HBM
+            if constexpr (LDSWS && !WIDE) { // the linearisation of this stage comes in from HBM
                 const lanes::Planes G = wsg(k);
                 const double gq = G.ld(P_GQ), rb = (k < N) ? G.ld(P_RB0) : 0.0;
                 double mpk[MP::NPK];
@@ -1291,12 +1298,27 @@ struct QpIpm {
     // Exchange area behind the instance's planes in the workgroup's LDS: [row][EX_N][16 lanes].  Row r leaves the terms of the stage it
     // has just processed in its own slice; the recursion reads slice j for the block's j-th stage in every row.
     enum : int { EX_GHB = 0, EX_GAMB, EX_DLB, EX_SXX, EX_SXY, EX_SYY, EX_GX, EX_GY, EX_LX, EX_LY, EX_MU1, EX_MU2, EX_N };
-    static constexpr int wide_lds_doubles(int N_) { return (N_ + 1) * NPL * LANES + 4 * EX_N * LANES; }
-    USV_DEV unsigned ex_at(int row, int plane) const { return (unsigned)((N + 1) * NPL * LANES + (row * EX_N + plane) * LANES + lane); }
+    static_assert(EX_N == WIDE_EX_PLANES, "host-side size of the exchange area");
+    static constexpr int wide_lds_doubles(int N_) { return (N_ + 1) * NPLW * LANES + 4 * EX_N * LANES; }
+    USV_DEV unsigned ex_at(int row, int plane) const { return (unsigned)((N + 1) * NPLW * LANES + (row * EX_N + plane) * LANES + lane); }
     USV_DEV void ex_put(int row, int plane, double v) const { lanes::dyn_lds()[ex_at(row, plane)] = v; }
     USV_DEV double ex_get(int row, int plane) const { return lanes::dyn_lds()[ex_at(row, plane)]; }
     // the planes of stage k for the row phase: every row stores the rows of ITS stage (own = this row has a stage in the block)
-    USV_DEV Planes ws_row(int k, bool own) const { return Planes(loff + (unsigned)(k * NPL * LANES), own); }
+    USV_DEV Planes ws_row(int k, bool own) const { return Planes(loff + (unsigned)(k * NPLW * LANES), own); }
+    // the lineariser's planes of a stage, for the recursion: from HBM / L2, asked for one stage ahead of their use
+    struct SeqIn { double mpk[MP::NPK], gq, rb; };
+    template <bool WANT_GQ>
+    USV_DEV void seq_load(int k, SeqIn &si) const
+    {
+        const lanes::Planes G = wsg(k);
+        if (k < N) { // wave-uniform
+            sfor<0, MP::NPK>([&](auto q) { si.mpk[q] = G.ld(P_MAT + q); });
+            si.rb = G.ld(P_RB0);
+        } else {
+            si.rb = 0.0;
+        }
+        if (WANT_GQ) si.gq = G.ld(P_GQ);
+    }
     // the row planes of a stage as obs_from wants them (all of them, whatever the stage: LDS, in bounds, unused values are masked)
     USV_DEV void load_rows(int k, const Planes &W, StageIn &in) const
     {
@@ -1315,6 +1337,8 @@ struct QpIpm {
             nm.rg = nm.rb = nm.rd = nm.rm = nm.musum = nm.nan = 0.0;
             rbscale = pend ? rbscale * (1.0 - a_prev) : rbscale; // the step applied in this sweep
         }
+        SeqIn nxt;
+        seq_load<FACT>(N, nxt);
         for (int kb = N; kb >= 0; kb -= 4) {
             // ---- row phase: row r on stage kb - r (with the pending update of the previous iteration applied first)
             {
@@ -1394,13 +1418,13 @@ struct QpIpm {
                 const int k = kb - j;
                 if (k < 0) break; // wave-uniform
                 const Planes W = ws(k);
-                double mpk[MP::NPK];
-                if (k < N) mat_issue(k, mpk);
+                const SeqIn cur = nxt;
+                if (k > 0) seq_load<FACT>(k - 1, nxt);
                 const double z = W.ld(P_Z), aux = W.ld(P_AUX);
                 const double zbx = aux_zx(aux), zby = aux_zy(aux);
                 const double ou1 = ounit ? 1.0 : 0.0;
                 const double hd = (k < N) ? hd_stage : hd_term;
-                double rb = (FACT && k < N) ? W.ld(P_RB0) * rbscale : 0.0;
+                double rb = FACT ? cur.rb * rbscale : 0.0;
                 const double gamb = ex_get(j, EX_GAMB), gx = ex_get(j, EX_GX), gy = ex_get(j, EX_GY);
                 double Ghb = 0.0, dlb = 0.0, Sxx = 0.0, Sxy = 0.0, Syy = 0.0, lx = 0.0, ly = 0.0;
                 if (FACT) {
@@ -1411,12 +1435,12 @@ struct QpIpm {
                     if constexpr (SOFT) nm.musum += ex_get(j, EX_MU2);
                 }
                 double bat[NX];
-                if (k < N) mat_unpack(mpk, bat); // wave-uniform
+                if (k < N) mat_unpack(cur.mpk, bat); // wave-uniform
                 else sfor<0, NX>([&](auto jj) { bat[jj] = 0.0; });
 
                 double rg, pik = 0.0;
                 if (FACT) {
-                    double t = W.ld(P_GQ);
+                    double t = cur.gq;
                     t = fma(hd, z, t);
                     lanes::settle(pin);
                     dot_lanes<NONUNIT, NU>(t, pin, [&](auto jj) { return bat[jj]; });
@@ -1532,6 +1556,8 @@ struct QpIpm {
             dzx = xlane ? W0.ld(P_DX0) - W0.ld(P_Z) : 0.0;
         }
         double q = 1.0, s1 = 0.0, s2 = 0.0;
+        SeqIn nxt;
+        seq_load<false>(0, nxt);
         for (int kb = 0; kb <= N; kb += 4) {
             // ---- the recursion over the block's stages, in all four rows alike; row r keeps the step of stage kb + r
             double mydz = 0.0;
@@ -1539,13 +1565,11 @@ struct QpIpm {
                 const int k = kb + j;
                 if (k > N) break; // wave-uniform
                 const Planes W = ws(k);
-                double mpk[MP::NPK], lzu[NU > 0 ? NU : 1], rb0 = 0.0;
+                const SeqIn cur = nxt;
+                if (k < N) seq_load<false>(k + 1, nxt);
+                double lzu[NU > 0 ? NU : 1];
                 const double aux = W.ld(P_AUX);
-                if (k < N) {
-                    mat_issue(k, mpk);
-                    sfor<0, NU>([&](auto l) { lzu[l] = W.ld(P_LZU + l); });
-                    rb0 = W.ld(P_RB0);
-                }
+                if (k < N) sfor<0, NU>([&](auto l) { lzu[l] = W.ld(P_LZU + l); });
                 double dz;
                 if (k < N) {
                     double t[NU], du[NU];
@@ -1566,7 +1590,7 @@ struct QpIpm {
                 W.st(FINAL ? P_DZ : P_DZA, dz);
                 mydz = (row == j) ? dz : mydz;
                 if (k < N) {
-                    const double dxn = mat_apply(mpk, dz, rb0 * rbscale);
+                    const double dxn = mat_apply(cur.mpk, dz, cur.rb * rbscale);
                     dzx = xlane ? dxn : 0.0;
                 }
             }

@@ -53,15 +53,24 @@ constexpr int qp_waves() { return (KCH >= 2 || SOFTBOX) ? 1 : USV_QP_WAVES; }
 // rows: instances a wave starts on (4; fewer when the workspace lives in LDS and only that many fit: LDSWS) - row r of block b
 // starts on group b * rows + r, surplus rows stay idle.
 // AUXLDS: the aux plane of the rows' instances in the wave's LDS instead of HBM (qp_ipm.hpp)
-template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false>
+// WIDE: the latency mapping - one instance per wave (rows = 1: rows 1 - 3 are handed row 0's group and share its LDS region; in the
+// sweeps they take over the row work of the neighbouring stages: qp_ipm.hpp)
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false, bool WIDE = false>
 __global__ void __launch_bounds__(64, (LDSWS ? 1 : qp_waves<KCH, SOFTBOX>())) usv_qp_rti(DevPtrs P, long ngroups, int phase, int queue0, int rows)
 {
     const int row = (int)(threadIdx.x >> 4);
     const long g0 = (long)blockIdx.x * rows;
     if (g0 >= ngroups) return;
     const bool has = row < rows;
-    QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, LDSWS, MERGE, AUXLDS> q(P, has ? g0 + row : g0, has ? row : -1);
+    QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, LDSWS, MERGE, AUXLDS, WIDE> q(P, has ? g0 + row : g0, has ? row : -1);
     q.solve(phase, queue0);
+}
+// (the wide instantiation exists for the one-chunk layouts only)
+template <class M, int KCH, bool SOFT>
+constexpr auto wide_kernel()
+{
+    if constexpr (KCH == 1) return &usv_qp_rti<M, KCH, SOFT, true, true, false, true, true, false, true>;
+    else return (decltype(&usv_qp_rti<M, KCH, SOFT, true, (KCH > 0), false, true, (KCH > 0)>))nullptr;
 }
 
 // Multiplier read-back (usvmpc_get "lam" / "t"): the inequality multipliers and slacks of every instance's last QP, from the
@@ -260,6 +269,9 @@ struct usvmpc_handle {
     bool dynamic_rows;        // QP kernel as a persistent launch whose rows pull instances from a queue (option "dynamic_rows")
     int lds_mode;             // workspace of the QP kernel in LDS: -1 when the batch is small enough (default), 0 never, 1 whenever it fits
     long lds_cap;             // waves an LDS-workspace launch holds at once (0: not yet known)
+    int wide_mode;            // the latency mapping (one instance per wave, QpIpm WIDE): -1 for small batches (default), 0 never, 1 whenever it applies
+    long wide_cap;            // waves a launch of the wide kernel holds at once (0: not yet known, -1: does not fit)
+    int last_wide;            // the last RTI launch ran on the wide kernel
     long max_waves;           // cap on the persistent waves of the QP kernel (0: as many as the device holds)
     int ncu;                  // compute units of the device
     long qp_cap;              // groups a full-occupancy launch of the QP kernel holds at once (0: not yet known)
@@ -689,8 +701,38 @@ int launch_pair(usvmpc_handle *h, int phase)
     // Small batches: the planes of every instance in flight fit in LDS (160 KB per CU), and a solve whose sweeps wait for
     // HBM at every stage - nothing else runs on the CU to hide it - becomes a solve on LDS.  rows_lds instances per wave
     // (as many whole horizons as fit), one wave per CU at a time; further instances come through the same queue.
-    auto launch_qp = [&](auto kern, decltype(kern) kern_lds, decltype(kern) kern_aux = nullptr) -> int {
+    auto launch_qp = [&](auto kern, decltype(kern) kern_lds, decltype(kern) kern_aux = nullptr, decltype(kern) kern_wide = nullptr) -> int {
         const long lds_inst = (long)(h->N + 1) * h->spec.npt * 128;
+        h->last_wide = 0;
+        // The latency mapping: ONE instance per wave (qp_ipm.hpp, WIDE) - planes in LDS, the four rows share out the stage-local row
+        // work.  A wave then finishes an instance ~1.8x sooner and the device holds a quarter of the instances at once: it pays while
+        // the batch leaves SIMDs idle anyway (a solve of the batch then lasts as long as its hardest instance on a lone wave).
+        if (kern_wide != nullptr && phase == 0 && h->wide_mode != 0 && h->ncu > 0) {
+            // (in LDS: the planes the solve writes - WsLayout's up to L_zu less the four box planes the packed layouts leave unused)
+            const size_t bytes = (size_t)(h->N + 1) * (size_t)(WsLayout<M, KCH, SOFT>::P_RB0 - 4) * 128 + (size_t)4 * WIDE_EX_PLANES * 128;
+            if (h->wide_cap == 0) {
+                int nb = 0;
+                hipFuncAttributes fa;
+                if (bytes <= 160u * 1024u && hipFuncGetAttributes(&fa, (const void *)kern_wide) == hipSuccess && fa.sharedSizeBytes + bytes <= 160u * 1024u &&
+                    hipFuncSetAttribute((const void *)kern_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess &&
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern_wide, qp_block, bytes) == hipSuccess && nb > 0)
+                    h->wide_cap = (long)std::min(nb, 4) * h->ncu;   // (one wave per SIMD at most: the point is a lone wave's issue rate)
+                else
+                    h->wide_cap = -1;
+            }
+            // default: while the batch fits the SIMDs twice over (the queue hands the second half to the waves that finish first)
+            const bool take = h->wide_cap > 0 && (h->wide_mode > 0 || (long)h->B <= 2 * h->wide_cap);
+            if (take) {
+                long nw = (long)h->B;
+                int q0 = -1;
+                if (h->dynamic_rows && nw > h->wide_cap) { nw = h->wide_cap; q0 = (int)nw; }
+                if (!h->dynamic_rows && nw > h->wide_cap) { /* without the queue every instance needs its wave at launch: still correct, later workgroups wait */ }
+                if (q0 >= 0) HIP_TRY(h, hipMemsetAsync(h->ptrs.queue, 0, sizeof(int), h->stream));
+                hipLaunchKernelGGL(kern_wide, dim3((unsigned)nw), dim3(qp_block), bytes, h->stream, h->ptrs, nw, phase, q0, 1);
+                h->last_wide = 1;
+                return 0;
+            }
+        }
         // (the kernel's own static LDS - exchange area, parked constants - comes out of the same 160 KB)
         long lds_static = 0;
         if (kern_lds != nullptr) {
@@ -764,7 +806,7 @@ int launch_pair(usvmpc_handle *h, int phase)
     // (one row pass when every box row rides in a slot lane: qp_ipm.hpp, MERGE)
     if (h->merge_rows && !h->spec.box_dense)
         rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true, CANPACK>,
-                        &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>);
+                        &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>, wide_kernel<M, KCH, SOFT>());
     else
         rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>,
                         &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>);
@@ -776,7 +818,7 @@ int launch_pair(usvmpc_handle *h, int phase)
         // (the packed layouts - every OCP of the reference, the bench workloads - also come with the aux plane in LDS)
         if (pack && h->merge_rows && !h->spec.box_dense)
             rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true, CANPACK>,
-                            &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>);
+                            &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>, wide_kernel<M, KCH, SOFT>());
         else
             rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>,
                                    &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>)
@@ -997,6 +1039,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->aux_cap = 0;
     h->lds_mode = -1;
     h->lds_cap = 0;
+    h->wide_mode = -1; h->wide_cap = 0; h->last_wide = 0;
     h->max_waves = 0;
     {
         hipDeviceProp_t prop;
@@ -1346,6 +1389,13 @@ int usvmpc_pipeline_stats(usvmpc_handle *h, long *used, long *discarded)
     return 0;
 }
 
+int usvmpc_last_mapping(usvmpc_handle *h, int *mapping)
+{
+    if (!h || !mapping) return USVMPC_E_ARG;
+    *mapping = h->last_wide;
+    return 0;
+}
+
 int usvmpc_last_kernel_ms(usvmpc_handle *h, float *linearize_ms, float *qp_ms)
 {
     return usvmpc_kernel_ms(h, 1, linearize_ms, qp_ms);
@@ -1412,6 +1462,11 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         h->lds_cap = 0;
         return 0;
     }
+    if (s == "wide") { // the latency mapping, one instance per wave: -1 for batches that leave SIMDs idle (default), 0 never, 1 whenever it applies
+        h->wide_mode = value < 0.0 ? -1 : (value > 0.0 ? 1 : 0);
+        h->wide_cap = 0;
+        return 0;
+    }
     if (s == "dynamic_rows") { // 0: one group per row for the whole launch (the rows of a wave wait for its slowest)
         h->dynamic_rows = value != 0.0;
         h->qp_cap = 0; h->aux_cap = 0;
@@ -1423,7 +1478,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
     }
     if (s == "merge_box_rows") { // 1 (default): box rows processed in their slot lanes when all of them ride there
         h->merge_rows = value != 0.0;
-        h->qp_cap = 0; h->lds_cap = 0; h->aux_cap = 0;
+        h->qp_cap = 0; h->lds_cap = 0; h->aux_cap = 0; h->wide_cap = 0;
         return 0;
     }
     if (s == "host_mirror") { // 0: drop the pinned host mirror of the caller-visible arrays (every set / get then goes to the device)

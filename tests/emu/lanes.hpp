@@ -190,6 +190,23 @@ struct PlanesLds {
     void st(int plane, double x) const { if (live) g_emu_lds[off + plane * 16] = x; }
 };
 
+template <class MAP>
+struct PlanesLdsMapped {
+    unsigned off;
+    bool live;
+    PlanesLdsMapped(unsigned o, bool l) : off(o), live(l) {}
+    double ld(int plane) const
+    {
+        if (MAP::at(plane) < 0) { std::fprintf(stderr, "PlanesLdsMapped::ld of a plane that is not kept in LDS (%d)\n", plane); std::abort(); }
+        return g_emu_lds[off + MAP::at(plane) * 16];
+    }
+    void st(int plane, double x) const
+    {
+        if (MAP::at(plane) < 0) { std::fprintf(stderr, "PlanesLdsMapped::st of a plane that is not kept in LDS (%d)\n", plane); std::abort(); }
+        if (live) g_emu_lds[off + MAP::at(plane) * 16] = x;
+    }
+};
+
 // run body(lane) on 16 fibers in lock step (rows = 4: on the 64 fibers of a whole wave, every row handed the same group)
 void run_group(long group, void (*body)(void *), void *arg, int rows = 1);
 

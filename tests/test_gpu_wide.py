@@ -1,0 +1,99 @@
+"""The latency mapping on the device (option "wide": ONE instance per wavefront, qp_ipm.hpp WIDE / usvmpc_last_mapping) against the
+throughput mapping (four instances per wavefront).  The wide sweeps take every sum in the order of the 16-lane sweeps: on the lane
+emulator, where no multiply-add is contracted, the two are bit-identical (tests/test_wide_emu.py).  On the device they are two
+instantiations the compiler contracts differently, so - as for the LDS / HBM workspace pair - the comparison is: statuses and
+iteration counts equal, iterates and multipliers equal to rounding, tick by tick FROM IDENTICAL INPUTS over a closed loop, with the
+work queue (more instances than resident waves) and without, hard-row and soft-row model, down to ONE instance.
+Parity of the wide mapping against the oracle at BASELINE configs[1]'s full size: tests/test_gpu_parity.py (its default there)."""
+import numpy as np
+import pytest
+
+from mpc_collisionavoidance_amd import BatchOcpSolver, scenario, usv_models
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(name, N, K, B, seed, opts):
+    wl = scenario.make_bench_batch(name, N, K, B, seed=seed)
+    ocp = usv_models.make_ocp(name, N * scenario.BENCH_DT, N, K)
+    ocp.solver_options.sim_method_num_steps = scenario.BENCH_SIM_STEPS[name]
+    s = BatchOcpSolver(ocp, B)
+    scenario.load_into(s, wl)
+    s.set_option("static_obstacles", 1)
+    s.set_option("disturbance_mask", scenario.NOISE_MASK[name])
+    for k, v in opts:
+        s.set_option(k, v)
+    return s
+
+
+def _compare(name, N, K, B, ticks, opts_a=(("wide", 1),), opts_b=(("wide", 0),), seed=1234, map_a=1, map_b=0):
+    a, b = _make(name, N, K, B, seed, opts_a), _make(name, N, K, B, seed, opts_b)
+    worst = 0.0
+    for t in range(ticks):
+        sa, sb = a.solve(), b.solve()
+        assert a.last_mapping() == map_a and b.last_mapping() == map_b
+        qa, qb = a.get_int("qp_iter"), b.get_int("qp_iter")
+        assert np.array_equal(sa, sb) and np.array_equal(a.get_int("qp_status"), b.get_int("qp_status"))
+        # (an instance whose exit test is passed by a hair's breadth on one side may take one iteration more on the other)
+        assert (qa != qb).sum() <= max(1, B // 200) and np.abs(qa - qb).max() <= 1, (t, np.where(qa != qb)[0])
+        ok = (sa == 0) & (qa == qb)
+        assert ok.mean() > 0.9 or B < 8
+        xa, ua = a.get_all("x"), a.get_all("u")
+        ex, eu = util.rel_err(xa[ok], b.get_all("x")[ok]), util.rel_err(ua[ok], b.get_all("u")[ok])
+        # (rounding differences of a few ulp, amplified by the IPM of the weakly determined usv_model_pf_ca controls)
+        assert ex < 1e-7 and eu < 1e-6, (t, ex, eu)
+        for f in ("pi", "lam", "t"):
+            fa, fb = a.get_all(f)[ok], b.get_all(f)[ok]
+            assert np.abs(fa - fb).max() <= 1e-6 * max(1.0, np.abs(fb).max()), (t, f)
+        worst = max(worst, ex, eu)
+        a.advance(1e-3, seed=77 + t)
+        a.sync()
+        # both continue from the wide side's state
+        b.set("x0", 0, a.get("x0", 0))
+        b.set_all("x", xa)
+        b.set_all("u", ua)
+    a.close()
+    b.close()
+    return worst
+
+
+@pytest.mark.parametrize("name,N,K,B,ticks", [("usv_model_pf_ca", 20, 3, 1024, 6),          # BASELINE configs[1]
+                                               ("usv_model_guidance_ca1", 20, 3, 1024, 4),
+                                               ("usv_model_pf_ca", 40, 9, 300, 3),
+                                               ("usv_model_guidance_ca1", 30, 8, 200, 3),
+                                               ("usv_model_pf_ca", 20, 3, 1, 5),              # the reference's shape: one instance
+                                               ("usv_model_pf_ca", 21, 3, 7, 3)])             # (horizon not a multiple of the block of four)
+def test_wide_mapping_equals_the_throughput_mapping(name, N, K, B, ticks):
+    w = _compare(name, N, K, B, ticks)
+    print("wide vs throughput mapping", name, N, K, B, "worst relative difference %.2e" % w)
+
+
+def test_wide_mapping_with_the_work_queue_and_without():
+    """4096 instances are more than the device holds waves of the wide kernel: the rest comes through the queue.  dynamic_rows = 0:
+    one workgroup per instance instead (the same kernel, so these two ARE bit-identical)."""
+    name, N, K, B = "usv_model_pf_ca", 20, 3, 4096
+    _compare(name, N, K, B, 2)
+    a, b = _make(name, N, K, B, 9, (("wide", 1),)), _make(name, N, K, B, 9, (("wide", 1), ("dynamic_rows", 0)))
+    sa, sb = a.solve(), b.solve()
+    assert a.last_mapping() == 1 and b.last_mapping() == 1
+    assert np.array_equal(sa, sb)
+    for f in ("x", "u", "pi", "lam", "t"):
+        assert np.array_equal(a.get_all(f), b.get_all(f)), f
+    assert np.array_equal(a.get_int("qp_iter"), b.get_int("qp_iter"))
+    a.close()
+    b.close()
+
+
+def test_default_takes_the_wide_mapping_for_small_batches_only():
+    name, N, K = "usv_model_pf_ca", 20, 3
+    for B, want in ((64, 1), (1024, 1), (16384, 0)):
+        s = _make(name, N, K, B, 5, ())
+        s.solve()
+        assert s.last_mapping() == want, (B, s.last_mapping())
+        s.close()
+    # a layout the wide sweeps do not cover (K = 10: one box row does not fit the idle obstacle lanes) stays on the throughput mapping
+    s = _make(name, 20, 10, 64, 5, (("wide", 1),))
+    s.solve()
+    assert s.last_mapping() == 0
+    s.close()

@@ -1,5 +1,6 @@
-"""Small-batch latency probe (GPU, development aid): ms per RTI solve of the whole batch for a range of batch sizes, with the
-workspace in HBM and in LDS.   python tools/latency_probe.py [model] [N] [K]"""
+"""Small-batch latency probe (GPU): ms per RTI solve of the whole batch for a range of batch sizes - the throughput mapping (four
+instances per wavefront) with the workspace in HBM and in LDS, and the latency mapping (option "wide": one instance per wavefront).
+python tools/latency_probe.py [model] [N] [K] [batch sizes, comma separated]"""
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,27 +8,33 @@ from mpc_collisionavoidance_amd import BatchOcpSolver, scenario, usv_models
 name = sys.argv[1] if len(sys.argv) > 1 else "usv_model_pf_ca"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-for B in (1, 64, 256, 512, 1024, 2048, 4096):
+sizes = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1, 64, 256, 512, 1024, 2048, 4096]
+TICKS = 20
+for B in sizes:
     wl = scenario.make_bench_batch(name, N, K, B)
     ocp = usv_models.make_ocp(name, N * scenario.BENCH_DT, N, K)
     ocp.solver_options.sim_method_num_steps = scenario.BENCH_SIM_STEPS[name]
     res = {}
-    for mode in (0, 1):
+    for mode, opts in (("hbm", (("lds_workspace", 0), ("wide", 0))), ("lds", (("lds_workspace", 1), ("wide", 0))), ("wide", (("wide", 1),))):
         s = BatchOcpSolver(ocp, B)
         scenario.load_into(s, wl)
         s.set_option("static_obstacles", 1)
         s.set_option("disturbance_mask", scenario.NOISE_MASK[name])
-        s.set_option("lds_workspace", mode)
+        for k, v in opts:
+            s.set_option(k, v)
         for t in range(3):
             s.solve_async(); s.advance(1e-3, seed=t)
         s.sync()
         t0 = time.perf_counter()
-        for t in range(10):
+        for t in range(TICKS):
             s.solve_async(); s.advance(1e-3, seed=10 + t)
         s.sync()
-        wall = (time.perf_counter() - t0) / 10 * 1e3
-        lin, qp = s.kernel_ms(10)
-        res[mode] = (wall, qp.mean(), s.get_all("x"), s.get_int("qp_iter").mean())
+        wall = (time.perf_counter() - t0) / TICKS * 1e3
+        lin, qp = s.kernel_ms(TICKS)
+        res[mode] = (wall, qp.mean(), lin.mean(), s.get_all("x"), s.get_int("qp_iter"), s.last_mapping())
         s.close()
-    same = np.array_equal(res[0][2], res[1][2])
-    print("B %5d  HBM: %.3f ms/tick (qp %.3f)   LDS: %.3f ms/tick (qp %.3f)   identical %s  iters %.1f" % (B, res[0][0], res[0][1], res[1][0], res[1][1], same, res[0][3]), flush=True)
+    same = np.array_equal(res["hbm"][3], res["wide"][3]) and np.array_equal(res["hbm"][3], res["lds"][3])
+    it = res["hbm"][4]
+    print("%s N=%d K=%d B %5d | HBM %.3f ms/tick (qp %.3f, lin %.3f) | LDS %.3f (qp %.3f) | wide[%d] %.3f (qp %.3f) | identical %s | qp_iter mean %.1f max %d"
+          % (name, N, K, B, res["hbm"][0], res["hbm"][1], res["hbm"][2], res["lds"][0], res["lds"][1], res["wide"][5], res["wide"][0], res["wide"][1],
+             same, it.mean(), it.max()), flush=True)

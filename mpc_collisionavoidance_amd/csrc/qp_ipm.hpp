@@ -240,7 +240,7 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false,
           bool WIDE = false>
 struct QpIpm {
-    static_assert(!WIDE || (LDSWS && MERGE && KCH == 1 && HDIAG), "the wide mapping works on the merged one-chunk layout with the planes in LDS");
+    static_assert(!WIDE || (LDSWS && PACK && KCH == 1 && HDIAG && !SOFTBOX), "the wide mapping works on the packed one-chunk layouts with the planes in LDS");
     static_assert(!MERGE || PACK, "merged row pass works on the packed layout");
     static_assert(!(AUXLDS && LDSWS), "with the whole workspace in LDS the aux plane is there already");
     static_assert(!PACK || KCH > 0, "box rows are packed into obstacle planes");
@@ -1297,7 +1297,7 @@ struct QpIpm {
     // ------------------------------------------------------------------ the sweeps of the WIDE mapping
     // Exchange area behind the instance's planes in the workgroup's LDS: [row][EX_N][16 lanes].  Row r leaves the terms of the stage it
     // has just processed in its own slice; the recursion reads slice j for the block's j-th stage in every row.
-    enum : int { EX_GHB = 0, EX_GAMB, EX_DLB, EX_SXX, EX_SXY, EX_SYY, EX_GX, EX_GY, EX_LX, EX_LY, EX_MU1, EX_MU2, EX_N };
+    enum : int { EX_GHB = 0, EX_GAMB, EX_DLB, EX_SXX, EX_SXY, EX_SYY, EX_GX, EX_GY, EX_LX, EX_LY, EX_MU1, EX_MU2, EX_MU3, EX_N };
     static_assert(EX_N == WIDE_EX_PLANES, "host-side size of the exchange area");
     static constexpr int wide_lds_doubles(int N_) { return (N_ + 1) * NPLW * LANES + 4 * EX_N * LANES; }
     USV_DEV unsigned ex_at(int row, int plane) const { return (unsigned)((N + 1) * NPLW * LANES + (row * EX_N + plane) * LANES + lane); }
@@ -1355,7 +1355,32 @@ struct QpIpm {
                 const double zbx = aux_zx(aux), zby = aux_zy(aux);
                 const double psel = pos_sel(zbx, zby);
                 const double znew = (FACT && pend) ? z + a_prev * dzp : z;
-                double Sxx = 0.0, Sxy = 0.0, Syy = 0.0, gx = 0.0, gy = 0.0, lx = 0.0, ly = 0.0, dl_m = 0.0, mu1 = 0.0, mu2 = 0.0;
+                double Sxx = 0.0, Sxy = 0.0, Syy = 0.0, gx = 0.0, gy = 0.0, lx = 0.0, ly = 0.0, dl_m = 0.0, mu1 = 0.0, mu2 = 0.0, mu3 = 0.0;
+                // the two-pass form (a box row rides in the dense part of the aux plane): the box rows in their variables' lanes first
+                double Ghb = 0.0, gamb = 0.0, dlb = 0.0, pk[4];
+                if constexpr (!MERGE) {
+                    BoxRow br;
+                    in.aux = aux;
+                    box_from(in, k, br);
+                    br.act = br.act && own;
+                    if (FACT) {
+                        if (pend && br.act) {
+                            chain(br, z, true, dzap, sigmu_prev, Ghb, gamb);
+                            br.expand(dzp);
+                            br.apply(a_prev);
+                        }
+                        const double dv = box_pack(br, pk);
+                        ws_row(k, own && isdense).st(P_AUX, dv); // (the recursion composes the aux plane around the dense lanes)
+                    }
+                    chain(br, znew, !FACT, dza, sigmu, Ghb, gamb);
+                    dlb = br.act ? br.ll - br.lu : 0.0;
+                    if (FACT && br.act) {
+                        rd_r = lanes::vmax(rd_r, lanes::vmax_abs2(br.rdl, br.rdu));
+                        rm_r = lanes::vmax(rm_r, lanes::vmax(br.ll * br.tl, br.lu * br.tu));
+                        mu3 = br.ll * br.tl + br.lu * br.tu;
+                        nan_r = fma(0.0, br.rdl + br.rdu, nan_r);
+                    }
+                }
                 ObsRow o;
                 double cx, cy, Gh, gam;
                 obs_from<0>(in, k, zbx, zby, o, cx, cy);
@@ -1367,7 +1392,7 @@ struct QpIpm {
                         o.expand(wp);
                         o.apply(a_prev);
                     }
-                    if (pend && (o.act || isslot)) obs_store(W, 0, o, nullptr);
+                    if (pend && (o.act || isslot)) obs_store(W, 0, o, MERGE ? nullptr : pk);
                 }
                 const double v = rowdot<0>(cx, cy, znew - psel, znew);
                 const double wa = FACT ? 0.0 : rowdot<0>(cx, cy, dza, dza);
@@ -1397,14 +1422,21 @@ struct QpIpm {
                     Sxx = lanes::gsum(Sxx); Sxy = lanes::gsum(Sxy); Syy = lanes::gsum(Syy);
                     lx = lanes::gsum(lx); ly = lanes::gsum(ly);
                 }
-                // the box rows' terms come home from their slot lanes (an inactive row has delivered zeros)
-                const double g1 = lanes::gather(gam, bsrc);
-                ex_put(row, EX_GAMB, hasb ? g1 : 0.0);
+                if constexpr (MERGE) { // the box rows' terms come home from their slot lanes (an inactive row has delivered zeros)
+                    const double g1 = lanes::gather(gam, bsrc);
+                    gamb = hasb ? g1 : 0.0;
+                    if (FACT) {
+                        const double g0 = lanes::gather(Gh, bsrc), g2 = lanes::gather(dl_m, bsrc);
+                        Ghb = hasb ? g0 : 0.0;
+                        dlb = hasb ? g2 : 0.0;
+                    }
+                }
+                ex_put(row, EX_GAMB, gamb);
                 ex_put(row, EX_GX, gx); ex_put(row, EX_GY, gy);
                 if (FACT) {
-                    const double g0 = lanes::gather(Gh, bsrc), g2 = lanes::gather(dl_m, bsrc);
-                    ex_put(row, EX_GHB, hasb ? g0 : 0.0);
-                    ex_put(row, EX_DLB, hasb ? g2 : 0.0);
+                    ex_put(row, EX_GHB, Ghb);
+                    ex_put(row, EX_DLB, dlb);
+                    if constexpr (!MERGE) ex_put(row, EX_MU3, mu3);
                     ex_put(row, EX_SXX, Sxx); ex_put(row, EX_SXY, Sxy); ex_put(row, EX_SYY, Syy);
                     ex_put(row, EX_LX, lx); ex_put(row, EX_LY, ly);
                     ex_put(row, EX_MU1, mu1);
@@ -1433,6 +1465,7 @@ struct QpIpm {
                     lx = ex_get(j, EX_LX); ly = ex_get(j, EX_LY);
                     nm.musum += ex_get(j, EX_MU1);
                     if constexpr (SOFT) nm.musum += ex_get(j, EX_MU2);
+                    if constexpr (!MERGE) nm.musum += ex_get(j, EX_MU3);
                 }
                 double bat[NX];
                 if (k < N) mat_unpack(cur.mpk, bat); // wave-uniform
@@ -1607,6 +1640,20 @@ struct QpIpm {
                 const double dza = FINAL ? W.ld(P_DZA) : dz;
                 load_rows(k, W, in);
                 const double zbx = aux_zx(aux), zby = aux_zy(aux);
+                if constexpr (!MERGE) { // (MERGE: the box rows are rows of the chunk below)
+                    BoxRow br;
+                    in.aux = aux;
+                    box_from(in, k, br);
+                    br.act = br.act && own;
+                    double Gh, gam;
+                    chain(br, z, FINAL, dza, sigmu, Gh, gam);
+                    br.expand(dz);
+                    q = br.blocking(q);
+                    if (!FINAL) {
+                        ex_put(row, 4, br.act ? br.ll * br.dtl + br.tl * br.dll + br.lu * br.dtu + br.tu * br.dlu : 0.0);
+                        ex_put(row, 5, br.act ? br.dll * br.dtl + br.dlu * br.dtu : 0.0);
+                    }
+                }
                 ObsRow o;
                 double cx, cy, Gh2, gam2;
                 obs_from<0>(in, k, zbx, zby, o, cx, cy);
@@ -1629,6 +1676,7 @@ struct QpIpm {
             if (!FINAL) { // the sums for mu_aff, stage by stage as the 16-lane sweep takes them
                 lanes::lds_fence();
                 for (int j = 0; j < 4; j++) {
+                    if constexpr (!MERGE) { s1 += ex_get(j, 4); s2 += ex_get(j, 5); }
                     s1 += ex_get(j, 0); s2 += ex_get(j, 1);
                     if constexpr (SOFT) { s1 += ex_get(j, 2); s2 += ex_get(j, 3); }
                 }

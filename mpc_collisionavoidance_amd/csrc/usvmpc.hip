@@ -66,11 +66,11 @@ __global__ void __launch_bounds__(64, (LDSWS ? 1 : qp_waves<KCH, SOFTBOX>())) us
     q.solve(phase, queue0);
 }
 // (the wide instantiation exists for the one-chunk layouts only)
-template <class M, int KCH, bool SOFT>
+template <class M, int KCH, bool SOFT, bool MERGE>
 constexpr auto wide_kernel()
 {
-    if constexpr (KCH == 1) return &usv_qp_rti<M, KCH, SOFT, true, true, false, true, true, false, true>;
-    else return (decltype(&usv_qp_rti<M, KCH, SOFT, true, (KCH > 0), false, true, (KCH > 0)>))nullptr;
+    if constexpr (KCH == 1) return &usv_qp_rti<M, KCH, SOFT, true, true, false, true, MERGE, false, true>;
+    else return (decltype(&usv_qp_rti<M, KCH, SOFT, true, (KCH > 0), false, true, MERGE>))nullptr;
 }
 
 // Multiplier read-back (usvmpc_get "lam" / "t"): the inequality multipliers and slacks of every instance's last QP, from the
@@ -717,6 +717,7 @@ int launch_pair(usvmpc_handle *h, int phase)
                     hipFuncSetAttribute((const void *)kern_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess &&
                     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern_wide, qp_block, bytes) == hipSuccess && nb > 0)
                     h->wide_cap = (long)std::min(nb, 4) * h->ncu;   // (one wave per SIMD at most: the point is a lone wave's issue rate)
+                if (h->wide_cap > 0 && h->max_waves > 0) h->wide_cap = std::min(h->wide_cap, h->max_waves); // option "max_waves"
                 else
                     h->wide_cap = -1;
             }
@@ -806,7 +807,7 @@ int launch_pair(usvmpc_handle *h, int phase)
     // (one row pass when every box row rides in a slot lane: qp_ipm.hpp, MERGE)
     if (h->merge_rows && !h->spec.box_dense)
         rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true, CANPACK>,
-                        &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>, wide_kernel<M, KCH, SOFT>());
+                        &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>, wide_kernel<M, KCH, SOFT, CANPACK>());
     else
         rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>,
                         &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>);
@@ -818,10 +819,10 @@ int launch_pair(usvmpc_handle *h, int phase)
         // (the packed layouts - every OCP of the reference, the bench workloads - also come with the aux plane in LDS)
         if (pack && h->merge_rows && !h->spec.box_dense)
             rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true, CANPACK>,
-                            &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>, wide_kernel<M, KCH, SOFT>());
+                            &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>, wide_kernel<M, KCH, SOFT, CANPACK>());
         else
             rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>,
-                                   &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>)
+                                   &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>, wide_kernel<M, KCH, SOFT, false>())
                        : launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, false>, &usv_qp_rti<M, KCH, SOFT, true, false, false, true>);
     } else {
         rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, false, CANPACK, false>, nullptr) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, false>, nullptr);
@@ -1429,7 +1430,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         if (!h->sort_enabled && h->ptrs.perm) { h->ptrs.perm = nullptr; h->map_changed = true; }
         return 0;
     }
-    if (s == "max_waves") { h->max_waves = (long)value; cond_release(h); return 0; }
+    if (s == "max_waves") { h->max_waves = (long)value; h->wide_cap = 0; cond_release(h); return 0; }
     if (s == "keep_multipliers") { // create the "lam" / "t" buffers now (a partially condensed solve fills them only if they exist)
         if (value == 0.0) return 0;
         DevPtrs &P = h->ptrs;

@@ -140,12 +140,12 @@ void qp_body(void *a)
 }
 
 // the WIDE mapping: the body runs on the 64 fibers of a whole wave; row 0 owns the LDS region, rows 1 - 3 share it
-template <class M, int KCH, bool SOFT>
+template <class M, int KCH, bool SOFT, bool MERGE>
 void qp_wide_body(void *a)
 {
     Job *j = (Job *)a;
     if constexpr (KCH == 1) {
-        QpIpm<M, KCH, SOFT, true, true, false, true, true, false, true> q(*j->P, j->gid, lanes::wave_row() == 0 ? 0 : -1);
+        QpIpm<M, KCH, SOFT, true, true, false, true, MERGE, false, true> q(*j->P, j->gid, lanes::wave_row() == 0 ? 0 : -1);
         q.solve(j->qp_phase, j->queue0);
     }
 }
@@ -252,10 +252,11 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
                 else lanes::run_group(g, &qp_body<M, KCH, SOFT, false, false, true>, &j);
                 continue;
             }
-            if (KCH == 1 && g_emu_wide && qp_phase == 0 && S.hdiag && pack && !S.box_dense) {
+            if (KCH == 1 && g_emu_wide && qp_phase == 0 && S.hdiag && pack) {
                 lds.assign(wide_lds<M, KCH, SOFT>(S.N), 0.0);
                 lanes::g_emu_lds = lds.data();
-                lanes::run_group(g, &qp_wide_body<M, KCH, SOFT>, &j, 4);
+                if (g_emu_merge && !S.box_dense) lanes::run_group(g, &qp_wide_body<M, KCH, SOFT, true>, &j, 4);
+                else lanes::run_group(g, &qp_wide_body<M, KCH, SOFT, false>, &j, 4);
                 g_emu_wide_runs++;
                 continue;
             }

@@ -11,8 +11,11 @@ from mpc_collisionavoidance_amd import _capi, scenario, usv_models
 from tests.test_emu_kernels import emu_rti, _d
 
 
+# (K = 10 / 11 for usv_model_pf_ca, 15 / 16 for usv_model_guidance_ca1: box rows that do not fit the idle obstacle lanes - the two-pass form)
 @pytest.mark.parametrize("name,N,K,rows", [("usv_model_pf_ca", 8, 3, 2), ("usv_model_pf_ca", 7, 4, 0), ("usv_model_pf_ca", 6, 9, 2),
-                                           ("usv_model_pf_ca", 5, 1, 1), ("usv_model_guidance_ca1", 7, 8, 2), ("usv_model_guidance_ca1", 6, 3, 0)])
+                                           ("usv_model_pf_ca", 5, 1, 1), ("usv_model_guidance_ca1", 7, 8, 2), ("usv_model_guidance_ca1", 6, 3, 0),
+                                           ("usv_model_pf_ca", 7, 10, 2), ("usv_model_pf_ca", 6, 11, 0), ("usv_model_pf_ca", 5, 10, 1),
+                                           ("usv_model_guidance_ca1", 6, 16, 2), ("usv_model_guidance_ca1", 5, 15, 0)])
 def test_wide_mapping_equals_the_16_lane_sweeps_bit_for_bit(emu, name, N, K, rows):
     B = 5
     wl = scenario.make_batch(name, N, K, B, dt=0.05, seed=17, generator="survey", sim_steps=scenario.BENCH_SIM_STEPS[name], clip_time=0.1)

@@ -306,6 +306,7 @@ def main():
 
     nk = min(args.steps, 64)
     lin_ms, qp_ms = solver.kernel_ms(nk)
+    mapping = solver.last_mapping()
     pipelined = B >= 16384 and not any(kv.split("=")[0] == "pipeline_linearize" and float(kv.split("=")[1]) == 0.0 for kv in args.option)
     fails = solver.fail_counts(nk)
     st = solver.get_int("status")
@@ -433,6 +434,8 @@ def main():
                 "qp_formulation": ("partially condensed on the device: %d stages -> %d dense stages of %d, IPM + Riccati on those, expansion "
                                    "(csrc/cond_ipm.hpp)" % (N, args.cond_N, N // args.cond_N)) if cond_applied
                 else "uncondensed: Riccati over the %d stages (blocks of one stage, the reference's own setting)" % N,
+                "mapping": ("one OCP instance per wavefront (option 'wide': the rows of the wave share out the stage-local row work; planes in LDS)"
+                            if mapping == 1 else "four OCP instances per wavefront (one per 16-lane row)"),
                 "lib_sha256": lib_hash,
                 "sharding": "batch-sharded x%d, no data-path collective" % world, "ranks_seen": ranks_seen,
             },

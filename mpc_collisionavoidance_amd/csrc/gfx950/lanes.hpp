@@ -354,16 +354,17 @@ struct Planes {
 // and slots holding constants (0.0, 1.0) replace the selects for entries that are structurally zero / one.  This is how
 // the packed stage matrix is turned into the row (backward sweeps) or column (forward sweeps) form the products need.
 // LDS operations of one wave execute in order; sync() only keeps the compiler from moving reads above the writes.
-template <int NENT>
+// ROWS = 1 (the WIDE mapping: the four rows hold the same values): one copy for the wave.
+template <int NENT, int ROWS = 4>
 struct Xpose {
     USV_DEV static double *area()
     {
-        __shared__ double s[NENT * 4];
+        __shared__ double s[NENT * ROWS];
         return s;
     }
-    USV_DEV static unsigned row() { return (threadIdx.x >> 4) & 3u; }
-    USV_DEV static void put(int slot, double v) { area()[slot * 4 + row()] = v; }
-    USV_DEV static double get(int slot) { return area()[slot * 4 + row()]; }
+    USV_DEV static unsigned row() { return ROWS == 1 ? 0u : ((threadIdx.x >> 4) & 3u); }
+    USV_DEV static void put(int slot, double v) { area()[slot * ROWS + row()] = v; }
+    USV_DEV static double get(int slot) { return area()[slot * ROWS + row()]; }
     USV_DEV static void sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 };
 
@@ -372,15 +373,16 @@ struct Xpose {
 // scratch (vector-memory) load, whose s_waitcnt vmcnt(0) waits for every plane load issued before it: the reload in the
 // middle of a stage drains the prefetch queue (this was the largest single stall of the QP kernel).
 // An LDS read waits on lgkmcnt only.
-template <int NSLOT>
+// WLANES = 16 (the WIDE mapping: the four rows hold the same values): one row's worth for the wave.
+template <int NSLOT, int WLANES = 64>
 struct Stash {
     USV_DEV static double *area()
     {
-        __shared__ double s[NSLOT * 64];
+        __shared__ double s[NSLOT * WLANES];
         return s;
     }
-    USV_DEV static void put(int slot, double v) { area()[slot * 64 + (threadIdx.x & 63u)] = v; }
-    USV_DEV static double get(int slot) { return area()[slot * 64 + (threadIdx.x & 63u)]; }
+    USV_DEV static void put(int slot, double v) { area()[slot * WLANES + (threadIdx.x & (unsigned)(WLANES - 1))] = v; }
+    USV_DEV static double get(int slot) { return area()[slot * WLANES + (threadIdx.x & (unsigned)(WLANES - 1))]; }
 };
 
 // The same planes held in the CU's LDS instead of HBM (small batches: the whole horizon of an instance's planes fits in

@@ -357,7 +357,7 @@ struct QpIpm {
     static constexpr unsigned CMASK = MP::col_mask();
     static constexpr int NCOL = __builtin_popcount(CMASK);
     static constexpr int ZSLOT = MP::NPK * 16, OSLOT = ZSLOT + 1;
-    using XP = lanes::Xpose<MP::NPK * 16 + 2>;
+    using XP = lanes::Xpose<MP::NPK * 16 + 2, (WIDE ? 1 : 4)>; // (WIDE: the rows hold the same matrix - one copy)
     unsigned rowtab[(NX + 3) / 4], coltab[(NCOL + 3) / 4];
     bool selfone; // this lane's state has the exact unit diagonal and its own column is not among the stored ones
     bool isslot, isdense, anydense;
@@ -373,7 +373,7 @@ struct QpIpm {
         ST_SLOT = ST_BOX + (SOFTBOX ? 6 : 0), // MERGE: bounds of the box row a slot lane carries
         ST_N = ST_SLOT + (MERGE ? 2 : 0)
     };
-    using ST = lanes::Stash<ST_N>;
+    using ST = lanes::Stash<ST_N, (WIDE ? 16 : 64)>; // (WIDE: the rows hold the same constants - one row's worth)
     struct CRef {
         int slot;
         USV_DEV operator double() const { return ST::get(slot); }
@@ -1297,7 +1297,8 @@ struct QpIpm {
     // ------------------------------------------------------------------ the sweeps of the WIDE mapping
     // Exchange area behind the instance's planes in the workgroup's LDS: [row][EX_N][16 lanes].  Row r leaves the terms of the stage it
     // has just processed in its own slice; the recursion reads slice j for the block's j-th stage in every row.
-    enum : int { EX_GHB = 0, EX_GAMB, EX_DLB, EX_SXX, EX_SXY, EX_SYY, EX_GX, EX_GY, EX_LX, EX_LY, EX_MU1, EX_MU2, EX_MU3, EX_N };
+    // (EX_SC: the row-uniform sums S_xx, S_xy, S_yy, g_x, g_y, l_x, l_y in lanes 0 .. 6 of one plane)
+    enum : int { EX_GHB = 0, EX_GAMB, EX_DLB, EX_SC, EX_MU1, EX_MU2, EX_MU3, EX_N };
     static_assert(EX_N == WIDE_EX_PLANES, "host-side size of the exchange area");
     static constexpr int wide_lds_doubles(int N_) { return (N_ + 1) * NPLW * LANES + 4 * EX_N * LANES; }
     USV_DEV unsigned ex_at(int row, int plane) const { return (unsigned)((N + 1) * NPLW * LANES + (row * EX_N + plane) * LANES + lane); }
@@ -1432,13 +1433,18 @@ struct QpIpm {
                     }
                 }
                 ex_put(row, EX_GAMB, gamb);
-                ex_put(row, EX_GX, gx); ex_put(row, EX_GY, gy);
+                {
+                    double sc = lane == 3 ? gx : gy; // (lanes beyond 6 are never read)
+                    if (FACT) {
+                        sc = lane == 0 ? Sxx : sc; sc = lane == 1 ? Sxy : sc; sc = lane == 2 ? Syy : sc;
+                        sc = lane == 5 ? lx : sc; sc = lane == 6 ? ly : sc;
+                    }
+                    ex_put(row, EX_SC, sc);
+                }
                 if (FACT) {
                     ex_put(row, EX_GHB, Ghb);
                     ex_put(row, EX_DLB, dlb);
                     if constexpr (!MERGE) ex_put(row, EX_MU3, mu3);
-                    ex_put(row, EX_SXX, Sxx); ex_put(row, EX_SXY, Sxy); ex_put(row, EX_SYY, Syy);
-                    ex_put(row, EX_LX, lx); ex_put(row, EX_LY, ly);
                     ex_put(row, EX_MU1, mu1);
                     if constexpr (SOFT) ex_put(row, EX_MU2, mu2);
                     if (pend) W.st(P_Z, znew);
@@ -1457,12 +1463,13 @@ struct QpIpm {
                 const double ou1 = ounit ? 1.0 : 0.0;
                 const double hd = (k < N) ? hd_stage : hd_term;
                 double rb = FACT ? cur.rb * rbscale : 0.0;
-                const double gamb = ex_get(j, EX_GAMB), gx = ex_get(j, EX_GX), gy = ex_get(j, EX_GY);
+                const double gamb = ex_get(j, EX_GAMB), sc = ex_get(j, EX_SC);
+                const double gx = lanes::bcast<3>(sc), gy = lanes::bcast<4>(sc);
                 double Ghb = 0.0, dlb = 0.0, Sxx = 0.0, Sxy = 0.0, Syy = 0.0, lx = 0.0, ly = 0.0;
                 if (FACT) {
                     Ghb = ex_get(j, EX_GHB); dlb = ex_get(j, EX_DLB);
-                    Sxx = ex_get(j, EX_SXX); Sxy = ex_get(j, EX_SXY); Syy = ex_get(j, EX_SYY);
-                    lx = ex_get(j, EX_LX); ly = ex_get(j, EX_LY);
+                    Sxx = lanes::bcast<0>(sc); Sxy = lanes::bcast<1>(sc); Syy = lanes::bcast<2>(sc);
+                    lx = lanes::bcast<5>(sc); ly = lanes::bcast<6>(sc);
                     nm.musum += ex_get(j, EX_MU1);
                     if constexpr (SOFT) nm.musum += ex_get(j, EX_MU2);
                     if constexpr (!MERGE) nm.musum += ex_get(j, EX_MU3);

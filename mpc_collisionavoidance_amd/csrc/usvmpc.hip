@@ -717,9 +717,9 @@ int launch_pair(usvmpc_handle *h, int phase)
                     hipFuncSetAttribute((const void *)kern_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess &&
                     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern_wide, qp_block, bytes) == hipSuccess && nb > 0)
                     h->wide_cap = (long)std::min(nb, 4) * h->ncu;   // (one wave per SIMD at most: the point is a lone wave's issue rate)
-                if (h->wide_cap > 0 && h->max_waves > 0) h->wide_cap = std::min(h->wide_cap, h->max_waves); // option "max_waves"
                 else
                     h->wide_cap = -1;
+                if (h->wide_cap > 0 && h->max_waves > 0) h->wide_cap = std::min(h->wide_cap, h->max_waves); // option "max_waves"
             }
             // default: while the batch fits the SIMDs twice over (the queue hands the second half to the waves that finish first)
             const bool take = h->wide_cap > 0 && (h->wide_mode > 0 || (long)h->B <= 2 * h->wide_cap);

@@ -161,18 +161,18 @@ struct Planes {
 };
 
 // wave-private exchange area (gfx950/lanes.hpp): one emulated row, sync() is a rendezvous of its 16 lanes
-template <int NENT>
+template <int NENT, int ROWS = 4>
 struct Xpose {
-    static double *area() { static double s[4][NENT]; return s[g_emu.cur >> 4]; }
+    static double *area() { static double s[4][NENT]; return s[ROWS == 1 ? 0 : (g_emu.cur >> 4)]; }
     static void put(int slot, double v) { area()[slot] = v; }
     static double get(int slot) { return area()[slot]; }
     static void sync() { (void)exchange(0.0, 0); }
 };
 
 // per-lane constants parked in LDS (gfx950/lanes.hpp): one emulated row
-template <int NSLOT>
+template <int NSLOT, int WLANES = 64>
 struct Stash {
-    static double *area() { static double s[4][NSLOT * 16]; return s[g_emu.cur >> 4]; }
+    static double *area() { static double s[4][NSLOT * 16]; return s[WLANES == 16 ? 0 : (g_emu.cur >> 4)]; }
     static void put(int slot, double v) { area()[slot * 16 + lane()] = v; }
     static double get(int slot) { return area()[slot * 16 + lane()]; }
 };

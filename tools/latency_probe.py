@@ -22,6 +22,8 @@ for B in sizes:
         s.set_option("disturbance_mask", scenario.NOISE_MASK[name])
         for k, v in opts:
             s.set_option(k, v)
+        if mode == "wide" and os.environ.get("MAXW"):
+            s.set_option("max_waves", float(os.environ["MAXW"]))   # (cap on the resident wide waves: what does a second round cost?)
         for t in range(3):
             s.solve_async(); s.advance(1e-3, seed=t)
         s.sync()

@@ -44,7 +44,10 @@ def _compare(name, N, K, B, ticks, opts_a=(("wide", 1),), opts_b=(("wide", 0),),
         # Rounding differences of a few ulp.  The soft-row model keeps them; the hard-row model (control weight R = 0) amplifies them on
         # its rounding-sensitive QPs exactly as it does between the device and its own emulator (tests/test_parity_outliers.py): median
         # and 90th percentile tight, every instance inside the parity rule's cap
-        if name == "usv_model_pf_ca":
+        if name == "usv_model_pf_ca" and e.size < 20:
+            assert e.max() <= 1e-6, (t, e)
+            tight = e <= 1e-7
+        elif name == "usv_model_pf_ca":
             assert np.median(e) <= 1e-10 and np.percentile(e, 90) <= 1e-7 and e.max() <= 5e-3, (t, np.median(e), np.percentile(e, 90), e.max())
             tight = e <= 1e-7
         else:

@@ -201,7 +201,7 @@ def test_full_size_batch_properties(oracle):
 # ------------------------------------------------------------------------------------------------------------------
 # The BASELINE configs on their SURVEY.md 8(d) workloads (dt = 0.05 s, obstacles inside the look-ahead: ACTIVE rows), closed loop
 # without disturbance, every tick compared from identical inputs (the iterate and x0 the device starts the tick from).
-def _run_survey(oracle, name, N, K, B, ticks, min_active, seed=1234, moving=False, min_ok=0.97):
+def _run_survey(oracle, name, N, K, B, ticks, min_active, seed=1234, moving=False, min_ok=0.97, mapping=None):
     from mpc_collisionavoidance_amd import usv_models
     wl = scenario.make_bench_batch(name, N, K, B, seed=seed, moving=moving)
     dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
@@ -221,6 +221,7 @@ def _run_survey(oracle, name, N, K, B, ticks, min_active, seed=1234, moving=Fals
         xs, us = s.get_all("x"), s.get_all("u")
         xs_in, us_in = xs.copy(), us.copy()   # (the oracle updates xs / us in place)
         st = s.solve()
+        assert mapping is None or s.last_mapping() == mapping
         sto, ito = oracle.rti_batch(spec, xs, us, x0, wl["yref"], wl["yref_e"], wl["p"], wl["lh"], threads=0)
         xg, ug, qs, qi = s.get_all("x"), s.get_all("u"), s.get_int("qp_status"), s.get_int("qp_iter")
         assert (st != sto).sum() <= slack, (name, t, np.where(st != sto)[0])
@@ -255,8 +256,9 @@ def _run_survey(oracle, name, N, K, B, ticks, min_active, seed=1234, moving=Fals
 
 @pytest.mark.parametrize("name", ["usv_model_pf_ca", "usv_model_guidance_ca1"])
 def test_config1_on_its_survey_workload_full_size(oracle, name):
-    """BASELINE configs[1] at full size: 1024 instances, N=20 (Tf = 1 s), 3 static obstacles."""
-    _run_survey(oracle, name, 20, 3, 1024, ticks=12, min_active=0.5)
+    """BASELINE configs[1] at full size: 1024 instances, N=20 (Tf = 1 s), 3 static obstacles - on the mapping such a handle takes by
+    default: ONE instance per wavefront (usvmpc_last_mapping = 1; tests/test_gpu_wide.py holds it against the other)."""
+    _run_survey(oracle, name, 20, 3, 1024, ticks=12, min_active=0.5, mapping=1)
 
 
 @pytest.mark.parametrize("name", ["usv_model_pf_ca", "usv_model_guidance_ca1"])

@@ -132,6 +132,7 @@ def test_device_reproduces_its_stored_outputs_and_its_emulator(emu):
     s = BatchOcpSolver(_ocp(f), n)
     wl = dict(x_init=f["x_in"], u_init=f["u_in"], K=f["K"], **{k: np.ascontiguousarray(f[k]) for k in ("x0", "yref", "yref_e", "p", "lh")})
     scenario.load_into(s, wl)
+    s.set_option("wide", 0)   # (the stored outputs are the throughput mapping's: a handle of twelve would take the latency mapping)
     st = s.solve()
     xg, ug, qi = s.get_all("x"), s.get_all("u"), s.get_int("qp_iter")
     s.close()

@@ -240,7 +240,7 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false,
           bool WIDE = false>
 struct QpIpm {
-    static_assert(!WIDE || (LDSWS && PACK && KCH == 1 && HDIAG && !SOFTBOX), "the wide mapping works on the packed one-chunk layouts with the planes in LDS");
+    static_assert(!WIDE || (PACK && KCH == 1 && HDIAG && !SOFTBOX && !AUXLDS), "the wide mapping works on the packed one-chunk layouts");
     static_assert(!MERGE || PACK, "merged row pass works on the packed layout");
     static_assert(!(AUXLDS && LDSWS), "with the whole workspace in LDS the aux plane is there already");
     static_assert(!PACK || KCH > 0, "box rows are packed into obstacle planes");
@@ -314,8 +314,8 @@ struct QpIpm {
     struct WideMap {
         static constexpr int at(int plane) { return plane < WL::P_BLL ? plane : (plane >= WL::P_OBS && plane < WL::P_RB0 ? plane - 4 : -1); }
     };
-    static constexpr int NPLW = WIDE ? WL::P_RB0 - 4 : WL::NPT; // planes per stage of an LDS region
-    using Planes = std::conditional_t<WIDE, lanes::PlanesLdsMapped<WideMap>, std::conditional_t<LDSWS, lanes::PlanesLds, lanes::Planes>>;
+    static constexpr int NPLW = (WIDE && LDSWS) ? WL::P_RB0 - 4 : WL::NPT; // planes per stage of an LDS region
+    using Planes = std::conditional_t<WIDE && LDSWS, lanes::PlanesLdsMapped<WideMap>, std::conditional_t<LDSWS, lanes::PlanesLds, lanes::Planes>>;
 
     const DevPtrs &P;
     const DevSpec &S;
@@ -339,6 +339,7 @@ struct QpIpm {
     bool auxlive;
     long stage_stride;     // doubles between consecutive stages of the workspace: Bp * NPL * 16
     unsigned stage_bytes;  // bytes of one stage's window
+    unsigned ws_all_bytes; // ... of all N + 1 (WIDE over HBM planes: rows address different stages through one window; the host keeps it below 2^31)
     bool xlane, ulane, valid, isPX, isPY;
     // per-lane constants, read once: box bounds of this lane's variable, Hessian diagonal
     // PACK: the box rows' (lambda_l, lambda_u, t_l, t_u) do not get four planes of their own.  A *slot* row
@@ -411,6 +412,7 @@ struct QpIpm {
             const long nbp = (long)lanes::uniform(S.Bp);
             stage_stride = nbp * NPL * LANES;
             stage_bytes = (unsigned)(nbp * NPL * 128);
+            ws_all_bytes = (unsigned)((long)(N + 1) * nbp * NPL * 128);
         }
         ulane = lane < NU;
         xlane = lane >= NU && lane < NZ;
@@ -605,7 +607,8 @@ struct QpIpm {
         }
     }
     // pk: the box rows gathered to their storage lanes (PACK, last chunk), else nullptr
-    USV_DEV void obs_store(const Planes &W, int c, const ObsRow &r, const double *pk = nullptr) const
+    template <class PL>
+    USV_DEV void obs_store(const PL &W, int c, const ObsRow &r, const double *pk = nullptr) const
     {
         const int p0 = P_OBS + c * OBSN;
         const bool sel = PACK && pk != nullptr && isslot;
@@ -696,7 +699,7 @@ struct QpIpm {
     // solved here, but a violated hard one makes acados' QP infeasible - status 4, iterate untouched.
     USV_DEV bool init(bool sel)
     {
-        const bool wr = sel && !keep;
+        const bool wr = sel && !keep && (!(WIDE && !LDSWS) || live); // (WIDE over HBM planes: the four rows would store the same values)
         double bad0 = 0.0;
         for (int k = 0; k <= N; k++) {
             const Planes W = ws(k);
@@ -1298,17 +1301,38 @@ struct QpIpm {
     // Exchange area behind the instance's planes in the workgroup's LDS: [row][EX_N][16 lanes].  Row r leaves the terms of the stage it
     // has just processed in its own slice; the recursion reads slice j for the block's j-th stage in every row.
     // (EX_SC: the row-uniform sums S_xx, S_xy, S_yy, g_x, g_y, l_x, l_y in lanes 0 .. 6 of one plane)
-    enum : int { EX_GHB = 0, EX_GAMB, EX_DLB, EX_SC, EX_MU1, EX_MU2, EX_MU3, EX_N };
-    static_assert(EX_N == WIDE_EX_PLANES, "host-side size of the exchange area");
-    static constexpr int wide_lds_doubles(int N_) { return (N_ + 1) * NPLW * LANES + 4 * EX_N * LANES; }
-    USV_DEV unsigned ex_at(int row, int plane) const { return (unsigned)((N + 1) * NPLW * LANES + (row * EX_N + plane) * LANES + lane); }
+    // EX_Z, EX_DV (planes in HBM only): the stage's iterate after the pending step and the dense box values, which with the planes in LDS
+    // the recursion reads back from the planes the row phase has just written.
+    enum : int { EX_GHB = 0, EX_GAMB, EX_DLB, EX_SC, EX_MU1, EX_MU2, EX_MU3, EX_Z, EX_DV, EX_ALL };
+    static constexpr int EX_N = LDSWS ? (int)EX_Z : (int)EX_ALL;
+    static_assert(EX_Z == WIDE_EX_PLANES && EX_ALL == WIDE_EX_PLANES_HBM, "host-side size of the exchange area");
+    static constexpr int wide_lds_doubles(int N_) { return (LDSWS ? (N_ + 1) * NPLW * LANES : 0) + 4 * EX_N * LANES; }
+    USV_DEV unsigned ex_at(int row, int plane) const { return (unsigned)((LDSWS ? (N + 1) * NPLW * LANES : 0) + (row * EX_N + plane) * LANES + lane); }
     USV_DEV void ex_put(int row, int plane, double v) const { lanes::dyn_lds()[ex_at(row, plane)] = v; }
     USV_DEV double ex_get(int row, int plane) const { return lanes::dyn_lds()[ex_at(row, plane)]; }
-    // the planes of stage k for the row phase: every row stores the rows of ITS stage (own = this row has a stage in the block)
-    USV_DEV Planes ws_row(int k, bool own) const { return Planes(loff + (unsigned)(k * NPLW * LANES), own); }
-    // the lineariser's planes of a stage, for the recursion: from HBM / L2, asked for one stage ahead of their use
-    struct SeqIn { double mpk[MP::NPK], gq, rb; };
-    template <bool WANT_GQ>
+    // The planes of one stage as the wide sweeps see them: every lane loads, the lanes `on` selects store.
+    struct WPl {
+        Planes W;
+        bool on;
+        USV_DEV double ld(int plane) const { return W.ld(plane); }
+        USV_DEV void st(int plane, double v) const
+        {
+            if constexpr (LDSWS) W.st(plane, v); // (the LDS planes carry the predicate themselves)
+            else { if (on) W.st(plane, v); }
+        }
+    };
+    // ... for the row phase: row r addresses ITS stage (own = this row has a stage in the block) and stores that stage's rows
+    USV_DEV WPl ws_row(int k, bool own) const
+    {
+        if constexpr (LDSWS) return WPl{Planes(loff + (unsigned)(k * NPLW * LANES), own), own};
+        else return WPl{lanes::Planes(P.ws, ws_all_bytes, voff + (unsigned)k * stage_bytes), own};
+    }
+    // ... for the recursion (the same stage in all rows): row 0 stores
+    USV_DEV WPl ws_seq(int k) const { return WPl{ws(k), live}; }
+    // What the recursion reads of a stage, asked for one stage ahead of its use: the lineariser's planes (always in HBM / L2) and - with
+    // the solver's planes in HBM too - the aux plane, P b and L_zu.
+    struct SeqIn { double mpk[MP::NPK], gq, rb, aux, pb, lzu[NU > 0 ? NU : 1]; };
+    template <int SW>
     USV_DEV void seq_load(int k, SeqIn &si) const
     {
         const lanes::Planes G = wsg(k);
@@ -1318,11 +1342,25 @@ struct QpIpm {
         } else {
             si.rb = 0.0;
         }
-        if (WANT_GQ) si.gq = G.ld(P_GQ);
+        if (SW == SW_BACK_A) si.gq = G.ld(P_GQ);
+        if constexpr (!LDSWS) {
+            si.aux = G.ld(P_AUX);
+            if (SW == SW_BACK_B) si.pb = (k < N) ? G.ld(P_PB) : 0.0;
+            if (SW != SW_BACK_A) {
+                if (k < N) sfor<0, NU>([&](auto l) { si.lzu[l] = G.ld(P_LZU + l); });
+                else sfor<0, NU>([&](auto l) { si.lzu[l] = 1.0; });
+            }
+        }
     }
-    // the row planes of a stage as obs_from wants them (all of them, whatever the stage: LDS, in bounds, unused values are masked)
-    USV_DEV void load_rows(int k, const Planes &W, StageIn &in) const
+    // What the row phase reads of its stage (all row planes whatever the stage: in bounds, unused values are masked).  With the planes in
+    // HBM the next block's are asked for before the recursion of this one starts.
+    template <int SW>
+    USV_DEV void row_load(int k, const WPl &W, StageIn &in) const
     {
+        in.z = W.ld(P_Z);
+        in.aux = W.ld(P_AUX);
+        if (SW == SW_BACK_A) in.dz = W.ld(P_DZ);
+        if (SW != SW_FWD_A) in.dza = W.ld(P_DZA);
         sfor<0, OBSN>([&](auto e) { in.obs[0][e] = W.ld(P_OBS + e); });
         if (!pstat) obs_raw<0>(k, in.raw[0]);
     }
@@ -1338,20 +1376,27 @@ struct QpIpm {
             nm.rg = nm.rb = nm.rd = nm.rm = nm.musum = nm.nan = 0.0;
             rbscale = pend ? rbscale * (1.0 - a_prev) : rbscale; // the step applied in this sweep
         }
+        constexpr int SW = FACT ? SW_BACK_A : SW_BACK_B;
         SeqIn nxt;
-        seq_load<FACT>(N, nxt);
+        seq_load<SW>(N, nxt);
+        StageIn rnx;
+        if constexpr (!LDSWS) {
+            const int kr = N - row;
+            row_load<SW>(kr >= 0 ? kr : 0, ws_row(kr >= 0 ? kr : 0, false), rnx);
+        }
         for (int kb = N; kb >= 0; kb -= 4) {
             // ---- row phase: row r on stage kb - r (with the pending update of the previous iteration applied first)
             {
                 const int kr = kb - row;
                 const bool own = kr >= 0;
                 const int k = own ? kr : 0;
-                const Planes W = ws_row(k, own);
+                const WPl W = ws_row(k, own);
                 StageIn in;
-                const double z = W.ld(P_Z), aux = W.ld(P_AUX);
-                const double dzp = FACT ? W.ld(P_DZ) : 0.0;
-                const double dzs = W.ld(P_DZA);
-                load_rows(k, W, in);
+                if constexpr (LDSWS) row_load<SW>(k, W, in);
+                else in = rnx;
+                const double z = in.z, aux = in.aux;
+                const double dzp = FACT ? in.dz : 0.0;
+                const double dzs = in.dza;
                 const double dzap = FACT ? dzs : 0.0, dza = FACT ? 0.0 : dzs;
                 const double zbx = aux_zx(aux), zby = aux_zy(aux);
                 const double psel = pos_sel(zbx, zby);
@@ -1371,7 +1416,9 @@ struct QpIpm {
                             br.apply(a_prev);
                         }
                         const double dv = box_pack(br, pk);
-                        ws_row(k, own && isdense).st(P_AUX, dv); // (the recursion composes the aux plane around the dense lanes)
+                        // (the recursion composes the aux plane around the dense lanes)
+                        if constexpr (LDSWS) ws_row(k, own && isdense).st(P_AUX, dv);
+                        else ex_put(row, EX_DV, dv);
                     }
                     chain(br, znew, !FACT, dza, sigmu, Ghb, gamb);
                     dlb = br.act ? br.ll - br.lu : 0.0;
@@ -1449,16 +1496,23 @@ struct QpIpm {
                     if constexpr (SOFT) ex_put(row, EX_MU2, mu2);
                     if (pend) W.st(P_Z, znew);
                 }
+                if constexpr (!LDSWS) ex_put(row, EX_Z, znew);
             }
             lanes::lds_fence();
+            if constexpr (!LDSWS) { // the next block's row planes go in flight before the recursion of this one
+                const int kr = kb - 4 - row;
+                if (kb >= 4) row_load<SW>(kr >= 0 ? kr : 0, ws_row(kr >= 0 ? kr : 0, false), rnx); // wave-uniform
+            }
             // ---- the recursion over the block's stages, in all four rows alike
             for (int j = 0; j < 4; j++) {
                 const int k = kb - j;
                 if (k < 0) break; // wave-uniform
-                const Planes W = ws(k);
+                const WPl W = ws_seq(k);
                 const SeqIn cur = nxt;
-                if (k > 0) seq_load<FACT>(k - 1, nxt);
-                const double z = W.ld(P_Z), aux = W.ld(P_AUX);
+                if (k > 0) seq_load<SW>(k - 1, nxt);
+                double z, aux;
+                if constexpr (LDSWS) { z = W.ld(P_Z); aux = W.ld(P_AUX); }
+                else { z = ex_get(j, EX_Z); aux = cur.aux; }
                 const double zbx = aux_zx(aux), zby = aux_zy(aux);
                 const double ou1 = ounit ? 1.0 : 0.0;
                 const double hd = (k < N) ? hd_stage : hd_term;
@@ -1544,10 +1598,13 @@ struct QpIpm {
                         W.st(P_PB, Pb);
                         sfor<0, NU>([&](auto l) { W.st(P_LZU + l, (lane == l) ? iLd[l] : Lzu[l]); });
                     } else {
-                        const double pb = W.ld(P_PB);
+                        double pb;
+                        if constexpr (LDSWS) pb = W.ld(P_PB);
+                        else pb = cur.pb;
                         Pb = xlane ? pb : 0.0;
                         sfor<0, NU>([&](auto l) {
-                            Lzu[l] = W.ld(P_LZU + l);
+                            if constexpr (LDSWS) Lzu[l] = W.ld(P_LZU + l);
+                            else Lzu[l] = cur.lzu[l];
                             iLd[l] = lanes::bcast<l>(Lzu[l]); // (stored as the reciprocal)
                         });
                     }
@@ -1568,12 +1625,17 @@ struct QpIpm {
                     pv = xlane ? pv : 0.0;
                     luv_new = luv;
                 }
-                if (!keep) W.st(P_AUX, aux_compose(aux, zbx, zby, rg, luv_new));
+                {
+                    double dense = aux;
+                    if constexpr (!LDSWS && !MERGE) { if (FACT) dense = ex_get(j, EX_DV); }
+                    if (!keep) W.st(P_AUX, aux_compose(dense, zbx, zby, rg, luv_new));
+                }
                 pn = pv;
                 pin = pik;
             }
             lanes::lds_fence();
         }
+        if constexpr (!LDSWS) lanes::drain_stores(); // (rows read each other's stores in the next sweep)
         if (FACT) {
             const Planes W0 = ws(0);
             const double e0 = xlane ? W0.ld(P_DX0) - W0.ld(P_Z) : 0.0; // x0 - (xbar_0 + dx_0)
@@ -1596,20 +1658,28 @@ struct QpIpm {
             dzx = xlane ? W0.ld(P_DX0) - W0.ld(P_Z) : 0.0;
         }
         double q = 1.0, s1 = 0.0, s2 = 0.0;
+        constexpr int SW = FINAL ? SW_FWD_B : SW_FWD_A;
         SeqIn nxt;
-        seq_load<false>(0, nxt);
+        seq_load<SW>(0, nxt);
+        StageIn rnx;
+        if constexpr (!LDSWS) row_load<SW>(row <= N ? row : N, ws_row(row <= N ? row : N, false), rnx);
         for (int kb = 0; kb <= N; kb += 4) {
             // ---- the recursion over the block's stages, in all four rows alike; row r keeps the step of stage kb + r
             double mydz = 0.0;
             for (int j = 0; j < 4; j++) {
                 const int k = kb + j;
                 if (k > N) break; // wave-uniform
-                const Planes W = ws(k);
+                const WPl W = ws_seq(k);
                 const SeqIn cur = nxt;
-                if (k < N) seq_load<false>(k + 1, nxt);
-                double lzu[NU > 0 ? NU : 1];
-                const double aux = W.ld(P_AUX);
-                if (k < N) sfor<0, NU>([&](auto l) { lzu[l] = W.ld(P_LZU + l); });
+                if (k < N) seq_load<SW>(k + 1, nxt);
+                double lzu[NU > 0 ? NU : 1], aux;
+                if constexpr (LDSWS) {
+                    aux = W.ld(P_AUX);
+                    if (k < N) sfor<0, NU>([&](auto l) { lzu[l] = W.ld(P_LZU + l); });
+                } else {
+                    aux = cur.aux;
+                    sfor<0, NU>([&](auto l) { lzu[l] = cur.lzu[l]; });
+                }
                 double dz;
                 if (k < N) {
                     double t[NU], du[NU];
@@ -1640,12 +1710,16 @@ struct QpIpm {
                 const int kr = kb + row;
                 const bool own = kr <= N;
                 const int k = own ? kr : N;
-                const Planes W = ws_row(k, false);
                 StageIn in;
-                const double z = W.ld(P_Z), aux = W.ld(P_AUX);
+                if constexpr (LDSWS) row_load<SW>(k, ws_row(k, false), in);
+                else {
+                    in = rnx;
+                    const int k2 = kr + 4 <= N ? kr + 4 : N;
+                    if (kb + 4 <= N) row_load<SW>(k2, ws_row(k2, false), rnx); // wave-uniform: the next block's, in flight during its recursion
+                }
+                const double z = in.z, aux = in.aux;
                 const double dz = mydz;
-                const double dza = FINAL ? W.ld(P_DZA) : dz;
-                load_rows(k, W, in);
+                const double dza = FINAL ? in.dza : dz;
                 const double zbx = aux_zx(aux), zby = aux_zy(aux);
                 if constexpr (!MERGE) { // (MERGE: the box rows are rows of the chunk below)
                     BoxRow br;
@@ -1690,6 +1764,7 @@ struct QpIpm {
                 lanes::lds_fence();
             }
         }
+        if constexpr (!LDSWS) lanes::drain_stores(); // (rows read each other's stores in the next sweep)
         alpha = 1.0 / lanes::gmax(lanes::xrow_max(q)); // q >= 1: alpha = min(1, min over blocking pairs of -v/dv)
         if (!FINAL) { S1 = lanes::gsum(s1); S2 = lanes::gsum(s2); }
     }

@@ -56,7 +56,7 @@ constexpr int qp_waves() { return (KCH >= 2 || SOFTBOX) ? 1 : USV_QP_WAVES; }
 // WIDE: the latency mapping - one instance per wave (rows = 1: rows 1 - 3 are handed row 0's group and share its LDS region; in the
 // sweeps they take over the row work of the neighbouring stages: qp_ipm.hpp)
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false, bool WIDE = false>
-__global__ void __launch_bounds__(64, (LDSWS ? 1 : qp_waves<KCH, SOFTBOX>())) usv_qp_rti(DevPtrs P, long ngroups, int phase, int queue0, int rows)
+__global__ void __launch_bounds__(64, ((LDSWS || WIDE) ? 1 : qp_waves<KCH, SOFTBOX>())) usv_qp_rti(DevPtrs P, long ngroups, int phase, int queue0, int rows)
 {
     const int row = (int)(threadIdx.x >> 4);
     const long g0 = (long)blockIdx.x * rows;
@@ -66,10 +66,11 @@ __global__ void __launch_bounds__(64, (LDSWS ? 1 : qp_waves<KCH, SOFTBOX>())) us
     q.solve(phase, queue0);
 }
 // (the wide instantiation exists for the one-chunk layouts only)
-template <class M, int KCH, bool SOFT, bool MERGE>
+// (LDSWS: the solver's planes in LDS - false: in HBM, for horizons that do not fit a CU's LDS)
+template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS = true>
 constexpr auto wide_kernel()
 {
-    if constexpr (KCH == 1) return &usv_qp_rti<M, KCH, SOFT, true, true, false, true, MERGE, false, true>;
+    if constexpr (KCH == 1) return &usv_qp_rti<M, KCH, SOFT, true, true, false, LDSWS, MERGE, false, true>;
     else return (decltype(&usv_qp_rti<M, KCH, SOFT, true, (KCH > 0), false, true, MERGE>))nullptr;
 }
 
@@ -271,6 +272,7 @@ struct usvmpc_handle {
     long lds_cap;             // waves an LDS-workspace launch holds at once (0: not yet known)
     int wide_mode;            // the latency mapping (one instance per wave, QpIpm WIDE): -1 for small batches (default), 0 never, 1 whenever it applies
     long wide_cap;            // waves a launch of the wide kernel holds at once (0: not yet known, -1: does not fit)
+    long wide_hbm_cap;        // the same for the wide kernel over planes in HBM (horizons that do not fit LDS)
     int last_wide;            // the last RTI launch ran on the wide kernel
     long max_waves;           // cap on the persistent waves of the QP kernel (0: as many as the device holds)
     int ncu;                  // compute units of the device
@@ -701,7 +703,8 @@ int launch_pair(usvmpc_handle *h, int phase)
     // Small batches: the planes of every instance in flight fit in LDS (160 KB per CU), and a solve whose sweeps wait for
     // HBM at every stage - nothing else runs on the CU to hide it - becomes a solve on LDS.  rows_lds instances per wave
     // (as many whole horizons as fit), one wave per CU at a time; further instances come through the same queue.
-    auto launch_qp = [&](auto kern, decltype(kern) kern_lds, decltype(kern) kern_aux = nullptr, decltype(kern) kern_wide = nullptr) -> int {
+    auto launch_qp = [&](auto kern, decltype(kern) kern_lds, decltype(kern) kern_aux = nullptr, decltype(kern) kern_wide = nullptr,
+                         decltype(kern) kern_wide_hbm = nullptr) -> int {
         const long lds_inst = (long)(h->N + 1) * h->spec.npt * 128;
         h->last_wide = 0;
         // The latency mapping: ONE instance per wave (qp_ipm.hpp, WIDE) - planes in LDS, the four rows share out the stage-local row
@@ -732,6 +735,30 @@ int launch_pair(usvmpc_handle *h, int phase)
                 hipLaunchKernelGGL(kern_wide, dim3((unsigned)nw), dim3(qp_block), bytes, h->stream, h->ptrs, nw, phase, q0, 1);
                 h->last_wide = 1;
                 return 0;
+            }
+            // The horizon's planes do not fit a CU's LDS (the reference node's own N = 100: nmpc_guidance_ca1.cpp:64): the same sweeps over
+            // the planes in HBM / L2 - the four rows of a wave address four stages through one window over the whole workspace (hence
+            // its size limit), the next block's row planes and the next stage's recursion planes are in flight ahead of their use.
+            const long ws_bytes = (long)(h->N + 1) * h->Bp * h->spec.npt * 128;
+            if (h->wide_cap < 0 && kern_wide_hbm != nullptr && ws_bytes < (1L << 31)) {
+                const size_t xbytes = (size_t)4 * WIDE_EX_PLANES_HBM * 128;
+                if (h->wide_hbm_cap == 0) {
+                    int nb = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern_wide_hbm, qp_block, xbytes) == hipSuccess && nb > 0)
+                        h->wide_hbm_cap = (long)std::min(nb, 4) * h->ncu;
+                    else
+                        h->wide_hbm_cap = -1;
+                    if (h->wide_hbm_cap > 0 && h->max_waves > 0) h->wide_hbm_cap = std::min(h->wide_hbm_cap, h->max_waves);
+                }
+                if (h->wide_hbm_cap > 0 && (h->wide_mode > 0 || (long)h->B <= h->wide_hbm_cap)) {
+                    long nw = (long)h->B;
+                    int q0 = -1;
+                    if (h->dynamic_rows && nw > h->wide_hbm_cap) { nw = h->wide_hbm_cap; q0 = (int)nw; }
+                    if (q0 >= 0) HIP_TRY(h, hipMemsetAsync(h->ptrs.queue, 0, sizeof(int), h->stream));
+                    hipLaunchKernelGGL(kern_wide_hbm, dim3((unsigned)nw), dim3(qp_block), xbytes, h->stream, h->ptrs, nw, phase, q0, 1);
+                    h->last_wide = 1;
+                    return 0;
+                }
             }
         }
         // (the kernel's own static LDS - exchange area, parked constants - comes out of the same 160 KB)
@@ -807,7 +834,7 @@ int launch_pair(usvmpc_handle *h, int phase)
     // (one row pass when every box row rides in a slot lane: qp_ipm.hpp, MERGE)
     if (h->merge_rows && !h->spec.box_dense)
         rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true, CANPACK>,
-                        &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>, wide_kernel<M, KCH, SOFT, CANPACK>());
+                        &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>, wide_kernel<M, KCH, SOFT, CANPACK>(), wide_kernel<M, KCH, SOFT, CANPACK, false>());
     else
         rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>,
                         &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>);
@@ -819,10 +846,10 @@ int launch_pair(usvmpc_handle *h, int phase)
         // (the packed layouts - every OCP of the reference, the bench workloads - also come with the aux plane in LDS)
         if (pack && h->merge_rows && !h->spec.box_dense)
             rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true, CANPACK>,
-                            &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>, wide_kernel<M, KCH, SOFT, CANPACK>());
+                            &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>, wide_kernel<M, KCH, SOFT, CANPACK>(), wide_kernel<M, KCH, SOFT, CANPACK, false>());
         else
             rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>,
-                                   &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>, wide_kernel<M, KCH, SOFT, false>())
+                                   &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>, wide_kernel<M, KCH, SOFT, false>(), wide_kernel<M, KCH, SOFT, false, false>())
                        : launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, false>, &usv_qp_rti<M, KCH, SOFT, true, false, false, true>);
     } else {
         rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, false, CANPACK, false>, nullptr) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, false>, nullptr);
@@ -1040,7 +1067,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->aux_cap = 0;
     h->lds_mode = -1;
     h->lds_cap = 0;
-    h->wide_mode = -1; h->wide_cap = 0; h->last_wide = 0;
+    h->wide_mode = -1; h->wide_cap = 0; h->wide_hbm_cap = 0; h->last_wide = 0;
     h->max_waves = 0;
     {
         hipDeviceProp_t prop;
@@ -1430,7 +1457,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         if (!h->sort_enabled && h->ptrs.perm) { h->ptrs.perm = nullptr; h->map_changed = true; }
         return 0;
     }
-    if (s == "max_waves") { h->max_waves = (long)value; h->wide_cap = 0; cond_release(h); return 0; }
+    if (s == "max_waves") { h->max_waves = (long)value; h->wide_cap = 0; h->wide_hbm_cap = 0; cond_release(h); return 0; }
     if (s == "keep_multipliers") { // create the "lam" / "t" buffers now (a partially condensed solve fills them only if they exist)
         if (value == 0.0) return 0;
         DevPtrs &P = h->ptrs;
@@ -1465,7 +1492,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
     }
     if (s == "wide") { // the latency mapping, one instance per wave: -1 for batches that leave SIMDs idle (default), 0 never, 1 whenever it applies
         h->wide_mode = value < 0.0 ? -1 : (value > 0.0 ? 1 : 0);
-        h->wide_cap = 0;
+        h->wide_cap = 0; h->wide_hbm_cap = 0;
         return 0;
     }
     if (s == "dynamic_rows") { // 0: one group per row for the whole launch (the rows of a wave wait for its slowest)

@@ -140,19 +140,19 @@ void qp_body(void *a)
 }
 
 // the WIDE mapping: the body runs on the 64 fibers of a whole wave; row 0 owns the LDS region, rows 1 - 3 share it
-template <class M, int KCH, bool SOFT, bool MERGE>
+template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS>
 void qp_wide_body(void *a)
 {
     Job *j = (Job *)a;
     if constexpr (KCH == 1) {
-        QpIpm<M, KCH, SOFT, true, true, false, true, MERGE, false, true> q(*j->P, j->gid, lanes::wave_row() == 0 ? 0 : -1);
+        QpIpm<M, KCH, SOFT, true, true, false, LDSWS, MERGE, false, true> q(*j->P, j->gid, lanes::wave_row() == 0 ? 0 : -1);
         q.solve(j->qp_phase, j->queue0);
     }
 }
 template <class M, int KCH, bool SOFT>
 size_t wide_lds(int N)
 {
-    if constexpr (KCH == 1) return (size_t)QpIpm<M, KCH, SOFT, true, true, false, true, true, false, true>::wide_lds_doubles(N);
+    if constexpr (KCH == 1) return (size_t)QpIpm<M, KCH, SOFT, true, true, false, true, true, false, true>::wide_lds_doubles(N) + 4 * 2 * LANES; // (either variant)
     else return 0;
 }
 
@@ -255,8 +255,10 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
             if (KCH == 1 && g_emu_wide && qp_phase == 0 && S.hdiag && pack) {
                 lds.assign(wide_lds<M, KCH, SOFT>(S.N), 0.0);
                 lanes::g_emu_lds = lds.data();
-                if (g_emu_merge && !S.box_dense) lanes::run_group(g, &qp_wide_body<M, KCH, SOFT, true>, &j, 4);
-                else lanes::run_group(g, &qp_wide_body<M, KCH, SOFT, false>, &j, 4);
+                // (lds mode off: the wide sweeps over the planes in HBM - horizons that do not fit a CU's LDS)
+                const bool mg = g_emu_merge && !S.box_dense;
+                if (g_emu_lds_mode) lanes::run_group(g, mg ? &qp_wide_body<M, KCH, SOFT, true, true> : &qp_wide_body<M, KCH, SOFT, false, true>, &j, 4);
+                else lanes::run_group(g, mg ? &qp_wide_body<M, KCH, SOFT, true, false> : &qp_wide_body<M, KCH, SOFT, false, false>, &j, 4);
                 g_emu_wide_runs++;
                 continue;
             }

@@ -16,7 +16,10 @@ from tests.test_emu_kernels import emu_rti, _d
                                            ("usv_model_pf_ca", 5, 1, 1), ("usv_model_guidance_ca1", 7, 8, 2), ("usv_model_guidance_ca1", 6, 3, 0),
                                            ("usv_model_pf_ca", 7, 10, 2), ("usv_model_pf_ca", 6, 11, 0), ("usv_model_pf_ca", 5, 10, 1),
                                            ("usv_model_guidance_ca1", 6, 16, 2), ("usv_model_guidance_ca1", 5, 15, 0)])
-def test_wide_mapping_equals_the_16_lane_sweeps_bit_for_bit(emu, name, N, K, rows):
+@pytest.mark.parametrize("lds", [1, 0])
+def test_wide_mapping_equals_the_16_lane_sweeps_bit_for_bit(emu, name, N, K, rows, lds):
+    """lds = 1: the solver's planes in (emulated) LDS; 0: in HBM - the variant for horizons that do not fit a CU's LDS (the row planes
+    of the next block and the recursion's planes of the next stage asked for ahead of their use)."""
     B = 5
     wl = scenario.make_batch(name, N, K, B, dt=0.05, seed=17, generator="survey", sim_steps=scenario.BENCH_SIM_STEPS[name], clip_time=0.1)
     ocp = usv_models.make_ocp(name, N * 0.05, N, K)
@@ -30,7 +33,7 @@ def test_wide_mapping_equals_the_16_lane_sweeps_bit_for_bit(emu, name, N, K, row
     emu.usv_emu_set_export.restype = None
     out = []
     try:
-        emu.usv_emu_set_mode(1, rows)   # (both with the workspace in emulated LDS)
+        emu.usv_emu_set_mode(lds, rows)
         for wide in (0, 1):
             emu.usv_emu_set_wide(wide)
             lam, t = np.zeros((B, N + 1, nlam)), np.zeros((B, N + 1, nlam))

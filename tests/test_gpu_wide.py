@@ -76,7 +76,13 @@ def _compare(name, N, K, B, ticks, opts_a=(("wide", 1),), opts_b=(("wide", 0),),
                                                ("usv_model_guidance_ca1", 20, 16, 100, 3),
                                                ("usv_model_pf_ca", 40, 10, 1, 4),
                                                ("usv_model_pf_ca", 20, 3, 1, 5),              # the reference's shape: one instance
-                                               ("usv_model_pf_ca", 21, 3, 7, 3)])             # (horizon not a multiple of the block of four)
+                                               ("usv_model_pf_ca", 21, 3, 7, 3),              # (horizon not a multiple of the block of four)
+                                               # horizons whose planes do not fit a CU's LDS: the wide sweeps over planes in HBM
+                                               ("usv_model_guidance_ca1", 100, 8, 1, 4),      # the reference node's own shape (nmpc_guidance_ca1.cpp:64)
+                                               ("usv_model_guidance_ca1", 100, 8, 40, 3),
+                                               ("usv_model_guidance_ca1", 70, 16, 24, 2),     # (two row passes)
+                                               ("usv_model_pf_ca", 100, 4, 16, 3),
+                                               ("usv_model_pf_ca", 99, 10, 8, 2)])
 def test_wide_mapping_equals_the_throughput_mapping(name, N, K, B, ticks):
     w = _compare(name, N, K, B, ticks)
     print("wide vs throughput mapping", name, N, K, B, "99th percentile of the relative difference %.2e" % w)

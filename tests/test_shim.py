@@ -53,6 +53,7 @@ def test_node_call_sequence_through_the_shim(oracle, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     rows = [ln.split() for ln in out.stdout.splitlines() if ln.startswith("tick")]
     assert len(rows) == ticks
+    print("\n".join(ln for ln in out.stdout.splitlines() if ln.startswith("timing")))   # (one instance, N = 100: the latency mapping over HBM planes)
     # the same closed loop on the oracle (scripts/usv_guidance_ca1/main.py protocol, N=100, Tf=5, K=8)
     N, K = 100, 8
     spec = oracle.spec(1, N, 5.0, K)

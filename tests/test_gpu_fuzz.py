@@ -1,6 +1,6 @@
 """Seeded sweep of shapes and options through the C ABI against the CPU oracle (`pytest -m gpu`): horizon, obstacle count (one
 and two lane chunks, none), batch sizes that leave rows of a wave idle, static / per-stage obstacle sets, the workspace in LDS or
-in HBM, the queue on or off - the corners that the fixed parity cases of test_gpu_parity.py do not visit.  Same bar as there:
+in HBM, the queue on or off, the latency / throughput mapping - the corners that the fixed parity cases of test_gpu_parity.py do not visit.  Same bar as there:
 statuses agree, iterates of instances converged on both sides within 1e-7 (relative, per component), IPM iteration counts
 within one."""
 import numpy as np
@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-7
 
 
-def _case(oracle, name, N, K, B, seed, static, lds, dyn, ticks=2):
+def _case(oracle, name, N, K, B, seed, static, lds, dyn, wide=-1, ticks=2):
     ocp, wl = util.make(name, N, K, B, seed=seed)
     dt = scenario.DT[name]
     s = BatchOcpSolver(ocp, B)
@@ -22,11 +22,12 @@ def _case(oracle, name, N, K, B, seed, static, lds, dyn, ticks=2):
         s.set_option("static_obstacles", static)
     s.set_option("lds_workspace", lds)
     s.set_option("dynamic_rows", dyn)
+    s.set_option("wide", wide)   # (-1: these batches are small - the latency mapping wherever the layout allows it; 0: never; 1: same as -1 here)
     spec = util.oracle_spec(oracle, name, N, dt, K)
     xo, uo = wl["x_init"].copy(), wl["u_init"].copy()
     good = np.ones(B, dtype=bool)
     slack = max(1, int(0.03 * B))
-    tag = (name, N, K, B, seed, static, lds, dyn)
+    tag = (name, N, K, B, seed, static, lds, dyn, wide)
     for it in range(ticks):
         st = s.solve()
         xo, uo, sto, ito = util.oracle_rti(oracle, spec, wl, xo, uo)
@@ -55,10 +56,11 @@ def _cases():
         N = int(rng.choice([2, 3, 7, 20, 33]))
         K = 0 if name == "usv_model" else int(rng.choice([1, 4, 9, 16, 17, 24]))
         B = int(rng.choice([1, 2, 3, 6, 9, 30, 67]))
-        out.append((name, N, K, B, int(rng.integers(1, 1000)), int(rng.integers(0, 2)), int(rng.choice([-1, 0, 1])), int(rng.integers(0, 2))))
+        out.append((name, N, K, B, int(rng.integers(1, 1000)), int(rng.integers(0, 2)), int(rng.choice([-1, 0, 1])), int(rng.integers(0, 2)),
+                    [-1, 0, 1][(i // 3) % 3]))
     return out
 
 
-@pytest.mark.parametrize("name,N,K,B,seed,static,lds,dyn", _cases())
-def test_shape_and_option_sweep(oracle, name, N, K, B, seed, static, lds, dyn):
-    _case(oracle, name, N, K, B, seed, static, lds, dyn)
+@pytest.mark.parametrize("name,N,K,B,seed,static,lds,dyn,wide", _cases())
+def test_shape_and_option_sweep(oracle, name, N, K, B, seed, static, lds, dyn, wide):
+    _case(oracle, name, N, K, B, seed, static, lds, dyn, wide)

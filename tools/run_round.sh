@@ -16,6 +16,9 @@ python bench.py --cpu-sample 0 --batch 1024 --horizon 20 --obstacles 3 > $out/be
 python bench.py --cpu-sample 0 --batch 1024 --horizon 20 --obstacles 3 --option wide=0 > $out/bench_cfg1_throughput_mapping_plain.json 2>/dev/null
 python bench.py --cpu-sample 0 --batch 1 --horizon 40 --obstacles 10 > $out/bench_one_instance_plain.json 2>/dev/null
 for m in usv_model_pf_ca usv_model_guidance_ca1; do python tools/latency_probe.py $m 20 3 1,64,512,1024,2048; python tools/latency_probe.py $m 40 10 1,64,256,512; done > $out/latency_probe.txt 2>&1
+python tools/latency_probe.py usv_model_guidance_ca1 100 8 1,16,128,1024 >> $out/latency_probe.txt 2>&1   # the reference node's own shape: N = 100, K = 8
+python tools/latency_probe.py usv_model_pf_ca 100 4 1,128,1024 >> $out/latency_probe.txt 2>&1
+python -m pytest tests/test_shim.py -m gpu -q -s 2>&1 | grep timing >> $out/latency_probe.txt
 python bench.py --cpu-sample 0 --horizon 80 --obstacles 20 --moving > $out/bench_cfg4_b65536_plain.json 2>/dev/null
 python bench.py --cpu-sample 0 --horizon 80 --obstacles 20 --moving --batch 8192 > $out/bench_cfg4_b8192_per_gpu_plain.json 2>/dev/null
 python bench.py --cpu-sample 0 --horizon 80 --obstacles 20 --moving --batch 8192 --cond-N 10 > $out/bench_cfg4_b8192_condN10_plain.json 2>/dev/null

@@ -154,8 +154,9 @@ int usvmpc_pipeline_stats(usvmpc_handle *h, long *used, long *discarded);
 /* Which mapping the last RTI solve ran on: 0 = four instances per wavefront (one per 16-lane row: the throughput mapping), 1 = ONE
  * instance per wavefront (option "wide": the latency mapping north_star names - the four rows of the wave share out the stage-local
  * constraint-row work of four consecutive stages; taken by default for batches that leave SIMDs idle, when the OCP's layout allows:
- * one obstacle chunk (K <= 16), every box row riding in an idle obstacle lane, the horizon's planes within a CU's LDS).  Results are
- * bit-identical on both.  The reference solves one instance per call: nmpc_guidance_ca1.cpp:577,612, usv_pf_ca/main.py:142-186. */
+ * one obstacle chunk (K <= 16), packed box rows, no soft state bounds; the planes live in the CU's LDS when the horizon fits, else in
+ * HBM).  The two mappings take every sum in the same order: results agree to rounding (two instantiations the compiler contracts
+ * differently), statuses and iteration counts are equal.  The reference solves one instance per call: nmpc_guidance_ca1.cpp:577,612, usv_pf_ca/main.py:142-186. */
 int usvmpc_last_mapping(usvmpc_handle *h, int *mapping);
 /* Closed-loop hand-over on the device: x0 <- x_1 (+ sigma * N(0,1) on the states selected by option
  * "disturbance_mask", default all), enqueued on the stream.

@@ -287,6 +287,9 @@ USV_DEV double xrow_shfl(double v, unsigned mask)
 USV_DEV double xrow_max(double v) { v = vmax(v, xrow_shfl(v, 16u)); v = vmax(v, xrow_shfl(v, 32u)); return v; }
 USV_DEV double xrow_sum(double v) { v += xrow_shfl(v, 16u); v += xrow_shfl(v, 32u); return v; }
 USV_DEV int wave_first_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// (several waves per instance: qp_ipm.hpp WW) this lane's row among the rows of the workgroup; workgroup barrier
+USV_DEV unsigned block_row() { return threadIdx.x >> 4; }
+USV_DEV void block_sync() { __syncthreads(); }
 USV_DEV void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 // the workgroup's dynamic LDS (one wave per workgroup in the QP kernel): the planes of PlanesLds, or the aux area of qp_ipm.hpp
 USV_DEV double *dyn_lds()

@@ -237,9 +237,14 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 // Riccati / forward recursion then runs over the block's stages in all four rows alike (a wave64 instruction costs the same for
 // one active row as for four: profiles/r03_exec16_microbench.txt).  Every sum is taken in the order of the 16-lane sweeps, so
 // the results equal theirs bit for bit; only row 0 writes results.
+// WW (with WIDE): waves per instance.  The row phase scales on: a workgroup of WW waves shares out the row work of 4 WW consecutive stages
+// (wave w, row r: stage kb -+ (4 w + r)), every wave runs the recursion over the block; the exchange area, the planes in LDS and the
+// parked constants are the workgroup's, phases are separated by workgroup barriers, wave 0 / row 0 writes.  For the single instance and
+// the few dozen: a CU (WW = 4) or half a CU (WW = 2) per instance.
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false,
-          bool WIDE = false>
+          bool WIDE = false, int WW = 1>
 struct QpIpm {
+    static_assert(WW == 1 || (WIDE && (WW == 2 || WW == 4)), "several waves per instance: the wide mapping only");
     static_assert(!WIDE || (PACK && KCH == 1 && HDIAG && !SOFTBOX && !AUXLDS), "the wide mapping works on the packed one-chunk layouts");
     static_assert(!MERGE || PACK, "merged row pass works on the packed layout");
     static_assert(!(AUXLDS && LDSWS), "with the whole workspace in LDS the aux plane is there already");
@@ -1306,7 +1311,43 @@ struct QpIpm {
     enum : int { EX_GHB = 0, EX_GAMB, EX_DLB, EX_SC, EX_MU1, EX_MU2, EX_MU3, EX_Z, EX_DV, EX_ALL };
     static constexpr int EX_N = LDSWS ? (int)EX_Z : (int)EX_ALL;
     static_assert(EX_Z == WIDE_EX_PLANES && EX_ALL == WIDE_EX_PLANES_HBM, "host-side size of the exchange area");
-    static constexpr int wide_lds_doubles(int N_) { return (LDSWS ? (N_ + 1) * NPLW * LANES : 0) + 4 * EX_N * LANES; }
+    static constexpr int BS = 4 * WW; // stages per block = rows of the workgroup
+    static constexpr int wide_lds_doubles(int N_) { return (LDSWS ? (N_ + 1) * NPLW * LANES : 0) + BS * EX_N * LANES + (WW > 1 ? LANES : 0); }
+    // phases of a sweep hand values from row to row through LDS (or, WW > 1, from wave to wave: a workgroup barrier)
+    USV_DEV static void wide_sync()
+    {
+        if constexpr (WW > 1) {
+            if constexpr (!LDSWS) lanes::drain_stores();
+            lanes::block_sync();
+        } else lanes::lds_fence();
+    }
+    // a wave-uniform value reduced over the workgroup's waves (WW > 1): through a few LDS words behind the exchange area
+    template <bool MAX>
+    USV_DEV double xwave(double v) const
+    {
+        if constexpr (WW == 1) return v;
+        else {
+            double *sc = lanes::dyn_lds() + (LDSWS ? (N + 1) * NPLW * LANES : 0) + BS * EX_N * LANES;
+            sc[lanes::block_row() >> 2] = v;
+            lanes::block_sync();
+            double r = sc[0];
+            for (int w = 1; w < WW; w++) r = MAX ? lanes::vmax(r, sc[w]) : r + sc[w];
+            lanes::block_sync();
+            return r;
+        }
+    }
+    USV_DEV int xwave_first_i(int v) const // wave 0's value
+    {
+        if constexpr (WW == 1) return v;
+        else {
+            double *sc = lanes::dyn_lds() + (LDSWS ? (N + 1) * NPLW * LANES : 0) + BS * EX_N * LANES;
+            if (lanes::block_row() < 4u) sc[0] = (double)v;
+            lanes::block_sync();
+            const int r = (int)sc[0];
+            lanes::block_sync();
+            return r;
+        }
+    }
     USV_DEV unsigned ex_at(int row, int plane) const { return (unsigned)((LDSWS ? (N + 1) * NPLW * LANES : 0) + (row * EX_N + plane) * LANES + lane); }
     USV_DEV void ex_put(int row, int plane, double v) const { lanes::dyn_lds()[ex_at(row, plane)] = v; }
     USV_DEV double ex_get(int row, int plane) const { return lanes::dyn_lds()[ex_at(row, plane)]; }
@@ -1368,7 +1409,7 @@ struct QpIpm {
     template <bool FACT>
     USV_DEV void backward_wide(Norms &nm, double sigmu, bool pend, double a_prev, double sigmu_prev)
     {
-        const int row = (int)lanes::wave_row();
+        const int row = (int)lanes::block_row();
         double Pn[NX], pn = 0.0, pin = 0.0;
         sfor<0, NX>([&](auto c) { Pn[c] = 0.0; });
         double rg_r = 0.0, rd_r = 0.0, rm_r = 0.0, nan_r = 0.0; // what the norms get from the rows this row has processed
@@ -1384,7 +1425,8 @@ struct QpIpm {
             const int kr = N - row;
             row_load<SW>(kr >= 0 ? kr : 0, ws_row(kr >= 0 ? kr : 0, false), rnx);
         }
-        for (int kb = N; kb >= 0; kb -= 4) {
+        wide_sync(); // (WW > 1: the cold start's / the last sweep's stores of wave 0 before the other waves' loads)
+        for (int kb = N; kb >= 0; kb -= BS) {
             // ---- row phase: row r on stage kb - r (with the pending update of the previous iteration applied first)
             {
                 const int kr = kb - row;
@@ -1498,13 +1540,13 @@ struct QpIpm {
                 }
                 if constexpr (!LDSWS) ex_put(row, EX_Z, znew);
             }
-            lanes::lds_fence();
+            wide_sync();
             if constexpr (!LDSWS) { // the next block's row planes go in flight before the recursion of this one
-                const int kr = kb - 4 - row;
-                if (kb >= 4) row_load<SW>(kr >= 0 ? kr : 0, ws_row(kr >= 0 ? kr : 0, false), rnx); // wave-uniform
+                const int kr = kb - BS - row;
+                if (kb >= BS) row_load<SW>(kr >= 0 ? kr : 0, ws_row(kr >= 0 ? kr : 0, false), rnx); // wave-uniform
             }
             // ---- the recursion over the block's stages, in all four rows alike
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < BS; j++) {
                 const int k = kb - j;
                 if (k < 0) break; // wave-uniform
                 const WPl W = ws_seq(k);
@@ -1633,25 +1675,32 @@ struct QpIpm {
                 pn = pv;
                 pin = pik;
             }
-            lanes::lds_fence();
+            wide_sync();
         }
         if constexpr (!LDSWS) lanes::drain_stores(); // (rows read each other's stores in the next sweep)
         if (FACT) {
             const Planes W0 = ws(0);
             const double e0 = xlane ? W0.ld(P_DX0) - W0.ld(P_Z) : 0.0; // x0 - (xbar_0 + dx_0)
-            nm.rg = lanes::gmax(lanes::vmax(nm.rg, lanes::xrow_max(rg_r)));
+            if constexpr (WW == 1) {
+                nm.rg = lanes::gmax(lanes::vmax(nm.rg, lanes::xrow_max(rg_r)));
+                nm.rd = lanes::gmax(lanes::xrow_max(rd_r));
+                nm.rm = lanes::gmax(lanes::xrow_max(rm_r));
+                nm.nan = lanes::gsum(nm.nan + lanes::xrow_sum(nan_r));
+            } else { // (maxima, and a sum of zeros or NaNs: the same values whatever the order)
+                nm.rg = lanes::vmax(lanes::gmax(nm.rg), xwave<true>(lanes::gmax(lanes::xrow_max(rg_r))));
+                nm.rd = xwave<true>(lanes::gmax(lanes::xrow_max(rd_r)));
+                nm.rm = xwave<true>(lanes::gmax(lanes::xrow_max(rm_r)));
+                nm.nan = lanes::gsum(nm.nan) + xwave<false>(lanes::gsum(lanes::xrow_sum(nan_r)));
+            }
             nm.rb = lanes::gmax(fmax(nm.rb, fabs(e0)));
-            nm.rd = lanes::gmax(lanes::xrow_max(rd_r));
-            nm.rm = lanes::gmax(lanes::xrow_max(rm_r));
             nm.musum = lanes::gsum(nm.musum);
-            nm.nan = lanes::gsum(nm.nan + lanes::xrow_sum(nan_r));
         }
     }
 
     template <bool FINAL>
     USV_DEV void forward_wide(double sigmu, double &alpha, double &S1, double &S2)
     {
-        const int row = (int)lanes::wave_row();
+        const int row = (int)lanes::block_row();
         double dzx;
         {
             const Planes W0 = ws(0);
@@ -1663,10 +1712,11 @@ struct QpIpm {
         seq_load<SW>(0, nxt);
         StageIn rnx;
         if constexpr (!LDSWS) row_load<SW>(row <= N ? row : N, ws_row(row <= N ? row : N, false), rnx);
-        for (int kb = 0; kb <= N; kb += 4) {
+        wide_sync();
+        for (int kb = 0; kb <= N; kb += BS) {
             // ---- the recursion over the block's stages, in all four rows alike; row r keeps the step of stage kb + r
             double mydz = 0.0;
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < BS; j++) {
                 const int k = kb + j;
                 if (k > N) break; // wave-uniform
                 const WPl W = ws_seq(k);
@@ -1704,7 +1754,7 @@ struct QpIpm {
                     dzx = xlane ? dxn : 0.0;
                 }
             }
-            lanes::lds_fence();
+            wide_sync();
             // ---- row phase: row r on the rows of stage kb + r
             {
                 const int kr = kb + row;
@@ -1714,8 +1764,8 @@ struct QpIpm {
                 if constexpr (LDSWS) row_load<SW>(k, ws_row(k, false), in);
                 else {
                     in = rnx;
-                    const int k2 = kr + 4 <= N ? kr + 4 : N;
-                    if (kb + 4 <= N) row_load<SW>(k2, ws_row(k2, false), rnx); // wave-uniform: the next block's, in flight during its recursion
+                    const int k2 = kr + BS <= N ? kr + BS : N;
+                    if (kb + BS <= N) row_load<SW>(k2, ws_row(k2, false), rnx); // wave-uniform: the next block's, in flight during its recursion
                 }
                 const double z = in.z, aux = in.aux;
                 const double dz = mydz;
@@ -1755,17 +1805,17 @@ struct QpIpm {
                 }
             }
             if (!FINAL) { // the sums for mu_aff, stage by stage as the 16-lane sweep takes them
-                lanes::lds_fence();
-                for (int j = 0; j < 4; j++) {
+                wide_sync();
+                for (int j = 0; j < BS; j++) {
                     if constexpr (!MERGE) { s1 += ex_get(j, 4); s2 += ex_get(j, 5); }
                     s1 += ex_get(j, 0); s2 += ex_get(j, 1);
                     if constexpr (SOFT) { s1 += ex_get(j, 2); s2 += ex_get(j, 3); }
                 }
-                lanes::lds_fence();
+                wide_sync();
             }
         }
         if constexpr (!LDSWS) lanes::drain_stores(); // (rows read each other's stores in the next sweep)
-        alpha = 1.0 / lanes::gmax(lanes::xrow_max(q)); // q >= 1: alpha = min(1, min over blocking pairs of -v/dv)
+        alpha = 1.0 / xwave<true>(lanes::gmax(lanes::xrow_max(q))); // q >= 1: alpha = min(1, min over blocking pairs of -v/dv)
         if (!FINAL) { S1 = lanes::gsum(s1); S2 = lanes::gsum(s2); }
     }
 
@@ -2075,8 +2125,8 @@ struct QpIpm {
                     // one ticket per finished row; beyond the batch there is nothing left and the row stays idle
                     int gn = 0;
                     if constexpr (WIDE) { // one ticket for the wave
-                        if (fin && lanes::wave_lane() == 0u) gn = queue0 + lanes::fetch_add(P.queue);
-                        gn = lanes::wave_first_i(gn);
+                        if (fin && lanes::block_row() == 0u && lane == 0) gn = queue0 + lanes::fetch_add(P.queue);
+                        gn = xwave_first_i(lanes::wave_first_i(gn));
                     } else {
                         if (fin && lane == 0) gn = queue0 + lanes::fetch_add(P.queue);
                         gn = lanes::bcast_i<0>(gn);

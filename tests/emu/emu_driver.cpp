@@ -111,7 +111,7 @@ struct Job { const DevPtrs *P; long gid; int qp_phase; int queue0; };
 int g_emu_lds_mode = 0; // 1: run the RTI solves with the workspace in (emulated) LDS
 int g_emu_merge = 1;    // 1: box rows processed in their slot lanes when all of them ride there (as the device library does)
 int g_emu_aux = 0;      // 1: RTI solves of the packed one-chunk layouts keep the aux plane in (emulated) LDS (AUXLDS instantiations)
-int g_emu_wide = 0;     // 1: RTI solves of the merged one-chunk layouts on the WIDE mapping (a whole emulated wave per instance)
+int g_emu_wide = 0;     // 1 / 2 / 4: RTI solves of the packed one-chunk layouts on the WIDE mapping, that many emulated waves per instance
 long g_emu_wide_runs = 0; // rows started on the WIDE mapping since the switch was set
 
 template <class M, int KCH, bool SOFT>
@@ -140,19 +140,26 @@ void qp_body(void *a)
 }
 
 // the WIDE mapping: the body runs on the 64 fibers of a whole wave; row 0 owns the LDS region, rows 1 - 3 share it
-template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS>
+template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS, int WW = 1>
 void qp_wide_body(void *a)
 {
     Job *j = (Job *)a;
     if constexpr (KCH == 1) {
-        QpIpm<M, KCH, SOFT, true, true, false, LDSWS, MERGE, false, true> q(*j->P, j->gid, lanes::wave_row() == 0 ? 0 : -1);
+        QpIpm<M, KCH, SOFT, true, true, false, LDSWS, MERGE, false, true, WW> q(*j->P, j->gid, lanes::block_row() == 0 ? 0 : -1);
         q.solve(j->qp_phase, j->queue0);
     }
+}
+template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS>
+void run_wide(long g, Job &j, int ww)
+{
+    if (ww == 4) lanes::run_group(g, &qp_wide_body<M, KCH, SOFT, MERGE, LDSWS, 4>, &j, 16);
+    else if (ww == 2) lanes::run_group(g, &qp_wide_body<M, KCH, SOFT, MERGE, LDSWS, 2>, &j, 8);
+    else lanes::run_group(g, &qp_wide_body<M, KCH, SOFT, MERGE, LDSWS, 1>, &j, 4);
 }
 template <class M, int KCH, bool SOFT>
 size_t wide_lds(int N)
 {
-    if constexpr (KCH == 1) return (size_t)QpIpm<M, KCH, SOFT, true, true, false, true, true, false, true>::wide_lds_doubles(N) + 4 * 2 * LANES; // (either variant)
+    if constexpr (KCH == 1) return (size_t)QpIpm<M, KCH, SOFT, true, true, false, true, true, false, true, 4>::wide_lds_doubles(N) + 16 * 2 * LANES; // (any variant)
     else return 0;
 }
 
@@ -257,8 +264,8 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
                 lanes::g_emu_lds = lds.data();
                 // (lds mode off: the wide sweeps over the planes in HBM - horizons that do not fit a CU's LDS)
                 const bool mg = g_emu_merge && !S.box_dense;
-                if (g_emu_lds_mode) lanes::run_group(g, mg ? &qp_wide_body<M, KCH, SOFT, true, true> : &qp_wide_body<M, KCH, SOFT, false, true>, &j, 4);
-                else lanes::run_group(g, mg ? &qp_wide_body<M, KCH, SOFT, true, false> : &qp_wide_body<M, KCH, SOFT, false, false>, &j, 4);
+                if (g_emu_lds_mode) { if (mg) run_wide<M, KCH, SOFT, true, true>(g, j, g_emu_wide); else run_wide<M, KCH, SOFT, false, true>(g, j, g_emu_wide); }
+                else { if (mg) run_wide<M, KCH, SOFT, true, false>(g, j, g_emu_wide); else run_wide<M, KCH, SOFT, false, false>(g, j, g_emu_wide); }
                 g_emu_wide_runs++;
                 continue;
             }

@@ -15,7 +15,7 @@
 namespace lanes {
 
 constexpr int GROUP = 16;
-constexpr int MAXF = 64;   // fibers of a whole emulated wave (the WIDE mapping of qp_ipm.hpp: four rows in lock step)
+constexpr int MAXF = 256;  // fibers of a whole emulated workgroup (the WIDE mapping of qp_ipm.hpp: 4 .. 16 rows in lock step)
 
 struct Emu {
     int cur = 0;           // fiber currently running: row * 16 + lane
@@ -120,9 +120,9 @@ inline int observe(const int *flag) { return *flag; }
 inline void set_bits(int *word, int bits) { *word |= bits; }
 
 // lane index inside the (emulated) wave: the group's quarter of its 4-group tile (a whole emulated wave: the fiber number)
-inline unsigned wave_lane() { return g_emu.rows > 1 ? (unsigned)g_emu.cur : (unsigned)((g_emu.group & 3) * 16 + g_emu.cur); }
+inline unsigned wave_lane() { return g_emu.rows > 1 ? (unsigned)(g_emu.cur & 63) : (unsigned)((g_emu.group & 3) * 16 + g_emu.cur); }
 // across the rows of a whole emulated wave (gfx950/lanes.hpp): rendezvous of all its fibers
-inline double xrow_shfl(double v, unsigned mask) { return exchange_wave(v, (int)((unsigned)g_emu.cur ^ mask) % (16 * g_emu.rows)); }
+inline double xrow_shfl(double v, unsigned mask) { return exchange_wave(v, (int)((unsigned)g_emu.cur ^ mask)); }
 inline double xrow_max(double v)
 {
     if (g_emu.rows < 4) return v;
@@ -135,8 +135,10 @@ inline double xrow_sum(double v)
     v += xrow_shfl(v, 16u); v += xrow_shfl(v, 32u);
     return v;
 }
-inline int wave_first_i(int v) { return (int)exchange_wave((double)v, 0); }
+inline int wave_first_i(int v) { return (int)exchange_wave((double)v, g_emu.cur & ~63); }
 inline void lds_fence() { (void)exchange(0.0, 0); }
+inline unsigned block_row() { return (unsigned)(g_emu.cur >> 4); }
+inline void block_sync() { (void)exchange(0.0, 0); }
 
 // the planes of one stage [group][plane][16] (plain pointers here; a buffer resource on the GPU)
 struct Planes {
@@ -163,7 +165,7 @@ struct Planes {
 // wave-private exchange area (gfx950/lanes.hpp): one emulated row, sync() is a rendezvous of its 16 lanes
 template <int NENT, int ROWS = 4>
 struct Xpose {
-    static double *area() { static double s[4][NENT]; return s[ROWS == 1 ? 0 : (g_emu.cur >> 4)]; }
+    static double *area() { static double s[4][NENT]; return s[ROWS == 1 ? 0 : ((g_emu.cur >> 4) & 3)]; }
     static void put(int slot, double v) { area()[slot] = v; }
     static double get(int slot) { return area()[slot]; }
     static void sync() { (void)exchange(0.0, 0); }
@@ -172,7 +174,7 @@ struct Xpose {
 // per-lane constants parked in LDS (gfx950/lanes.hpp): one emulated row
 template <int NSLOT, int WLANES = 64>
 struct Stash {
-    static double *area() { static double s[4][NSLOT * 16]; return s[WLANES == 16 ? 0 : (g_emu.cur >> 4)]; }
+    static double *area() { static double s[4][NSLOT * 16]; return s[WLANES == 16 ? 0 : ((g_emu.cur >> 4) & 3)]; }
     static void put(int slot, double v) { area()[slot * 16 + lane()] = v; }
     static double get(int slot) { return area()[slot * 16 + lane()]; }
 };
@@ -180,7 +182,7 @@ struct Stash {
 // the workgroup's LDS (one emulated row per "wave")
 extern double *g_emu_lds;
 constexpr int WAVE_ROWS = 1;
-inline unsigned wave_row() { return (unsigned)(g_emu.cur >> 4); }
+inline unsigned wave_row() { return (unsigned)((g_emu.cur >> 4) & 3); }
 inline double *dyn_lds() { return g_emu_lds; }
 struct PlanesLds {
     unsigned off;

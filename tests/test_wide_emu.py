@@ -16,10 +16,11 @@ from tests.test_emu_kernels import emu_rti, _d
                                            ("usv_model_pf_ca", 5, 1, 1), ("usv_model_guidance_ca1", 7, 8, 2), ("usv_model_guidance_ca1", 6, 3, 0),
                                            ("usv_model_pf_ca", 7, 10, 2), ("usv_model_pf_ca", 6, 11, 0), ("usv_model_pf_ca", 5, 10, 1),
                                            ("usv_model_guidance_ca1", 6, 16, 2), ("usv_model_guidance_ca1", 5, 15, 0)])
-@pytest.mark.parametrize("lds", [1, 0])
-def test_wide_mapping_equals_the_16_lane_sweeps_bit_for_bit(emu, name, N, K, rows, lds):
+@pytest.mark.parametrize("lds,ww", [(1, 1), (0, 1), (1, 4), (0, 2), (1, 2), (0, 4)])
+def test_wide_mapping_equals_the_16_lane_sweeps_bit_for_bit(emu, name, N, K, rows, lds, ww):
     """lds = 1: the solver's planes in (emulated) LDS; 0: in HBM - the variant for horizons that do not fit a CU's LDS (the row planes
-    of the next block and the recursion's planes of the next stage asked for ahead of their use)."""
+    of the next block and the recursion's planes of the next stage asked for ahead of their use).
+    ww: waves per instance (qp_ipm.hpp WW) - a workgroup of ww waves shares out the row work of 4 ww consecutive stages."""
     B = 5
     wl = scenario.make_batch(name, N, K, B, dt=0.05, seed=17, generator="survey", sim_steps=scenario.BENCH_SIM_STEPS[name], clip_time=0.1)
     ocp = usv_models.make_ocp(name, N * 0.05, N, K)
@@ -34,7 +35,7 @@ def test_wide_mapping_equals_the_16_lane_sweeps_bit_for_bit(emu, name, N, K, row
     out = []
     try:
         emu.usv_emu_set_mode(lds, rows)
-        for wide in (0, 1):
+        for wide in (0, ww):
             emu.usv_emu_set_wide(wide)
             lam, t = np.zeros((B, N + 1, nlam)), np.zeros((B, N + 1, nlam))
             emu.usv_emu_set_export(_d(lam), _d(t))

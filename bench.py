@@ -434,8 +434,9 @@ def main():
                 "qp_formulation": ("partially condensed on the device: %d stages -> %d dense stages of %d, IPM + Riccati on those, expansion "
                                    "(csrc/cond_ipm.hpp)" % (N, args.cond_N, N // args.cond_N)) if cond_applied
                 else "uncondensed: Riccati over the %d stages (blocks of one stage, the reference's own setting)" % N,
-                "mapping": ("one OCP instance per wavefront (option 'wide': the rows of the wave share out the stage-local row work; planes in LDS)"
-                            if mapping == 1 else "four OCP instances per wavefront (one per 16-lane row)"),
+                "mapping": ("one OCP instance per wavefront (option 'wide': the rows of the wave share out the stage-local row work)" if mapping == 1
+                            else "one OCP instance per workgroup of four wavefronts (options 'wide' / 'wide_waves')" if mapping == 4
+                            else "four OCP instances per wavefront (one per 16-lane row)"),
                 "lib_sha256": lib_hash,
                 "sharding": "batch-sharded x%d, no data-path collective" % world, "ranks_seen": ranks_seen,
             },

@@ -330,7 +330,8 @@ class BatchOcpSolver:
         return a.value, b.value
 
     def last_mapping(self):
-        """0: the last RTI solve ran four instances per wavefront; 1: one instance per wavefront (option "wide", usvmpc_last_mapping)."""
+        """0: the last RTI solve ran four instances per wavefront; 1: one instance per wavefront (option "wide"); 4: one instance per
+        workgroup of four wavefronts (option "wide_waves") - usvmpc_last_mapping."""
         a = C.c_int()
         self._check(self._lib.usvmpc_last_mapping(self._h, C.byref(a)))
         return a.value

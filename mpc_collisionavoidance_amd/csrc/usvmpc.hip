@@ -55,23 +55,34 @@ constexpr int qp_waves() { return (KCH >= 2 || SOFTBOX) ? 1 : USV_QP_WAVES; }
 // AUXLDS: the aux plane of the rows' instances in the wave's LDS instead of HBM (qp_ipm.hpp)
 // WIDE: the latency mapping - one instance per wave (rows = 1: rows 1 - 3 are handed row 0's group and share its LDS region; in the
 // sweeps they take over the row work of the neighbouring stages: qp_ipm.hpp)
-template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false, bool WIDE = false>
-__global__ void __launch_bounds__(64, ((LDSWS || WIDE) ? 1 : qp_waves<KCH, SOFTBOX>())) usv_qp_rti(DevPtrs P, long ngroups, int phase, int queue0, int rows)
+// WW > 1 (with WIDE): a workgroup of WW waves per instance (qp_ipm.hpp)
+template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false, bool WIDE = false,
+          int WW = 1>
+__global__ void __launch_bounds__(64 * WW, ((LDSWS || WIDE) ? 1 : qp_waves<KCH, SOFTBOX>())) usv_qp_rti(DevPtrs P, long ngroups, int phase, int queue0, int rows)
 {
     const int row = (int)(threadIdx.x >> 4);
     const long g0 = (long)blockIdx.x * rows;
     if (g0 >= ngroups) return;
     const bool has = row < rows;
-    QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, LDSWS, MERGE, AUXLDS, WIDE> q(P, has ? g0 + row : g0, has ? row : -1);
+    QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, LDSWS, MERGE, AUXLDS, WIDE, WW> q(P, has ? g0 + row : g0, has ? row : -1);
     q.solve(phase, queue0);
 }
 // (the wide instantiation exists for the one-chunk layouts only)
 // (LDSWS: the solver's planes in LDS - false: in HBM, for horizons that do not fit a CU's LDS)
-template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS = true>
+template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS = true, int WW = 1>
 constexpr auto wide_kernel()
 {
-    if constexpr (KCH == 1) return &usv_qp_rti<M, KCH, SOFT, true, true, false, LDSWS, MERGE, false, true>;
+    if constexpr (KCH == 1) return &usv_qp_rti<M, KCH, SOFT, true, true, false, LDSWS, MERGE, false, true, WW>;
     else return (decltype(&usv_qp_rti<M, KCH, SOFT, true, (KCH > 0), false, true, MERGE>))nullptr;
+}
+// the wide kernels of one layout: [planes in LDS, planes in HBM] x [one wave, four waves per instance]
+using qp_kernel_t = void (*)(DevPtrs, long, int, int, int);
+struct WideSet { qp_kernel_t lds1, hbm1, lds4, hbm4; };
+template <class M, int KCH, bool SOFT, bool MERGE>
+constexpr WideSet wide_set()
+{
+    return WideSet{wide_kernel<M, KCH, SOFT, MERGE, true, 1>(), wide_kernel<M, KCH, SOFT, MERGE, false, 1>(),
+                   wide_kernel<M, KCH, SOFT, MERGE, true, 4>(), wide_kernel<M, KCH, SOFT, MERGE, false, 4>()};
 }
 
 // Multiplier read-back (usvmpc_get "lam" / "t"): the inequality multipliers and slacks of every instance's last QP, from the
@@ -273,6 +284,8 @@ struct usvmpc_handle {
     int wide_mode;            // the latency mapping (one instance per wave, QpIpm WIDE): -1 for small batches (default), 0 never, 1 whenever it applies
     long wide_cap;            // waves a launch of the wide kernel holds at once (0: not yet known, -1: does not fit)
     long wide_hbm_cap;        // the same for the wide kernel over planes in HBM (horizons that do not fit LDS)
+    int wide_waves;           // waves per instance of the latency mapping: -1 four while the batch is at most one instance per CU, else one (default); 1; 4
+    long wide4_cap, wide4_hbm_cap; // workgroups of four waves a launch holds at once (0: not yet known, -1: does not fit)
     int last_wide;            // the last RTI launch ran on the wide kernel
     long max_waves;           // cap on the persistent waves of the QP kernel (0: as many as the device holds)
     int ncu;                  // compute units of the device
@@ -703,10 +716,43 @@ int launch_pair(usvmpc_handle *h, int phase)
     // Small batches: the planes of every instance in flight fit in LDS (160 KB per CU), and a solve whose sweeps wait for
     // HBM at every stage - nothing else runs on the CU to hide it - becomes a solve on LDS.  rows_lds instances per wave
     // (as many whole horizons as fit), one wave per CU at a time; further instances come through the same queue.
-    auto launch_qp = [&](auto kern, decltype(kern) kern_lds, decltype(kern) kern_aux = nullptr, decltype(kern) kern_wide = nullptr,
-                         decltype(kern) kern_wide_hbm = nullptr) -> int {
+    auto launch_qp = [&](auto kern, decltype(kern) kern_lds, decltype(kern) kern_aux = nullptr, WideSet wide = WideSet{nullptr, nullptr, nullptr, nullptr}) -> int {
         const long lds_inst = (long)(h->N + 1) * h->spec.npt * 128;
         h->last_wide = 0;
+        const qp_kernel_t kern_wide = wide.lds1, kern_wide_hbm = wide.hbm1;
+        // Four waves per instance (qp_ipm.hpp, WW): a workgroup = a whole CU shares out the row work of 16 consecutive stages - for the
+        // single instance and batches of at most one instance per CU.
+        if (wide.lds4 != nullptr && phase == 0 && h->wide_mode != 0 && h->wide_waves != 1 && h->ncu > 0) {
+            const size_t pl = (size_t)(h->N + 1) * (size_t)(WsLayout<M, KCH, SOFT>::P_RB0 - 4) * 128;
+            const size_t b4 = pl + (size_t)16 * WIDE_EX_PLANES * 128 + 128, x4 = (size_t)16 * WIDE_EX_PLANES_HBM * 128 + 128;
+            const long ws_bytes = (long)(h->N + 1) * h->Bp * h->spec.npt * 128;
+            if (h->wide4_cap == 0) {
+                int nb = 0;
+                hipFuncAttributes fa;
+                if (b4 <= 160u * 1024u && hipFuncGetAttributes(&fa, (const void *)wide.lds4) == hipSuccess && fa.sharedSizeBytes + b4 <= 160u * 1024u &&
+                    hipFuncSetAttribute((const void *)wide.lds4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b4) == hipSuccess &&
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wide.lds4, 4 * qp_block, b4) == hipSuccess && nb > 0)
+                    h->wide4_cap = (long)h->ncu;
+                else
+                    h->wide4_cap = -1;
+            }
+            if (h->wide4_cap < 0 && h->wide4_hbm_cap == 0) {
+                int nb = 0;
+                h->wide4_hbm_cap = (wide.hbm4 != nullptr && ws_bytes < (1L << 31) &&
+                                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wide.hbm4, 4 * qp_block, x4) == hipSuccess && nb > 0) ? (long)h->ncu : -1;
+            }
+            const bool lds = h->wide4_cap > 0;
+            const long cap = lds ? h->wide4_cap : h->wide4_hbm_cap;
+            if (cap > 0 && ((long)h->B <= cap || h->wide_waves == 4)) {
+                long nw = (long)h->B;
+                int q0 = -1;
+                if (h->dynamic_rows && nw > cap) { nw = cap; q0 = (int)nw; }
+                if (q0 >= 0) HIP_TRY(h, hipMemsetAsync(h->ptrs.queue, 0, sizeof(int), h->stream));
+                hipLaunchKernelGGL(lds ? wide.lds4 : wide.hbm4, dim3((unsigned)nw), dim3(4 * qp_block), lds ? b4 : x4, h->stream, h->ptrs, nw, phase, q0, 1);
+                h->last_wide = 4;
+                return 0;
+            }
+        }
         // The latency mapping: ONE instance per wave (qp_ipm.hpp, WIDE) - planes in LDS, the four rows share out the stage-local row
         // work.  A wave then finishes an instance ~1.8x sooner and the device holds a quarter of the instances at once: it pays while
         // the batch leaves SIMDs idle anyway (a solve of the batch then lasts as long as its hardest instance on a lone wave).
@@ -834,7 +880,7 @@ int launch_pair(usvmpc_handle *h, int phase)
     // (one row pass when every box row rides in a slot lane: qp_ipm.hpp, MERGE)
     if (h->merge_rows && !h->spec.box_dense)
         rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true, CANPACK>,
-                        &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>, wide_kernel<M, KCH, SOFT, CANPACK>(), wide_kernel<M, KCH, SOFT, CANPACK, false>());
+                        &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>, wide_set<M, KCH, SOFT, CANPACK>());
     else
         rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>,
                         &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>);
@@ -846,10 +892,10 @@ int launch_pair(usvmpc_handle *h, int phase)
         // (the packed layouts - every OCP of the reference, the bench workloads - also come with the aux plane in LDS)
         if (pack && h->merge_rows && !h->spec.box_dense)
             rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true, CANPACK>,
-                            &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>, wide_kernel<M, KCH, SOFT, CANPACK>(), wide_kernel<M, KCH, SOFT, CANPACK, false>());
+                            &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, true>, wide_set<M, KCH, SOFT, CANPACK>());
         else
             rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>,
-                                   &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>, wide_kernel<M, KCH, SOFT, false>(), wide_kernel<M, KCH, SOFT, false, false>())
+                                   &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>, wide_set<M, KCH, SOFT, false>())
                        : launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, false>, &usv_qp_rti<M, KCH, SOFT, true, false, false, true>);
     } else {
         rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, false, CANPACK, false>, nullptr) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, false>, nullptr);
@@ -1068,6 +1114,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->lds_mode = -1;
     h->lds_cap = 0;
     h->wide_mode = -1; h->wide_cap = 0; h->wide_hbm_cap = 0; h->last_wide = 0;
+    h->wide_waves = -1; h->wide4_cap = 0; h->wide4_hbm_cap = 0;
     h->max_waves = 0;
     {
         hipDeviceProp_t prop;
@@ -1493,6 +1540,10 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
     if (s == "wide") { // the latency mapping, one instance per wave: -1 for batches that leave SIMDs idle (default), 0 never, 1 whenever it applies
         h->wide_mode = value < 0.0 ? -1 : (value > 0.0 ? 1 : 0);
         h->wide_cap = 0; h->wide_hbm_cap = 0;
+        return 0;
+    }
+    if (s == "wide_waves") { // waves per instance of the latency mapping: -1 (default) four up to one instance per CU, else one; 1; 4
+        h->wide_waves = value < 0.0 ? -1 : (value >= 4.0 ? 4 : 1);
         return 0;
     }
     if (s == "dynamic_rows") { // 0: one group per row for the whole launch (the rows of a wave wait for its slowest)

@@ -65,7 +65,7 @@ def _closed_loop(oracle, name, N, K, B, ticks, sigma, tol_max, seed=1234, wide=N
         sts, its = oracle.rti_batch(spec, xs, us, x0, *data, threads=8)
         stf, itf = oracle.rti_batch(spec, xf, uf, x0, *data, threads=8)
         stg, qs, qi = s.get_int("status"), s.get_int("qp_status"), s.get_int("qp_iter")
-        assert wide is None or s.last_mapping() == wide
+        assert wide is None or (s.last_mapping() > 0) == (wide > 0)   # (1: one wave per instance, 4: four - small batches)
         assert int(s.fail_counts(1)[0]) == int((stg != 0).sum())          # the on-device audit counter
         xg, ug = s.get_all("x"), s.get_all("u")
         # ---- same inputs: status of every instance, failing set, iteration counts, iterate

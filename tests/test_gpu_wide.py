@@ -27,7 +27,7 @@ def _make(name, N, K, B, seed, opts):
     return s
 
 
-def _compare(name, N, K, B, ticks, opts_a=(("wide", 1),), opts_b=(("wide", 0),), seed=1234, map_a=1, map_b=0):
+def _compare(name, N, K, B, ticks, opts_a=(("wide", 1), ("wide_waves", 1)), opts_b=(("wide", 0),), seed=1234, map_a=1, map_b=0):
     a, b = _make(name, N, K, B, seed, opts_a), _make(name, N, K, B, seed, opts_b)
     worst = 0.0
     for t in range(ticks):
@@ -88,12 +88,24 @@ def test_wide_mapping_equals_the_throughput_mapping(name, N, K, B, ticks):
     print("wide vs throughput mapping", name, N, K, B, "99th percentile of the relative difference %.2e" % w)
 
 
+@pytest.mark.parametrize("name,N,K,B,ticks", [("usv_model_pf_ca", 20, 3, 200, 4), ("usv_model_guidance_ca1", 20, 3, 1, 4),
+                                               ("usv_model_pf_ca", 40, 10, 64, 3), ("usv_model_guidance_ca1", 40, 10, 256, 3),
+                                               ("usv_model_pf_ca", 21, 9, 5, 3), ("usv_model_guidance_ca1", 100, 8, 1, 4),
+                                               ("usv_model_guidance_ca1", 100, 8, 30, 2), ("usv_model_pf_ca", 99, 10, 8, 2),
+                                               ("usv_model_pf_ca", 20, 3, 600, 2)])     # (more instances than CUs: the rest through the queue)
+def test_four_waves_per_instance_equal_the_throughput_mapping(name, N, K, B, ticks):
+    """Option wide_waves = 4 (usvmpc_last_mapping = 4): a workgroup of four wavefronts - a whole CU - per instance, the row work of 16
+    consecutive stages at once; planes in LDS or (N = 99 / 100) in HBM."""
+    w = _compare(name, N, K, B, ticks, opts_a=(("wide", 1), ("wide_waves", 4)), map_a=4)
+    print("four waves per instance vs throughput mapping", name, N, K, B, "99th percentile of the relative difference %.2e" % w)
+
+
 def test_wide_mapping_with_the_work_queue_and_without():
     """4096 instances are more than the device holds waves of the wide kernel: the rest comes through the queue.  dynamic_rows = 0:
     one workgroup per instance instead (the same kernel, so these two ARE bit-identical)."""
     name, N, K, B = "usv_model_pf_ca", 20, 3, 4096
     _compare(name, N, K, B, 2)
-    a, b = _make(name, N, K, B, 9, (("wide", 1),)), _make(name, N, K, B, 9, (("wide", 1), ("dynamic_rows", 0)))
+    a, b = _make(name, N, K, B, 9, (("wide", 1), ("wide_waves", 1))), _make(name, N, K, B, 9, (("wide", 1), ("wide_waves", 1), ("dynamic_rows", 0)))
     sa, sb = a.solve(), b.solve()
     assert a.last_mapping() == 1 and b.last_mapping() == 1
     assert np.array_equal(sa, sb)
@@ -106,7 +118,7 @@ def test_wide_mapping_with_the_work_queue_and_without():
 
 def test_default_takes_the_wide_mapping_for_small_batches_only():
     name, N, K = "usv_model_pf_ca", 20, 3
-    for B, want in ((64, 1), (1024, 1), (16384, 0)):
+    for B, want in ((64, 4), (256, 4), (1024, 1), (16384, 0)):   # (up to one instance per CU: four waves each)
         s = _make(name, N, K, B, 5, ())
         s.solve()
         assert s.last_mapping() == want, (B, s.last_mapping())

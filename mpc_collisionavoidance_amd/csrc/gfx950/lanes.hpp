@@ -357,15 +357,16 @@ struct Planes {
 // and slots holding constants (0.0, 1.0) replace the selects for entries that are structurally zero / one.  This is how
 // the packed stage matrix is turned into the row (backward sweeps) or column (forward sweeps) form the products need.
 // LDS operations of one wave execute in order; sync() only keeps the compiler from moving reads above the writes.
-// ROWS = 1 (the WIDE mapping: the four rows hold the same values): one copy for the wave.
-template <int NENT, int ROWS = 4>
+// PERWAVE (the WIDE mapping: the four rows of a wave hold the same values): one copy per wave, ROWS = waves of the workgroup - the
+// waves of a workgroup drift apart between its barriers, so they must not share one.
+template <int NENT, int ROWS = 4, bool PERWAVE = false>
 struct Xpose {
     USV_DEV static double *area()
     {
         __shared__ double s[NENT * ROWS];
         return s;
     }
-    USV_DEV static unsigned row() { return ROWS == 1 ? 0u : ((threadIdx.x >> 4) & 3u); }
+    USV_DEV static unsigned row() { return PERWAVE ? (ROWS == 1 ? 0u : (threadIdx.x >> 6)) : ((threadIdx.x >> 4) & 3u); }
     USV_DEV static void put(int slot, double v) { area()[slot * ROWS + row()] = v; }
     USV_DEV static double get(int slot) { return area()[slot * ROWS + row()]; }
     USV_DEV static void sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }

@@ -363,7 +363,7 @@ struct QpIpm {
     static constexpr unsigned CMASK = MP::col_mask();
     static constexpr int NCOL = __builtin_popcount(CMASK);
     static constexpr int ZSLOT = MP::NPK * 16, OSLOT = ZSLOT + 1;
-    using XP = lanes::Xpose<MP::NPK * 16 + 2, (WIDE ? 1 : 4)>; // (WIDE: the rows hold the same matrix - one copy)
+    using XP = lanes::Xpose<MP::NPK * 16 + 2, (WIDE ? WW : 4), WIDE>; // (WIDE: the rows of a wave hold the same matrix - one copy per wave)
     unsigned rowtab[(NX + 3) / 4], coltab[(NCOL + 3) / 4];
     bool selfone; // this lane's state has the exact unit diagonal and its own column is not among the stored ones
     bool isslot, isdense, anydense;
@@ -1316,10 +1316,14 @@ struct QpIpm {
     // phases of a sweep hand values from row to row through LDS (or, WW > 1, from wave to wave: a workgroup barrier)
     USV_DEV static void wide_sync()
     {
-        if constexpr (WW > 1) {
-            if constexpr (!LDSWS) lanes::drain_stores();
-            lanes::block_sync();
-        } else lanes::lds_fence();
+        if constexpr (WW > 1) lanes::block_sync();
+        else lanes::lds_fence();
+    }
+    // ... at the start of a sweep: the cold start's / the last sweep's stores of other waves have landed
+    USV_DEV static void sweep_sync()
+    {
+        if constexpr (WW > 1 && !LDSWS) lanes::drain_stores();
+        wide_sync();
     }
     // a wave-uniform value reduced over the workgroup's waves (WW > 1): through a few LDS words behind the exchange area
     template <bool MAX>
@@ -1418,6 +1422,7 @@ struct QpIpm {
             rbscale = pend ? rbscale * (1.0 - a_prev) : rbscale; // the step applied in this sweep
         }
         constexpr int SW = FACT ? SW_BACK_A : SW_BACK_B;
+        sweep_sync();
         SeqIn nxt;
         seq_load<SW>(N, nxt);
         StageIn rnx;
@@ -1425,7 +1430,6 @@ struct QpIpm {
             const int kr = N - row;
             row_load<SW>(kr >= 0 ? kr : 0, ws_row(kr >= 0 ? kr : 0, false), rnx);
         }
-        wide_sync(); // (WW > 1: the cold start's / the last sweep's stores of wave 0 before the other waves' loads)
         for (int kb = N; kb >= 0; kb -= BS) {
             // ---- row phase: row r on stage kb - r (with the pending update of the previous iteration applied first)
             {
@@ -1678,6 +1682,7 @@ struct QpIpm {
             wide_sync();
         }
         if constexpr (!LDSWS) lanes::drain_stores(); // (rows read each other's stores in the next sweep)
+        if constexpr (!LDSWS && WW > 1) lanes::block_sync(); // (... and stage 0's iterate of another wave right below)
         if (FACT) {
             const Planes W0 = ws(0);
             const double e0 = xlane ? W0.ld(P_DX0) - W0.ld(P_Z) : 0.0; // x0 - (xbar_0 + dx_0)
@@ -1708,11 +1713,11 @@ struct QpIpm {
         }
         double q = 1.0, s1 = 0.0, s2 = 0.0;
         constexpr int SW = FINAL ? SW_FWD_B : SW_FWD_A;
+        sweep_sync();
         SeqIn nxt;
         seq_load<SW>(0, nxt);
         StageIn rnx;
         if constexpr (!LDSWS) row_load<SW>(row <= N ? row : N, ws_row(row <= N ? row : N, false), rnx);
-        wide_sync();
         for (int kb = 0; kb <= N; kb += BS) {
             // ---- the recursion over the block's stages, in all four rows alike; row r keeps the step of stage kb + r
             double mydz = 0.0;
@@ -2133,6 +2138,7 @@ struct QpIpm {
                     }
                     const bool take = fin && gn < nB;
                     if (lanes::wave_any(take)) { // wave-uniform
+                        if constexpr (WW > 1) lanes::block_sync(); // (the parked constants are the workgroup's: no wave may still be reading the old instance's)
                         bind((long)gn, take);
                         const bool bad = init(take) && take;
                         real = take ? (WIDE ? live : true) : real;

@@ -163,9 +163,9 @@ struct Planes {
 };
 
 // wave-private exchange area (gfx950/lanes.hpp): one emulated row, sync() is a rendezvous of its 16 lanes
-template <int NENT, int ROWS = 4>
+template <int NENT, int ROWS = 4, bool PERWAVE = false>
 struct Xpose {
-    static double *area() { static double s[4][NENT]; return s[ROWS == 1 ? 0 : ((g_emu.cur >> 4) & 3)]; }
+    static double *area() { static double s[4][NENT]; return s[PERWAVE ? (g_emu.cur >> 6) : ((g_emu.cur >> 4) & 3)]; }
     static void put(int slot, double v) { area()[slot] = v; }
     static double get(int slot) { return area()[slot]; }
     static void sync() { (void)exchange(0.0, 0); }

@@ -153,7 +153,7 @@ int usvmpc_unconverged_counts(usvmpc_handle *h, int n, int *counts);
 int usvmpc_pipeline_stats(usvmpc_handle *h, long *used, long *discarded);
 /* Which mapping the last RTI solve ran on: 0 = four instances per wavefront (one per 16-lane row: the throughput mapping), 1 = ONE
  * instance per wavefront, 4 = one instance per workgroup of FOUR wavefronts (option "wide_waves": a whole CU shares out the row work of
- * 16 consecutive stages; default for batches of at most one instance per CU) (option "wide": the latency mapping north_star names - the four rows of the wave share out the stage-local
+ * 16 consecutive stages; default for soft-row OCPs in batches of at most one instance per CU) (option "wide": the latency mapping north_star names - the four rows of the wave share out the stage-local
  * constraint-row work of four consecutive stages; taken by default for batches that leave SIMDs idle, when the OCP's layout allows:
  * one obstacle chunk (K <= 16), packed box rows, no soft state bounds; the planes live in the CU's LDS when the horizon fits, else in
  * HBM).  The two mappings take every sum in the same order: results agree to rounding (two instantiations the compiler contracts
@@ -191,8 +191,8 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  *   "merge_box_rows" (default 1) - when every box row rides in an idle lane of the last obstacle chunk's planes the sweeps
  *       process them there (one row pass instead of two).  A separately compiled instantiation: statuses and iteration
  *       counts equal, iterates agree to rounding - as with "lds_workspace";
- *   "wide_waves" (default -1) - wavefronts per instance of the latency mapping: -1 four while the batch is at most one instance per
- *       CU and one beyond, 1, 4;
+ *   "wide_waves" (default -1) - wavefronts per instance of the latency mapping: -1 four for OCPs with soft obstacle rows while the batch
+ *       is at most one instance per CU (their row work is the larger share: 6 - 12 % per tick), one otherwise; 1; 4;
  *   "wide" (default -1) - the latency mapping, ONE instance per wavefront (usvmpc_last_mapping): -1 while the batch fits the device's
  *       SIMDs twice over, 0 never, 1 whenever the OCP's layout allows it; results do not change by a bit;
  *   "aux_in_lds" (default 1) - an RTI solve keeps the per-stage aux plane (dense box rows, linearisation point, r_g, l_u) in the

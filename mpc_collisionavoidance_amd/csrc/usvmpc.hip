@@ -284,7 +284,7 @@ struct usvmpc_handle {
     int wide_mode;            // the latency mapping (one instance per wave, QpIpm WIDE): -1 for small batches (default), 0 never, 1 whenever it applies
     long wide_cap;            // waves a launch of the wide kernel holds at once (0: not yet known, -1: does not fit)
     long wide_hbm_cap;        // the same for the wide kernel over planes in HBM (horizons that do not fit LDS)
-    int wide_waves;           // waves per instance of the latency mapping: -1 four while the batch is at most one instance per CU, else one (default); 1; 4
+    int wide_waves;           // waves per instance of the latency mapping: -1 (default) four for soft-row OCPs while the batch is at most one instance per CU, else one; 1; 4
     long wide4_cap, wide4_hbm_cap; // workgroups of four waves a launch holds at once (0: not yet known, -1: does not fit)
     int last_wide;            // the last RTI launch ran on the wide kernel
     long max_waves;           // cap on the persistent waves of the QP kernel (0: as many as the device holds)
@@ -743,7 +743,10 @@ int launch_pair(usvmpc_handle *h, int phase)
             }
             const bool lds = h->wide4_cap > 0;
             const long cap = lds ? h->wide4_cap : h->wide4_hbm_cap;
-            if (cap > 0 && ((long)h->B <= cap || h->wide_waves == 4)) {
+            // default: for the soft-row OCPs only - their row work is the larger share (measured, one instance / 256 instances per tick:
+            // usv_model_guidance_ca1 N = 100 1.78 -> 1.59 / 5.6 -> 5.0 ms, N = 40 0.94 -> 0.86 / 2.05 -> 1.87; usv_model_pf_ca 3 - 7 % SLOWER:
+            // its recursion dominates and pays the barriers)
+            if (cap > 0 && (h->wide_waves == 4 || (SOFT && (long)h->B <= cap))) {
                 long nw = (long)h->B;
                 int q0 = -1;
                 if (h->dynamic_rows && nw > cap) { nw = cap; q0 = (int)nw; }
@@ -1542,7 +1545,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         h->wide_cap = 0; h->wide_hbm_cap = 0;
         return 0;
     }
-    if (s == "wide_waves") { // waves per instance of the latency mapping: -1 (default) four up to one instance per CU, else one; 1; 4
+    if (s == "wide_waves") { // waves per instance of the latency mapping: -1 (default) four for soft-row OCPs up to one instance per CU, else one; 1; 4
         h->wide_waves = value < 0.0 ? -1 : (value >= 4.0 ? 4 : 1);
         return 0;
     }

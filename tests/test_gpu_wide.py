@@ -118,8 +118,13 @@ def test_wide_mapping_with_the_work_queue_and_without():
 
 def test_default_takes_the_wide_mapping_for_small_batches_only():
     name, N, K = "usv_model_pf_ca", 20, 3
-    for B, want in ((64, 4), (256, 4), (1024, 1), (16384, 0)):   # (up to one instance per CU: four waves each)
+    for B, want in ((64, 1), (1024, 1), (16384, 0)):
         s = _make(name, N, K, B, 5, ())
+        s.solve()
+        assert s.last_mapping() == want, (B, s.last_mapping())
+        s.close()
+    for B, want in ((1, 4), (256, 4), (300, 1)):   # (soft-row OCP, up to one instance per CU: four waves each)
+        s = _make("usv_model_guidance_ca1", N, K, B, 5, ())
         s.solve()
         assert s.last_mapping() == want, (B, s.last_mapping())
         s.close()

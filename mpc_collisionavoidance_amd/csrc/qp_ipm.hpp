@@ -245,7 +245,8 @@ template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = fal
           bool WIDE = false, int WW = 1>
 struct QpIpm {
     static_assert(WW == 1 || (WIDE && (WW == 2 || WW == 4)), "several waves per instance: the wide mapping only");
-    static_assert(!WIDE || (PACK && KCH == 1 && HDIAG && !SOFTBOX && !AUXLDS), "the wide mapping works on the packed one-chunk layouts");
+    static_assert(!WIDE || (((PACK && KCH == 1) || (!PACK && KCH == 0)) && HDIAG && !SOFTBOX && !AUXLDS),
+                  "the wide mapping works on the packed one-chunk layouts and on the layout without obstacle rows");
     static_assert(!MERGE || PACK, "merged row pass works on the packed layout");
     static_assert(!(AUXLDS && LDSWS), "with the whole workspace in LDS the aux plane is there already");
     static_assert(!PACK || KCH > 0, "box rows are packed into obstacle planes");
@@ -317,9 +318,13 @@ struct QpIpm {
     // touch are squeezed out and the lineariser's planes (P_RB0, P_GQ, P_MAT..: read once per sweep) stay in HBM, so that the
     // horizon of an instance takes half the LDS and twice as many waves are resident.
     struct WideMap {
-        static constexpr int at(int plane) { return plane < WL::P_BLL ? plane : (plane >= WL::P_OBS && plane < WL::P_RB0 ? plane - 4 : -1); }
+        static constexpr int at(int plane)
+        {
+            if (!PACK) return plane < WL::P_RB0 ? plane : -1; // (no obstacle rows: the box planes are in use)
+            return plane < WL::P_BLL ? plane : (plane >= WL::P_OBS && plane < WL::P_RB0 ? plane - 4 : -1);
+        }
     };
-    static constexpr int NPLW = (WIDE && LDSWS) ? WL::P_RB0 - 4 : WL::NPT; // planes per stage of an LDS region
+    static constexpr int NPLW = (WIDE && LDSWS) ? WL::P_RB0 - (PACK ? 4 : 0) : WL::NPT; // planes per stage of an LDS region
     using Planes = std::conditional_t<WIDE && LDSWS, lanes::PlanesLdsMapped<WideMap>, std::conditional_t<LDSWS, lanes::PlanesLds, lanes::Planes>>;
 
     const DevPtrs &P;
@@ -569,7 +574,8 @@ struct QpIpm {
             r.zl = bzl; r.zu = bzu; r.Zl = bZl; r.Zu = bZu; r.bsl = bbsl; r.bsu = bbsu;
         }
     }
-    USV_DEV static void box_store(const Planes &W, const BoxRow &r)
+    template <class PL>
+    USV_DEV static void box_store(const PL &W, const BoxRow &r)
     {
         W.st(P_BLL, r.ll); W.st(P_BLU, r.lu); W.st(P_BTL, r.tl); W.st(P_BTU, r.tu);
         if constexpr (SOFTBOX) {
@@ -1406,8 +1412,11 @@ struct QpIpm {
         in.aux = W.ld(P_AUX);
         if (SW == SW_BACK_A) in.dz = W.ld(P_DZ);
         if (SW != SW_FWD_A) in.dza = W.ld(P_DZA);
-        sfor<0, OBSN>([&](auto e) { in.obs[0][e] = W.ld(P_OBS + e); });
-        if (!pstat) obs_raw<0>(k, in.raw[0]);
+        if constexpr (KCH > 0) {
+            sfor<0, OBSN>([&](auto e) { in.obs[0][e] = W.ld(P_OBS + e); });
+            if (!pstat) obs_raw<0>(k, in.raw[0]);
+        }
+        if constexpr (!PACK) { in.box[0] = W.ld(P_BLL); in.box[1] = W.ld(P_BLU); in.box[2] = W.ld(P_BTL); in.box[3] = W.ld(P_BTU); }
     }
 
     template <bool FACT>
@@ -1461,10 +1470,15 @@ struct QpIpm {
                             br.expand(dzp);
                             br.apply(a_prev);
                         }
-                        const double dv = box_pack(br, pk);
-                        // (the recursion composes the aux plane around the dense lanes)
-                        if constexpr (LDSWS) ws_row(k, own && isdense).st(P_AUX, dv);
-                        else ex_put(row, EX_DV, dv);
+                        if constexpr (PACK) {
+                            const double dv = box_pack(br, pk);
+                            // (the recursion composes the aux plane around the dense lanes)
+                            if constexpr (LDSWS) ws_row(k, own && isdense).st(P_AUX, dv);
+                            else ex_put(row, EX_DV, dv);
+                        } else {
+                            if (pend && br.act) box_store(W, br);
+                            if constexpr (!LDSWS) ex_put(row, EX_DV, aux);
+                        }
                     }
                     chain(br, znew, !FACT, dza, sigmu, Ghb, gamb);
                     dlb = br.act ? br.ll - br.lu : 0.0;
@@ -1475,6 +1489,7 @@ struct QpIpm {
                         nan_r = fma(0.0, br.rdl + br.rdu, nan_r);
                     }
                 }
+                if constexpr (KCH > 0) {
                 ObsRow o;
                 double cx, cy, Gh, gam;
                 obs_from<0>(in, k, zbx, zby, o, cx, cy);
@@ -1525,6 +1540,7 @@ struct QpIpm {
                         dlb = hasb ? g2 : 0.0;
                     }
                 }
+                } // (KCH > 0)
                 ex_put(row, EX_GAMB, gamb);
                 {
                     double sc = lane == 3 ? gx : gy; // (lanes beyond 6 are never read)
@@ -1790,6 +1806,7 @@ struct QpIpm {
                         ex_put(row, 5, br.act ? br.dll * br.dtl + br.dlu * br.dtu : 0.0);
                     }
                 }
+                if constexpr (KCH > 0) {
                 ObsRow o;
                 double cx, cy, Gh2, gam2;
                 obs_from<0>(in, k, zbx, zby, o, cx, cy);
@@ -1808,13 +1825,14 @@ struct QpIpm {
                         ex_put(row, 3, o.act ? o.dlsl * o.dtsl + o.dlsu * o.dtsu : 0.0);
                     }
                 }
+                } // (KCH > 0)
             }
             if (!FINAL) { // the sums for mu_aff, stage by stage as the 16-lane sweep takes them
                 wide_sync();
                 for (int j = 0; j < BS; j++) {
                     if constexpr (!MERGE) { s1 += ex_get(j, 4); s2 += ex_get(j, 5); }
-                    s1 += ex_get(j, 0); s2 += ex_get(j, 1);
-                    if constexpr (SOFT) { s1 += ex_get(j, 2); s2 += ex_get(j, 3); }
+                    if constexpr (KCH > 0) { s1 += ex_get(j, 0); s2 += ex_get(j, 1); }
+                    if constexpr (KCH > 0 && SOFT) { s1 += ex_get(j, 2); s2 += ex_get(j, 3); }
                 }
                 wide_sync();
             }

@@ -73,6 +73,7 @@ template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS = true, int WW = 1
 constexpr auto wide_kernel()
 {
     if constexpr (KCH == 1) return &usv_qp_rti<M, KCH, SOFT, true, true, false, LDSWS, MERGE, false, true, WW>;
+    else if constexpr (KCH == 0 && !MERGE) return &usv_qp_rti<M, KCH, SOFT, true, false, false, LDSWS, false, false, true, WW>; // (no obstacle rows: box rows in their own planes)
     else return (decltype(&usv_qp_rti<M, KCH, SOFT, true, (KCH > 0), false, true, MERGE>))nullptr;
 }
 // the wide kernels of one layout: [planes in LDS, planes in HBM] x [one wave, four waves per instance]
@@ -723,7 +724,7 @@ int launch_pair(usvmpc_handle *h, int phase)
         // Four waves per instance (qp_ipm.hpp, WW): a workgroup = a whole CU shares out the row work of 16 consecutive stages - for the
         // single instance and batches of at most one instance per CU.
         if (wide.lds4 != nullptr && phase == 0 && h->wide_mode != 0 && h->wide_waves != 1 && h->ncu > 0) {
-            const size_t pl = (size_t)(h->N + 1) * (size_t)(WsLayout<M, KCH, SOFT>::P_RB0 - 4) * 128;
+            const size_t pl = (size_t)(h->N + 1) * (size_t)(WsLayout<M, KCH, SOFT>::P_RB0 - (KCH > 0 ? 4 : 0)) * 128;
             const size_t b4 = pl + (size_t)16 * WIDE_EX_PLANES * 128 + 128, x4 = (size_t)16 * WIDE_EX_PLANES_HBM * 128 + 128;
             const long ws_bytes = (long)(h->N + 1) * h->Bp * h->spec.npt * 128;
             if (h->wide4_cap == 0) {
@@ -761,7 +762,7 @@ int launch_pair(usvmpc_handle *h, int phase)
         // the batch leaves SIMDs idle anyway (a solve of the batch then lasts as long as its hardest instance on a lone wave).
         if (kern_wide != nullptr && phase == 0 && h->wide_mode != 0 && h->ncu > 0) {
             // (in LDS: the planes the solve writes - WsLayout's up to L_zu less the four box planes the packed layouts leave unused)
-            const size_t bytes = (size_t)(h->N + 1) * (size_t)(WsLayout<M, KCH, SOFT>::P_RB0 - 4) * 128 + (size_t)4 * WIDE_EX_PLANES * 128;
+            const size_t bytes = (size_t)(h->N + 1) * (size_t)(WsLayout<M, KCH, SOFT>::P_RB0 - (KCH > 0 ? 4 : 0)) * 128 + (size_t)4 * WIDE_EX_PLANES * 128;
             if (h->wide_cap == 0) {
                 int nb = 0;
                 hipFuncAttributes fa;
@@ -899,7 +900,8 @@ int launch_pair(usvmpc_handle *h, int phase)
         else
             rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>,
                                    &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>, wide_set<M, KCH, SOFT, false>())
-                       : launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, false>, &usv_qp_rti<M, KCH, SOFT, true, false, false, true>);
+                       : launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, false>, &usv_qp_rti<M, KCH, SOFT, true, false, false, true>, nullptr,
+                                   KCH == 0 ? wide_set<M, KCH, SOFT, false>() : WideSet{nullptr, nullptr, nullptr, nullptr});
     } else {
         rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, false, CANPACK, false>, nullptr) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, false>, nullptr);
     }

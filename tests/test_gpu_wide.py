@@ -20,7 +20,8 @@ def _make(name, N, K, B, seed, opts):
     ocp.solver_options.sim_method_num_steps = scenario.BENCH_SIM_STEPS[name]
     s = BatchOcpSolver(ocp, B)
     scenario.load_into(s, wl)
-    s.set_option("static_obstacles", 1)
+    if K > 0:
+        s.set_option("static_obstacles", 1)
     s.set_option("disturbance_mask", scenario.NOISE_MASK[name])
     for k, v in opts:
         s.set_option(k, v)
@@ -82,7 +83,9 @@ def _compare(name, N, K, B, ticks, opts_a=(("wide", 1), ("wide_waves", 1)), opts
                                                ("usv_model_guidance_ca1", 100, 8, 40, 3),
                                                ("usv_model_guidance_ca1", 70, 16, 24, 2),     # (two row passes)
                                                ("usv_model_pf_ca", 100, 4, 16, 3),
-                                               ("usv_model_pf_ca", 99, 10, 8, 2)])
+                                               ("usv_model_pf_ca", 99, 10, 8, 2),
+                                               ("usv_model", 20, 0, 1, 4),                    # BASELINE configs[0]'s shape: no obstacle rows
+                                               ("usv_model", 20, 0, 500, 3), ("usv_model", 150, 0, 6, 2)])
 def test_wide_mapping_equals_the_throughput_mapping(name, N, K, B, ticks):
     w = _compare(name, N, K, B, ticks)
     print("wide vs throughput mapping", name, N, K, B, "99th percentile of the relative difference %.2e" % w)
@@ -92,7 +95,8 @@ def test_wide_mapping_equals_the_throughput_mapping(name, N, K, B, ticks):
                                                ("usv_model_pf_ca", 40, 10, 64, 3), ("usv_model_guidance_ca1", 40, 10, 256, 3),
                                                ("usv_model_pf_ca", 21, 9, 5, 3), ("usv_model_guidance_ca1", 100, 8, 1, 4),
                                                ("usv_model_guidance_ca1", 100, 8, 30, 2), ("usv_model_pf_ca", 99, 10, 8, 2),
-                                               ("usv_model_pf_ca", 20, 3, 600, 2)])     # (more instances than CUs: the rest through the queue)
+                                               ("usv_model_pf_ca", 20, 3, 600, 2),      # (more instances than CUs: the rest through the queue)
+                                               ("usv_model", 20, 0, 3, 3)])
 def test_four_waves_per_instance_equal_the_throughput_mapping(name, N, K, B, ticks):
     """Option wide_waves = 4 (usvmpc_last_mapping = 4): a workgroup of four wavefronts - a whole CU - per instance, the row work of 16
     consecutive stages at once; planes in LDS or (N = 99 / 100) in HBM."""

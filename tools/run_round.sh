@@ -18,6 +18,7 @@ python bench.py --cpu-sample 0 --batch 1 --horizon 40 --obstacles 10 > $out/benc
 for m in usv_model_pf_ca usv_model_guidance_ca1; do python tools/latency_probe.py $m 20 3 1,64,512,1024,2048; python tools/latency_probe.py $m 40 10 1,64,256,512; done > $out/latency_probe.txt 2>&1
 python tools/latency_probe.py usv_model_guidance_ca1 100 8 1,16,128,1024 >> $out/latency_probe.txt 2>&1   # the reference node's own shape: N = 100, K = 8
 python tools/latency_probe.py usv_model_pf_ca 100 4 1,128,1024 >> $out/latency_probe.txt 2>&1
+python tools/latency_probe.py usv_model 20 0 1,64,1024,2048 >> $out/latency_probe.txt 2>&1   # BASELINE configs[0]'s OCP (one instance) and batches of it
 python -m pytest tests/test_shim.py -m gpu -q -s 2>&1 | grep timing >> $out/latency_probe.txt
 python bench.py --cpu-sample 0 --horizon 80 --obstacles 20 --moving > $out/bench_cfg4_b65536_plain.json 2>/dev/null
 python bench.py --cpu-sample 0 --horizon 80 --obstacles 20 --moving --batch 8192 > $out/bench_cfg4_b8192_per_gpu_plain.json 2>/dev/null

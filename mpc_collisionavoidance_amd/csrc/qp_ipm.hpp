@@ -230,13 +230,15 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 // per stage) lives in the wave's LDS for the whole launch instead of being streamed with the planes: 4 reads + 2 writes of the
 // 59 + 13 plane accesses per stage and IPM iteration go (the kernel streams at the HBM ceiling: profiles/r03_bound_experiment.txt).
 // RTI launches whose horizon fits (host: usvmpc.hip); finish() leaves a copy in the HBM plane for the read-back paths.
-// WIDE (with LDSWS + MERGE, one obstacle chunk): the latency mapping - ONE instance per wave.  The four rows of the wave are given the
+// WIDE (one obstacle chunk with packed box rows - either row-pass form -, or no obstacle rows at all; the solver's planes in LDS, LDSWS, or
+// for horizons that do not fit there in HBM): the latency mapping - ONE instance per wave.  The four rows of the wave are given the
 // same instance and hold the same values; what a lone row spends most of a sweep on, the chains of a stage's box / obstacle rows
 // (stage-local: they depend on nothing outside their stage), the rows do for FOUR CONSECUTIVE STAGES at once - row r takes stage
 // kb -+ r of a block - and leave each stage's terms (Gamma, gamma, S_xx ...) in an exchange area of the workgroup's LDS; the
 // Riccati / forward recursion then runs over the block's stages in all four rows alike (a wave64 instruction costs the same for
 // one active row as for four: profiles/r03_exec16_microbench.txt).  Every sum is taken in the order of the 16-lane sweeps, so
-// the results equal theirs bit for bit; only row 0 writes results.
+// the results equal theirs bit for bit (lane emulator; on the device to rounding: the compiler contracts the two instantiations
+// differently); only row 0 writes results.
 // WW (with WIDE): waves per instance.  The row phase scales on: a workgroup of WW waves shares out the row work of 4 WW consecutive stages
 // (wave w, row r: stage kb -+ (4 w + r)), every wave runs the recursion over the block; the exchange area, the planes in LDS and the
 // parked constants are the workgroup's, phases are separated by workgroup barriers, wave 0 / row 0 writes.  For the single instance and

@@ -758,7 +758,7 @@ int launch_pair(usvmpc_handle *h, int phase)
             }
         }
         // The latency mapping: ONE instance per wave (qp_ipm.hpp, WIDE) - planes in LDS, the four rows share out the stage-local row
-        // work.  A wave then finishes an instance ~1.8x sooner and the device holds a quarter of the instances at once: it pays while
+        // work.  A wave then finishes an instance 1.4x (hard rows) to 1.8x (soft rows) sooner and the device holds a quarter of the instances at once: it pays while
         // the batch leaves SIMDs idle anyway (a solve of the batch then lasts as long as its hardest instance on a lone wave).
         if (kern_wide != nullptr && phase == 0 && h->wide_mode != 0 && h->ncu > 0) {
             // (in LDS: the planes the solve writes - WsLayout's up to L_zu less the four box planes the packed layouts leave unused)

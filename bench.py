@@ -90,10 +90,11 @@ def make_workload(name, N, K, batch, global_batch, workload, moving, rank, world
     (the contiguous slices of sharding.shard_bounds); every rank generates the whole batch and keeps its slice."""
     from mpc_collisionavoidance_amd import scenario, sharding
     gen_B, gen_seed = (global_batch, 1234) if global_batch else (batch, 1234 + rank)
-    if workload == "survey":
+    if workload in ("survey", "survey-verbatim"):
+        verbatim = workload == "survey-verbatim"
         dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
-        wl = scenario.make_bench_batch(name, N, K, gen_B, seed=gen_seed, moving=moving)
-        sigma, mask = 1e-3, scenario.NOISE_MASK[name]
+        wl = scenario.make_bench_batch(name, N, K, gen_B, seed=gen_seed, moving=moving, verbatim=verbatim)
+        sigma, mask = 1e-3, (scenario.ALL_STATES_MASK if verbatim else scenario.NOISE_MASK[name])
     else:
         dt, steps = scenario.DT[name], 1
         wl = scenario.make_batch(name, N, K, gen_B, seed=gen_seed, moving=moving)
@@ -135,8 +136,10 @@ def main():
     ap.add_argument("--horizon", type=int, default=40)
     ap.add_argument("--obstacles", type=int, default=10)
     ap.add_argument("--moving", action="store_true", help="obstacles move: per-stage p (BASELINE configs[4])")
-    ap.add_argument("--workload", default="survey", choices=["survey", "r01"],
-                    help="survey: SURVEY.md 8(d) (dt 0.05 s); r01: the round-1 workload (reference dt, no disturbance)")
+    ap.add_argument("--workload", default="survey", choices=["survey", "survey-verbatim", "r01"],
+                    help="survey: SURVEY.md 8(d) (dt 0.05 s) with the stated departures (config.workload); survey-verbatim: the generator as "
+                         "SURVEY words it - no obstacle clip, initial guess x_k = x0, disturbance on every state (the RK4 step count stays); "
+                         "r01: the round-1 workload (reference dt, no disturbance)")
     ap.add_argument("--sigma", type=float, default=None,
                     help="std of the Gaussian disturbance added at the hand-over (default: 1e-3 for survey, 0 for r01)")
     ap.add_argument("--cond-N", type=int, default=0, help="qp_solver_cond_N (0: acados default = N, no condensing)")
@@ -306,6 +309,11 @@ def main():
 
     nk = min(args.steps, 64)
     lin_ms, qp_ms = solver.kernel_ms(nk)
+    # per-step times on the device clock ("report median"): start of tick i to start of tick i + 1 on the solver's stream;
+    # the last step closes with the wall-clock remainder of the timed region
+    tick_ms = [float(v) for v in solver.tick_ms(nk)]
+    if nk == args.steps:
+        tick_ms.append(max(0.0, elapsed * 1e3 - sum(tick_ms)))
     mapping = solver.last_mapping()
     pipelined = B >= 16384 and not any(kv.split("=")[0] == "pipeline_linearize" and float(kv.split("=")[1]) == 0.0 for kv in args.option)
     fails = solver.fail_counts(nk)
@@ -334,12 +342,18 @@ def main():
     # every launch (usvmpc_unconverged_counts: qp_status != 0)
     unconv = float(solver.unconverged_counts(nk).sum()) * (args.steps / float(nk))
     solves_here = float(B * args.steps)
+    b_min = b_max = B
     if dist is not None:
         t = torch.tensor([unconv, solves_here], dtype=torch.float64, device="cuda")
         dist.all_reduce(t)
         unconv, total_solves = float(t[0].item()), float(t[1].item())
+        # (--global-batch not divisible by the ranks: the shards are ragged - the line reports the sum and the extremes, not rank 0's size)
+        tb = torch.tensor([float(B), -float(B)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        b_max, b_min = int(tb[0].item()), int(-tb[1].item())
     else:
         total_solves = solves_here
+    instances_total = int(round(total_solves / args.steps))
     value_all = total_solves / elapsed
     value = (total_solves - unconv) / elapsed
     balg = algorithmic_bytes(nx, nu, N, K, moving=args.moving)
@@ -404,6 +418,10 @@ def main():
                       "the course ray would enter closer than 0.4 m + %.2g s * u is moved outwards along its bearing (11 %% of the obstacles at "
                       "N=40), field scaled with the horizon (range up to %.3g m); (3) initial guess = zero-input roll-out with the solver's "
                       "integrator instead of x_k = x0; (4) disturbance on (u, r) only" % (steps, 1.1 * N * dt if N * dt > 2.0 + 1e-9 else 0.6 * N * dt, 3.0 * N * dt))
+    elif args.workload == "survey-verbatim":
+        departures = ("%d RK4 step(s) per interval%s; otherwise the generator as SURVEY 8(d) words it: no obstacle clip, initial guess x_k = x0 "
+                      "(acados' own), disturbance on every state" % (steps, " (one RK4 step of 0.05 s is outside usv_model_pf_ca's stability region: "
+                                                                            "scenario.py DT)" if steps > 1 else ""))
     elif args.workload == "survey":
         departures = "obstacle field scaled with the horizon (range up to %.3g m); initial guess = straight-line roll-out" % (3.0 * N * dt)
     if rank == 0:
@@ -417,6 +435,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_median": float(np.median(tick_ms)) if tick_ms else None,
+            "ms_per_step_min_max": [float(min(tick_ms)), float(max(tick_ms))] if tick_ms else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -425,11 +445,12 @@ def main():
             "config": {
                 "workload": "%s: batch=%d per GPU, %s, N=%d, Tf=%g s (dt=%g s, %d RK4 step(s) per interval), %d %s obstacles, "
                             "GN SQP-RTI, generator '%s', closed loop x0<-x1+N(0,%g) on states mask 0x%x, %s; departures from SURVEY 8(d): %s"
-                            % (baseline_config(name, B if not G else G // world, world, N, K, args.moving), B, name, N, N * dt, dt, steps, K,
+                            % (baseline_config(name, B if not G else G // world, world, N, K, args.moving), b_max, name, N, N * dt, dt, steps, K,
                                "moving" if args.moving else "static", wl["generator"], sigma, mask,
                                ("ONE seed-1234 batch of %d, shard b -> GPU floor(b*%d/%d)" % (G, world, G)) if G else "seed 1234+rank",
                                departures),
-                "ocp": name, "instances_per_gpu": B, "instances_total": world * B, "horizon": N, "obstacles": K,
+                "ocp": name, "instances_per_gpu": B if b_min == b_max else None, "instances_per_gpu_min_max": [b_min, b_max],
+                "instances_total": instances_total, "horizon": N, "obstacles": K,
                 "qp_solver_cond_N": args.cond_N if cond_applied else N,
                 "qp_formulation": ("partially condensed on the device: %d stages -> %d dense stages of %d, IPM + Riccati on those, expansion "
                                    "(csrc/cond_ipm.hpp)" % (N, args.cond_N, N // args.cond_N)) if cond_applied
@@ -466,6 +487,7 @@ def main():
                 "qp_not_converged_frac": float((qs != 0).mean()),
                 "solves_per_s_counting_unconverged_ones": value_all,
                 "unconverged_solves_in_timed_region": unconv,
+                "unconverged_counted_over_steps": nk,   # (the device keeps the last 64 launches' counts: beyond that the figure is scaled up)
                 "active_row_frac": float((tmin < 1e-3).mean()) if K > 0 else 0.0,
                 "qp_iter_mean": float(qi.mean()), "qp_iter_p50": float(np.percentile(qi, 50)),
                 "qp_iter_p99": float(np.percentile(qi, 99)), "qp_iter_max": int(qi.max()),

@@ -140,6 +140,10 @@ int usvmpc_get_device_ptr(usvmpc_handle *h, const char *field, void **dptr);
  * (oldest first, n <= 64), measured on the stream the kernels were launched on */
 int usvmpc_last_kernel_ms(usvmpc_handle *h, float *linearize_ms, float *qp_ms);
 int usvmpc_kernel_ms(usvmpc_handle *h, int n, float *linearize_ms, float *qp_ms);
+/* tick-to-tick times (ms) over the last n solves: ms[i] = start of solve i + 1 minus start of solve i on the handle's stream (n - 1 values,
+ * oldest first, 2 <= n <= 64) - everything a closed-loop step enqueued in between (QP launch, hand-over, the caller's own kernels) included;
+ * what bench.py reports the median of ("report median") */
+int usvmpc_tick_ms(usvmpc_handle *h, int n, float *ms);
 /* number of instances whose solve ended with status != 0, for each of the last n solves (oldest first, n <= 64); counted on
  * the device by the solve itself, so a closed loop can be audited without a read-back per tick */
 int usvmpc_fail_counts(usvmpc_handle *h, int n, int *counts);
@@ -152,12 +156,16 @@ int usvmpc_unconverged_counts(usvmpc_handle *h, int n, int *counts);
  * two solves in a row without such a write, so a caller that sets yref every tick (the reference's protocol) discards none. */
 int usvmpc_pipeline_stats(usvmpc_handle *h, long *used, long *discarded);
 /* Which mapping the last RTI solve ran on: 0 = four instances per wavefront (one per 16-lane row: the throughput mapping), 1 = ONE
- * instance per wavefront, 4 = one instance per workgroup of FOUR wavefronts (option "wide_waves": a whole CU shares out the row work of
- * 16 consecutive stages; default for soft-row OCPs in batches of at most one instance per CU) (option "wide": the latency mapping north_star names - the four rows of the wave share out the stage-local
- * constraint-row work of four consecutive stages; taken by default for batches that leave SIMDs idle, when the OCP's layout allows:
- * one obstacle chunk (K <= 16), packed box rows, no soft state bounds; the planes live in the CU's LDS when the horizon fits, else in
- * HBM).  The two mappings take every sum in the same order: results agree to rounding (two instantiations the compiler contracts
- * differently), statuses and iteration counts are equal.  The reference solves one instance per call: nmpc_guidance_ca1.cpp:577,612, usv_pf_ca/main.py:142-186. */
+ * instance per wavefront (option "wide": the latency mapping north_star names - the four rows of the wave share out the stage-local
+ * constraint-row work of four consecutive stages), 4 = one instance per workgroup of FOUR wavefronts (option "wide_waves": a whole CU
+ * shares out the row work of 16 consecutive stages; default for soft-row OCPs in batches of at most one instance per CU).  The latency
+ * mapping is taken by default for batches that leave SIMDs idle, when the OCP's layout allows: one obstacle chunk (K <= 16) with packed
+ * box rows, or no obstacle rows; no soft state bounds; the planes live in the CU's LDS when the horizon fits, else in HBM.
+ * WHICH mapping ran does not show in the results: all of them take every sum in the same order and contract multiply-adds the same way
+ * (qp_ipm.hpp: #pragma clang fp contract(on)), so statuses, iteration counts, iterates and multipliers are the same BITS - an instance
+ * solved in a handle of 1, of 512 or of 65 536 returns the same answer (tests/test_gpu_wide.py, test_gpu_closed_loop.py::
+ * test_shards_that_land_on_the_other_mapping_equal_the_unsharded_batch).  The reference solves one instance per call:
+ * nmpc_guidance_ca1.cpp:577,612, usv_pf_ca/main.py:142-186. */
 int usvmpc_last_mapping(usvmpc_handle *h, int *mapping);
 /* Closed-loop hand-over on the device: x0 <- x_1 (+ sigma * N(0,1) on the states selected by option
  * "disturbance_mask", default all), enqueued on the stream.
@@ -166,8 +174,8 @@ int usvmpc_last_mapping(usvmpc_handle *h, int *mapping);
 int usvmpc_advance(usvmpc_handle *h, double sigma, unsigned long long seed);
 /* Adopt a caller-owned HIP stream (e.g. torch's current stream) for all subsequent work */
 int usvmpc_set_stream(usvmpc_handle *h, void *stream);
-/* run-time options (scheduling / placement only; none changes the arithmetic beyond rounding - see the two marked -, except
- * "qp_cond_N", which selects another formulation of the same QP):
+/* run-time options (scheduling / placement only: results are the same bits whatever they are set to - except "merge_box_rows", which
+ * changes rounding, and "qp_cond_N", which selects another formulation of the same QP):
  *   "qp_cond_N" (default 0) - acados' qp_solver_cond_N (qp_solver = PARTIAL_CONDENSING_HPIPM:
  *       catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/acados_settings.py:172; the reference never sets it, i.e. blocks of one stage = the
  *       default here).  A value N2 < N makes every RTI solve condense its QP to N2 dense stages first (HPIPM d_part_cond_qp:
@@ -186,18 +194,19 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  *   "dynamic_rows" (default 1) - an RTI solve is one persistent launch whose wavefront rows pull instances from a device
  *       queue as their QPs converge (0: every row keeps its first instance and idles until its wave is done);
  *   "lds_workspace" (default -1) - per-stage planes of the QP in the CU's LDS instead of HBM: -1 when one round of
- *       workgroups covers the batch (an instance's whole horizon must fit in 160 KB), 0 never, 1 whenever it fits.  Results
- *       agree with the HBM placement to rounding (a separately compiled instantiation of the same code);
+ *       workgroups covers the batch (an instance's whole horizon must fit in 160 KB), 0 never, 1 whenever it fits.  The same
+ *       bits as the HBM placement (a separately compiled instantiation of the same code, contracted the same way);
  *   "merge_box_rows" (default 1) - when every box row rides in an idle lane of the last obstacle chunk's planes the sweeps
- *       process them there (one row pass instead of two).  A separately compiled instantiation: statuses and iteration
- *       counts equal, iterates agree to rounding - as with "lds_workspace";
+ *       process them there (one row pass instead of two).  THE option that changes rounding: a row's share of the complementarity
+ *       sums is added in another lane, so statuses and iteration counts are equal and iterates agree to rounding, not to the bit;
+ *       a handle keeps one setting for its lifetime unless the caller changes it;
  *   "wide_waves" (default -1) - wavefronts per instance of the latency mapping: -1 four for OCPs with soft obstacle rows while the batch
  *       is at most one instance per CU (their row work is the larger share: 6 - 12 % per tick), one otherwise; 1; 4;
  *   "wide" (default -1) - the latency mapping, ONE instance per wavefront (usvmpc_last_mapping): -1 while the batch fits the device's
  *       SIMDs twice over, 0 never, 1 whenever the OCP's layout allows it; results do not change by a bit;
  *   "aux_in_lds" (default 1) - an RTI solve keeps the per-stage aux plane (dense box rows, linearisation point, r_g, l_u) in the
  *       wavefronts' LDS instead of streaming it, when the horizon fits without costing a resident wavefront (a separately
- *       compiled instantiation of the same arithmetic: results equal to rounding at most);
+ *       compiled instantiation of the same arithmetic: the same bits);
  *   "pipeline_linearize" (default 1; RTI solves of handles with >= 16384 instances) - the lineariser of the NEXT tick is enqueued on a
  *       second stream behind the QP launch and runs in that launch's tail, instance by instance as results become final (the
  *       few it has to skip are redone in front of the next QP launch); any usvmpc_set, option change or device-pointer access in

@@ -317,6 +317,15 @@ class BatchOcpSolver:
         self._check(self._lib.usvmpc_kernel_ms(self._h, n, a, b))
         return np.array(a[:]), np.array(b[:])
 
+    def tick_ms(self, n):
+        """Tick-to-tick times over the last n solves (n - 1 values, oldest first): start of solve i + 1 minus start of solve i on the
+        solver's stream (usvmpc_tick_ms)."""
+        if n < 2:
+            return np.zeros(0)
+        a = (C.c_float * (n - 1))()
+        self._check(self._lib.usvmpc_tick_ms(self._h, n, a))
+        return np.array(a[:])
+
     def fail_counts(self, n):
         """Instances with status != 0 in each of the last n solves (oldest first), counted on the device."""
         a = (C.c_int * n)()

@@ -59,7 +59,7 @@ __device__ __forceinline__ void body2ned(double psi, double nedx, double nedy, d
 // numpy.linalg.inv; here the inverse is written out (adjugate / determinant), which agrees to rounding.
 // The body-frame list is what obstaclesCallback of the NMPC node receives: it is written straight into the
 // front end's input buffers, so a scenario sweep needs no host round trip between "sensor" and solver.
-__global__ void usv_obstacle_sim(GuidancePtrs G, const double *world, int nw, double max_radius, int B)
+static __global__ void usv_obstacle_sim(GuidancePtrs G, const double *world, int nw, double max_radius, int B)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -83,7 +83,7 @@ __global__ void usv_obstacle_sim(GuidancePtrs G, const double *world, int nw, do
     const_cast<int *>(G.nobs)[b] = n;
 }
 
-__global__ void usv_guidance_reset(GuidancePtrs G, const double *psi, int B)
+static __global__ void usv_guidance_reset(GuidancePtrs G, const double *psi, int B)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -94,7 +94,7 @@ __global__ void usv_guidance_reset(GuidancePtrs G, const double *psi, int B)
 }
 
 // writes x0, stage-0 p and lh of the solver (static-obstacle mode) for instance b
-__global__ void usv_guidance_pre(DevPtrs P, GuidancePtrs G)
+static __global__ void usv_guidance_pre(DevPtrs P, GuidancePtrs G)
 {
     const DevSpec &S = *P.spec;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -179,7 +179,7 @@ __global__ void usv_guidance_pre(DevPtrs P, GuidancePtrs G)
     }
 }
 
-__global__ void usv_guidance_post(DevPtrs P, GuidancePtrs G)
+static __global__ void usv_guidance_post(DevPtrs P, GuidancePtrs G)
 {
     const DevSpec &S = *P.spec;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;

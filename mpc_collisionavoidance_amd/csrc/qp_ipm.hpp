@@ -48,6 +48,14 @@
 #define USV_PAIRED_RCP 1 // both reciprocals of a row's slack pair / multiplier pair from one v_rcp_f64 (lanes::frcp2)
 #endif
 
+// Floating-point contraction is taken out of the optimiser's hands for everything in this file: a multiply-add is fused where ONE source
+// expression says a * b + c (the language rule, formed by the front end before any inlining) or where the code says fma / lanes::fma_bc,
+// and nowhere else.  Under the default (fuse whatever ends up adjacent after inlining) the same source contracted differently from
+// instantiation to instantiation, and the mappings of one library - 16 lanes per instance, one instance per wave, planes in LDS or in
+// HBM - returned iterates that differed by rounding, which the hard-row model amplifies (an instance's result then depended on the size
+// of the batch it sat in).  With it they return the same bits (tests/test_gpu_wide.py).
+#pragma clang fp contract(on)
+
 namespace usv {
 
 // One two-sided inequality row  dl <= v (+ sl),  v (- su) <= du  with its multipliers/slacks,
@@ -2197,3 +2205,5 @@ struct QpIpm {
 };
 
 } // namespace usv
+
+#pragma clang fp contract(fast)

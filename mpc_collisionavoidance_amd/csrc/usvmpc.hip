@@ -7,6 +7,17 @@
 //                             RTI / SQP step, NLP residual test for the full SQP  (qp_ipm.hpp)
 // Both are FP64 VALU + DPP kernels (lane gathers go through the LDS crossbar, no LDS memory, no MFMA: the
 // blocks are at most 16x16).
+//
+// Build parts.  The QP kernel templates are what takes minutes to compile, and one (model, obstacle chunks) pair has nothing in common
+// with another: __graft_entry__.build() therefore compiles THIS file several times in parallel, -DUSV_PART=0 for the C ABI, the handle
+// bookkeeping and the small kernels, -DUSV_PART=1 .. 5 for one launch_pair / export_pair instantiation each (explicit instantiation
+// there, extern template everywhere else), and links the objects.  Without USV_PART everything is one translation unit (the generated-
+// model libraries of genbuild.py, tools/dev_build.sh).
+#ifndef USV_PART
+#define USV_PART -1
+#endif
+#define USV_MAIN (USV_PART <= 0)
+
 #include "gfx950/lanes.hpp"
 
 #include "guidance.hpp"
@@ -101,7 +112,7 @@ __global__ void __launch_bounds__(64) usv_qp_export(DevPtrs P, long ngroups)
 // launch, per workgroup in LDS and one atomic per workgroup (usvmpc_unconverged_counts; SURVEY.md 8(d) counts converged solves).  Not inside
 // QpIpm::finish(): one more counter there moved the headline kernel's register allocation (12 -> 17 spilled registers, +1.3 % per launch in a
 // same-box A/B).
-__global__ void __launch_bounds__(256) usv_count_unconverged(const int *qp_status, int B, int *count)
+static __global__ void __launch_bounds__(256) usv_count_unconverged(const int *qp_status, int B, int *count)
 {
     __shared__ int loc;
     if (threadIdx.x == 0) loc = 0;
@@ -112,6 +123,7 @@ __global__ void __launch_bounds__(256) usv_count_unconverged(const int *qp_statu
     if (threadIdx.x == 0 && loc != 0) atomicAdd(count, loc);
 }
 
+#if USV_MAIN
 // full SQP bookkeeping: start of a call (everything running) and end (still running = max iterations)
 __global__ void usv_sqp_begin(DevPtrs P, int B)
 {
@@ -197,6 +209,7 @@ __global__ void __launch_bounds__(64) usv_calib_stream(DevPtrs P, long ngroups, 
     for (int i = 0; i < nread; i++) acc += W.ld(i);
     W.st(nread, acc);
 }
+#endif // USV_MAIN
 
 // Difficulty binning: a wave carries four instances and runs until the slowest one converges, so
 // instances are grouped by the IPM iteration count of their previous solve (a counting sort on the
@@ -215,7 +228,7 @@ __device__ __forceinline__ int sort_key(const int *qp_iter, const int *qp_iter_p
     return min(max(max(qp_iter[i], qp_iter_prev[i]), 0), SORT_BINS - 1);
 }
 
-__global__ void __launch_bounds__(256) usv_sort_hist(const int *qp_iter, const int *qp_iter_prev, int B, int *hist)
+static __global__ void __launch_bounds__(256) usv_sort_hist(const int *qp_iter, const int *qp_iter_prev, int B, int *hist)
 {
     __shared__ int loc[SORT_BINS];
     if (threadIdx.x < SORT_BINS) loc[threadIdx.x] = 0;
@@ -226,7 +239,7 @@ __global__ void __launch_bounds__(256) usv_sort_hist(const int *qp_iter, const i
     if (threadIdx.x < SORT_BINS && loc[threadIdx.x] != 0) atomicAdd(&hist[threadIdx.x], loc[threadIdx.x]);
 }
 
-__global__ void usv_sort_scan(int *hist, int *cursor)
+static __global__ void usv_sort_scan(int *hist, int *cursor)
 {
     if (threadIdx.x == 0) {
         int pos = 0;
@@ -238,7 +251,7 @@ __global__ void usv_sort_scan(int *hist, int *cursor)
     }
 }
 
-__global__ void __launch_bounds__(256) usv_sort_scatter(const int *qp_iter, const int *qp_iter_prev, int B, int *cursor, int *perm)
+static __global__ void __launch_bounds__(256) usv_sort_scatter(const int *qp_iter, const int *qp_iter_prev, int B, int *cursor, int *perm)
 {
     __shared__ int loc[SORT_BINS], base[SORT_BINS];
     if (threadIdx.x < SORT_BINS) loc[threadIdx.x] = 0;
@@ -379,6 +392,15 @@ void dev_free(usvmpc_handle *h, void *p, size_t nbytes)
     h->bytes -= nbytes;
 }
 
+// Forget what the occupancy queries said about the QP kernels: whatever changes WHICH kernel a launch takes (row layout, mapping,
+// wave cap, workspace placement) makes launch_qp ask again - for every instantiation, with its dynamic LDS size set afresh.
+void reset_caps(usvmpc_handle *h)
+{
+    h->qp_cap = 0; h->lds_cap = 0; h->aux_cap = 0;
+    h->wide_cap = 0; h->wide_hbm_cap = 0; h->wide4_cap = 0; h->wide4_hbm_cap = 0;
+}
+
+#if USV_MAIN
 struct Field {
     double *base;   // device pointer
     int n;          // per-stage length
@@ -456,6 +478,8 @@ int mirror_quiesce(usvmpc_handle *h)
     return 0;
 }
 
+#endif // USV_MAIN
+
 // upload what the mirror holds newer than the device: consecutive dirty fields go as one copy
 int mirror_flush(usvmpc_handle *h)
 {
@@ -478,6 +502,7 @@ int mirror_flush(usvmpc_handle *h)
     return 0;
 }
 
+#if USV_MAIN
 int copy_field(usvmpc_handle *h, const char *field, int stage, double *host, size_t n, bool set)
 {
     if (!h) return USVMPC_E_ARG;
@@ -568,6 +593,8 @@ int copy_field(usvmpc_handle *h, const char *field, int stage, double *host, siz
     return 0;
 }
 
+#endif // USV_MAIN
+
 // the condensed QP solve of an RTI iteration (after the lineariser): buffers on first use; the kernels live in cond_kernels.hip
 int launch_cond(usvmpc_handle *h)
 {
@@ -608,6 +635,9 @@ void cond_release(usvmpc_handle *h)
     h->d_cond_scratch = nullptr; h->d_cond_dims = nullptr; h->cond_teams = 0;
 }
 
+} // namespace
+
+// (external linkage: a split build defines each instantiation in a translation unit of its own - see "Build parts" at the top)
 template <class M, int KCH, bool SOFT>
 int launch_pair(usvmpc_handle *h, int phase)
 {
@@ -743,7 +773,8 @@ int launch_pair(usvmpc_handle *h, int phase)
                                     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wide.hbm4, 4 * qp_block, x4) == hipSuccess && nb > 0) ? (long)h->ncu : -1;
             }
             const bool lds = h->wide4_cap > 0;
-            const long cap = lds ? h->wide4_cap : h->wide4_hbm_cap;
+            long cap = lds ? h->wide4_cap : h->wide4_hbm_cap;
+            if (cap > 0 && h->max_waves > 0) cap = std::max<long>(1, std::min(cap, h->max_waves / 4)); // option "max_waves" counts wavefronts
             // default: for the soft-row OCPs only - their row work is the larger share (measured, one instance / 256 instances per tick:
             // usv_model_guidance_ca1 N = 100 1.78 -> 1.59 / 5.6 -> 5.0 ms, N = 40 0.94 -> 0.86 / 2.05 -> 1.87; usv_model_pf_ca 3 - 7 % SLOWER:
             // its recursion dominates and pays the barriers)
@@ -942,6 +973,59 @@ int launch_pair(usvmpc_handle *h, int phase)
     return 0;
 }
 
+// ---- multiplier read-back: buffers on first use, one kernel per solve they are asked for
+template <class M, int KCH, bool SOFT>
+int export_pair(usvmpc_handle *h)
+{
+    constexpr bool CANPACK = KCH > 0;
+    const bool pack = CANPACK && h->spec.boxpack != 0;
+    const dim3 grid((unsigned)((h->Bp + 3) / 4)), block(64);
+    if (h->spec.any_bsoft) hipLaunchKernelGGL((usv_qp_export<M, KCH, SOFT, false, true>), grid, block, 0, h->stream, h->ptrs, (long)h->Bp);
+    else if (pack) hipLaunchKernelGGL((usv_qp_export<M, KCH, SOFT, CANPACK, false>), grid, block, 0, h->stream, h->ptrs, (long)h->Bp);
+    else hipLaunchKernelGGL((usv_qp_export<M, KCH, SOFT, false, false>), grid, block, 0, h->stream, h->ptrs, (long)h->Bp);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+// The instantiations of the stock library, one per build part
+#if USV_PART >= 0 && !defined(USV_GEN_ONLY)
+#if USV_PART == 1
+#define USV_PAIR_1(M, KCH, SOFT) template int launch_pair<M, KCH, SOFT>(usvmpc_handle *, int); template int export_pair<M, KCH, SOFT>(usvmpc_handle *);
+#else
+#define USV_PAIR_1(M, KCH, SOFT) extern template int launch_pair<M, KCH, SOFT>(usvmpc_handle *, int); extern template int export_pair<M, KCH, SOFT>(usvmpc_handle *);
+#endif
+#if USV_PART == 2
+#define USV_PAIR_2(M, KCH, SOFT) template int launch_pair<M, KCH, SOFT>(usvmpc_handle *, int); template int export_pair<M, KCH, SOFT>(usvmpc_handle *);
+#else
+#define USV_PAIR_2(M, KCH, SOFT) extern template int launch_pair<M, KCH, SOFT>(usvmpc_handle *, int); extern template int export_pair<M, KCH, SOFT>(usvmpc_handle *);
+#endif
+#if USV_PART == 3
+#define USV_PAIR_3(M, KCH, SOFT) template int launch_pair<M, KCH, SOFT>(usvmpc_handle *, int); template int export_pair<M, KCH, SOFT>(usvmpc_handle *);
+#else
+#define USV_PAIR_3(M, KCH, SOFT) extern template int launch_pair<M, KCH, SOFT>(usvmpc_handle *, int); extern template int export_pair<M, KCH, SOFT>(usvmpc_handle *);
+#endif
+#if USV_PART == 4
+#define USV_PAIR_4(M, KCH, SOFT) template int launch_pair<M, KCH, SOFT>(usvmpc_handle *, int); template int export_pair<M, KCH, SOFT>(usvmpc_handle *);
+#else
+#define USV_PAIR_4(M, KCH, SOFT) extern template int launch_pair<M, KCH, SOFT>(usvmpc_handle *, int); extern template int export_pair<M, KCH, SOFT>(usvmpc_handle *);
+#endif
+#if USV_PART == 5
+#define USV_PAIR_5(M, KCH, SOFT) template int launch_pair<M, KCH, SOFT>(usvmpc_handle *, int); template int export_pair<M, KCH, SOFT>(usvmpc_handle *);
+#else
+#define USV_PAIR_5(M, KCH, SOFT) extern template int launch_pair<M, KCH, SOFT>(usvmpc_handle *, int); extern template int export_pair<M, KCH, SOFT>(usvmpc_handle *);
+#endif
+#ifndef USV_BENCH_ONLY
+USV_PAIR_1(ModelM0, 0, false)
+USV_PAIR_3(ModelM1, 2, true)
+USV_PAIR_5(ModelM2, 2, false)
+#endif
+USV_PAIR_2(ModelM1, 1, true)
+USV_PAIR_4(ModelM2, 1, false)
+#endif
+
+#if USV_MAIN
+namespace {
+
 // planes per stage of the packed [B A] for this model (MatPack)
 int model_mat_planes(int model)
 {
@@ -977,20 +1061,6 @@ int launch(usvmpc_handle *h, int phase = 0)
     }
     h->err = "unknown model";
     return USVMPC_E_ARG;
-}
-
-// ---- multiplier read-back: buffers on first use, one kernel per solve they are asked for
-template <class M, int KCH, bool SOFT>
-int export_pair(usvmpc_handle *h)
-{
-    constexpr bool CANPACK = KCH > 0;
-    const bool pack = CANPACK && h->spec.boxpack != 0;
-    const dim3 grid((unsigned)((h->Bp + 3) / 4)), block(64);
-    if (h->spec.any_bsoft) hipLaunchKernelGGL((usv_qp_export<M, KCH, SOFT, false, true>), grid, block, 0, h->stream, h->ptrs, (long)h->Bp);
-    else if (pack) hipLaunchKernelGGL((usv_qp_export<M, KCH, SOFT, CANPACK, false>), grid, block, 0, h->stream, h->ptrs, (long)h->Bp);
-    else hipLaunchKernelGGL((usv_qp_export<M, KCH, SOFT, false, false>), grid, block, 0, h->stream, h->ptrs, (long)h->Bp);
-    HIP_TRY(h, hipGetLastError());
-    return 0;
 }
 
 int ensure_export(usvmpc_handle *h)
@@ -1378,6 +1448,19 @@ int usvmpc_kernel_ms(usvmpc_handle *h, int n, float *linearize_ms, float *qp_ms)
     return 0;
 }
 
+int usvmpc_tick_ms(usvmpc_handle *h, int n, float *ms)
+{
+    if (!h || n < 2 || !ms) return USVMPC_E_ARG;
+    if (h->nsolves < n || n > usvmpc_handle::RING) { h->err = "fewer solves recorded than requested"; return USVMPC_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (int i = 0; i + 1 < n; i++) { // oldest of the last n first
+        hipEvent_t *ev = h->ev[(h->nsolves - n + i) % usvmpc_handle::RING], *evn = h->ev[(h->nsolves - n + i + 1) % usvmpc_handle::RING];
+        HIP_TRY(h, hipEventSynchronize(evn[0]));
+        HIP_TRY(h, hipEventElapsedTime(&ms[i], ev[0], evn[0]));
+    }
+    return 0;
+}
+
 int usvmpc_debug_model_eval(int model, int device, int n, const double *x, const double *u, double *f, double *J)
 {
     int nx, nu;
@@ -1509,7 +1592,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         if (!h->sort_enabled && h->ptrs.perm) { h->ptrs.perm = nullptr; h->map_changed = true; }
         return 0;
     }
-    if (s == "max_waves") { h->max_waves = (long)value; h->wide_cap = 0; h->wide_hbm_cap = 0; cond_release(h); return 0; }
+    if (s == "max_waves") { h->max_waves = (long)value; reset_caps(h); cond_release(h); return 0; }
     if (s == "keep_multipliers") { // create the "lam" / "t" buffers now (a partially condensed solve fills them only if they exist)
         if (value == 0.0) return 0;
         DevPtrs &P = h->ptrs;
@@ -1536,24 +1619,25 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         return 0;
     }
     if (s == "sort_two_ticks") { h->sort_two = value != 0.0; return 0; }
-    if (s == "aux_in_lds") { h->aux_lds = value != 0.0; h->aux_cap = 0; return 0; }
+    if (s == "aux_in_lds") { h->aux_lds = value != 0.0; reset_caps(h); return 0; }
     if (s == "lds_workspace") { // -1: when the batch is small (default), 0: never, 1: whenever an instance's planes fit in LDS
         h->lds_mode = value < 0.0 ? -1 : (value > 0.0 ? 1 : 0);
-        h->lds_cap = 0;
+        reset_caps(h);
         return 0;
     }
     if (s == "wide") { // the latency mapping, one instance per wave: -1 for batches that leave SIMDs idle (default), 0 never, 1 whenever it applies
         h->wide_mode = value < 0.0 ? -1 : (value > 0.0 ? 1 : 0);
-        h->wide_cap = 0; h->wide_hbm_cap = 0;
+        reset_caps(h);
         return 0;
     }
     if (s == "wide_waves") { // waves per instance of the latency mapping: -1 (default) four for soft-row OCPs up to one instance per CU, else one; 1; 4
         h->wide_waves = value < 0.0 ? -1 : (value >= 4.0 ? 4 : 1);
+        reset_caps(h);
         return 0;
     }
     if (s == "dynamic_rows") { // 0: one group per row for the whole launch (the rows of a wave wait for its slowest)
         h->dynamic_rows = value != 0.0;
-        h->qp_cap = 0; h->aux_cap = 0;
+        reset_caps(h);
         return 0;
     }
     if (s == "disturbance_mask") { // bit j: usvmpc_advance adds its noise to state j
@@ -1561,8 +1645,8 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         return 0;
     }
     if (s == "merge_box_rows") { // 1 (default): box rows processed in their slot lanes when all of them ride there
-        h->merge_rows = value != 0.0;
-        h->qp_cap = 0; h->lds_cap = 0; h->aux_cap = 0; h->wide_cap = 0;
+        h->merge_rows = value != 0.0;   // (another set of kernels: merged / two-pass instantiations, wide ones included)
+        reset_caps(h);
         return 0;
     }
     if (s == "host_mirror") { // 0: drop the pinned host mirror of the caller-visible arrays (every set / get then goes to the device)
@@ -1579,7 +1663,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
     }
     if (s == "static_obstacles" || s == "pack_box_rows") {
         if (s == "static_obstacles") h->spec.p_static = value != 0.0;
-        else { h->spec.boxpack = (value != 0.0 && h->spec.boxpack_ok) ? 1 : 0; h->qp_cap = 0; h->lds_cap = 0; h->aux_cap = 0; h->layout_dirty = true; }
+        else { h->spec.boxpack = (value != 0.0 && h->spec.boxpack_ok) ? 1 : 0; reset_caps(h); h->layout_dirty = true; }
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipMemcpyAsync(h->d_spec, &h->spec, sizeof(DevSpec), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1781,6 +1865,7 @@ size_t usvmpc_device_bytes(usvmpc_handle *h) { return h ? h->bytes : 0; }
 const char *usvmpc_last_error(usvmpc_handle *h) { return h ? h->err.c_str() : "null handle"; }
 
 } // extern "C"
+#endif // USV_MAIN
 
 #ifndef USV_COND_SEPARATE // (one translation unit by default - generated-model and development builds; the shipped library compiles it on its own)
 #include "cond_kernels.hip"

@@ -35,6 +35,8 @@ BENCH_DT = 0.05
 BENCH_SIM_STEPS = {"usv_model": 1, "usv_model_guidance_ca1": 1, "usv_model_pf_ca": 5}
 NOISE_MASK = {"usv_model": (1 << 5) - 1, "usv_model_guidance_ca1": (1 << 8) - 1, "usv_model_pf_ca": (1 << 3) | (1 << 5)}
 
+ALL_STATES_MASK = (1 << 14) - 1   # SURVEY.md 8(d) as worded: "x0 <- previous x1 + N(0, 1e-3)" on every state
+
 _CY = 0.5 * (-40.0 * 1000.0) * (1.1 + 0.0045 * (1.01 / 0.09) - 0.1 * (0.27 / 0.09) + 0.016 * ((0.27 / 0.09) ** 2))
 
 
@@ -97,13 +99,17 @@ def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None, g
                  the course ray would enter closer than 0.4 m + 1.2 s * u is moved outwards along its bearing until it
                  does not (hard rows: nearer than that the first QP has no feasible point - the vehicle can neither
                  stop nor turn in time); initial guess = zero-input simulation with the solver's integrator.
+      "survey_verbatim" - SURVEY.md 8(d) to the letter: the same draws as "survey" (same seed -> same vehicles, same obstacles before
+                 the clip), NO clip, and acados' own initial guess x_k = x0, u = 0.  For usv_model_pf_ca's hard rows that means a
+                 share of first QPs without a feasible point (the line reports them: status_nonzero_frac, qp_not_converged_frac).
       "beside" - round-1 workload for the reference's dt = 0.01 s (0.4 s look-ahead at N = 40): v ~ U(-0.03, 0.03),
                  obstacles beside the straight-line roll-out; kept for the parity tests at the reference's step size."""
     if dt is None:
         dt = DT[name]
-    if generator not in ("survey", "beside"):
+    if generator not in ("survey", "survey_verbatim", "beside"):
         raise ValueError(generator)
-    survey = generator == "survey" and name == "usv_model_pf_ca"
+    verbatim = generator == "survey_verbatim"
+    survey = generator in ("survey", "survey_verbatim") and name == "usv_model_pf_ca"
     rng = np.random.default_rng(seed)
     x1, y1, x2, y2 = PATH
     ak = np.arctan2(y2 - y1, x2 - x1)
@@ -154,7 +160,7 @@ def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None, g
             # polar about the vehicle: bearing within +-60 deg of the course, range R+0.7 .. 6 m
             rad = (R + 0.7) + rng.uniform(0.0, 1.0, (B, K)) * np.maximum(max_range - (R + 0.7), 0.0)
             rel = rng.uniform(-np.pi / 3, np.pi / 3, (B, K))
-            if survey:
+            if survey and not verbatim:
                 # hard rows: the course ray enters the keep-out circle (radius lh) at s = lon - sqrt(lh^2 - lat^2);
                 # obstacles with s < s_min(u) move out along their bearing to the range where s = s_min
                 smin = (0.4 + clip_time * u)[:, None]
@@ -214,7 +220,9 @@ def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None, g
     vx = (u * np.cos(psi) - v * np.sin(psi))[:, None]
     vy = (u * np.sin(psi) + v * np.cos(psi))[:, None]
     yed = -vx * np.sin(ak) + vy * np.cos(ak)
-    if name == "usv_model_guidance_ca1":
+    if verbatim:
+        pass  # x_k = x0: what AcadosOcpSolver starts from when the caller sets nothing (scripts/usv_pf_ca/main.py sets no iterate)
+    elif name == "usv_model_guidance_ca1":
         x_init[:, :, 2] += tk * yed
         x_init[:, :, 5] += tk * vx
         x_init[:, :, 6] += tk * vy
@@ -229,16 +237,19 @@ def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None, g
                 nx=nx, nu=nu, K=K, N=N, dt=dt, sim_steps=sim_steps, generator=generator)
 
 
-def make_bench_batch(name, N, K, B, seed=1234, moving=False):
+def make_bench_batch(name, N, K, B, seed=1234, moving=False, verbatim=False):
     """The benchmark workload of SURVEY.md 8(d) for `name`: dt = 0.05 s, the "survey" generator.  SURVEY's obstacle field
     (range up to 6 m, course ray clear for 0.4 m + 1.2 s * u) is sized for the 2 s look-ahead of N = 40; other horizons scale
     both with it.  Shorter (BASELINE configs[1], Tf = 1 s): range up to 3 Tf metres, clear for 0.6 Tf - with the 2 s field a 1 s
     look-ahead never reaches an obstacle (2 % of the instances with an active row after 12 closed-loop ticks; scaled: 71 %, no
     failed solve).  Longer (configs[4], Tf = 4 s): range up to 3 Tf, clear for 1.1 Tf - at N = 80 the same circles in the same
-    6 m sector wall the vehicle in and a third of the hard-row QPs have no feasible point."""
+    6 m sector wall the vehicle in and a third of the hard-row QPs have no feasible point.
+    verbatim: SURVEY.md 8(d) without the builder's departures (make_batch, "survey_verbatim"): no obstacle clip, x_k = x0 as the initial
+    guess; the disturbance then goes on every state (ALL_STATES_MASK); the 5 RK4 steps of usv_model_pf_ca stay - one RK4 step of 0.05 s
+    is outside the model's stability region (DT above), the solves would be NaN."""
     Tf = N * BENCH_DT
     long_h = Tf > 2.0 + 1e-9
-    return make_batch(name, N, K, B, dt=BENCH_DT, seed=seed, moving=moving, generator="survey",
+    return make_batch(name, N, K, B, dt=BENCH_DT, seed=seed, moving=moving, generator="survey_verbatim" if verbatim else "survey",
                       sim_steps=BENCH_SIM_STEPS[name], max_range=3.0 * Tf,
                       clip_time=1.1 * Tf if long_h else 0.6 * Tf)
 

@@ -221,6 +221,45 @@ def test_two_handles_on_shards_equal_unsharded(name, B):
         assert np.array_equal(np.concatenate([parts[0][i], parts[1][i]], axis=0), whole[i]), i
 
 
+@pytest.mark.parametrize("name,N,K,G,world", [("usv_model_pf_ca", 20, 3, 4096, 8), ("usv_model_guidance_ca1", 20, 3, 4096, 8),
+                                               ("usv_model_pf_ca", 40, 10, 3000, 6)])
+def test_shards_that_land_on_the_other_mapping_equal_the_unsharded_batch(name, N, K, G, world):
+    """The mapping is chosen from the size of the handle's batch (usvmpc.hip launch_qp: the latency mapping while the batch leaves SIMDs idle):
+    4096 instances in one handle run four per wavefront, the same instances as 8 shards of 512 run one per wavefront (or, soft-row OCP,
+    one per workgroup of four).  An instance's result must not depend on which: bit for bit, over a closed loop (VERDICT r04
+    weak 2 - the mappings used to agree to rounding only, amplified to 5e-3 by the hard-row model)."""
+    wl = scenario.make_bench_batch(name, N, K, G, seed=99)
+    dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
+    ocp = usv_models.make_ocp(name, N * dt, N, K)
+    ocp.solver_options.sim_method_num_steps = steps
+
+    def run(w, n):
+        s = BatchOcpSolver(ocp, n)
+        scenario.load_into(s, w)
+        s.set_option("static_obstacles", 1)
+        s.set_option("disturbance_mask", scenario.NOISE_MASK[name])
+        maps = []
+        for t in range(3):
+            s.solve()
+            maps.append(s.last_mapping())
+            s.advance(0.0)
+        s.sync()
+        out = (s.get_all("x"), s.get_all("u"), s.get_int("status"), s.get_int("qp_iter"), s.get("x0", 0), s.get_all("pi"), s.get_all("lam"), s.get_all("t"))
+        s.close()
+        return out, maps
+
+    whole, maps_whole = run(wl, G)
+    parts, maps_parts = [], []
+    for r in range(world):
+        lo, hi = sharding.shard_bounds(G, world, r)
+        o, m = run(sharding.split_workload(wl, world, r), hi - lo)
+        parts.append(o)
+        maps_parts += m
+    assert set(maps_whole) == {0} and 0 not in set(maps_parts), (maps_whole, maps_parts)   # the test is about crossing the threshold
+    for i in range(len(whole)):
+        assert np.array_equal(np.concatenate([q[i] for q in parts], axis=0), whole[i]), i
+
+
 def test_bench_scale_shards_equal_the_unsharded_batch():
     """bench.py --global-batch at BASELINE configs[2] scale on ONE GPU: the seed-1234 batch of 65 536 instances solved as two handles on
     the slices two ranks would get (bench.make_workload: shard b -> rank floor(b * 2 / B)) returns, bit for bit, what one handle returns for

@@ -53,3 +53,28 @@ def test_legacy_generator_unchanged_defaults():
     d = scenario.make_bench_batch("usv_model_guidance_ca1", 20, 4, 16)
     e = scenario.make_batch("usv_model_guidance_ca1", 20, 4, 16, dt=0.05, max_range=3.0)
     assert all(np.array_equal(d[k], e[k]) for k in ("x0", "p", "lh", "x_init"))
+
+
+def test_survey_verbatim_is_the_survey_generator_without_the_departures():
+    """bench.py --workload survey-verbatim: the same seed-1234 vehicles and obstacle draws as the default workload,
+    NO obstacle clip, acados' own initial guess x_k = x0, the disturbance on every state."""
+    import bench
+    name, N, K, B = "usv_model_pf_ca", 40, 10, 4000
+    a = scenario.make_bench_batch(name, N, K, B)
+    b = scenario.make_bench_batch(name, N, K, B, verbatim=True)
+    assert np.array_equal(a["x0"], b["x0"]) and np.array_equal(a["lh"], b["lh"]) and np.array_equal(a["yref"], b["yref"])
+    moved = (a["p"][:, 0] != b["p"][:, 0]).reshape(B, K, 2).any(axis=2)
+    assert 0.08 < moved.mean() < 0.14                      # "11 % of the obstacles" are what the clip moves
+    # an unclipped obstacle sits at least as near as its clipped version
+    pos = a["x0"][:, 10:12]
+    da = np.linalg.norm(a["p"][:, 0].reshape(B, K, 2) - pos[:, None, :], axis=2)
+    db = np.linalg.norm(b["p"][:, 0].reshape(B, K, 2) - pos[:, None, :], axis=2)
+    assert (db <= da + 1e-12).all() and (db[moved] < da[moved]).all()
+    assert np.array_equal(b["x_init"], np.repeat(b["x0"][:, None, :], N + 1, axis=1)) and not b["u_init"].any()
+    assert b["generator"] == "survey_verbatim"
+    wl, Bn, dt, steps, sigma, mask = bench.make_workload(name, N, K, 64, 0, "survey-verbatim", False, 0, 1)
+    assert mask == scenario.ALL_STATES_MASK == (1 << 14) - 1 and steps == 5 and dt == 0.05 and sigma == 1e-3 and Bn == 64
+    assert wl["generator"] == "survey_verbatim"
+    # the soft-row model has no clip and no roll-out to drop: only the initial guess changes
+    c, d = scenario.make_bench_batch("usv_model_guidance_ca1", 20, 3, 50), scenario.make_bench_batch("usv_model_guidance_ca1", 20, 3, 50, verbatim=True)
+    assert np.array_equal(c["p"], d["p"]) and np.array_equal(d["x_init"], np.repeat(d["x0"][:, None, :], 21, axis=1))

@@ -6,9 +6,10 @@ L = "/opt/rocm/lib/llvm/bin"
 lib, pat = sys.argv[1], sys.argv[2]
 minsz = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 tmp = tempfile.mkdtemp()
-subprocess.run([f"{L}/llvm-objcopy", "--dump-section", f".hip_fatbin={tmp}/fat.bin", lib, f"{tmp}/s"], check=True)
-subprocess.run([f"{L}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={tmp}/fat.bin", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={tmp}/co.o"], check=True)
-dis = subprocess.run([f"{L}/llvm-objdump", "-d", "--no-show-raw-insn", f"{tmp}/co.o"], capture_output=True, text=True).stdout.splitlines()
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
+from mpc_collisionavoidance_amd import dpp_check   # (the library holds one offload bundle per translation unit: all of them)
+cos, _tmp = dpp_check.code_objects(lib)
+dis = sum((subprocess.run([f"{L}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout.splitlines() for co in cos), [])
 on = False; ins = []
 for ln in dis:
     m = re.match(r"^[0-9a-f]+ <([^>]*)>:", ln)

@@ -5,9 +5,10 @@ import re, subprocess, sys, tempfile
 L = "/opt/rocm/lib/llvm/bin"
 lib = sys.argv[1]; pat = sys.argv[2] if len(sys.argv) > 2 else ""
 tmp = tempfile.mkdtemp()
-subprocess.run([f"{L}/llvm-objcopy", "--dump-section", f".hip_fatbin={tmp}/fat.bin", lib, f"{tmp}/s"], check=True)
-subprocess.run([f"{L}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={tmp}/fat.bin", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={tmp}/co.o"], check=True)
-notes = subprocess.run([f"{L}/llvm-readelf", "--notes", f"{tmp}/co.o"], capture_output=True, text=True).stdout
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
+from mpc_collisionavoidance_amd import dpp_check   # (the library holds one offload bundle per translation unit: all of them)
+cos, _tmp = dpp_check.code_objects(lib)
+notes = "".join(subprocess.run([f"{L}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout for co in cos)
 for blk in notes.split("- .agpr_count:")[1:]:
     g = lambda k: (re.search(r"\." + k + r":\s+(\S+)", blk) or [None, "?"])[1]
     name = g("name")

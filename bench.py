@@ -144,6 +144,9 @@ def main():
                     help="std of the Gaussian disturbance added at the hand-over (default: 1e-3 for survey, 0 for r01)")
     ap.add_argument("--cond-N", type=int, default=0, help="qp_solver_cond_N (0: acados default = N, no condensing)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="instances timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--oracle-opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="option of the CPU oracle in the un-timed parity leg (oracle/usv_oracle.h usv_opts), e.g. itref_corr_max=2 or "
+                         "cond_pred_corr=1: HPIPM options the restatement leaves off by default; may be repeated")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="solver run-time option (usvmpc_set_option), e.g. dynamic_rows=0; may be repeated")
     args = ap.parse_args()
@@ -215,7 +218,8 @@ def main():
         from oracle import binding as ob
         per_solve_ms = {"usv_model": 0.12, "usv_model_guidance_ca1": 1.2, "usv_model_pf_ca": 3.5}[name] * N / 40.0 * (1 + 0.15 * (steps - 1))
         S1 = int(max(32, min(B, 4000.0 / per_solve_ms)))               # ~4 s per tick on one core
-        spec = ob.spec(_ID[name], N, N * dt, K, sim_steps=steps)
+        oopts = {kv.split("=")[0]: (float(kv.split("=")[1]) if kv.split("=")[0] == "cpc_factor" else int(float(kv.split("=")[1]))) for kv in args.oracle_opt}
+        spec = ob.spec(_ID[name], N, N * dt, K, sim_steps=steps, **oopts)
         x0o = wl["x0"][:S1].copy()
         errs, errs_x, errs_u = [], [], []
         same_status = n_ok = n_conv_dev = n_cert = n_above = n_above_uncert = 0
@@ -290,6 +294,7 @@ def main():
                   "kkt_certified_frac": n_cert / float(max(1, n_conv_dev)),
                   "kkt": "every solve the device reports converged, checked against the KKT conditions of its QP (stat <= 1e-6, "
                          "eq / ineq / comp <= 1e-8, lam, t >= 0) by tests/kkt.py on the oracle's linearisation: %d of %d" % (n_cert, n_conv_dev),
+                  "oracle_options": oopts or "defaults (oracle/usv_oracle.h: plain Mehrotra iteration, no cond_pred_corr, no iterative refinement)",
                   "vs": "CPU oracle (port; parity vs acados itself is unpinned); closed loop, every tick from the iterate "
                         "and x0 the device starts it from; error of an instance = max over (x, u) components of |dev - oracle| / "
                         "(that component's max |oracle| over the sample)"}

@@ -151,6 +151,8 @@ int usvmpc_fail_counts(usvmpc_handle *h, int n, int *counts);
  * a hard keep-out circle), per solve likewise: solves minus this = "solves" as SURVEY.md 8(d) counts them (IPM converged to the stated
  * tolerance).  RTI solves (usvmpc_solve / usvmpc_solve_async); counted by a small kernel behind the QP launch. */
 int usvmpc_unconverged_counts(usvmpc_handle *h, int n, int *counts);
+/* option "handover_iter": how many instances each of the last n RTI launches handed over to its follow-up launch (oldest first, n <= 64) */
+int usvmpc_handover_counts(usvmpc_handle *h, int n, int *counts);
 /* option "pipeline_linearize": how many linearisations made ahead of time (on the second stream, beside the previous tick's QP launch)
  * were used by the following solve / discarded because the caller wrote x, u or yref in between.  The lineariser only runs ahead after
  * two solves in a row without such a write, so a caller that sets yref every tick (the reference's protocol) discards none. */
@@ -217,6 +219,11 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  *       of one synchronising copy per call (the reference issues 3N+4 setters per tick: scripts/usv_guidance_ca1/main.py:
  *       123-130, src/nmpc_guidance_ca1.cpp:567-574); x / u / status come back in one copy and usvmpc_get "x" / "u" is served
  *       from it.  0 switches it off for the handle (it cannot be switched on again);
+ *   "handover_iter" (default 0 = off) - RTI launches that pull instances from the queue: once every instance has been handed out, a row
+ *       whose instance has passed this many IPM iterations leaves it to a follow-up launch on the latency mapping (one instance per
+ *       wavefront over the same workspace planes), which finishes it 1.6x faster per iteration than a lone 16-lane row - the tail of a
+ *       65 536-instance launch is a handful of 30 - 50 iteration instances on an otherwise idle device.  Scheduling only: the mappings
+ *       return the same bits.  Layouts with a latency mapping (one obstacle chunk / no obstacle rows, no soft state bounds);
  *   "disturbance_mask" (default all ones) - bit j set: usvmpc_advance adds its noise to state j (the reference's commented
  *       hooks disturb x0[3] and x0[5] only: catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/main.py:181-183). */
 int usvmpc_set_option(usvmpc_handle *h, const char *name, double value);

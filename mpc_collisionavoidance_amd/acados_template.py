@@ -351,6 +351,12 @@ class BatchOcpSolver:
         self._check(self._lib.usvmpc_unconverged_counts(self._h, n, a))
         return np.array(a[:])
 
+    def handover_counts(self, n):
+        """Instances each of the last n RTI launches handed over to its follow-up launch (option "handover_iter"), oldest first."""
+        a = (C.c_int * n)()
+        self._check(self._lib.usvmpc_handover_counts(self._h, n, a))
+        return np.array(a[:])
+
     def advance(self, sigma=0.0, seed=0):
         """Closed-loop hand-over on the device: x0 <- x_1 (+ sigma N(0,1)); asynchronous."""
         self._check(self._lib.usvmpc_advance(self._h, float(sigma), int(seed)))

@@ -49,15 +49,10 @@ USV_DEV int bcast_i(int v)
     return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, true);
 }
 
-#ifndef USV_FUSED_DPP_FMA
-#define USV_FUSED_DPP_FMA 1
-#endif
-
 // c += bcast<K>(b_remote) * a_own
 template <int K>
 USV_DEV void fma_bc(double &c, double b_remote, double a_own)
 {
-#if USV_FUSED_DPP_FMA
     // v_fmac_f64_dpp with row_newbcast is the one DP-ALU DPP form gfx950 has and costs what a plain v_fma_f64 costs
     // (profiles/r02_microbench.txt), but hipcc does not select it from builtins.  Inside asm the compiler cannot pad the
     // one hazard it has (a VALU write of the DPP source b_remote within the 2 preceding wait states - measured on the
@@ -65,9 +60,6 @@ USV_DEV void fma_bc(double &c, double b_remote, double a_own)
     // instead: tools/check_dpp_hazard.py walks the disassembly and build() fails on a violation; lanes::settle() is the
     // cure at a site it flags.
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(c) : "v"(b_remote), "v"(a_own), "n"(K));
-#else
-    c = __builtin_fma(bcast<K>(b_remote), a_own, c);
-#endif
 }
 
 // The same for up to four terms into one accumulator, in the order given: c += bcast<K0>(b0) * a0; c += bcast<K1>(b1) * a1; ...
@@ -78,46 +70,32 @@ USV_DEV void fma_bc(double &c, double b_remote, double a_own)
 template <int K0, int K1>
 USV_DEV void fma_bc2(double &c, double b0, double a0, double b1, double a1)
 {
-#if USV_FUSED_DPP_FMA
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %0, %3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
         : "+&v"(c) : "v"(b0), "v"(a0), "v"(b1), "v"(a1), "n"(K0), "n"(K1));
-#else
-    fma_bc<K0>(c, b0, a0); fma_bc<K1>(c, b1, a1);
-#endif
 }
 template <int K0, int K1, int K2>
 USV_DEV void fma_bc3(double &c, double b0, double a0, double b1, double a1, double b2, double a2)
 {
-#if USV_FUSED_DPP_FMA
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %0, %3, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %0, %5, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
         : "+&v"(c) : "v"(b0), "v"(a0), "v"(b1), "v"(a1), "v"(b2), "v"(a2), "n"(K0), "n"(K1), "n"(K2));
-#else
-    fma_bc<K0>(c, b0, a0); fma_bc<K1>(c, b1, a1); fma_bc<K2>(c, b2, a2);
-#endif
 }
 template <int K0, int K1, int K2, int K3>
 USV_DEV void fma_bc4(double &c, double b0, double a0, double b1, double a1, double b2, double a2, double b3, double a3)
 {
-#if USV_FUSED_DPP_FMA
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %0, %3, %4 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %0, %5, %6 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %0, %7, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf"
         : "+&v"(c) : "v"(b0), "v"(a0), "v"(b1), "v"(a1), "v"(b2), "v"(a2), "v"(b3), "v"(a3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
-#else
-    fma_bc<K0>(c, b0, a0); fma_bc<K1>(c, b1, a1); fma_bc<K2>(c, b2, a2); fma_bc<K3>(c, b3, a3);
-#endif
 }
 
 // two wait states on a value that is about to be a DPP source (see fma_bc)
 USV_DEV void settle(double &v)
 {
-#if USV_FUSED_DPP_FMA
     asm volatile("s_nop 1" : "+v"(v));
-#endif
 }
 
 // value held by lane `src` (0..15, run-time, may differ per lane) of this group: ds_bpermute_b32 goes
@@ -202,26 +180,14 @@ USV_DEV int fetch_add(int *p) { return atomicAdd(p, 1); }
 // true if the predicate holds in any lane of the wave (four instances)
 USV_DEV bool wave_any(bool p) { return __any((int)p) != 0; }
 
-#ifndef USV_NEWTON_STEPS
-#define USV_NEWTON_STEPS 2
-#endif
-// 1: IEEE-correct division and square root in place of the estimate + Newton forms below (a second build of the library for
-// the parity experiments of tools/parity_tail.py: is a device-vs-oracle difference made by the reciprocals?)
-#ifndef USV_EXACT_DIV
-#define USV_EXACT_DIV 0
-#endif
-// 1/x and 1/sqrt(x) from the hardware estimate + two Newton steps (full FP64 accuracy for the
-// normal-range operands of the IPM; ~10 instructions instead of the ~25 of an IEEE division)
+// 1/x and 1/sqrt(x) from the hardware estimate + two Newton steps (full FP64 accuracy for the normal-range operands of the IPM;
+// ~10 instructions instead of the ~25 of an IEEE division).  The arithmetic of the shipped kernels is THIS, with no build-time
+// variant: the IEEE-division build of the parity experiment (profiles/r03_parity_tail.txt) is a patch, tools/experiments/exact_div.patch.
 USV_DEV double frcp(double x)
 {
-#if USV_EXACT_DIV
-    return 1.0 / x;
-#endif
     double r = __builtin_amdgcn_rcp(x);
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-#if USV_NEWTON_STEPS > 1
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-#endif
     return r;
 }
 // 1/a and 1/b from ONE reciprocal: r = 1/(a b), 1/a = r b, 1/b = r a.  v_rcp_f64 is quarter rate and the Newton steps are four
@@ -229,24 +195,15 @@ USV_DEV double frcp(double x)
 // the double range (slacks and multipliers of the IPM: the C ABI refuses bounds beyond 1e100).
 USV_DEV void frcp2(double a, double b, double &ia, double &ib)
 {
-#if USV_EXACT_DIV
-    ia = 1.0 / a; ib = 1.0 / b;
-    return;
-#endif
     const double r = frcp(a * b);
     ia = r * b;
     ib = r * a;
 }
 USV_DEV double frsqrt(double x)
 {
-#if USV_EXACT_DIV
-    return 1.0 / sqrt(x);
-#endif
     double y = __builtin_amdgcn_rsq(x);
     y = __builtin_fma(0.5 * y, __builtin_fma(-x * y, y, 1.0), y);
-#if USV_NEWTON_STEPS > 1
     y = __builtin_fma(0.5 * y, __builtin_fma(-x * y, y, 1.0), y);
-#endif
     return y;
 }
 
@@ -308,15 +265,7 @@ USV_DEV double *dyn_lds()
 // A stored plane is not read again before tens of gigabytes have passed: non-temporal STORES measure -3 % (M2) /
 // -5 % (M1) on the QP kernel; non-temporal loads +-0, both together +6 % (tools/micro/store_policy.hip has the
 // isolated streams).
-#ifndef USV_PLANE_LOAD_AUX
-#define USV_PLANE_LOAD_AUX 0
-#endif
-#ifndef USV_PLANE_STORE_AUX
-#define USV_PLANE_STORE_AUX 2
-#endif
-#ifndef USV_MAT_LOAD_AUX
-#define USV_MAT_LOAD_AUX USV_PLANE_LOAD_AUX // packed matrix planes alone (non-temporal: measured +-0, profiles/r03_kernel_resources.txt)
-#endif
+constexpr int PLANE_LOAD_AUX = 0, PLANE_STORE_AUX = 2;
 struct Planes {
     __amdgpu_buffer_rsrc_t rsrc;
     unsigned voff; // byte offset of this lane's entry of plane 0 inside the stage window
@@ -332,21 +281,13 @@ struct Planes {
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
         // (plane offset added to the VGPR offset: the compiler folds the constant into the instruction's 12-bit offset field;
         // passed as the scalar offset operand it costs an s_movk per access)
-        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff + (unsigned)(plane * 128)), 0, USV_PLANE_LOAD_AUX);
-        return __builtin_bit_cast(double, v);
-    }
-    // the same load with a cache policy of its own (experiments: the packed matrix planes are read once per sweep and never hit)
-    template <int AUX>
-    USV_DEV double ld_policy(int plane) const
-    {
-        typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff + (unsigned)(plane * 128)), 0, AUX);
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff + (unsigned)(plane * 128)), 0, PLANE_LOAD_AUX);
         return __builtin_bit_cast(double, v);
     }
     USV_DEV void st(int plane, double x) const
     {
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), rsrc, (int)(voff + (unsigned)(plane * 128)), 0, USV_PLANE_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), rsrc, (int)(voff + (unsigned)(plane * 128)), 0, PLANE_STORE_AUX);
     }
 };
 

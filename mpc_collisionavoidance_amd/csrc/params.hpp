@@ -173,6 +173,13 @@ struct DevPtrs {
     // multiplier read-back (kernel usv_qp_export): [B][N+1][nlam] each, nlam = 2 (nrow + ns) - DevSpec
     double *lam_out, *t_out;
     int nlam;
+    // hand-over of long runners (qp_ipm.hpp QpIpm::suspend / resume; usvmpc.hip launch_qp, option "handover_iter"): once the queue of a
+    // launch is empty, a row whose instance has passed handover_iter IPM iterations leaves it - state in the workspace planes, the
+    // scalars of the iteration in susp_rec - to the follow-up launch, which finishes it on the latency mapping (one instance per wave)
+    int *susp_count;      // [1]     instances suspended by this launch; nullptr: no hand-over
+    int *susp_list;       // [B]     their groups
+    double *susp_rec;     // [B][4]  per instance: step length and centring target of the pending step, residual scale, iterations done
+    int handover_iter;
 };
 
 } // namespace usv

@@ -41,13 +41,6 @@
 #include "params.hpp"
 #include "sfor.hpp"
 
-#ifndef USV_MAT_LOAD_AUX
-#define USV_MAT_LOAD_AUX 0 // cache policy of the packed matrix plane loads (lanes.hpp; the emulator has none)
-#endif
-#ifndef USV_PAIRED_RCP
-#define USV_PAIRED_RCP 1 // both reciprocals of a row's slack pair / multiplier pair from one v_rcp_f64 (lanes::frcp2)
-#endif
-
 // Floating-point contraction is taken out of the optimiser's hands for everything in this file: a multiply-add is fused where ONE source
 // expression says a * b + c (the language rule, formed by the front end before any inlining) or where the code says fma / lanes::fma_bc,
 // and nowhere else.  Under the default (fuse whatever ends up adjacent after inlining) the same source contracted differently from
@@ -89,23 +82,13 @@ struct RowCalc {
     {
         rdl = v + sl - dl - tl;
         rdu = du - v + su - tu;
-#if USV_PAIRED_RCP
-        lanes::frcp2(tl, tu, itl, itu);
-#else
-        itl = lanes::frcp(tl);
-        itu = lanes::frcp(tu);
-#endif
+        lanes::frcp2(tl, tu, itl, itu); // (both reciprocals of a pair from one v_rcp_f64)
         if constexpr (SOFTROW) {
             rsl = Zl * sl + zl - ll - lsl;
             rsu = Zu * su + zu - lu - lsu;
             rdsl = sl - bsl - tsl;
             rdsu = su - bsu - tsu;
-#if USV_PAIRED_RCP
             lanes::frcp2(tsl, tsu, itsl, itsu);
-#else
-            itsl = lanes::frcp(tsl);
-            itsu = lanes::frcp(tsu);
-#endif
             if constexpr (MIXED) {
                 if (!soft) { rsl = 0.0; rsu = 0.0; rdsl = 0.0; rdsu = 0.0; }
             }
@@ -181,23 +164,15 @@ struct RowCalc {
     {
         if (!act) return q;
         q = lanes::vmax(q, -dtl * itl); q = lanes::vmax(q, -dtu * itu);
-#if USV_PAIRED_RCP
         double ill, ilu;
         lanes::frcp2(ll, lu, ill, ilu);
         q = lanes::vmax(q, -dll * ill); q = lanes::vmax(q, -dlu * ilu);
-#else
-        q = lanes::vmax(q, -dll * lanes::frcp(ll)); q = lanes::vmax(q, -dlu * lanes::frcp(lu));
-#endif
         if constexpr (SOFTROW) {
             if (is_soft()) {
                 q = lanes::vmax(q, -dtsl * itsl); q = lanes::vmax(q, -dtsu * itsu);
-#if USV_PAIRED_RCP
                 double ilsl, ilsu;
                 lanes::frcp2(lsl, lsu, ilsl, ilsu);
                 q = lanes::vmax(q, -dlsl * ilsl); q = lanes::vmax(q, -dlsu * ilsu);
-#else
-                q = lanes::vmax(q, -dlsl * lanes::frcp(lsl)); q = lanes::vmax(q, -dlsu * lanes::frcp(lsu));
-#endif
             }
         }
         return q;
@@ -219,14 +194,9 @@ struct RowCalc {
 USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 {
     const double d2 = dx * dx + dy * dy;
-#if defined(USV_EXACT_DIV) && USV_EXACT_DIV
-    d = sqrt(d2);
-    ux = dx / d; uy = dy / d;
-#else
     const double id = lanes::frsqrt(d2);
     d = d2 * id;
     ux = dx * id; uy = dy * id;
-#endif
 }
 
 // LDSWS: the workspace planes of a row's instance live in LDS for the whole solve (lanes::PlanesLds) - for batches small
@@ -359,7 +329,6 @@ struct QpIpm {
     bool auxlive;
     long stage_stride;     // doubles between consecutive stages of the workspace: Bp * NPL * 16
     unsigned stage_bytes;  // bytes of one stage's window
-    unsigned ws_all_bytes; // ... of all N + 1 (WIDE over HBM planes: rows address different stages through one window; the host keeps it below 2^31)
     bool xlane, ulane, valid, isPX, isPY;
     // per-lane constants, read once: box bounds of this lane's variable, Hessian diagonal
     // PACK: the box rows' (lambda_l, lambda_u, t_l, t_u) do not get four planes of their own.  A *slot* row
@@ -432,7 +401,6 @@ struct QpIpm {
             const long nbp = (long)lanes::uniform(S.Bp);
             stage_stride = nbp * NPL * LANES;
             stage_bytes = (unsigned)(nbp * NPL * 128);
-            ws_all_bytes = (unsigned)((long)(N + 1) * nbp * NPL * 128);
         }
         ulane = lane < NU;
         xlane = lane >= NU && lane < NZ;
@@ -682,8 +650,7 @@ struct QpIpm {
     USV_DEV void mat_issue(int k, double *pk) const
     {
         const Planes W = ws(k);
-        if constexpr (LDSWS) sfor<0, MP::NPK>([&](auto q) { pk[q] = W.ld(P_MAT + q); });
-        else sfor<0, MP::NPK>([&](auto q) { pk[q] = W.template ld_policy<USV_MAT_LOAD_AUX>(P_MAT + q); });
+        sfor<0, MP::NPK>([&](auto q) { pk[q] = W.ld(P_MAT + q); });
     }
     // (call under wave-uniform control flow)
     USV_DEV void mat_put(const double *pk) const
@@ -1382,12 +1349,19 @@ struct QpIpm {
             else { if (on) W.st(plane, v); }
         }
     };
-    // ... for the row phase: row r addresses ITS stage (own = this row has a stage in the block) and stores that stage's rows
-    USV_DEV WPl ws_row(int k, bool own) const
+    // ... for the row phase: row r addresses ITS stage (own = this row has a stage in the block) and stores that stage's rows.
+    // Planes in HBM: the rows of a workgroup address the BS consecutive stages of a block through ONE buffer window that starts at the
+    // block's lowest stage kbase (wave-uniform) - offsets stay below 2^32 whatever the batch (BS stage windows; the host checks), so
+    // the mapping also serves the long runners a 65 536-instance launch hands over (suspend / resume below).
+    USV_DEV WPl ws_row(int k, int kbase, bool own) const
     {
         if constexpr (LDSWS) return WPl{Planes(loff + (unsigned)(k * NPLW * LANES), own), own};
-        else return WPl{lanes::Planes(P.ws, ws_all_bytes, voff + (unsigned)k * stage_bytes), own};
+        else {
+            const int nst = (N + 1 - kbase < BS) ? N + 1 - kbase : BS;
+            return WPl{lanes::Planes(P.ws + (long)kbase * stage_stride, (unsigned)nst * stage_bytes, voff + (unsigned)(k - kbase) * stage_bytes), own};
+        }
     }
+    USV_DEV static int base_back(int kb) { return kb >= BS - 1 ? kb - (BS - 1) : 0; } // lowest stage of the backward sweeps' block at kb
     // ... for the recursion (the same stage in all rows): row 0 stores
     USV_DEV WPl ws_seq(int k) const { return WPl{ws(k), live}; }
     // What the recursion reads of a stage, asked for one stage ahead of its use: the lineariser's planes (always in HBM / L2) and - with
@@ -1447,7 +1421,7 @@ struct QpIpm {
         StageIn rnx;
         if constexpr (!LDSWS) {
             const int kr = N - row;
-            row_load<SW>(kr >= 0 ? kr : 0, ws_row(kr >= 0 ? kr : 0, false), rnx);
+            row_load<SW>(kr >= 0 ? kr : 0, ws_row(kr >= 0 ? kr : 0, base_back(N), false), rnx);
         }
         for (int kb = N; kb >= 0; kb -= BS) {
             // ---- row phase: row r on stage kb - r (with the pending update of the previous iteration applied first)
@@ -1455,7 +1429,7 @@ struct QpIpm {
                 const int kr = kb - row;
                 const bool own = kr >= 0;
                 const int k = own ? kr : 0;
-                const WPl W = ws_row(k, own);
+                const WPl W = ws_row(k, base_back(kb), own);
                 StageIn in;
                 if constexpr (LDSWS) row_load<SW>(k, W, in);
                 else in = rnx;
@@ -1483,7 +1457,7 @@ struct QpIpm {
                         if constexpr (PACK) {
                             const double dv = box_pack(br, pk);
                             // (the recursion composes the aux plane around the dense lanes)
-                            if constexpr (LDSWS) ws_row(k, own && isdense).st(P_AUX, dv);
+                            if constexpr (LDSWS) ws_row(k, 0, own && isdense).st(P_AUX, dv);
                             else ex_put(row, EX_DV, dv);
                         } else {
                             if (pend && br.act) box_store(W, br);
@@ -1573,7 +1547,7 @@ struct QpIpm {
             wide_sync();
             if constexpr (!LDSWS) { // the next block's row planes go in flight before the recursion of this one
                 const int kr = kb - BS - row;
-                if (kb >= BS) row_load<SW>(kr >= 0 ? kr : 0, ws_row(kr >= 0 ? kr : 0, false), rnx); // wave-uniform
+                if (kb >= BS) row_load<SW>(kr >= 0 ? kr : 0, ws_row(kr >= 0 ? kr : 0, base_back(kb - BS), false), rnx); // wave-uniform
             }
             // ---- the recursion over the block's stages, in all four rows alike
             for (int j = 0; j < BS; j++) {
@@ -1743,7 +1717,7 @@ struct QpIpm {
         SeqIn nxt;
         seq_load<SW>(0, nxt);
         StageIn rnx;
-        if constexpr (!LDSWS) row_load<SW>(row <= N ? row : N, ws_row(row <= N ? row : N, false), rnx);
+        if constexpr (!LDSWS) row_load<SW>(row <= N ? row : N, ws_row(row <= N ? row : N, 0, false), rnx);
         for (int kb = 0; kb <= N; kb += BS) {
             // ---- the recursion over the block's stages, in all four rows alike; row r keeps the step of stage kb + r
             double mydz = 0.0;
@@ -1792,11 +1766,11 @@ struct QpIpm {
                 const bool own = kr <= N;
                 const int k = own ? kr : N;
                 StageIn in;
-                if constexpr (LDSWS) row_load<SW>(k, ws_row(k, false), in);
+                if constexpr (LDSWS) row_load<SW>(k, ws_row(k, 0, false), in);
                 else {
                     in = rnx;
                     const int k2 = kr + BS <= N ? kr + BS : N;
-                    if (kb + BS <= N) row_load<SW>(k2, ws_row(k2, false), rnx); // wave-uniform: the next block's, in flight during its recursion
+                    if (kb + BS <= N) row_load<SW>(k2, ws_row(k2, kb + BS, false), rnx); // wave-uniform: the next block's, in flight during its recursion
                 }
                 const double z = in.z, aux = in.aux;
                 const double dz = mydz;
@@ -2092,15 +2066,46 @@ struct QpIpm {
         }
     }
 
+    // ------------------------------------------------------------------ hand-over of long runners
+    // A persistent launch ends with a handful of rows finishing instances that need 30 - 50 IPM iterations and were handed out late,
+    // while the rest of the device idles (profiles/r03_tail.txt).  What shortens that tail is a faster pass for ONE instance - the
+    // latency mapping.  Once every instance of the launch has been handed out (the queue counter has passed the batch), a row whose
+    // instance has done handover_iter iterations leaves it where it stands: everything an iteration hands to the next is in the
+    // workspace planes already (the pending step in P_DZ / P_DZA, multipliers and slacks in the row planes, the iterate in P_Z); what
+    // lives in registers - step length and centring target of the pending step, the residual scale, the iteration count - goes into
+    // the instance's record, the group into the list.  The follow-up launch (usvmpc.hip: usv_qp_resume) picks the list up one instance
+    // per wave and carries on from exactly that state, on the same planes: the mappings return the same bits, so WHERE an instance
+    // is finished does not show in its result (scheduling only; tests/test_gpu_handover.py, emulator tests/test_wide_emu.py).
+    static constexpr bool CAN_SUSPEND = !WIDE && !LDSWS && HDIAG && !SOFTBOX && ((PACK && KCH == 1) || (!PACK && KCH == 0));
+    USV_DEV void suspend(bool sel, int it, double a_prev, double sig_prev)
+    {
+        if constexpr (AUXLDS) { // (the aux plane of this launch lives in the wave's LDS: the resuming wave reads the HBM plane)
+            for (int k = 0; k <= N; k++) {
+                const Planes W = ws(k);
+                const double a = aux_ld(k, W);
+                if (sel) W.st(P_AUX, a);
+            }
+        }
+        if (sel && lane == 0) {
+            const int slot = lanes::fetch_add(P.susp_count);
+            P.susp_list[slot] = (int)g;
+            double *r = P.susp_rec + 4 * b;
+            r[0] = a_prev; r[1] = sig_prev; r[2] = rbscale; r[3] = (double)it;
+        }
+    }
+
     // ------------------------------------------------------------------ driver
     // phase 0: one SQP-RTI iteration.  phase 1 / 2: one iteration of the full SQP (first / later): test the NLP
     // residuals, and unless the instance has converged (or finished earlier) solve the QP and take the step.
+    // phase 3 (the latency mapping over planes in HBM): carry on with an RTI solve that another launch has suspended.
     // queue0 >= 0: the rows of this wave started on groups below queue0 and take further groups queue0, queue0 + 1, ...
     // from the counter P.queue as they finish (phase 0 only); queue0 < 0: every row keeps its first group.
     USV_DEV void solve(int phase, int queue0)
     {
         bool frozen = false;
         keep = false;
+        const bool resume = phase == 3;
+        if (resume) phase = 0;
         if (phase > 0) {
             const bool real0 = g < nB;
             frozen = !real0 || P.sqp_state[b] >= 0;
@@ -2119,7 +2124,7 @@ struct QpIpm {
             if (!lanes::wave_any(!frozen)) return;
         }
         keep = frozen;
-        const bool bad0 = init(true);
+        const bool bad0 = resume ? false : init(true);
         // ---- per-row state of the IPM (every row is in its own iteration)
         rbscale = 1.0;
         const bool own = WIDE ? true : live;     // (WIDE: all four rows iterate on the wave's instance, row 0 - live - writes)
@@ -2135,6 +2140,16 @@ struct QpIpm {
         double a_prev = 0.0, sig_prev = 0.0;
         const double nc = (double)S.nc;
         const bool refill = phase == 0 && queue0 >= 0; // wave-uniform
+        if constexpr (WIDE && !LDSWS) {
+            if (resume) { // the state the suspending row left (all rows of the wave read the same record)
+                const double *r = P.susp_rec + 4 * b;
+                a_prev = r[0]; sig_prev = r[1]; rbscale = r[2]; it = (int)r[3];
+                iters = it;
+                pend = true;
+            }
+        }
+        // (hand-over: kernel argument, wave-uniform; only launches that refill from a queue have a tail worth handing over)
+        const int hand_it = (CAN_SUSPEND && refill && P.susp_count != nullptr) ? P.handover_iter : 0;
         for (;;) {
             backward<true>(nm, 0.0, pend && !done, a_prev, sig_prev);
             bool fin = late;
@@ -2200,6 +2215,17 @@ struct QpIpm {
             pend = run ? true : pend;
             it = run ? it + 1 : it;
             fresh = false;
+            if constexpr (CAN_SUSPEND) {
+                if (hand_it > 0) { // wave-uniform
+                    const bool drained = lanes::observe(P.queue) >= nB - queue0; // every instance of the launch has been handed out
+                    const bool sus = drained && !done && real && it >= hand_it;
+                    if (lanes::wave_any(sus)) { // wave-uniform
+                        suspend(sus, it, a_prev, sig_prev);
+                        done = done || sus;
+                        real = sus ? false : real;
+                    }
+                }
+            }
         }
     }
 };

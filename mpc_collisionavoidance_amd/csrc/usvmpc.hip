@@ -87,14 +87,33 @@ constexpr auto wide_kernel()
     else if constexpr (KCH == 0 && !MERGE) return &usv_qp_rti<M, KCH, SOFT, true, false, false, LDSWS, false, false, true, WW>; // (no obstacle rows: box rows in their own planes)
     else return (decltype(&usv_qp_rti<M, KCH, SOFT, true, (KCH > 0), false, true, MERGE>))nullptr;
 }
-// the wide kernels of one layout: [planes in LDS, planes in HBM] x [one wave, four waves per instance]
+// The follow-up of a launch that handed long runners over (QpIpm::suspend, option "handover_iter"): one wave per suspended instance,
+// on the latency mapping over the planes in HBM - the planes the suspending row was working on.  Workgroup i takes entries i,
+// i + gridDim, ... of the list; with an empty list the launch is a few microseconds.
+template <class M, int KCH, bool SOFT, bool MERGE>
+__global__ void __launch_bounds__(64, 1) usv_qp_resume(DevPtrs P)
+{
+    const int n = lanes::uniform(*P.susp_count);
+    for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
+        QpIpm<M, KCH, SOFT, true, (KCH > 0), false, false, MERGE, false, true, 1> q(P, (long)P.susp_list[i], (threadIdx.x >> 4) == 0 ? 0 : -1);
+        q.solve(3, -1);
+    }
+}
+using qp_resume_t = void (*)(DevPtrs);
+template <class M, int KCH, bool SOFT, bool MERGE>
+constexpr qp_resume_t resume_kernel()
+{
+    if constexpr (KCH == 1 || (KCH == 0 && !MERGE)) return &usv_qp_resume<M, KCH, SOFT, MERGE>;
+    else return nullptr;
+}
+// the wide kernels of one layout: [planes in LDS, planes in HBM] x [one wave, four waves per instance], and the follow-up kernel
 using qp_kernel_t = void (*)(DevPtrs, long, int, int, int);
-struct WideSet { qp_kernel_t lds1, hbm1, lds4, hbm4; };
+struct WideSet { qp_kernel_t lds1, hbm1, lds4, hbm4; qp_resume_t resume; };
 template <class M, int KCH, bool SOFT, bool MERGE>
 constexpr WideSet wide_set()
 {
     return WideSet{wide_kernel<M, KCH, SOFT, MERGE, true, 1>(), wide_kernel<M, KCH, SOFT, MERGE, false, 1>(),
-                   wide_kernel<M, KCH, SOFT, MERGE, true, 4>(), wide_kernel<M, KCH, SOFT, MERGE, false, 4>()};
+                   wide_kernel<M, KCH, SOFT, MERGE, true, 4>(), wide_kernel<M, KCH, SOFT, MERGE, false, 4>(), resume_kernel<M, KCH, SOFT, MERGE>()};
 }
 
 // Multiplier read-back (usvmpc_get "lam" / "t"): the inequality multipliers and slacks of every instance's last QP, from the
@@ -301,6 +320,10 @@ struct usvmpc_handle {
     int wide_waves;           // waves per instance of the latency mapping: -1 (default) four for soft-row OCPs while the batch is at most one instance per CU, else one; 1; 4
     long wide4_cap, wide4_hbm_cap; // workgroups of four waves a launch holds at once (0: not yet known, -1: does not fit)
     int last_wide;            // the last RTI launch ran on the wide kernel
+    int handover_iter;        // option "handover_iter": IPM iterations after which a row of a drained launch hands its instance to the follow-up launch (0: never)
+    int *d_susp_count, *d_susp_list; // [RING] instances each of the last launches handed over / [B] their groups
+    double *d_susp_rec;       // [B][4] (DevPtrs::susp_rec)
+    long resume_cap;          // workgroups of the follow-up launch (0: not yet known, -1: the kernel cannot be launched)
     long max_waves;           // cap on the persistent waves of the QP kernel (0: as many as the device holds)
     int ncu;                  // compute units of the device
     long qp_cap;              // groups a full-occupancy launch of the QP kernel holds at once (0: not yet known)
@@ -397,7 +420,7 @@ void dev_free(usvmpc_handle *h, void *p, size_t nbytes)
 void reset_caps(usvmpc_handle *h)
 {
     h->qp_cap = 0; h->lds_cap = 0; h->aux_cap = 0;
-    h->wide_cap = 0; h->wide_hbm_cap = 0; h->wide4_cap = 0; h->wide4_hbm_cap = 0;
+    h->wide_cap = 0; h->wide_hbm_cap = 0; h->wide4_cap = 0; h->wide4_hbm_cap = 0; h->resume_cap = 0;
 }
 
 #if USV_MAIN
@@ -720,6 +743,7 @@ int launch_pair(usvmpc_handle *h, int phase)
     h->ptrs.fail_count = h->d_fail_ring + h->nsolves % usvmpc_handle::RING;
     HIP_TRY(h, hipMemsetAsync(h->ptrs.fail_count, 0, sizeof(int), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_unconv_ring + h->nsolves % usvmpc_handle::RING, 0, sizeof(int), h->stream));
+    if (h->d_susp_count) HIP_TRY(h, hipMemsetAsync(h->d_susp_count + h->nsolves % usvmpc_handle::RING, 0, sizeof(int), h->stream)); // (hand-over count of this launch)
     const int *next_perm = nullptr;
     if (spec_next) {
         // the NEXT tick's map, from the counts this launch is about to overwrite, into the buffer this tick does not use
@@ -747,16 +771,17 @@ int launch_pair(usvmpc_handle *h, int phase)
     // Small batches: the planes of every instance in flight fit in LDS (160 KB per CU), and a solve whose sweeps wait for
     // HBM at every stage - nothing else runs on the CU to hide it - becomes a solve on LDS.  rows_lds instances per wave
     // (as many whole horizons as fit), one wave per CU at a time; further instances come through the same queue.
-    auto launch_qp = [&](auto kern, decltype(kern) kern_lds, decltype(kern) kern_aux = nullptr, WideSet wide = WideSet{nullptr, nullptr, nullptr, nullptr}) -> int {
+    auto launch_qp = [&](auto kern, decltype(kern) kern_lds, decltype(kern) kern_aux = nullptr, WideSet wide = WideSet{nullptr, nullptr, nullptr, nullptr, nullptr}) -> int {
         const long lds_inst = (long)(h->N + 1) * h->spec.npt * 128;
         h->last_wide = 0;
+        h->ptrs.susp_count = nullptr; h->ptrs.susp_list = nullptr; h->ptrs.susp_rec = nullptr; h->ptrs.handover_iter = 0; // (set by the path that hands over)
         const qp_kernel_t kern_wide = wide.lds1, kern_wide_hbm = wide.hbm1;
         // Four waves per instance (qp_ipm.hpp, WW): a workgroup = a whole CU shares out the row work of 16 consecutive stages - for the
         // single instance and batches of at most one instance per CU.
         if (wide.lds4 != nullptr && phase == 0 && h->wide_mode != 0 && h->wide_waves != 1 && h->ncu > 0) {
             const size_t pl = (size_t)(h->N + 1) * (size_t)(WsLayout<M, KCH, SOFT>::P_RB0 - (KCH > 0 ? 4 : 0)) * 128;
             const size_t b4 = pl + (size_t)16 * WIDE_EX_PLANES * 128 + 128, x4 = (size_t)16 * WIDE_EX_PLANES_HBM * 128 + 128;
-            const long ws_bytes = (long)(h->N + 1) * h->Bp * h->spec.npt * 128;
+            const long win_bytes = (long)std::min(h->N + 1, 16) * h->Bp * h->spec.npt * 128; // (the window of a block of 16 stages: 32-bit offsets)
             if (h->wide4_cap == 0) {
                 int nb = 0;
                 hipFuncAttributes fa;
@@ -769,7 +794,7 @@ int launch_pair(usvmpc_handle *h, int phase)
             }
             if (h->wide4_cap < 0 && h->wide4_hbm_cap == 0) {
                 int nb = 0;
-                h->wide4_hbm_cap = (wide.hbm4 != nullptr && ws_bytes < (1L << 31) &&
+                h->wide4_hbm_cap = (wide.hbm4 != nullptr && win_bytes < (1L << 32) &&
                                     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wide.hbm4, 4 * qp_block, x4) == hipSuccess && nb > 0) ? (long)h->ncu : -1;
             }
             const bool lds = h->wide4_cap > 0;
@@ -820,8 +845,8 @@ int launch_pair(usvmpc_handle *h, int phase)
             // The horizon's planes do not fit a CU's LDS (the reference node's own N = 100: nmpc_guidance_ca1.cpp:64): the same sweeps over
             // the planes in HBM / L2 - the four rows of a wave address four stages through one window over the whole workspace (hence
             // its size limit), the next block's row planes and the next stage's recursion planes are in flight ahead of their use.
-            const long ws_bytes = (long)(h->N + 1) * h->Bp * h->spec.npt * 128;
-            if (h->wide_cap < 0 && kern_wide_hbm != nullptr && ws_bytes < (1L << 31)) {
+            const long win_bytes = (long)std::min(h->N + 1, 4) * h->Bp * h->spec.npt * 128; // (the window of a block of four stages: 32-bit offsets)
+            if (h->wide_cap < 0 && kern_wide_hbm != nullptr && win_bytes < (1L << 32)) {
                 const size_t xbytes = (size_t)4 * WIDE_EX_PLANES_HBM * 128;
                 if (h->wide_hbm_cap == 0) {
                     int nb = 0;
@@ -902,8 +927,34 @@ int launch_pair(usvmpc_handle *h, int phase)
             if (cap > 0 && cap < qp_groups) { ng = cap; q0 = (int)ng; }
         }
         if (q0 >= 0) HIP_TRY(h, hipMemsetAsync(h->ptrs.queue, 0, sizeof(int), h->stream));
+        // Hand-over of long runners (qp_ipm.hpp, QpIpm::suspend): a launch that refills from the queue ends with a few rows finishing
+        // instances of 30 - 50 iterations on an idling device; past "handover_iter" iterations those go to a follow-up launch on the
+        // latency mapping (one instance per wave over the same planes: 1.6x per pass for usv_model_pf_ca at N = 40).  Scheduling only.
+        bool hand = false;
+        const size_t xbytes = (size_t)4 * WIDE_EX_PLANES_HBM * 128;
+        if (q0 >= 0 && h->handover_iter > 0 && wide.resume != nullptr && (long)std::min(h->N + 1, 4) * h->Bp * h->spec.npt * 128 < (1L << 32)) {
+            if (h->resume_cap == 0) {
+                int nb = 0;
+                h->resume_cap = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wide.resume, qp_block, xbytes) == hipSuccess && nb > 0 && h->ncu > 0)
+                                    ? (long)std::min(nb, 4) * h->ncu : -1;
+            }
+            if (h->resume_cap > 0 && !h->d_susp_list) {
+                if (dev_alloc(h, &h->d_susp_count, (size_t)usvmpc_handle::RING, true) || dev_alloc(h, &h->d_susp_list, (size_t)h->B, false) ||
+                    dev_alloc(h, &h->d_susp_rec, (size_t)h->B * 4, false))
+                    return USVMPC_E_HIP;
+            }
+            hand = h->resume_cap > 0;
+        }
+        h->ptrs.susp_count = hand ? h->d_susp_count + h->nsolves % usvmpc_handle::RING : nullptr;
+        h->ptrs.susp_list = hand ? h->d_susp_list : nullptr;
+        h->ptrs.susp_rec = hand ? h->d_susp_rec : nullptr;
+        h->ptrs.handover_iter = hand ? h->handover_iter : 0;
         const dim3 qg((unsigned)((ng * LANES + qp_block - 1) / qp_block)), qb(qp_block);
         hipLaunchKernelGGL(kern, qg, qb, aux_bytes, h->stream, h->ptrs, ng, phase, q0, 4);
+        if (hand) {
+            const long nwg = std::min<long>(h->resume_cap, (long)h->B);
+            hipLaunchKernelGGL(wide.resume, dim3((unsigned)nwg), dim3(qp_block), xbytes, h->stream, h->ptrs);
+        }
         return 0;
     };
     int rcq = 0;
@@ -932,7 +983,7 @@ int launch_pair(usvmpc_handle *h, int phase)
             rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>,
                                    &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>, wide_set<M, KCH, SOFT, false>())
                        : launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, false>, &usv_qp_rti<M, KCH, SOFT, true, false, false, true>, nullptr,
-                                   KCH == 0 ? wide_set<M, KCH, SOFT, false>() : WideSet{nullptr, nullptr, nullptr, nullptr});
+                                   KCH == 0 ? wide_set<M, KCH, SOFT, false>() : WideSet{nullptr, nullptr, nullptr, nullptr, nullptr});
     } else {
         rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, false, CANPACK, false>, nullptr) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, false>, nullptr);
     }
@@ -1190,6 +1241,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->lds_cap = 0;
     h->wide_mode = -1; h->wide_cap = 0; h->wide_hbm_cap = 0; h->last_wide = 0;
     h->wide_waves = -1; h->wide4_cap = 0; h->wide4_hbm_cap = 0;
+    h->handover_iter = 0; h->d_susp_count = nullptr; h->d_susp_list = nullptr; h->d_susp_rec = nullptr; h->resume_cap = 0;
     h->max_waves = 0;
     {
         hipDeviceProp_t prop;
@@ -1544,6 +1596,19 @@ int usvmpc_unconverged_counts(usvmpc_handle *h, int n, int *counts)
     return 0;
 }
 
+int usvmpc_handover_counts(usvmpc_handle *h, int n, int *counts)
+{
+    if (!h || n < 1 || !counts) return USVMPC_E_ARG;
+    if (h->nsolves < n || n > usvmpc_handle::RING) { h->err = "fewer solves recorded than requested"; return USVMPC_E_ARG; }
+    if (!h->d_susp_count) { for (int i = 0; i < n; i++) counts[i] = 0; return 0; } // (no launch of this handle has handed anything over)
+    HIP_TRY(h, hipSetDevice(h->device));
+    int ring[usvmpc_handle::RING];
+    HIP_TRY(h, hipMemcpyAsync(ring, h->d_susp_count, sizeof(ring), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; i++) counts[i] = ring[(h->nsolves - n + i) % usvmpc_handle::RING];
+    return 0;
+}
+
 int usvmpc_pipeline_stats(usvmpc_handle *h, long *used, long *discarded)
 {
     if (!h) return USVMPC_E_ARG;
@@ -1638,6 +1703,11 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
     if (s == "dynamic_rows") { // 0: one group per row for the whole launch (the rows of a wave wait for its slowest)
         h->dynamic_rows = value != 0.0;
         reset_caps(h);
+        return 0;
+    }
+    if (s == "handover_iter") { // IPM iterations after which a row of a drained launch hands its instance over to the follow-up launch; 0: never
+        if (value < 0.0 || value > 1e6) { h->err = "handover_iter must be >= 0"; return USVMPC_E_ARG; }
+        h->handover_iter = (int)value;
         return 0;
     }
     if (s == "disturbance_mask") { // bit j: usvmpc_advance adds its noise to state j

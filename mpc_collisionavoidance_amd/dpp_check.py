@@ -205,7 +205,7 @@ def check(co):
 
 def check_library(path, expect_fused=True):
     """(number of hand-placed DPP instructions, list of violation strings) for one library / code object.
-    expect_fused: the library was built with USV_FUSED_DPP_FMA = 1 (the default), so finding NO such instruction means the
+    expect_fused: the library holds the hand-placed v_fmac_f64_dpp of lanes::fma_bc*, so finding NO such instruction means the
     disassembly was not understood (objdump format change) - a violation, not a pass."""
     cos, tmp = code_objects(path)
     total, msgs = 0, []

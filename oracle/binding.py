@@ -24,7 +24,8 @@ _ip = C.POINTER(C.c_int)
 class Opts(C.Structure):
     _fields_ = [("qp_iter_max", C.c_int), ("mu0", C.c_double), ("thr0", C.c_double),
                 ("tol_stat", C.c_double), ("tol_eq", C.c_double), ("tol_ineq", C.c_double),
-                ("tol_comp", C.c_double), ("alpha_min", C.c_double), ("riccati", C.c_int)]
+                ("tol_comp", C.c_double), ("alpha_min", C.c_double), ("riccati", C.c_int),
+                ("cond_pred_corr", C.c_int), ("cpc_factor", C.c_double), ("itref_corr_max", C.c_int)]
 
 
 class Spec(C.Structure):
@@ -58,7 +59,7 @@ class QpSol(C.Structure):
     _fields_ = [("dz", _dp), ("pi", _dp), ("lam_bu", _dp), ("t_bu", _dp), ("lam_bx", _dp), ("t_bx", _dp),
                 ("lam_g", _dp), ("t_g", _dp), ("sl", _dp), ("su", _dp), ("lam_s", _dp), ("t_s", _dp),
                 ("sl_bx", _dp), ("su_bx", _dp), ("lam_sbx", _dp), ("t_sbx", _dp),
-                ("iter", C.c_int), ("status", C.c_int), ("res", C.c_double * 4)]
+                ("iter", C.c_int), ("status", C.c_int), ("res", C.c_double * 4), ("cpc_fallbacks", C.c_int)]
 
 
 def build(force=False):
@@ -223,7 +224,7 @@ def linearize_and_solve(s, x, u, x0, yref, yref_e, p, lh, solve=True):
                    lam_s=_np_from(sc.lam_s, (N + 1, 2, K)), t_s=_np_from(sc.t_s, (N + 1, 2, K)),
                    sl_bx=_np_from(sc.sl_bx, (N + 1, nbx)), su_bx=_np_from(sc.su_bx, (N + 1, nbx)),
                    lam_sbx=_np_from(sc.lam_sbx, (N + 1, 2, nbx)), t_sbx=_np_from(sc.t_sbx, (N + 1, 2, nbx)),
-                   iter=sc.iter, status=sc.status, res=np.array(sc.res[:]))
+                   iter=sc.iter, status=sc.status, res=np.array(sc.res[:]), cpc_fallbacks=sc.cpc_fallbacks)
         L.usv_qp_sol_free(sp)
     L.usv_qp_free(q)
     return qp, sol

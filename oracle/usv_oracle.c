@@ -345,6 +345,9 @@ void usv_opts_defaults(usv_opts *o)
     o->tol_comp = 1e-8;
     o->alpha_min = 1e-12;
     o->riccati = USV_RICCATI_SQRT;
+    o->cond_pred_corr = 0;
+    o->cpc_factor = 2.0;
+    o->itref_corr_max = 0;
 }
 
 int usv_spec_defaults(usv_spec *s, int model, int N, double Tf, int K)
@@ -1062,6 +1065,119 @@ static double step_length(ipm_ws *w)
     return a;
 }
 
+/* ---- HPIPM options beyond the plain Mehrotra iteration (usv_opts: off by default) -------------------------------------------------
+ * Restated from HPIPM's published d_ocp_qp_ipm_solve (cond_pred_corr, itref_corr_max) as recalled - the acados tree is absent here. */
+
+/* duality measure after a step of length a along the current direction */
+static double mu_after(const ipm_ws *w, double a)
+{
+    double m = 0.0;
+    int k, i;
+    for (k = 0; k <= w->q->N; k++)
+        for (i = 0; i < w->st[k].m; i++) {
+            const row_t *r = &w->st[k].r[i];
+            m += (r->ll + a * r->dll) * (r->tl + a * r->dtl) + (r->lu + a * r->dlu) * (r->tu + a * r->dtu);
+            if (r->soft)
+                m += (r->lsl + a * r->dlsl) * (r->tsl + a * r->dtsl) + (r->lsu + a * r->dlsu) * (r->tsu + a * r->dtsu);
+        }
+    return w->nc ? m / w->nc : 0.0;
+}
+
+/* One round of iterative refinement of the step held in (dz, dpi, row steps): the residual of every equation of the Newton system at
+ * that step becomes the right-hand side of a second solve on the same factorisation, whose solution is added (HPIPM
+ * d_ocp_qp_res_compute_lin + d_ocp_qp_solve_kkt_step).  Returns 0 without solving when the residual norms (stat, eq, ineq, comp)
+ * are all below tol[] already. */
+static int refine_step(ipm_ws *w, const double *tol)
+{
+    const usv_qp *q = w->q;
+    const int N = q->N, nx = q->nx, nu = q->nu, nz = q->nz;
+    stage_t *keep = (stage_t *)malloc(sizeof(stage_t) * ((size_t)N + 1));
+    double nrm[4] = {0.0, 0.0, 0.0, 0.0};
+    int k, i, j;
+    memcpy(keep, w->st, sizeof(stage_t) * ((size_t)N + 1));
+    for (k = 0; k <= N; k++) { /* residuals of the linear system at the current step, written over the rhs fields */
+        stage_t *s = &w->st[k];
+        const stage_t *o = &keep[k];
+        const double *H = q->H + (size_t)k * nz * nz;
+        for (i = 0; i < nz; i++) {
+            double a = o->rg[i];
+            for (j = 0; j < nz; j++) a += H[i * nz + j] * o->dz[j];
+            s->rg[i] = a;
+        }
+        if (k < N) {
+            const double *A = q->A + (size_t)k * nx * nx, *B = q->B + (size_t)k * nx * nu;
+            const stage_t *on = &keep[k + 1];
+            for (i = 0; i < nx; i++) {
+                double a = o->rb[i] - on->dz[nu + i];
+                for (j = 0; j < nx; j++) a += A[i * nx + j] * o->dz[nu + j];
+                for (j = 0; j < nu; j++) a += B[i * nu + j] * o->dz[j];
+                s->rb[i] = a;
+                nrm[1] = fmax(nrm[1], fabs(a));
+            }
+            for (j = 0; j < nu; j++) for (i = 0; i < nx; i++) s->rg[j] += B[i * nu + j] * on->dpi[i];
+            for (j = 0; j < nx; j++) for (i = 0; i < nx; i++) s->rg[nu + j] += A[i * nx + j] * on->dpi[i];
+        }
+        if (k >= 1) for (i = 0; i < nx; i++) s->rg[nu + i] -= o->dpi[i];
+        for (i = 0; i < s->m; i++) {
+            row_t *r = &s->r[i];
+            const row_t *c = &o->r[i];
+            const double wv = row_dot(c, o->dz);
+            row_axpy(c, -(c->dll - c->dlu), s->rg);
+            r->rdl = c->rdl + wv + c->dsl - c->dtl;
+            r->rdu = c->rdu - wv + c->dsu - c->dtu;
+            r->ml = c->ml + c->ll * c->dtl + c->tl * c->dll;
+            r->mu_ = c->mu_ + c->lu * c->dtu + c->tu * c->dlu;
+            nrm[2] = fmax(nrm[2], fmax(fabs(r->rdl), fabs(r->rdu)));
+            nrm[3] = fmax(nrm[3], fmax(fabs(r->ml), fabs(r->mu_)));
+            if (c->soft) {
+                r->rsl = c->rsl + q->Zl[c->ks] * c->dsl - c->dll - c->dlsl;
+                r->rsu = c->rsu + q->Zu[c->ks] * c->dsu - c->dlu - c->dlsu;
+                r->rdsl = c->rdsl + c->dsl - c->dtsl;
+                r->rdsu = c->rdsu + c->dsu - c->dtsu;
+                r->msl = c->msl + c->lsl * c->dtsl + c->tsl * c->dlsl;
+                r->msu = c->msu + c->lsu * c->dtsu + c->tsu * c->dlsu;
+                nrm[0] = fmax(nrm[0], fmax(fabs(r->rsl), fabs(r->rsu)));
+                nrm[2] = fmax(nrm[2], fmax(fabs(r->rdsl), fabs(r->rdsu)));
+                nrm[3] = fmax(nrm[3], fmax(fabs(r->msl), fabs(r->msu)));
+            }
+        }
+        for (i = (k == N ? nu : 0); i < nz; i++) {
+            if (k == 0 && i >= nu) continue;
+            nrm[0] = fmax(nrm[0], fabs(s->rg[i]));
+        }
+    }
+    if (nrm[0] <= tol[0] && nrm[1] <= tol[1] && nrm[2] <= tol[2] && nrm[3] <= tol[3]) {
+        memcpy(w->st, keep, sizeof(stage_t) * ((size_t)N + 1));
+        free(keep);
+        return 0;
+    }
+    for (i = 0; i < nx; i++) w->st[0].dz[nu + i] = 0.0; /* dx_0 of the correction: the x0 equation holds exactly */
+    for (k = 0; k < N; k++) /* P_{k+1} b_k for the correction's b_k (riccati_factor made it for the step's) */
+        for (i = 0; i < nx; i++) {
+            double a = 0.0;
+            for (j = 0; j < nx; j++) a += w->st[k + 1].P[i * nx + j] * w->st[k].rb[j];
+            w->st[k].Pb[i] = a;
+        }
+    reduce_rows(w, 0);
+    riccati_solve(w);
+    expand_rows(w);
+    for (k = 0; k <= N; k++) { /* step := step + correction, right-hand sides back */
+        stage_t *s = &w->st[k];
+        stage_t *o = &keep[k];
+        for (i = 0; i < nz; i++) o->dz[i] += s->dz[i];
+        for (i = 0; i < nx; i++) o->dpi[i] += s->dpi[i];
+        for (i = 0; i < s->m; i++) {
+            row_t *c = &o->r[i];
+            const row_t *r = &s->r[i];
+            c->dll += r->dll; c->dlu += r->dlu; c->dtl += r->dtl; c->dtu += r->dtu;
+            c->dsl += r->dsl; c->dsu += r->dsu; c->dlsl += r->dlsl; c->dlsu += r->dlsu; c->dtsl += r->dtsl; c->dtsu += r->dtsu;
+        }
+    }
+    memcpy(w->st, keep, sizeof(stage_t) * ((size_t)N + 1));
+    free(keep);
+    return 1;
+}
+
 int usv_qp_solve(const usv_qp *q, const usv_opts *o, usv_qp_sol *sol)
 {
     const int N = q->N, nx = q->nx, nu = q->nu, nz = q->nz, K = q->K;
@@ -1073,6 +1189,7 @@ int usv_qp_solve(const usv_qp *q, const usv_opts *o, usv_qp_sol *sol)
     build_rows(&w);
     init_cold(&w, o);
     residuals(&w);
+    sol->cpc_fallbacks = 0;
     for (it = 0; it < o->qp_iter_max; it++) {
         double a_aff, a, mu_aff = 0.0, sigma;
         if (w.res[0] != w.res[0] || w.res[1] != w.res[1] || w.res[2] != w.res[2] || w.res[3] != w.res[3]) {
@@ -1123,6 +1240,32 @@ int usv_qp_solve(const usv_qp *q, const usv_opts *o, usv_qp_sol *sol)
             reduce_rows(&w, 0);
             riccati_solve(&w);
             expand_rows(&w);
+            if (o->itref_corr_max > 0) {
+                const double tol[4] = {o->tol_stat, o->tol_eq, o->tol_ineq, o->tol_comp};
+                int rr;
+                for (rr = 0; rr < o->itref_corr_max; rr++)
+                    if (!refine_step(&w, tol)) break;
+            }
+            if (o->cond_pred_corr) {
+                /* the corrected step must not leave the central path further than the predictor promised: otherwise centring only */
+                const double a_pc = step_length(&w);
+                if (mu_after(&w, a_pc) > o->cpc_factor * mu_aff) {
+                    for (k = 0; k <= N; k++)
+                        for (i = 0; i < w.st[k].m; i++) {
+                            row_t *r = &w.st[k].r[i];
+                            r->ml = r->ll * r->tl - sigma * w.mu;
+                            r->mu_ = r->lu * r->tu - sigma * w.mu;
+                            if (r->soft) {
+                                r->msl = r->lsl * r->tsl - sigma * w.mu;
+                                r->msu = r->lsu * r->tsu - sigma * w.mu;
+                            }
+                        }
+                    reduce_rows(&w, 0);
+                    riccati_solve(&w);
+                    expand_rows(&w);
+                    sol->cpc_fallbacks++;
+                }
+            }
         }
         a = step_length(&w);
         if (a < o->alpha_min) { status = 2; break; }

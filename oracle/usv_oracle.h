@@ -69,6 +69,14 @@ typedef struct usv_opts {
     double tol_comp;      /* 1e-8 */
     double alpha_min;     /* 1e-12 */
     int riccati;          /* USV_RICCATI_SQRT */
+    /* HPIPM options the mode acados selects (BALANCE) runs with and this restatement does NOT adopt by default - off here, on request for
+     * the experiments of tests/test_parity_outliers.py (DESIGN.md section 2 lists every d_ocp_qp_ipm_arg field, adopted or not): */
+    int cond_pred_corr;   /* 0.  1: conditional predictor-corrector - when the corrected step leaves the duality measure above
+                           * cpc_factor x the predictor's mu_aff, the step is replaced by the centring-only one (no second-order term) */
+    double cpc_factor;    /* 2.0 */
+    int itref_corr_max;   /* 0.  > 0: that many rounds of iterative refinement of the corrector's KKT solve (residual of the linear
+                           * system with the step just computed, solved again on the same factorisation, added), each skipped once the
+                           * residual is below the exit tolerances */
 } usv_opts;
 
 /* One OCP definition, shared by every instance of a batch. Dense row-major matrices. */
@@ -152,6 +160,7 @@ typedef struct usv_qp_sol {
     double *lam_sbx, *t_sbx; /* [N+1][2*nbx] */
     int iter, status;       /* status: 0 ok, 1 max iter, 2 min step, 3 nan */
     double res[4];          /* inf-norms: stat, eq, ineq, comp */
+    int cpc_fallbacks;      /* usv_opts.cond_pred_corr: iterations whose corrected step was replaced by the centring-only one */
 } usv_qp_sol;
 
 usv_qp *usv_qp_alloc(const usv_spec *s);

@@ -113,6 +113,9 @@ int g_emu_merge = 1;    // 1: box rows processed in their slot lanes when all of
 int g_emu_aux = 0;      // 1: RTI solves of the packed one-chunk layouts keep the aux plane in (emulated) LDS (AUXLDS instantiations)
 int g_emu_wide = 0;     // 1 / 2 / 4: RTI solves of the packed one-chunk layouts on the WIDE mapping, that many emulated waves per instance
 long g_emu_wide_runs = 0; // rows started on the WIDE mapping since the switch was set
+int g_emu_handover = 0; // > 0: RTI solves on the 16-lane mapping hand instances past this many iterations over once the queue is empty (QpIpm::suspend);
+                        // the follow-up pass resumes them on the WIDE mapping over the planes in "HBM" (usv_qp_resume on the device)
+long g_emu_handed = 0;  // instances handed over since the switch was set
 
 template <class M, int KCH, bool SOFT>
 void lin_body(void *a)
@@ -232,24 +235,32 @@ void expand_packed(const DevPtrs &P, const DevSpec &S)
 }
 
 template <class M, int KCH, bool SOFT>
-void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
+void run_all(const DevPtrs &P_, const DevSpec &S, int phase, int qp_phase)
 {
     const_cast<DevSpec &>(S).npt = S.any_bsoft ? WsLayout<M, KCH, SOFT, true>::NPT : WsLayout<M, KCH, SOFT, false>::NPT;
     if (phase & 1)
         for (long gid = 0; gid < (long)(S.N + 1) * S.Bp; gid++) {
-            Job j{&P, gid, 0, -1};
+            Job j{&P_, gid, 0, -1};
             lanes::run_group(gid, &lin_body<M, KCH, SOFT>, &j);
         }
-    if ((phase & 1) && (g_dbg_BAt || g_dbg_rb0 || g_dbg_gq)) expand_packed<M, KCH, SOFT>(P, S);
+    if ((phase & 1) && (g_dbg_BAt || g_dbg_rb0 || g_dbg_gq)) expand_packed<M, KCH, SOFT>(P_, S);
     // RTI: a few persistent rows that pull the remaining groups from the queue (as the device launch does); full SQP: one
     // group per row
     if ((phase & 2) && qp_phase == 0 && g_emu_cond_N2 > 0 && !S.any_bsoft) {
-        if (cond_all<M, KCH, SOFT>(P, S, g_emu_cond_N2)) std::abort();
+        if (cond_all<M, KCH, SOFT>(P_, S, g_emu_cond_N2)) std::abort();
         return;
     }
     const bool queue = qp_phase == 0 && g_emu_rows > 0 && g_emu_rows < S.Bp;
     const long nrows = queue ? g_emu_rows : S.Bp;
-    if (queue) *P.queue = 0;
+    if (queue) *P_.queue = 0;
+    // hand-over (RTI launches that refill from the queue, layouts with a WIDE mapping): the lists of this "launch"
+    std::vector<int> susp_list((size_t)S.B + 1, 0);
+    std::vector<double> susp_rec((size_t)S.B * 4 + 4, 0.0);
+    int susp_count = 0;
+    DevPtrs Ph = P_;
+    const bool hand = queue && g_emu_handover > 0 && !g_emu_wide && !g_emu_lds_mode && S.hdiag && !S.any_bsoft && ((KCH == 1 && S.boxpack != 0) || KCH == 0);
+    if (hand) { Ph.susp_count = &susp_count; Ph.susp_list = susp_list.data(); Ph.susp_rec = susp_rec.data(); Ph.handover_iter = g_emu_handover; }
+    const DevPtrs &P = Ph;
     if (phase & 2)
         for (long g = 0; g < nrows; g++) {
             static std::vector<double> lds; // the emulated row's LDS region (allocated here: the body runs once per lane)
@@ -277,6 +288,20 @@ void run_all(const DevPtrs &P, const DevSpec &S, int phase, int qp_phase)
             else if (S.hdiag) lanes::run_group(g, pack ? &qp_body<M, KCH, SOFT, true, CANPACK> : &qp_body<M, KCH, SOFT, true, false>, &j);
             else lanes::run_group(g, pack ? &qp_body<M, KCH, SOFT, false, CANPACK> : &qp_body<M, KCH, SOFT, false, false>, &j);
         }
+    if constexpr (KCH <= 1) {
+        if ((phase & 2) && hand) { // the follow-up launch: one emulated wave per suspended instance, planes in "HBM"
+            static std::vector<double> lds;
+            for (int i = 0; i < susp_count; i++) {
+                lds.assign(wide_lds<M, KCH, SOFT>(S.N), 0.0);
+                lanes::g_emu_lds = lds.data();
+                Job j{&P, (long)susp_list[i], 3, -1};
+                const bool mg = KCH == 1 && g_emu_merge && !S.box_dense;
+                if (mg) run_wide<M, KCH, SOFT, true, false>((long)susp_list[i], j, 1);
+                else run_wide<M, KCH, SOFT, false, false>((long)susp_list[i], j, 1);
+            }
+            g_emu_handed += susp_count;
+        }
+    }
     if ((phase & 2) && P.lam_out)
         for (long g = 0; g < S.Bp; g++) {
             Job j{&P, g, 0, -1};
@@ -382,6 +407,8 @@ extern "C" void usv_emu_set_cond(int N2) { g_emu_cond_N2 = N2; }
 extern "C" void usv_emu_set_aux(int aux) { g_emu_aux = aux; }
 extern "C" void usv_emu_set_wide(int wide) { g_emu_wide = wide; g_emu_wide_runs = 0; }
 extern "C" long usv_emu_wide_runs() { return g_emu_wide_runs; }
+extern "C" void usv_emu_set_handover(int iters) { g_emu_handover = iters; g_emu_handed = 0; }
+extern "C" long usv_emu_handed() { return g_emu_handed; }
 // the next solves also deliver the multipliers / slacks of their QPs (the device's usvmpc_get "lam" / "t"); NULL switches it off
 extern "C" void usv_emu_set_export(double *lam, double *t) { g_emu_lam = lam; g_emu_t = t; }
 

@@ -1,0 +1,80 @@
+"""Hand-over of long runners on the device (option "handover_iter"; qp_ipm.hpp QpIpm::suspend / solve phase 3, usvmpc.hip usv_qp_resume).
+A launch of more instances than the device holds rows hands them out through a queue and ends with a few rows finishing instances of 30 - 50
+IPM iterations while the device idles.  With the option, a row of a drained launch whose instance has passed that many iterations leaves it
+to a follow-up launch on the latency mapping (one instance per wavefront over the same workspace planes).  Scheduling only: statuses,
+iteration counts, iterates, multipliers and slacks are the same BITS as without it (the mappings agree bit for bit: tests/test_gpu_wide.py;
+the lane emulator runs the same hand-over: tests/test_wide_emu.py)."""
+import numpy as np
+import pytest
+
+from mpc_collisionavoidance_amd import BatchOcpSolver, scenario, usv_models
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(name, N, K, B, seed, opts):
+    wl = scenario.make_bench_batch(name, N, K, B, seed=seed)
+    ocp = usv_models.make_ocp(name, N * scenario.BENCH_DT, N, K if name != "usv_model" else None)
+    ocp.solver_options.sim_method_num_steps = scenario.BENCH_SIM_STEPS[name]
+    s = BatchOcpSolver(ocp, B)
+    scenario.load_into(s, wl)
+    if K > 0:
+        s.set_option("static_obstacles", 1)
+    s.set_option("disturbance_mask", scenario.NOISE_MASK[name])
+    for k, v in opts:
+        s.set_option(k, v)
+    return s
+
+
+@pytest.mark.parametrize("name,N,K,B,hand,opts", [
+    ("usv_model_pf_ca", 20, 3, 12000, 8, ()),                          # one row pass (box rows in idle obstacle lanes), aux plane in LDS
+    ("usv_model_pf_ca", 40, 10, 10000, 12, ()),                        # the headline layout: one box row in the aux plane, two row passes
+    ("usv_model_pf_ca", 40, 10, 10000, 12, (("aux_in_lds", 0),)),      # ... aux plane streamed
+    ("usv_model_guidance_ca1", 20, 8, 12000, 6, ()),                   # soft rows
+    ("usv_model_guidance_ca1", 40, 16, 9000, 6, ()),                   # soft rows, two row passes
+    ("usv_model", 20, 0, 12000, 5, (("max_waves", 1024),)),            # no obstacle rows (three waves per SIMD hold 12 288 rows: fewer, so that the queue is used)
+    ("usv_model_pf_ca", 20, 3, 12000, 8, (("max_waves", 512),)),       # a quarter of the rows: most of the batch through the queue
+])
+def test_handover_does_not_change_a_bit(name, N, K, B, hand, opts):
+    a = _make(name, N, K, B, 1234, (("wide", 0), ("lds_workspace", 0)) + tuple(opts))
+    b = _make(name, N, K, B, 1234, (("wide", 0), ("lds_workspace", 0), ("handover_iter", hand)) + tuple(opts))
+    handed = 0
+    for t in range(3):
+        sa, sb = a.solve(), b.solve()
+        assert a.last_mapping() == 0 and b.last_mapping() == 0
+        assert int(a.handover_counts(1)[0]) == 0
+        handed += int(b.handover_counts(1)[0])
+        assert np.array_equal(sa, sb), t
+        for f in ("qp_status", "qp_iter"):
+            assert np.array_equal(a.get_int(f), b.get_int(f)), (t, f)
+        fields = ("x", "u", "pi", "lam", "t", "res") + (("sl", "su") if name == "usv_model_guidance_ca1" else ())
+        for f in fields:
+            fa, fb = (a.get(f, 0), b.get(f, 0)) if f == "res" else (a.get_all(f), b.get_all(f))
+            assert np.array_equal(fa, fb, equal_nan=True), (t, f, float(np.nanmax(np.abs(fa - fb))))
+        assert int(a.unconverged_counts(1)[0]) == int(b.unconverged_counts(1)[0]) and int(a.fail_counts(1)[0]) == int(b.fail_counts(1)[0])
+        a.advance(1e-3, seed=5 + t)
+        b.advance(1e-3, seed=5 + t)
+    assert handed > 0, "no instance was handed over: the test did not exercise the follow-up launch"
+    assert np.array_equal(a.get("x0", 0), b.get("x0", 0))
+    print("handed over", name, N, K, B, handed)
+    a.close()
+    b.close()
+
+
+def test_handover_with_the_pipelined_lineariser():
+    """Large handles run the next tick's lineariser in the tail of the QP launch, instance by instance as results become final
+    (pipeline_linearize): the follow-up launch publishes its instances' epochs like the main launch does."""
+    name, N, K, B = "usv_model_pf_ca", 20, 3, 20000
+    a = _make(name, N, K, B, 7, ())
+    b = _make(name, N, K, B, 7, (("handover_iter", 10),))
+    for t in range(6):
+        a.solve_async(); a.advance(1e-3, seed=t)
+        b.solve_async(); b.advance(1e-3, seed=t)
+    a.sync(); b.sync()
+    assert b.pipeline_stats()[0] >= 3                 # the lineariser did run ahead
+    assert int(b.handover_counts(4).sum()) > 0
+    for f in ("x", "u", "pi"):
+        assert np.array_equal(a.get_all(f), b.get_all(f), equal_nan=True), f
+    assert np.array_equal(a.get_int("qp_iter"), b.get_int("qp_iter")) and np.array_equal(a.get("x0", 0), b.get("x0", 0))
+    a.close()
+    b.close()

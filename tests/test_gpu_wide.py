@@ -40,7 +40,8 @@ def _compare(name, N, K, B, ticks, opts_a=(("wide", 1), ("wide_waves", 1)), opts
         # bit for bit: the iterate, the dynamics multipliers, the inequality multipliers and slacks
         for f in ("x", "u", "pi", "lam", "t"):
             fa, fb = (xa if f == "x" else ua if f == "u" else a.get_all(f)), b.get_all(f)
-            assert np.array_equal(fa, fb), (t, f, float(np.abs(fa - fb).max()))
+            # (equal_nan: the multipliers of an instance whose IPM ended in NaN - status 4, iterate untouched - are NaN on both sides)
+            assert np.array_equal(fa, fb, equal_nan=f in ("pi", "lam", "t")), (t, f, float(np.nanmax(np.abs(fa - fb))))
         a.advance(1e-3, seed=77 + t)
         a.sync()
         # both continue from the wide side's state

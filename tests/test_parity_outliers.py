@@ -96,11 +96,41 @@ def test_oracle_replays_and_the_gap_is_the_factorisation_form(oracle):
     # and over the set the oracle's two forms differ from each other by MORE than the device differs from the oracle: at this
     # model's conditioning (control weight R = 0) an iterate that passes the exit test is not determined to 1e-5
     both = stc == 0
-    assert cls_sqrt[both].max() >= dev_sqrt.max()
+    assert cls_sqrt[both].max() >= 0.99 * dev_sqrt.max()   # (on the largest outlier the classical form IS the device's point: the two gaps coincide)
     assert (cls_sqrt > 1e-5).sum() >= (dev_sqrt > 1e-5).sum()
     # ordinary instances: all three agree to rounding
     o = f["kind"] == "ordinary"
     assert dev_sqrt[o].max() <= 1e-11 and dev_cls[o].max() <= 1e-11 and cls_sqrt[o].max() <= 1e-11
+
+
+def test_hpipm_options_not_adopted_by_default_on_the_outliers(oracle):
+    """The two HPIPM options of acados' modes that the restatement leaves off (usv_opts): what they do to THIS set.
+    * cond_pred_corr (on in HPIPM's SPEED / BALANCE / ROBUST): the fallback to the centring-only step never fires on these QPs - the
+      oracle's outputs do not change by a bit;
+    * itref_corr_max = 2 (BALANCE): iterative refinement of the corrector's KKT solve fires on ONE instance, the largest outlier - and
+      moves the oracle's square-root form onto the device's point (same iteration count as the device, <= 1e-6 instead of 5e-4).  The
+      device (classical Riccati, no refinement), the oracle's classical form and the refined square-root form agree there; the plain
+      square-root form is the odd one out: that outlier is the oracle's solve accuracy, not the device's.  Every other instance is
+      untouched (their linear-system residuals are below the exit tolerances, as HPIPM tests before refining)."""
+    f = _load()
+    xs, us, sts, its = _oracle(oracle, f)
+    xc, uc, stc, itc = _oracle(oracle, f, cond_pred_corr=1)
+    assert np.array_equal(xs, xc) and np.array_equal(us, uc) and np.array_equal(its, itc)
+    xr, ur, str_, itr = _oracle(oracle, f, itref_corr_max=2)
+    assert (str_ == 0).all()
+    dev_plain = _err(f, f["x_dev"], f["u_dev"], xs, us)
+    dev_ref = _err(f, f["x_dev"], f["u_dev"], xr, ur)
+    moved = _err(f, xr, ur, xs, us)
+    print("device vs oracle, refined", dev_ref, "\noracle refined vs plain ", moved)
+    worst = int(np.argmax(dev_plain))
+    assert f["kind"][worst] == "outlier" and moved[worst] > 1e-4
+    assert itr[worst] == f["it_dev"][worst] != its[worst]
+    assert dev_ref[worst] <= 1e-6 and dev_ref[worst] <= 1e-3 * dev_plain[worst]
+    others = np.arange(len(moved)) != worst
+    assert (moved[others] == 0.0).all() and np.array_equal(itr[others], its[others])
+    # both together: the same as refinement alone
+    xb, ub, stb, itb = _oracle(oracle, f, cond_pred_corr=1, itref_corr_max=2)
+    assert np.array_equal(xb, xr) and np.array_equal(ub, ur)
 
 
 def test_lane_emulator_reproduces_the_device_on_the_outliers(emu):

@@ -53,3 +53,47 @@ def test_wide_mapping_equals_the_16_lane_sweeps_bit_for_bit(emu, name, N, K, row
     assert (out[0][2] == 0).any() and out[0][9].any() and out[0][4].max() >= 3
     for n, (a, b) in enumerate(zip(out[0], out[1])):
         assert np.array_equal(a, b), (n, np.abs(np.asarray(a, float) - np.asarray(b, float)).max())
+
+
+@pytest.mark.parametrize("name,N,K", [("usv_model_pf_ca", 8, 3), ("usv_model_pf_ca", 7, 10), ("usv_model_guidance_ca1", 7, 8),
+                                      ("usv_model_guidance_ca1", 6, 16), ("usv_model", 7, 0)])
+@pytest.mark.parametrize("aux", [0, 1])
+@pytest.mark.parametrize("hand_it", [1, 3])
+def test_handed_over_instances_finish_with_the_same_bits(emu, name, N, K, aux, hand_it):
+    """Option "handover_iter" (QpIpm::suspend / solve phase 3, usvmpc.hip usv_qp_resume): once the queue of a launch is empty a 16-lane row
+    whose instance has passed hand_it IPM iterations leaves it - state in the workspace planes, four scalars in its record - and the
+    follow-up pass finishes it on the WIDE mapping over the same planes.  Scheduling only: every output equals the plain run's bit for
+    bit (aux = 1: the suspending row keeps its aux plane in LDS and writes it out on the way)."""
+    B = 6
+    wl = scenario.make_batch(name, N, K, B, dt=0.05, seed=23, generator="survey", sim_steps=scenario.BENCH_SIM_STEPS[name], clip_time=0.1)
+    ocp = usv_models.make_ocp(name, N * 0.05, N, K)
+    ocp.solver_options.sim_method_num_steps = scenario.BENCH_SIM_STEPS[name]
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    soft = name == "usv_model_guidance_ca1"
+    nlam = 2 * (desc.nbu + desc.nbx + K + (K if soft else 0))
+    emu.usv_emu_set_mode.argtypes = [C.c_int, C.c_long]
+    emu.usv_emu_set_export.argtypes = [_capi._dp, _capi._dp]
+    emu.usv_emu_set_export.restype = None
+    emu.usv_emu_set_handover.argtypes = [C.c_int]
+    emu.usv_emu_handed.restype = C.c_long
+    emu.usv_emu_set_aux.argtypes = [C.c_int]
+    out = []
+    try:
+        emu.usv_emu_set_mode(0, 2)          # two persistent rows, the other four instances through the queue
+        emu.usv_emu_set_aux(aux if K > 0 else 0)
+        for hand in (0, hand_it):
+            emu.usv_emu_set_handover(hand)
+            lam, t = np.zeros((B, N + 1, nlam)), np.zeros((B, N + 1, nlam))
+            emu.usv_emu_set_export(_d(lam), _d(t))
+            r = emu_rti(emu, desc, wl, wl["x_init"], wl["u_init"])
+            r2 = emu_rti(emu, desc, wl, r["x"], r["u"])
+            if hand:
+                assert emu.usv_emu_handed() >= 2, emu.usv_emu_handed()   # (the instances the two rows were on when the queue ran dry)
+            out.append((r2["x"], r2["u"], r2["status"], r2["qp_status"], r2["qp_iter"], r2["sl"], r2["su"], r2["pi"], r2["res"], lam.copy(), t.copy()))
+    finally:
+        emu.usv_emu_set_handover(0)
+        emu.usv_emu_set_aux(0)
+        emu.usv_emu_set_export(None, None)
+    assert (out[0][2] == 0).any() and out[0][4].max() >= hand_it
+    for n, (a, b) in enumerate(zip(out[0], out[1])):
+        assert np.array_equal(a, b), (n, np.abs(np.asarray(a, float) - np.asarray(b, float)).max())

@@ -3,7 +3,7 @@ profiles/r03_parity_tail.txt).
 
 Per closed-loop tick and instance, all from IDENTICAL inputs (the iterate and x0 the stock device build starts the tick from):
   dev     the shipped library (estimate + Newton reciprocals, paired reciprocals)
-  exact   the same kernels built with -DUSV_EXACT_DIV=1 (IEEE division / square root everywhere): build_ab/libusvmpc_exactdiv.so
+  exact   the same kernels with tools/experiments/exact_div.patch applied (IEEE division / square root everywhere): build_ab/libusvmpc_exactdiv.so
   oracle  oracle/usv_oracle.c at the default IPM tolerances (square-root Riccati)
   tight   the oracle converged to 1e-11 ("the solution of the QP")
 and the independent KKT certificate of tests/kkt.py for both device builds.  For every instance with dev-vs-oracle > 1e-5

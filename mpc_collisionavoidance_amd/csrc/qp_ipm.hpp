@@ -502,7 +502,7 @@ struct QpIpm {
         const long gi = g < nB ? g : (long)nB - 1;
         const long bn = P.perm ? (long)P.perm[gi] : gi;
         b = sel ? bn : b;
-        voff = lanes::Planes::lane_offset(g, NPL, lane);
+        voff = sel ? lanes::Planes::lane_offset(g, NPL, lane) : voff; // (a parked row - solve() - stays parked)
         if constexpr (KCH > 0) {
             sfor<0, KCH>([&](auto c) {
                 const int i = c * LANES + lane;
@@ -2169,6 +2169,7 @@ struct QpIpm {
             if (lanes::wave_any(fin)) { // wave-uniform
                 finish(fin, real, status, iters, phase);
                 real = fin ? false : real;
+                bool took = false;
                 if (refill) {
                     // one ticket per finished row; beyond the batch there is nothing left and the row stays idle
                     int gn = 0;
@@ -2180,6 +2181,7 @@ struct QpIpm {
                         gn = lanes::bcast_i<0>(gn);
                     }
                     const bool take = fin && gn < nB;
+                    took = take;
                     if (lanes::wave_any(take)) { // wave-uniform
                         if constexpr (WW > 1) lanes::block_sync(); // (the parked constants are the workgroup's: no wave may still be reading the old instance's)
                         bind((long)gn, take);
@@ -2193,10 +2195,22 @@ struct QpIpm {
                         it = take ? 0 : it;
                         iters = take ? 0 : iters;
                         status = take ? (bad ? 4 : 1) : status;
+                        // (the freshly started row sits out the three remaining sweeps of this pass: parked meanwhile - see below - so that
+                        // it does not stream its new group's planes for nothing; back at the end of the pass)
+                        if constexpr (!LDSWS && !WIDE) voff = take ? stage_bytes + (unsigned)(lane * 8) : voff;
                     }
                 }
+                // A row that has nothing more to do in this launch stops streaming.  The sweeps run in lock step for the four rows of the
+                // wave whatever their state, plane loads and stores included - and the launch ends with a drain of ~13 ms in which more
+                // and more rows are idle beside rows that still iterate (profiles/r05_handover.txt).  The idle row's offset goes to the
+                // end of the stage window: the buffer range check then answers its loads with 0 and drops its stores, no memory access
+                // is made.  (RTI launches over planes in HBM; its results are out, nothing of its group is needed again.)
+                if constexpr (!LDSWS && !WIDE) {
+                    if (phase == 0) voff = (fin && !took) ? stage_bytes + (unsigned)(lane * 8) : voff;
+                }
             }
-            if (!lanes::wave_any(!done)) break;
+            // (a row that has just taken an instance whose x0 sits inside a hard keep-out circle is done AND still owes its results: late)
+            if (!lanes::wave_any(!done || late)) break;
             const bool run = !done && !fresh; // rows that take part in the rest of this pass
             const double mu = nc > 0.0 ? nm.musum / nc : 0.0;
             double a_aff = 1.0, S1 = 0.0, S2 = 0.0, a = 1.0, d1, d2;
@@ -2214,6 +2228,7 @@ struct QpIpm {
             sig_prev = run ? sigmu : sig_prev;
             pend = run ? true : pend;
             it = run ? it + 1 : it;
+            if constexpr (!LDSWS && !WIDE) voff = fresh ? lanes::Planes::lane_offset(g, NPL, lane) : voff;
             fresh = false;
             if constexpr (CAN_SUSPEND) {
                 if (hand_it > 0) { // wave-uniform
@@ -2223,6 +2238,7 @@ struct QpIpm {
                         suspend(sus, it, a_prev, sig_prev);
                         done = done || sus;
                         real = sus ? false : real;
+                        voff = sus ? stage_bytes + (unsigned)(lane * 8) : voff; // (parked: see above - the follow-up launch owns the planes now)
                     }
                 }
             }

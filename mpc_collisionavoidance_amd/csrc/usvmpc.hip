@@ -1267,7 +1267,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     DevPtrs &P = h->ptrs;
     h->spec.npt = ws_planes(h->nx, h->nu, h->kch, h->soft, model_mat_planes(h->desc.model), h->spec.any_bsoft != 0);
     // one stage of the workspace is addressed through ONE 32-bit buffer window (lanes::Planes: group * npt * 128 + ...)
-    if ((size_t)h->Bp * (size_t)h->spec.npt * 128u > (size_t)UINT32_MAX) {
+    if ((size_t)h->Bp * (size_t)h->spec.npt * 128u > (size_t)UINT32_MAX - 16384u) { // (16 KB of headroom: a parked row addresses just past the window - qp_ipm.hpp)
         h->err = "batch too large for one handle: batch * " + std::to_string(h->spec.npt * 128) + " bytes per stage exceed the 4 GiB "
                  "buffer window (at most " + std::to_string((size_t)UINT32_MAX / ((size_t)h->spec.npt * 128u) / 4 * 4) + " instances); use several handles";
         return fail(USVMPC_E_ARG);

@@ -146,9 +146,12 @@ struct Planes {
     unsigned nbytes, voff;
     static unsigned lane_offset(long group, int nplanes, int lane) { return (unsigned)(group * nplanes * 128 + lane * 8); }
     Planes(const double *b, unsigned n, unsigned v) : base(const_cast<double *>(b)), nbytes(n), voff(v) {}
+    // (a row that has nothing more to do parks its offset at the end of the window: the GPU's buffer range check returns 0 for its
+    // loads and drops its stores - qp_ipm.hpp QpIpm::solve; any OTHER access outside the window is a bug)
     double ld(int plane) const
     {
         const unsigned o = voff + (unsigned)plane * 128u;
+        if (voff >= nbytes) return 0.0;
         if (plane < 0 || o + 8 > nbytes) { std::fprintf(stderr, "Planes::ld out of window (plane %d)\n", plane); std::abort(); }
         return base[o / 8];
     }
@@ -157,6 +160,7 @@ struct Planes {
     void st(int plane, double x) const
     {
         const unsigned o = voff + (unsigned)plane * 128u;
+        if (voff >= nbytes) return;
         if (plane < 0 || o + 8 > nbytes) { std::fprintf(stderr, "Planes::st out of window (plane %d)\n", plane); std::abort(); }
         base[o / 8] = x;
     }

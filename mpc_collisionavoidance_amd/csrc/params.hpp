@@ -111,8 +111,9 @@ struct MatPack {
 // arrays cost scalar registers, and once those ran out the compiler moved plane offsets to vector registers
 // and wrapped the loads in waterfall loops).
 // planes of the exchange area of the wide mapping (qp_ipm.hpp, WIDE: [4 rows][WIDE_EX_PLANES][16 lanes] behind the instance's planes in LDS)
-constexpr int WIDE_EX_PLANES = 7;     // ... with the solver's planes in LDS
-constexpr int WIDE_EX_PLANES_HBM = 9; // ... in HBM (two more: qp_ipm.hpp)
+// (kch obstacle chunks per stage: the complementarity sums of a stage are handed over chunk by chunk - qp_ipm.hpp EX_*)
+constexpr int wide_ex_planes(int kch) { return kch <= 1 ? 7 : 10; }      // ... with the solver's planes in LDS
+constexpr int wide_ex_planes_hbm(int kch) { return kch <= 1 ? 9 : 11; }  // ... in HBM (two more: qp_ipm.hpp)
 
 template <class M, int KCH, bool SOFT, bool SOFTBOX = false>
 struct WsLayout {

@@ -225,8 +225,8 @@ template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = fal
           bool WIDE = false, int WW = 1>
 struct QpIpm {
     static_assert(WW == 1 || (WIDE && (WW == 2 || WW == 4)), "several waves per instance: the wide mapping only");
-    static_assert(!WIDE || (((PACK && KCH == 1) || (!PACK && KCH == 0)) && HDIAG && !SOFTBOX && !AUXLDS),
-                  "the wide mapping works on the packed one-chunk layouts and on the layout without obstacle rows");
+    static_assert(!WIDE || (((PACK && KCH >= 1) || (!PACK && KCH == 0)) && HDIAG && !SOFTBOX && !AUXLDS),
+                  "the wide mapping works on the packed layouts and on the layout without obstacle rows");
     static_assert(!MERGE || PACK, "merged row pass works on the packed layout");
     static_assert(!(AUXLDS && LDSWS), "with the whole workspace in LDS the aux plane is there already");
     static_assert(!PACK || KCH > 0, "box rows are packed into obstacle planes");
@@ -1291,9 +1291,12 @@ struct QpIpm {
     // (EX_SC: the row-uniform sums S_xx, S_xy, S_yy, g_x, g_y, l_x, l_y in lanes 0 .. 6 of one plane)
     // EX_Z, EX_DV (planes in HBM only): the stage's iterate after the pending step and the dense box values, which with the planes in LDS
     // the recursion reads back from the planes the row phase has just written.
-    enum : int { EX_GHB = 0, EX_GAMB, EX_DLB, EX_SC, EX_MU1, EX_MU2, EX_MU3, EX_Z, EX_DV, EX_ALL };
-    static constexpr int EX_N = LDSWS ? (int)EX_Z : (int)EX_ALL;
-    static_assert(EX_Z == WIDE_EX_PLANES && EX_ALL == WIDE_EX_PLANES_HBM, "host-side size of the exchange area");
+    // (EX_MU1 + c, EX_MU2 + c: the complementarity sums of obstacle chunk c - hard pairs, slack pairs -, EX_MU3: of the box rows of the two-pass
+    // form; the forward sweeps reuse the area for the sums of mu_aff: chunk c in planes 4 c .. 4 c + 3, the box rows in 4 KC, 4 KC + 1)
+    enum : int { EX_GHB = 0, EX_GAMB, EX_DLB, EX_SC, EX_MU1, EX_MU2 = EX_MU1 + KC, EX_MU3 = EX_MU2 + KC, EX_Z, EX_DV, EX_ALL };
+    static constexpr int EX_FWD = 4 * KC + 2;
+    static constexpr int EX_N = LDSWS ? ((int)EX_Z > EX_FWD ? (int)EX_Z : EX_FWD) : ((int)EX_ALL > EX_FWD ? (int)EX_ALL : EX_FWD);
+    static_assert(!WIDE || EX_N == (LDSWS ? wide_ex_planes(KCH) : wide_ex_planes_hbm(KCH)), "host-side size of the exchange area");
     static constexpr int BS = 4 * WW; // stages per block = rows of the workgroup
     static constexpr int wide_lds_doubles(int N_) { return (LDSWS ? (N_ + 1) * NPLW * LANES : 0) + BS * EX_N * LANES + (WW > 1 ? LANES : 0); }
     // phases of a sweep hand values from row to row through LDS (or, WW > 1, from wave to wave: a workgroup barrier)
@@ -1397,8 +1400,10 @@ struct QpIpm {
         if (SW == SW_BACK_A) in.dz = W.ld(P_DZ);
         if (SW != SW_FWD_A) in.dza = W.ld(P_DZA);
         if constexpr (KCH > 0) {
-            sfor<0, OBSN>([&](auto e) { in.obs[0][e] = W.ld(P_OBS + e); });
-            if (!pstat) obs_raw<0>(k, in.raw[0]);
+            sfor<0, KCH>([&](auto c) {
+                sfor<0, OBSN>([&](auto e) { in.obs[c][e] = W.ld(P_OBS + c * OBSN + e); });
+                if (!pstat) obs_raw<c>(k, in.raw[c]);
+            });
         }
         if constexpr (!PACK) { in.box[0] = W.ld(P_BLL); in.box[1] = W.ld(P_BLU); in.box[2] = W.ld(P_BTL); in.box[3] = W.ld(P_BTU); }
     }
@@ -1440,7 +1445,7 @@ struct QpIpm {
                 const double zbx = aux_zx(aux), zby = aux_zy(aux);
                 const double psel = pos_sel(zbx, zby);
                 const double znew = (FACT && pend) ? z + a_prev * dzp : z;
-                double Sxx = 0.0, Sxy = 0.0, Syy = 0.0, gx = 0.0, gy = 0.0, lx = 0.0, ly = 0.0, dl_m = 0.0, mu1 = 0.0, mu2 = 0.0, mu3 = 0.0;
+                double Sxx = 0.0, Sxy = 0.0, Syy = 0.0, gx = 0.0, gy = 0.0, lx = 0.0, ly = 0.0, dl_m = 0.0, mu3 = 0.0;
                 // the two-pass form (a box row rides in the dense part of the aux plane): the box rows in their variables' lanes first
                 double Ghb = 0.0, gamb = 0.0, dlb = 0.0, pk[4];
                 if constexpr (!MERGE) {
@@ -1473,53 +1478,60 @@ struct QpIpm {
                         nan_r = fma(0.0, br.rdl + br.rdu, nan_r);
                     }
                 }
+                double mu1[KC], mu2[KC];
+                sfor<0, KC>([&](auto c) { mu1[c] = 0.0; mu2[c] = 0.0; });
                 if constexpr (KCH > 0) {
-                ObsRow o;
-                double cx, cy, Gh, gam;
-                obs_from<0>(in, k, zbx, zby, o, cx, cy);
-                o.act = o.act && own;
-                if (FACT) {
-                    const double vo = rowdot<0>(cx, cy, z - psel, z), wp = rowdot<0>(cx, cy, dzp, dzp), wap = rowdot<0>(cx, cy, dzap, dzap);
-                    if (pend && o.act) {
-                        chain(o, vo, true, wap, sigmu_prev, Gh, gam);
-                        o.expand(wp);
-                        o.apply(a_prev);
+                double Gh_m = 0.0, gam_m = 0.0; // the last chunk's per-row terms (MERGE: the box rows are among them)
+                sfor<0, KCH>([&](auto c) {
+                    ObsRow o;
+                    double cx, cy, Gh, gam;
+                    obs_from<c>(in, k, zbx, zby, o, cx, cy);
+                    o.act = o.act && own;
+                    if (FACT) {
+                        const double vo = rowdot<c>(cx, cy, z - psel, z), wp = rowdot<c>(cx, cy, dzp, dzp), wap = rowdot<c>(cx, cy, dzap, dzap);
+                        if (pend && o.act) {
+                            chain(o, vo, true, wap, sigmu_prev, Gh, gam);
+                            o.expand(wp);
+                            o.apply(a_prev);
+                        }
+                        const bool slot_here = c == KCH - 1 && isslot;
+                        if (pend && (o.act || slot_here)) obs_store(W, c, o, (!MERGE && c == KCH - 1) ? pk : nullptr);
                     }
-                    if (pend && (o.act || isslot)) obs_store(W, 0, o, MERGE ? nullptr : pk);
-                }
-                const double v = rowdot<0>(cx, cy, znew - psel, znew);
-                const double wa = FACT ? 0.0 : rowdot<0>(cx, cy, dza, dza);
-                chain(o, v, !FACT, wa, sigmu, Gh, gam);
-                gx += gam * cx; gy += gam * cy;
-                if (FACT) {
-                    Sxx += Gh * cx * cx; Sxy += Gh * cx * cy; Syy += Gh * cy * cy;
-                    const double dl_ = o.act ? o.ll - o.lu : 0.0;
-                    dl_m = dl_;
-                    lx += dl_ * cx; ly += dl_ * cy;
-                    if (o.act) {
-                        rd_r = lanes::vmax(rd_r, lanes::vmax_abs2(o.rdl, o.rdu));
-                        rm_r = lanes::vmax(rm_r, lanes::vmax(o.ll * o.tl, o.lu * o.tu));
-                        mu1 = o.ll * o.tl + o.lu * o.tu;
-                        nan_r = fma(0.0, o.rdl + o.rdu, nan_r);
-                        if constexpr (SOFT) {
-                            rg_r = lanes::vmax(rg_r, lanes::vmax_abs2(o.rsl, o.rsu));
-                            rd_r = lanes::vmax(rd_r, lanes::vmax_abs2(o.rdsl, o.rdsu));
-                            rm_r = lanes::vmax(rm_r, lanes::vmax(o.lsl * o.tsl, o.lsu * o.tsu));
-                            mu2 = o.lsl * o.tsl + o.lsu * o.tsu;
-                            nan_r = fma(0.0, o.rsl + o.rsu + o.rdsl + o.rdsu, nan_r);
+                    const double v = rowdot<c>(cx, cy, znew - psel, znew);
+                    const double wa = FACT ? 0.0 : rowdot<c>(cx, cy, dza, dza);
+                    chain(o, v, !FACT, wa, sigmu, Gh, gam);
+                    gx += gam * cx; gy += gam * cy;
+                    if constexpr (c == KCH - 1) { Gh_m = Gh; gam_m = gam; }
+                    if (FACT) {
+                        Sxx += Gh * cx * cx; Sxy += Gh * cx * cy; Syy += Gh * cy * cy;
+                        const double dl_ = o.act ? o.ll - o.lu : 0.0;
+                        if constexpr (c == KCH - 1) dl_m = dl_;
+                        lx += dl_ * cx; ly += dl_ * cy;
+                        if (o.act) {
+                            rd_r = lanes::vmax(rd_r, lanes::vmax_abs2(o.rdl, o.rdu));
+                            rm_r = lanes::vmax(rm_r, lanes::vmax(o.ll * o.tl, o.lu * o.tu));
+                            mu1[c] = o.ll * o.tl + o.lu * o.tu;
+                            nan_r = fma(0.0, o.rdl + o.rdu, nan_r);
+                            if constexpr (SOFT) {
+                                rg_r = lanes::vmax(rg_r, lanes::vmax_abs2(o.rsl, o.rsu));
+                                rd_r = lanes::vmax(rd_r, lanes::vmax_abs2(o.rdsl, o.rdsu));
+                                rm_r = lanes::vmax(rm_r, lanes::vmax(o.lsl * o.tsl, o.lsu * o.tsu));
+                                mu2[c] = o.lsl * o.tsl + o.lsu * o.tsu;
+                                nan_r = fma(0.0, o.rsl + o.rsu + o.rdsl + o.rdsu, nan_r);
+                            }
                         }
                     }
-                }
+                });
                 gx = lanes::gsum(gx); gy = lanes::gsum(gy);
                 if (FACT) {
                     Sxx = lanes::gsum(Sxx); Sxy = lanes::gsum(Sxy); Syy = lanes::gsum(Syy);
                     lx = lanes::gsum(lx); ly = lanes::gsum(ly);
                 }
                 if constexpr (MERGE) { // the box rows' terms come home from their slot lanes (an inactive row has delivered zeros)
-                    const double g1 = lanes::gather(gam, bsrc);
+                    const double g1 = lanes::gather(gam_m, bsrc);
                     gamb = hasb ? g1 : 0.0;
                     if (FACT) {
-                        const double g0 = lanes::gather(Gh, bsrc), g2 = lanes::gather(dl_m, bsrc);
+                        const double g0 = lanes::gather(Gh_m, bsrc), g2 = lanes::gather(dl_m, bsrc);
                         Ghb = hasb ? g0 : 0.0;
                         dlb = hasb ? g2 : 0.0;
                     }
@@ -1538,8 +1550,10 @@ struct QpIpm {
                     ex_put(row, EX_GHB, Ghb);
                     ex_put(row, EX_DLB, dlb);
                     if constexpr (!MERGE) ex_put(row, EX_MU3, mu3);
-                    ex_put(row, EX_MU1, mu1);
-                    if constexpr (SOFT) ex_put(row, EX_MU2, mu2);
+                    sfor<0, KC>([&](auto c) {
+                        ex_put(row, EX_MU1 + c, mu1[c]);
+                        if constexpr (SOFT) ex_put(row, EX_MU2 + c, mu2[c]);
+                    });
                     if (pend) W.st(P_Z, znew);
                 }
                 if constexpr (!LDSWS) ex_put(row, EX_Z, znew);
@@ -1570,8 +1584,10 @@ struct QpIpm {
                     Ghb = ex_get(j, EX_GHB); dlb = ex_get(j, EX_DLB);
                     Sxx = lanes::bcast<0>(sc); Sxy = lanes::bcast<1>(sc); Syy = lanes::bcast<2>(sc);
                     lx = lanes::bcast<5>(sc); ly = lanes::bcast<6>(sc);
-                    nm.musum += ex_get(j, EX_MU1);
-                    if constexpr (SOFT) nm.musum += ex_get(j, EX_MU2);
+                    sfor<0, KC>([&](auto c) { // (chunk by chunk, hard pairs then slack pairs: the order of the 16-lane sweep)
+                        nm.musum += ex_get(j, EX_MU1 + c);
+                        if constexpr (SOFT) nm.musum += ex_get(j, EX_MU2 + c);
+                    });
                     if constexpr (!MERGE) nm.musum += ex_get(j, EX_MU3);
                 }
                 double bat[NX];
@@ -1786,37 +1802,43 @@ struct QpIpm {
                     br.expand(dz);
                     q = br.blocking(q);
                     if (!FINAL) {
-                        ex_put(row, 4, br.act ? br.ll * br.dtl + br.tl * br.dll + br.lu * br.dtu + br.tu * br.dlu : 0.0);
-                        ex_put(row, 5, br.act ? br.dll * br.dtl + br.dlu * br.dtu : 0.0);
+                        ex_put(row, 4 * KC, br.act ? br.ll * br.dtl + br.tl * br.dll + br.lu * br.dtu + br.tu * br.dlu : 0.0);
+                        ex_put(row, 4 * KC + 1, br.act ? br.dll * br.dtl + br.dlu * br.dtu : 0.0);
                     }
                 }
                 if constexpr (KCH > 0) {
-                ObsRow o;
-                double cx, cy, Gh2, gam2;
-                obs_from<0>(in, k, zbx, zby, o, cx, cy);
-                o.act = o.act && own;
-                const double v = rowdot<0>(cx, cy, z - pos_sel(zbx, zby), z);
-                const double w = rowdot<0>(cx, cy, dz, dz);
-                const double wa = FINAL ? rowdot<0>(cx, cy, dza, dza) : w;
-                chain(o, v, FINAL, wa, sigmu, Gh2, gam2);
-                o.expand(w);
-                q = o.blocking(q);
-                if (!FINAL) {
-                    ex_put(row, 0, o.act ? o.ll * o.dtl + o.tl * o.dll + o.lu * o.dtu + o.tu * o.dlu : 0.0);
-                    ex_put(row, 1, o.act ? o.dll * o.dtl + o.dlu * o.dtu : 0.0);
-                    if constexpr (SOFT) {
-                        ex_put(row, 2, o.act ? o.lsl * o.dtsl + o.tsl * o.dlsl + o.lsu * o.dtsu + o.tsu * o.dlsu : 0.0);
-                        ex_put(row, 3, o.act ? o.dlsl * o.dtsl + o.dlsu * o.dtsu : 0.0);
+                sfor<0, KCH>([&](auto c) {
+                    ObsRow o;
+                    double cx, cy, Gh2, gam2;
+                    obs_from<c>(in, k, zbx, zby, o, cx, cy);
+                    o.act = o.act && own;
+                    const double v = rowdot<c>(cx, cy, z - pos_sel(zbx, zby), z);
+                    const double w = rowdot<c>(cx, cy, dz, dz);
+                    const double wa = FINAL ? rowdot<c>(cx, cy, dza, dza) : w;
+                    chain(o, v, FINAL, wa, sigmu, Gh2, gam2);
+                    o.expand(w);
+                    q = o.blocking(q);
+                    if (!FINAL) {
+                        ex_put(row, 4 * c, o.act ? o.ll * o.dtl + o.tl * o.dll + o.lu * o.dtu + o.tu * o.dlu : 0.0);
+                        ex_put(row, 4 * c + 1, o.act ? o.dll * o.dtl + o.dlu * o.dtu : 0.0);
+                        if constexpr (SOFT) {
+                            ex_put(row, 4 * c + 2, o.act ? o.lsl * o.dtsl + o.tsl * o.dlsl + o.lsu * o.dtsu + o.tsu * o.dlsu : 0.0);
+                            ex_put(row, 4 * c + 3, o.act ? o.dlsl * o.dtsl + o.dlsu * o.dtsu : 0.0);
+                        }
                     }
-                }
+                });
                 } // (KCH > 0)
             }
             if (!FINAL) { // the sums for mu_aff, stage by stage as the 16-lane sweep takes them
                 wide_sync();
                 for (int j = 0; j < BS; j++) {
-                    if constexpr (!MERGE) { s1 += ex_get(j, 4); s2 += ex_get(j, 5); }
-                    if constexpr (KCH > 0) { s1 += ex_get(j, 0); s2 += ex_get(j, 1); }
-                    if constexpr (KCH > 0 && SOFT) { s1 += ex_get(j, 2); s2 += ex_get(j, 3); }
+                    if constexpr (!MERGE) { s1 += ex_get(j, 4 * KC); s2 += ex_get(j, 4 * KC + 1); }
+                    if constexpr (KCH > 0) {
+                        sfor<0, KCH>([&](auto c) {
+                            s1 += ex_get(j, 4 * c); s2 += ex_get(j, 4 * c + 1);
+                            if constexpr (SOFT) { s1 += ex_get(j, 4 * c + 2); s2 += ex_get(j, 4 * c + 3); }
+                        });
+                    }
                 }
                 wide_sync();
             }

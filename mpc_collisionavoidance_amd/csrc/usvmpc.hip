@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(64 * WW, ((LDSWS || WIDE) ? 1 : qp_waves<KCH, 
 template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS = true, int WW = 1>
 constexpr auto wide_kernel()
 {
-    if constexpr (KCH == 1) return &usv_qp_rti<M, KCH, SOFT, true, true, false, LDSWS, MERGE, false, true, WW>;
+    // (two obstacle chunks, K = 17 .. 32 - BASELINE configs[4]'s OCP: one wave per instance; four waves are built for one chunk only)
+    if constexpr (KCH == 1 || (KCH == 2 && WW == 1)) return &usv_qp_rti<M, KCH, SOFT, true, true, false, LDSWS, MERGE, false, true, WW>;
     else if constexpr (KCH == 0 && !MERGE) return &usv_qp_rti<M, KCH, SOFT, true, false, false, LDSWS, false, false, true, WW>; // (no obstacle rows: box rows in their own planes)
     else return (decltype(&usv_qp_rti<M, KCH, SOFT, true, (KCH > 0), false, true, MERGE>))nullptr;
 }
@@ -780,7 +781,7 @@ int launch_pair(usvmpc_handle *h, int phase)
         // single instance and batches of at most one instance per CU.
         if (wide.lds4 != nullptr && phase == 0 && h->wide_mode != 0 && h->wide_waves != 1 && h->ncu > 0) {
             const size_t pl = (size_t)(h->N + 1) * (size_t)(WsLayout<M, KCH, SOFT>::P_RB0 - (KCH > 0 ? 4 : 0)) * 128;
-            const size_t b4 = pl + (size_t)16 * WIDE_EX_PLANES * 128 + 128, x4 = (size_t)16 * WIDE_EX_PLANES_HBM * 128 + 128;
+            const size_t b4 = pl + (size_t)16 * wide_ex_planes(KCH) * 128 + 128, x4 = (size_t)16 * wide_ex_planes_hbm(KCH) * 128 + 128;
             const long win_bytes = (long)std::min(h->N + 1, 16) * h->Bp * h->spec.npt * 128; // (the window of a block of 16 stages: 32-bit offsets)
             if (h->wide4_cap == 0) {
                 int nb = 0;
@@ -818,7 +819,7 @@ int launch_pair(usvmpc_handle *h, int phase)
         // the batch leaves SIMDs idle anyway (a solve of the batch then lasts as long as its hardest instance on a lone wave).
         if (kern_wide != nullptr && phase == 0 && h->wide_mode != 0 && h->ncu > 0) {
             // (in LDS: the planes the solve writes - WsLayout's up to L_zu less the four box planes the packed layouts leave unused)
-            const size_t bytes = (size_t)(h->N + 1) * (size_t)(WsLayout<M, KCH, SOFT>::P_RB0 - (KCH > 0 ? 4 : 0)) * 128 + (size_t)4 * WIDE_EX_PLANES * 128;
+            const size_t bytes = (size_t)(h->N + 1) * (size_t)(WsLayout<M, KCH, SOFT>::P_RB0 - (KCH > 0 ? 4 : 0)) * 128 + (size_t)4 * wide_ex_planes(KCH) * 128;
             if (h->wide_cap == 0) {
                 int nb = 0;
                 hipFuncAttributes fa;
@@ -847,7 +848,7 @@ int launch_pair(usvmpc_handle *h, int phase)
             // its size limit), the next block's row planes and the next stage's recursion planes are in flight ahead of their use.
             const long win_bytes = (long)std::min(h->N + 1, 4) * h->Bp * h->spec.npt * 128; // (the window of a block of four stages: 32-bit offsets)
             if (h->wide_cap < 0 && kern_wide_hbm != nullptr && win_bytes < (1L << 32)) {
-                const size_t xbytes = (size_t)4 * WIDE_EX_PLANES_HBM * 128;
+                const size_t xbytes = (size_t)4 * wide_ex_planes_hbm(KCH) * 128;
                 if (h->wide_hbm_cap == 0) {
                     int nb = 0;
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern_wide_hbm, qp_block, xbytes) == hipSuccess && nb > 0)
@@ -931,7 +932,7 @@ int launch_pair(usvmpc_handle *h, int phase)
         // instances of 30 - 50 iterations on an idling device; past "handover_iter" iterations those go to a follow-up launch on the
         // latency mapping (one instance per wave over the same planes: 1.6x per pass for usv_model_pf_ca at N = 40).  Scheduling only.
         bool hand = false;
-        const size_t xbytes = (size_t)4 * WIDE_EX_PLANES_HBM * 128;
+        const size_t xbytes = (size_t)4 * wide_ex_planes_hbm(KCH) * 128;
         if (q0 >= 0 && h->handover_iter > 0 && wide.resume != nullptr && (long)std::min(h->N + 1, 4) * h->Bp * h->spec.npt * 128 < (1L << 32)) {
             if (h->resume_cap == 0) {
                 int nb = 0;

@@ -147,7 +147,7 @@ template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS, int WW = 1>
 void qp_wide_body(void *a)
 {
     Job *j = (Job *)a;
-    if constexpr (KCH == 1) {
+    if constexpr (KCH >= 1) {
         QpIpm<M, KCH, SOFT, true, true, false, LDSWS, MERGE, false, true, WW> q(*j->P, j->gid, lanes::block_row() == 0 ? 0 : -1);
         q.solve(j->qp_phase, j->queue0);
     } else if constexpr (KCH == 0 && !MERGE) {
@@ -165,7 +165,7 @@ void run_wide(long g, Job &j, int ww)
 template <class M, int KCH, bool SOFT>
 size_t wide_lds(int N)
 {
-    if constexpr (KCH == 1) return (size_t)QpIpm<M, KCH, SOFT, true, true, false, true, true, false, true, 4>::wide_lds_doubles(N) + 16 * 2 * LANES; // (any variant)
+    if constexpr (KCH >= 1) return (size_t)QpIpm<M, KCH, SOFT, true, true, false, true, true, false, true, 4>::wide_lds_doubles(N) + 16 * 2 * LANES; // (any variant)
     else if constexpr (KCH == 0) return (size_t)QpIpm<M, KCH, SOFT, true, false, false, true, false, false, true, 4>::wide_lds_doubles(N) + 16 * 2 * LANES;
     else return 0;
 }
@@ -274,11 +274,11 @@ void run_all(const DevPtrs &P_, const DevSpec &S, int phase, int qp_phase)
                 else lanes::run_group(g, &qp_body<M, KCH, SOFT, false, false, true>, &j);
                 continue;
             }
-            if (((KCH == 1 && pack) || KCH == 0) && g_emu_wide && qp_phase == 0 && S.hdiag) {
+            if (((KCH >= 1 && pack) || KCH == 0) && g_emu_wide && qp_phase == 0 && S.hdiag) {
                 lds.assign(wide_lds<M, KCH, SOFT>(S.N), 0.0);
                 lanes::g_emu_lds = lds.data();
                 // (lds mode off: the wide sweeps over the planes in HBM - horizons that do not fit a CU's LDS)
-                const bool mg = KCH == 1 && g_emu_merge && !S.box_dense;
+                const bool mg = KCH >= 1 && g_emu_merge && !S.box_dense;
                 if (g_emu_lds_mode) { if (mg) run_wide<M, KCH, SOFT, true, true>(g, j, g_emu_wide); else run_wide<M, KCH, SOFT, false, true>(g, j, g_emu_wide); }
                 else { if (mg) run_wide<M, KCH, SOFT, true, false>(g, j, g_emu_wide); else run_wide<M, KCH, SOFT, false, false>(g, j, g_emu_wide); }
                 g_emu_wide_runs++;

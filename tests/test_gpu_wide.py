@@ -68,6 +68,10 @@ def _compare(name, N, K, B, ticks, opts_a=(("wide", 1), ("wide_waves", 1)), opts
                                                ("usv_model_guidance_ca1", 70, 16, 24, 2),     # (two row passes)
                                                ("usv_model_pf_ca", 100, 4, 16, 3),
                                                ("usv_model_pf_ca", 99, 10, 8, 2),
+                                               # two obstacle chunks: BASELINE configs[4]'s OCP (N = 80, K = 20: planes in HBM), and shapes that fit LDS
+                                               ("usv_model_pf_ca", 80, 20, 64, 3), ("usv_model_pf_ca", 80, 20, 1, 3), ("usv_model_pf_ca", 40, 20, 200, 3),
+                                               ("usv_model_pf_ca", 20, 26, 100, 2), ("usv_model_guidance_ca1", 30, 20, 100, 3),
+                                               ("usv_model_guidance_ca1", 100, 32, 8, 2),
                                                ("usv_model", 20, 0, 1, 4),                    # BASELINE configs[0]'s shape: no obstacle rows
                                                ("usv_model", 20, 0, 500, 3), ("usv_model", 150, 0, 6, 2)])
 def test_wide_mapping_equals_the_throughput_mapping(name, N, K, B, ticks):
@@ -114,8 +118,9 @@ def test_default_takes_the_wide_mapping_for_small_batches_only():
         s.solve()
         assert s.last_mapping() == want, (B, s.last_mapping())
         s.close()
-    # a layout the wide sweeps do not cover (two obstacle chunks) stays on the throughput mapping
-    s = _make(name, 20, 20, 64, 5, (("wide", 1),))
-    s.solve()
-    assert s.last_mapping() == 0
-    s.close()
+    # two obstacle chunks (K = 17 .. 32, BASELINE configs[4]'s OCP has K = 20): one wave per instance since round 5, by default for small batches
+    for B, want in ((64, 1), (20000, 0)):
+        s = _make(name, 20, 20, B, 5, ())
+        s.solve()
+        assert s.last_mapping() == want, (B, s.last_mapping())
+        s.close()

@@ -344,6 +344,9 @@ struct usvmpc_handle {
     char *mirror;             // pinned host copy of the arena, or nullptr (arena larger than MIRROR_MAX)
     size_t arena_bytes, f_off[F_COUNT + 1], f_len[F_COUNT];
     size_t dirty_lo[F_COUNT], dirty_hi[F_COUNT]; // byte range inside each field that the mirror holds newer than the device (lo >= hi: none)
+    // one stage of several instances set at a time (the reference protocol on a small multi-instance handle): the rows of that stage are not
+    // contiguous, so they are remembered per (field, stage) and go up at the next launch as 2-D copies of runs of consecutive stages
+    std::vector<char> dirty_stage[F_COUNT];
     bool inflight;            // a copy between mirror and arena may still be running on the stream
     bool out_valid;           // the mirror's [x | u | status] is what the device holds (or newer)
     bool extern_access;       // a device pointer was handed out: the device arrays may change behind the mirror
@@ -508,6 +511,23 @@ int mirror_quiesce(usvmpc_handle *h)
 int mirror_flush(usvmpc_handle *h)
 {
     if (!h->mirror) return 0;
+    for (int fi = 0; fi < usvmpc_handle::F_COUNT; fi++) { // stage-wise sets of a multi-instance handle: runs of consecutive dirty stages
+        std::vector<char> &ds = h->dirty_stage[fi];
+        if (ds.empty()) continue;
+        const size_t stages = ds.size(), pitch = h->f_len[fi] / (size_t)h->B, row = pitch / stages;
+        for (size_t a = 0; a < stages;) {
+            if (!ds[a]) { a++; continue; }
+            size_t b = a;
+            while (b + 1 < stages && ds[b + 1]) b++;
+            // (a whole-field range that is dirty as well is uploaded below and covers these rows: same bytes, the order does not matter)
+            HIP_TRY(h, hipMemcpy2DAsync(h->arena + h->f_off[fi] + a * row, pitch, h->mirror + h->f_off[fi] + a * row, pitch, (b - a + 1) * row, (size_t)h->B,
+                                        hipMemcpyHostToDevice, h->stream));
+            h->inflight = true;
+            for (size_t i = a; i <= b; i++) ds[i] = 0;
+            a = b + 1;
+        }
+        ds.clear();
+    }
     int f = 0;
     while (f < usvmpc_handle::F_COUNT) {
         if (h->dirty_lo[f] >= h->dirty_hi[f]) { f++; continue; }
@@ -575,10 +595,11 @@ int copy_field(usvmpc_handle *h, const char *field, int stage, double *host, siz
         if (set && !whole && B > 1) {
             // one stage of several instances: the rows are not contiguous, and a dirty RANGE over them would later upload the mirror's
             // copy of everything in between - stale where a device-side writer (the guidance kernels, a caller holding a device pointer)
-            // has written behind the mirror.  The rows go up now, each on its own (asynchronous, from the pinned mirror).
-            HIP_TRY(h, hipSetDevice(h->device));
-            HIP_TRY(h, hipMemcpy2DAsync(h->arena + h->f_off[fi] + first, pitch, m + first, pitch, row, B, hipMemcpyHostToDevice, h->stream));
-            h->inflight = true;
+            // has written behind the mirror.  The stage is remembered; its rows go up with the next launch (mirror_flush), as one 2-D copy
+            // per run of consecutive dirty stages - no HIP call here (the immediate copy made the NEXT set synchronise)
+            std::vector<char> &ds = h->dirty_stage[fi];
+            if (ds.size() != (size_t)f.stages) ds.assign((size_t)f.stages, 0);
+            ds[(size_t)(stage - f.stage_off)] = 1;
         } else if (set) {
             const size_t lo = first, hi = whole ? B * pitch : first + row;
             if (h->dirty_lo[fi] >= h->dirty_hi[fi]) { h->dirty_lo[fi] = lo; h->dirty_hi[fi] = hi; }

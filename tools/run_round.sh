@@ -10,6 +10,9 @@ BENCH_ARGS='--model usv_model_guidance_ca1' tools/profile_round.sh ${R}_m1 > $ou
 BENCH_ARGS='--batch 1024 --horizon 20 --obstacles 3' tools/profile_round.sh ${R}_cfg1 > $out/prof_cfg1.log 2>&1
 BENCH_ARGS='--horizon 80 --obstacles 20 --moving' tools/profile_round.sh ${R}_cfg4 > $out/prof_cfg4.log 2>&1
 python bench.py > $out/bench_plain.json 2> $out/bench_plain.err; echo "rc $?" >> $out/bench_plain.err
+python bench.py --workload survey-verbatim > $out/bench_survey_verbatim_plain.json 2> $out/bench_survey_verbatim_plain.err; echo "rc $?" >> $out/bench_survey_verbatim_plain.err
+python bench.py --workload survey-verbatim --model usv_model_guidance_ca1 --cpu-sample 0 > $out/bench_survey_verbatim_m1_plain.json 2>/dev/null
+python bench.py --oracle-opt itref_corr_max=2 --oracle-opt cond_pred_corr=1 > $out/bench_oracle_itref2_cpc_plain.json 2>/dev/null
 python bench.py --cpu-sample 0 --model usv_model_guidance_ca1 > $out/bench_m1_plain.json 2>/dev/null
 python bench.py --cpu-sample 0 --model usv_model --horizon 20 > $out/bench_m0_plain.json 2>/dev/null
 python bench.py --cpu-sample 0 --batch 1024 --horizon 20 --obstacles 3 > $out/bench_cfg1_plain.json 2>/dev/null
@@ -19,6 +22,10 @@ for m in usv_model_pf_ca usv_model_guidance_ca1; do python tools/latency_probe.p
 python tools/latency_probe.py usv_model_guidance_ca1 100 8 1,16,128,1024 >> $out/latency_probe.txt 2>&1   # the reference node's own shape: N = 100, K = 8
 python tools/latency_probe.py usv_model_pf_ca 100 4 1,128,1024 >> $out/latency_probe.txt 2>&1
 python tools/latency_probe.py usv_model 20 0 1,64,1024,2048 >> $out/latency_probe.txt 2>&1   # BASELINE configs[0]'s OCP (one instance) and batches of it
+python tools/latency_probe.py usv_model_pf_ca 80 20 1,64,256,512 >> $out/latency_probe.txt 2>&1   # BASELINE configs[4]'s OCP (two obstacle chunks)
+# (the single-instance figures the docs quote: a second take, the worse of the two is what gets quoted - VERDICT r04 next 8)
+for m in usv_model_pf_ca usv_model_guidance_ca1; do python tools/latency_probe.py $m 20 3 1; python tools/latency_probe.py $m 40 10 1; done > $out/latency_probe_take2.txt 2>&1
+python tools/latency_probe.py usv_model_guidance_ca1 100 8 1 >> $out/latency_probe_take2.txt 2>&1
 python -m pytest tests/test_shim.py -m gpu -q -s 2>&1 | grep timing >> $out/latency_probe.txt
 python bench.py --cpu-sample 0 --horizon 80 --obstacles 20 --moving > $out/bench_cfg4_b65536_plain.json 2>/dev/null
 python bench.py --cpu-sample 0 --horizon 80 --obstacles 20 --moving --batch 8192 > $out/bench_cfg4_b8192_per_gpu_plain.json 2>/dev/null

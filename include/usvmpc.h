@@ -219,6 +219,11 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  *       of one synchronising copy per call (the reference issues 3N+4 setters per tick: scripts/usv_guidance_ca1/main.py:
  *       123-130, src/nmpc_guidance_ca1.cpp:567-574); x / u / status come back in one copy and usvmpc_get "x" / "u" is served
  *       from it.  0 switches it off for the handle (it cannot be switched on again);
+ *   "cond_pred_corr" (default 0 = off), "cpc_factor" (default 2) - HPIPM's conditional predictor-corrector, an option of the QP solver the
+ *       reference selects (qp_solver = PARTIAL_CONDENSING_HPIPM: catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/acados_settings.py:172) that its modes
+ *       switch on and this library leaves off by default (DESIGN.md section 2 lists every HPIPM argument, adopted or not): an IPM iteration whose
+ *       corrected step leaves the duality measure above cpc_factor x the predictor's is redone with the centring-only step.  THE option that
+ *       changes results beyond rounding (another iteration path to the same tolerance); throughput mapping only;
  *   "handover_iter" (default 0 = off) - RTI launches that pull instances from the queue: once every instance has been handed out, a row
  *       whose instance has passed this many IPM iterations leaves it to a follow-up launch on the latency mapping (one instance per
  *       wavefront over the same workspace planes), which finishes it 1.6x faster per iteration than a lone 16-lane row - the tail of a

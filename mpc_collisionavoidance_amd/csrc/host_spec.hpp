@@ -156,6 +156,7 @@ inline std::string build_spec(const usvmpc_desc &d, DevSpec &S)
     if (S.iter_max < 1) return "qp_iter_max must be >= 1";
     if (d.sim_num_steps < 0 || d.sim_num_steps > 64) return "sim_num_steps out of range (1..64)";
     S.sim_steps = d.sim_num_steps > 0 ? d.sim_num_steps : 1;
+    S.cpc = 0; S.cpc_factor = 2.0; // (option "cond_pred_corr": off - DESIGN.md section 2)
     S.nlp_tol[0] = d.nlp_tol_stat > 0.0 ? d.nlp_tol_stat : 1e-6;
     S.nlp_tol[1] = d.nlp_tol_eq > 0.0 ? d.nlp_tol_eq : 1e-6;
     S.nlp_tol[2] = d.nlp_tol_ineq > 0.0 ? d.nlp_tol_ineq : 1e-6;

@@ -47,6 +47,9 @@ struct DevSpec {
     int nbu, nbx, nsbx;
     int box_pos[LANES];           // variable r of [u;x] -> position of its row in [bu.., bx..] (only where has_b)
     int sbx_pos[LANES];           // variable r -> position of its slack pair among the soft state bounds (only where bsoft)
+    // option "cond_pred_corr" (HPIPM's conditional predictor-corrector; qp_ipm.hpp QpIpm::solve): 0 off (default)
+    int cpc;
+    double cpc_factor;            // 2.0
 };
 
 // How the stage matrix [B A] (nx x nz) is kept in HBM.  Only entries that carry information are stored: the model

@@ -99,14 +99,20 @@ struct RowCalc {
         ml = ll * tl; mu = lu * tu;
         if constexpr (SOFTROW) { msl = lsl * tsl; msu = lsu * tsu; }
     }
-    USV_DEV void targets_corr(double sigmu) // uses the affine step currently held in d*
+    // CPC (option "cond_pred_corr"): so = 1 - the Mehrotra corrector as above -, or 0: the centring-only target of a row whose corrected step
+    // was refused (QpIpm::solve); with so = 1 the values are the plain form's bit for bit (1 * x is x)
+    template <bool CPC = false>
+    USV_DEV void targets_corr(double sigmu, double so = 1.0) // uses the affine step currently held in d*
     {
-        ml = ll * tl + dll * dtl - sigmu; mu = lu * tu + dlu * dtu - sigmu;
-        if constexpr (SOFTROW) {
-            msl = lsl * tsl + dlsl * dtsl - sigmu; msu = lsu * tsu + dlsu * dtsu - sigmu;
-            if constexpr (MIXED) {
-                if (!soft) { msl = 0.0; msu = 0.0; }
-            }
+        if constexpr (!CPC) {
+            ml = ll * tl + dll * dtl - sigmu; mu = lu * tu + dlu * dtu - sigmu;
+            if constexpr (SOFTROW) { msl = lsl * tsl + dlsl * dtsl - sigmu; msu = lsu * tsu + dlsu * dtsu - sigmu; }
+        } else {
+            ml = ll * tl + so * (dll * dtl) - sigmu; mu = lu * tu + so * (dlu * dtu) - sigmu;
+            if constexpr (SOFTROW) { msl = lsl * tsl + so * (dlsl * dtsl) - sigmu; msu = lsu * tsu + so * (dlsu * dtsu) - sigmu; }
+        }
+        if constexpr (SOFTROW && MIXED) {
+            if (!soft) { msl = 0.0; msu = 0.0; }
         }
     }
     // Gh: coefficient of c c' added to the stage Hessian; gam: coefficient of c added to the gradient
@@ -221,9 +227,12 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 // (wave w, row r: stage kb -+ (4 w + r)), every wave runs the recursion over the block; the exchange area, the planes in LDS and the
 // parked constants are the workgroup's, phases are separated by workgroup barriers, wave 0 / row 0 writes.  For the single instance and
 // the few dozen: a CU (WW = 4) or half a CU (WW = 2) per instance.
+// CPC: HPIPM's conditional predictor-corrector built in (option "cond_pred_corr"; QpIpm::solve) - instantiations of their own, launched
+// when the option is on: the stock kernels carry none of it.
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false,
-          bool WIDE = false, int WW = 1>
+          bool WIDE = false, int WW = 1, bool CPC = false>
 struct QpIpm {
+    static_assert(!CPC || (!WIDE && !LDSWS), "the conditional predictor-corrector is built into the throughput sweeps over planes in HBM");
     static_assert(WW == 1 || (WIDE && (WW == 2 || WW == 4)), "several waves per instance: the wide mapping only");
     static_assert(!WIDE || (((PACK && KCH >= 1) || (!PACK && KCH == 0)) && HDIAG && !SOFTBOX && !AUXLDS),
                   "the wide mapping works on the packed layouts and on the layout without obstacle rows");
@@ -361,7 +370,8 @@ struct QpIpm {
         ST_ZL = ST_SOFT, ST_ZU = ST_ZL + (SOFT ? KC : 0), ST_QL = ST_ZU + (SOFT ? KC : 0), ST_QU = ST_QL + (SOFT ? KC : 0),
         ST_BSL = ST_QU + (SOFT ? KC : 0), ST_BSU = ST_BSL + (SOFT ? KC : 0), ST_BOX = ST_BSU + (SOFT ? KC : 0),
         ST_SLOT = ST_BOX + (SOFTBOX ? 6 : 0), // MERGE: bounds of the box row a slot lane carries
-        ST_N = ST_SLOT + (MERGE ? 2 : 0)
+        ST_CPC = ST_SLOT + (MERGE ? 2 : 0),   // option "cond_pred_corr": second-order factor of this pass's / of the pending step's corrector targets
+        ST_N = ST_CPC + (CPC ? 2 : 0)
     };
     using ST = lanes::Stash<ST_N, (WIDE ? 16 : 64)>; // (WIDE: the rows hold the same constants - one row's worth)
     struct CRef {
@@ -380,6 +390,7 @@ struct QpIpm {
     };
     CVal<ST_LB> lbv; CVal<ST_UB> ubv; CVal<ST_HDS> hd_stage; CVal<ST_HDT> hd_term;
     CVal<ST_SLOT> slot_lb; CVal<ST_SLOT + 1> slot_ub;
+    CVal<ST_CPC> so_cur; CVal<ST_CPC + 1> so_prv; // (parked in LDS like the other per-lane constants: they must not cost the sweeps a register)
     bool bsoft;                               // SOFTBOX: this lane's state bound is soft
     // its slack penalties (scaled by dt) and slack lower bounds
     CVal<ST_BOX + 0> bzl; CVal<ST_BOX + 1> bzu; CVal<ST_BOX + 2> bZl; CVal<ST_BOX + 3> bZu; CVal<ST_BOX + 4> bbsl; CVal<ST_BOX + 5> bbsu;
@@ -761,15 +772,15 @@ struct QpIpm {
     struct Norms { double rg, rb, rd, rm, musum, nan; };
 
     // row chain up to the elimination; corr: predictor step (from w_aff) then corrector targets
-    template <class R>
-    USV_DEV static void chain(R &r, double v, bool corr, double w_aff, double sigmu, double &Gh, double &gam)
+    template <bool CP = false, class R>
+    USV_DEV static void chain(R &r, double v, bool corr, double w_aff, double sigmu, double &Gh, double &gam, double so = 1.0)
     {
         r.resid(v);
         r.targets_pred();
         r.reduce(Gh, gam);
         if (corr) {
             r.expand(w_aff);
-            r.targets_corr(sigmu);
+            r.template targets_corr<CP>(sigmu, so);
             r.reduce(Gh, gam);
         }
     }
@@ -901,11 +912,15 @@ struct QpIpm {
     // FACT = true : apply the pending step (pend), residuals + norms, adjoint multipliers, Hessian
     //               reduction, Riccati factorisation, predictor rhs
     // FACT = false: corrector rhs only, reusing the stored factors
+    // CPC (option "cond_pred_corr", throughput kernels over planes in HBM): the rows' corrector targets carry the per-row factor so_cur (this
+    // pass) / so_prv (the pending step, replayed in backward A) - 0 where the corrected step was refused and the centring-only one taken
     template <bool FACT>
     USV_DEV void backward(Norms &nm, double sigmu, bool pend, double a_prev, double sigmu_prev)
     {
         if constexpr (WIDE) { backward_wide<FACT>(nm, sigmu, pend, a_prev, sigmu_prev); return; }
         constexpr int SW = FACT ? SW_BACK_A : SW_BACK_B;
+        double so_c = 1.0, so_p = 1.0;
+        if constexpr (CPC) { so_c = so_cur; so_p = so_prv; }
         double Pn[NX], pn = 0.0, pin = 0.0;
         sfor<0, NX>([&](auto c) { Pn[c] = 0.0; });
         if (FACT) {
@@ -961,14 +976,14 @@ struct QpIpm {
                 box_from(in, k, br);
                 if (FACT) {
                     if (pend && br.act) {
-                        chain(br, z, true, dzap, sigmu_prev, Ghb, gamb);
+                        chain<CPC>(br, z, true, dzap, sigmu_prev, Ghb, gamb, so_p);
                         br.expand(dzp);
                         br.apply(a_prev);
                         if constexpr (!PACK) box_store(W, br);
                     }
                 }
                 if constexpr (FACT && PACK) dv = box_pack(br, pk);
-                chain(br, znew, !FACT, dza, sigmu, Ghb, gamb);
+                chain<CPC>(br, znew, !FACT, dza, sigmu, Ghb, gamb, so_c);
                 dlb = br.act ? br.ll - br.lu : 0.0;
             }
             double Gh_m = 0.0, gam_m = 0.0, dl_m = 0.0; // MERGE: the last chunk's per-row terms, for the box rows among them
@@ -981,7 +996,7 @@ struct QpIpm {
                     if (FACT) {
                         const double vo = rowdot<c>(cx, cy, z - psel, z), wp = rowdot<c>(cx, cy, dzp, dzp), wap = rowdot<c>(cx, cy, dzap, dzap);
                         if (pend && o.act) {
-                            chain(o, vo, true, wap, sigmu_prev, Gh, gam);
+                            chain<CPC>(o, vo, true, wap, sigmu_prev, Gh, gam, so_p);
                             o.expand(wp);
                             o.apply(a_prev);
                         }
@@ -990,7 +1005,7 @@ struct QpIpm {
                     }
                     const double v = rowdot<c>(cx, cy, znew - psel, znew);
                     const double wa = FACT ? 0.0 : rowdot<c>(cx, cy, dza, dza);
-                    chain(o, v, !FACT, wa, sigmu, Gh, gam);
+                    chain<CPC>(o, v, !FACT, wa, sigmu, Gh, gam, so_c);
                     gx += gam * cx; gy += gam * cy;
                     if constexpr (MERGE && c == KCH - 1) { Gh_m = Gh; gam_m = gam; }
                     if (FACT) {
@@ -1185,10 +1200,14 @@ struct QpIpm {
     // ------------------------------------------------------------------ forward sweeps
     // FINAL = false: affine step -> alpha_aff and the sums for mu_aff, stores dza
     // FINAL = true : corrected step -> alpha, stores dz
+    // (CPC: the corrected step also delivers the sums S1, S2 - the duality measure after a step of length a is (musum + a S1 + a^2 S2) / nc)
     template <bool FINAL>
     USV_DEV void forward(double sigmu, double &alpha, double &S1, double &S2)
     {
         if constexpr (WIDE) { forward_wide<FINAL>(sigmu, alpha, S1, S2); return; }
+        constexpr bool SUMS = !FINAL || CPC;
+        double so_c = 1.0;
+        if constexpr (CPC) so_c = so_cur;
         constexpr int SW = FINAL ? SW_FWD_B : SW_FWD_A;
         double dzx;
         {
@@ -1236,10 +1255,10 @@ struct QpIpm {
                     BoxRow br;
                     box_from(in, k, br);
                     double Gh, gam;
-                    chain(br, z, FINAL, dza, sigmu, Gh, gam);
+                    chain<CPC>(br, z, FINAL, dza, sigmu, Gh, gam, so_c);
                     br.expand(dz);
                     q = br.blocking(q);
-                    if (!FINAL && br.act) {
+                    if (SUMS && br.act) {
                         s1 += br.ll * br.dtl + br.tl * br.dll + br.lu * br.dtu + br.tu * br.dlu;
                         s2 += br.dll * br.dtl + br.dlu * br.dtu;
                         if constexpr (SOFTBOX) {
@@ -1258,10 +1277,10 @@ struct QpIpm {
                         const double v = rowdot<c>(cx, cy, z - pos_sel(zbx, zby), z);
                         const double w = rowdot<c>(cx, cy, dz, dz);
                         const double wa = FINAL ? rowdot<c>(cx, cy, dza, dza) : w;
-                        chain(o, v, FINAL, wa, sigmu, Gh2, gam2);
+                        chain<CPC>(o, v, FINAL, wa, sigmu, Gh2, gam2, so_c);
                         o.expand(w);
                         q = o.blocking(q);
-                        if (!FINAL && o.act) {
+                        if (SUMS && o.act) {
                             s1 += o.ll * o.dtl + o.tl * o.dll + o.lu * o.dtu + o.tu * o.dlu;
                             s2 += o.dll * o.dtl + o.dlu * o.dtu;
                             if constexpr (SOFT) {
@@ -1282,7 +1301,7 @@ struct QpIpm {
         }
         ws(N).st(FINAL ? P_DZ : P_DZA, dfr_dz);
         alpha = 1.0 / lanes::gmax(q); // q >= 1: alpha = min(1, min over blocking pairs of -v/dv)
-        if (!FINAL) { S1 = lanes::gsum(s1); S2 = lanes::gsum(s2); }
+        if (SUMS) { S1 = lanes::gsum(s1); S2 = lanes::gsum(s2); }
     }
 
     // ------------------------------------------------------------------ the sweeps of the WIDE mapping
@@ -2098,6 +2117,7 @@ struct QpIpm {
     // the instance's record, the group into the list.  The follow-up launch (usvmpc.hip: usv_qp_resume) picks the list up one instance
     // per wave and carries on from exactly that state, on the same planes: the mappings return the same bits, so WHERE an instance
     // is finished does not show in its result (scheduling only; tests/test_gpu_handover.py, emulator tests/test_wide_emu.py).
+    static constexpr bool HAS_CPC = CPC;
     static constexpr bool CAN_SUSPEND = !WIDE && !LDSWS && HDIAG && !SOFTBOX && ((PACK && KCH == 1) || (!PACK && KCH == 0));
     USV_DEV void suspend(bool sel, int it, double a_prev, double sig_prev)
     {
@@ -2162,6 +2182,8 @@ struct QpIpm {
         double a_prev = 0.0, sig_prev = 0.0;
         const double nc = (double)S.nc;
         const bool refill = phase == 0 && queue0 >= 0; // wave-uniform
+        constexpr bool cpc = CPC; // option "cond_pred_corr": the host launches this instantiation
+        if constexpr (HAS_CPC) { if (cpc) { so_prv = 1.0; so_cur = 1.0; } }
         if constexpr (WIDE && !LDSWS) {
             if (resume) { // the state the suspending row left (all rows of the wave read the same record)
                 const double *r = P.susp_rec + 4 * b;
@@ -2217,6 +2239,7 @@ struct QpIpm {
                         it = take ? 0 : it;
                         iters = take ? 0 : iters;
                         status = take ? (bad ? 4 : 1) : status;
+                        if constexpr (HAS_CPC) { if (cpc) { const double sp = so_prv; so_prv = take ? 1.0 : sp; } }
                         // (the freshly started row sits out the three remaining sweeps of this pass: parked meanwhile - see below - so that
                         // it does not stream its new group's planes for nothing; back at the end of the pass)
                         if constexpr (!LDSWS && !WIDE) voff = take ? stage_bytes + (unsigned)(lane * 8) : voff;
@@ -2235,19 +2258,44 @@ struct QpIpm {
             if (!lanes::wave_any(!done || late)) break;
             const bool run = !done && !fresh; // rows that take part in the rest of this pass
             const double mu = nc > 0.0 ? nm.musum / nc : 0.0;
-            double a_aff = 1.0, S1 = 0.0, S2 = 0.0, a = 1.0, d1, d2;
+            double a_aff = 1.0, S1 = 0.0, S2 = 0.0, a = 1.0, d1 = 0.0, d2 = 0.0;
             forward<false>(0.0, a_aff, S1, S2);
-            double sigmu = 0.0;
+            double sigmu = 0.0, mu_aff = 0.0;
             if (nc > 0.0) {
-                const double mu_aff = (nm.musum + a_aff * S1 + a_aff * a_aff * S2) / nc;
+                mu_aff = (nm.musum + a_aff * S1 + a_aff * a_aff * S2) / nc;
                 const double sg = mu_aff / mu;
                 sigmu = sg * sg * sg * mu;
             }
-            backward<false>(nm, sigmu, false, 0.0, 0.0);
-            forward<true>(sigmu, a, d1, d2);
+            bool cpc_done = false;
+            if constexpr (HAS_CPC) {
+                if (cpc) { // wave-uniform (DevSpec)
+                    // HPIPM's conditional predictor-corrector (d_ocp_qp_ipm_arg.cond_pred_corr, on in its SPEED / BALANCE / ROBUST modes; as
+                    // recalled - DESIGN.md section 2): a corrected step that leaves the duality measure above cpc_factor x the predictor's
+                    // mu_aff is refused and the centring-only step (the corrector's target without its second-order term) taken instead.
+                    // Per row; the sweeps are the wave's, so the rows that keep their step recompute it (so = 1: the same bits).
+                    so_cur = 1.0;
+                    backward<false>(nm, sigmu, false, 0.0, 0.0);
+                    forward<true>(sigmu, a, d1, d2);
+                    const double mu_pc = nc > 0.0 ? (nm.musum + a * d1 + a * a * d2) / nc : 0.0;
+                    const bool refuse = run && nc > 0.0 && mu_pc > S.cpc_factor * mu_aff;
+                    if (lanes::wave_any(refuse)) { // wave-uniform
+                        so_cur = refuse ? 0.0 : 1.0; // (LDS operations of a wave execute in order: the sweeps below read what is written here)
+                        double a2 = 1.0;
+                        backward<false>(nm, sigmu, false, 0.0, 0.0);
+                        forward<true>(sigmu, a2, d1, d2);
+                        a = refuse ? a2 : a;
+                    }
+                    cpc_done = true;
+                }
+            }
+            if (!cpc_done) {
+                backward<false>(nm, sigmu, false, 0.0, 0.0);
+                forward<true>(sigmu, a, d1, d2);
+            }
             if (run && a < S.alpha_min) { status = 2; done = true; late = true; iters = it; }
             a_prev = run ? a * ((1.0 - a) * 0.99 + a * 0.9999999) : a_prev;
             sig_prev = run ? sigmu : sig_prev;
+            if constexpr (HAS_CPC) { if (cpc) { const double sp = so_prv, sc = so_cur; so_prv = run ? sc : sp; } }
             pend = run ? true : pend;
             it = run ? it + 1 : it;
             if constexpr (!LDSWS && !WIDE) voff = fresh ? lanes::Planes::lane_offset(g, NPL, lane) : voff;

@@ -137,8 +137,32 @@ def check(co):
     # in these libraries computes a branch).  Which callee a call reaches is a register value, so the walk is conservative: in front of
     # the instruction after ANY call sit the tails of ALL called functions' returns (and, as if the callee were empty, the call site's own
     # predecessors); in front of a called function's first instruction sit ALL call sites.
+    # Long branches: a kernel of more than 128 KB of code (the soft-state-bound instantiations with two obstacle chunks) gets jumps beyond the
+    # 16-bit offset of s_branch relaxed into  s_getpc_b64 s[a:b] / s_add_u32 sa, sa, LO / s_addc_u32 sb, sb, HI / s_setpc_b64 s[a:b]:
+    # an unconditional branch to (address of the instruction after s_getpc) + (HI:LO).  Recognised as exactly that sequence, nothing looser.
+    long_branch = set()
+    for i, (a, mn, ops) in enumerate(prog):
+        if mn != "s_setpc_b64" or i < 3:
+            continue
+        g, lo, hi = prog[i - 3], prog[i - 2], prog[i - 1]
+        m = re.match(r"s\[(\d+):(\d+)\]$", ops.strip())
+        if not (m and g[1] == "s_getpc_b64" and g[2].strip() == ops.strip() and lo[1] == "s_add_u32" and hi[1] == "s_addc_u32"):
+            continue
+        ra, rb = m.group(1), m.group(2)
+        ml = re.match(r"s%s, s%s, (0x[0-9a-f]+|\d+)$" % (ra, ra), lo[2].strip())
+        mh = re.match(r"s%s, s%s, (0x[0-9a-f]+|\d+|-1)$" % (rb, rb), hi[2].strip())
+        if not (ml and mh):
+            continue
+        off = int(ml.group(1), 0) + ((int(mh.group(1), 0) & 0xffffffff) << 32)
+        if off >= 1 << 63:
+            off -= 1 << 64
+        tgt = addr_index.get(lo[0] + off)
+        if tgt is None:
+            continue
+        branches_to.setdefault(tgt, []).append(i)
+        long_branch.add(i)
     calls = [i for i, (_, mn, _) in enumerate(prog) if mn == "s_swappc_b64"]
-    returns = [i for i, (_, mn, _) in enumerate(prog) if mn == "s_setpc_b64"]
+    returns = [i for i, (_, mn, _) in enumerate(prog) if mn == "s_setpc_b64" and i not in long_branch]
     kernels = {funcs[i] for i, (_, mn, _) in enumerate(prog) if mn == "s_endpgm"}
     entry_of = {}       # index of a called function's first instruction -> True
     for i in range(len(prog)):

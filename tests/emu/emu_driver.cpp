@@ -108,6 +108,8 @@ namespace {
 using namespace usv;
 
 struct Job { const DevPtrs *P; long gid; int qp_phase; int queue0; };
+int g_emu_cpc = 0;          // option "cond_pred_corr" of the next solves (the CPC instantiations of the 16-lane sweeps)
+double g_emu_cpc_factor = 2.0;
 int g_emu_lds_mode = 0; // 1: run the RTI solves with the workspace in (emulated) LDS
 int g_emu_merge = 1;    // 1: box rows processed in their slot lanes when all of them ride there (as the device library does)
 int g_emu_aux = 0;      // 1: RTI solves of the packed one-chunk layouts keep the aux plane in (emulated) LDS (AUXLDS instantiations)
@@ -135,6 +137,11 @@ void qp_body(void *a)
     }
     if constexpr (HDIAG && PACK && !SOFTBOX) if (g_emu_aux && j->qp_phase == 0) {
         QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, false, MERGE, true> q(*j->P, j->gid);
+        q.solve(j->qp_phase, j->queue0);
+        return;
+    }
+    if constexpr (HDIAG && !SOFTBOX) if (g_emu_cpc) { // option "cond_pred_corr": the instantiation with the conditional predictor-corrector
+        QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, false, MERGE, false, false, 1, true> q(*j->P, j->gid);
         q.solve(j->qp_phase, j->queue0);
         return;
     }
@@ -331,6 +338,7 @@ static int emu_run(const usvmpc_desc *d, int sqp, double *x, double *u, const do
         std::fprintf(stderr, "usv_emu_solve: %s\n", err.c_str());
         return -1;
     }
+    S.cpc = g_emu_cpc; S.cpc_factor = g_emu_cpc_factor;
     int nx, nu;
     model_dims(d->model, nx, nu);
     const int N = S.N;
@@ -407,6 +415,7 @@ extern "C" void usv_emu_set_cond(int N2) { g_emu_cond_N2 = N2; }
 extern "C" void usv_emu_set_aux(int aux) { g_emu_aux = aux; }
 extern "C" void usv_emu_set_wide(int wide) { g_emu_wide = wide; g_emu_wide_runs = 0; }
 extern "C" long usv_emu_wide_runs() { return g_emu_wide_runs; }
+extern "C" void usv_emu_set_cpc(int on, double factor) { g_emu_cpc = on; g_emu_cpc_factor = factor; }
 extern "C" void usv_emu_set_handover(int iters) { g_emu_handover = iters; g_emu_handed = 0; }
 extern "C" long usv_emu_handed() { return g_emu_handed; }
 // the next solves also deliver the multipliers / slacks of their QPs (the device's usvmpc_get "lam" / "t"); NULL switches it off

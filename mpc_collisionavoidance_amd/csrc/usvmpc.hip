@@ -840,7 +840,8 @@ int launch_pair(usvmpc_handle *h, int phase)
         // The latency mapping: ONE instance per wave (qp_ipm.hpp, WIDE) - planes in LDS, the four rows share out the stage-local row
         // work.  A wave then finishes an instance 1.4x (hard rows) to 1.8x (soft rows) sooner and the device holds a quarter of the instances at once: it pays while
         // the batch leaves SIMDs idle anyway (a solve of the batch then lasts as long as its hardest instance on a lone wave).
-        if (kern_wide != nullptr && phase == 0 && h->wide_mode != 0 && h->ncu > 0 && !plain) {
+        if (kern_wide != nullptr && h->wide_mode != 0 && h->ncu > 0 && !plain) {
+          if (phase == 0) { // (the launches of a full SQP find their multipliers in the group's planes in HBM: the variant over planes in HBM below)
             // (in LDS: the planes the solve writes - WsLayout's up to L_zu less the four box planes the packed layouts leave unused)
             const size_t bytes = (size_t)(h->N + 1) * (size_t)(WsLayout<M, KCH, SOFT>::P_RB0 - (KCH > 0 ? 4 : 0)) * 128 + (size_t)4 * wide_ex_planes(KCH) * 128;
             if (h->wide_cap == 0) {
@@ -866,11 +867,12 @@ int launch_pair(usvmpc_handle *h, int phase)
                 h->last_wide = 1;
                 return 0;
             }
-            // The horizon's planes do not fit a CU's LDS (the reference node's own N = 100: nmpc_guidance_ca1.cpp:64): the same sweeps over
-            // the planes in HBM / L2 - the four rows of a wave address four stages through one window over the whole workspace (hence
-            // its size limit), the next block's row planes and the next stage's recursion planes are in flight ahead of their use.
+          }
+            // The horizon's planes do not fit a CU's LDS (the reference node's own N = 100: nmpc_guidance_ca1.cpp:64), or the launch belongs to a
+            // full SQP: the same sweeps over the planes in HBM / L2 - the four rows of a wave address the four stages of a block through one
+            // window, the next block's row planes and the next stage's recursion planes are in flight ahead of their use.
             const long win_bytes = (long)std::min(h->N + 1, 4) * h->Bp * h->spec.npt * 128; // (the window of a block of four stages: 32-bit offsets)
-            if (h->wide_cap < 0 && kern_wide_hbm != nullptr && win_bytes < (1L << 32)) {
+            if ((h->wide_cap < 0 || phase != 0) && kern_wide_hbm != nullptr && win_bytes < (1L << 32)) {
                 const size_t xbytes = (size_t)4 * wide_ex_planes_hbm(KCH) * 128;
                 if (h->wide_hbm_cap == 0) {
                     int nb = 0;
@@ -883,7 +885,8 @@ int launch_pair(usvmpc_handle *h, int phase)
                 if (h->wide_hbm_cap > 0 && (h->wide_mode > 0 || (long)h->B <= h->wide_hbm_cap)) {
                     long nw = (long)h->B;
                     int q0 = -1;
-                    if (h->dynamic_rows && nw > h->wide_hbm_cap) { nw = h->wide_hbm_cap; q0 = (int)nw; }
+                    // (full SQP: one group per workgroup for the whole call - its multipliers persist in the group's planes)
+                    if (h->dynamic_rows && phase == 0 && nw > h->wide_hbm_cap) { nw = h->wide_hbm_cap; q0 = (int)nw; }
                     if (q0 >= 0) HIP_TRY(h, hipMemsetAsync(h->ptrs.queue, 0, sizeof(int), h->stream));
                     hipLaunchKernelGGL(kern_wide_hbm, dim3((unsigned)nw), dim3(qp_block), xbytes, h->stream, h->ptrs, nw, phase, q0, 1);
                     h->last_wide = 1;

@@ -281,7 +281,8 @@ void run_all(const DevPtrs &P_, const DevSpec &S, int phase, int qp_phase)
                 else lanes::run_group(g, &qp_body<M, KCH, SOFT, false, false, true>, &j);
                 continue;
             }
-            if (((KCH >= 1 && pack) || KCH == 0) && g_emu_wide && qp_phase == 0 && S.hdiag) {
+            // (the launches of a full SQP - qp_phase 1 / 2 - on the WIDE mapping: over the planes in HBM, where the multipliers persist)
+            if (((KCH >= 1 && pack) || KCH == 0) && g_emu_wide && (qp_phase == 0 || !g_emu_lds_mode) && S.hdiag) {
                 lds.assign(wide_lds<M, KCH, SOFT>(S.N), 0.0);
                 lanes::g_emu_lds = lds.data();
                 // (lds mode off: the wide sweeps over the planes in HBM - horizons that do not fit a CU's LDS)

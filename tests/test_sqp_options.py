@@ -103,6 +103,34 @@ def test_full_sqp_kernels_match_oracle(oracle, emu, name, K):
         assert np.allclose(r["nlp_res"][same], reso[same], rtol=1e-3, atol=1e-9)
 
 
+@pytest.mark.parametrize("name,K", [("usv_model", 0), ("usv_model_guidance_ca1", 4), ("usv_model_pf_ca", 3), ("usv_model_pf_ca", 10), ("usv_model_pf_ca", 20)])
+def test_full_sqp_on_the_latency_mapping_equals_the_16_lane_sweeps(emu, name, K):
+    """The launches of a full SQP on the one-instance-per-wave sweeps over planes in HBM (round 5: usvmpc.hip launch_qp takes them for small
+    batches; the multipliers persist in the group's planes between the launches of a call, as with the 16-lane sweeps): every output of the
+    run equals the 16-lane run's bit for bit - iterate, statuses, SQP iteration counts, NLP residuals; a second call from the converged
+    point solves no QP."""
+    N, B = 6, 5
+    wl = scenario.make_batch(name, N, K, B, seed=21)
+    desc = _capi.desc_from_ocp(_ocp(name, N, K, nlp_solver_type="SQP", nlp_solver_max_iter=30), batch=B)
+    emu.usv_emu_set_wide.argtypes = [C.c_int]
+    emu.usv_emu_set_mode.argtypes = [C.c_int, C.c_long]
+    emu.usv_emu_wide_runs.restype = C.c_long
+    out = []
+    try:
+        emu.usv_emu_set_mode(0, 2)
+        for wide in (0, 1):
+            emu.usv_emu_set_wide(wide)
+            r = emu_sqp(emu, desc, wl, wl["x_init"], wl["u_init"])
+            if wide:
+                assert emu.usv_emu_wide_runs() >= B    # (the wide sweeps did run)
+            out.append(r)
+    finally:
+        emu.usv_emu_set_wide(0)
+    assert (out[0]["status"] == 0).all() and out[0]["sqp_iter"].min() >= 1
+    for f in ("x", "u", "status", "sqp_iter", "nlp_res"):
+        assert np.array_equal(out[0][f], out[1][f]), f
+
+
 def test_full_sqp_max_iter_status(oracle, emu):
     name, N, K, B = "usv_model_pf_ca", 6, 3, 2
     wl = scenario.make_batch(name, N, K, B, seed=21)
@@ -155,6 +183,36 @@ def test_gpu_full_sqp_and_multi_step(oracle, name, K):
     st2 = s.solve_sqp()
     assert (s.get_int("sqp_iter")[ok] == 0).all() and (st2[ok] == 0).all()
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,N,K,B", [("usv_model_pf_ca", 20, 10, 96), ("usv_model_guidance_ca1", 30, 8, 64), ("usv_model", 20, 0, 40),
+                                         ("usv_model_pf_ca", 20, 20, 48), ("usv_model_guidance_ca1", 100, 8, 1)])
+def test_gpu_full_sqp_on_the_latency_mapping(name, N, K, B):
+    """Full SQP of a small batch: its launches run on the one-instance-per-wave sweeps over planes in HBM (default for batches that leave
+    SIMDs idle; usvmpc_last_mapping = 1) and return what the throughput mapping returns, bit for bit - after RTI solves on the LDS variant
+    of the latency mapping (their multipliers are written back to the group's planes), and with a second call from the converged point."""
+    from mpc_collisionavoidance_amd import BatchOcpSolver
+    wl = scenario.make_batch(name, N, K, B, seed=9)
+    out = []
+    for wide in (0, -1):
+        s = BatchOcpSolver(_ocp(name, N, K, nlp_solver_type="SQP", nlp_solver_max_iter=40), B)
+        scenario.load_into(s, wl)
+        s.set_option("wide", wide)
+        s.solve(); s.solve()
+        m_rti = s.last_mapping()
+        st = s.solve_sqp()
+        m_sqp = s.last_mapping()
+        it1, res1, x1 = s.get_int("sqp_iter").copy(), s.get("nlp_res", 0).copy(), s.get_all("x")
+        st2 = s.solve_sqp()
+        out.append((st.copy(), it1, res1, x1, s.get_all("u"), st2.copy(), s.get_int("sqp_iter").copy(), s.get_all("pi"), s.get_all("lam"), m_rti, m_sqp))
+        s.close()
+    assert out[0][9] == 0 and out[0][10] == 0 and out[1][9] in (1, 4) and out[1][10] == 1, [o[9:] for o in out]
+    assert (out[0][0] == 0).mean() > 0.8
+    for i in range(9):
+        assert np.array_equal(out[0][i], out[1][i], equal_nan=i in (2, 3, 4, 7, 8)), i
+    ok = out[0][0] == 0
+    assert (out[0][6][ok] == 0).all()     # second call: converged already, no QP
 
 
 @pytest.mark.gpu

@@ -12,7 +12,9 @@ BENCH_ARGS='--horizon 80 --obstacles 20 --moving' tools/profile_round.sh ${R}_cf
 python bench.py > $out/bench_plain.json 2> $out/bench_plain.err; echo "rc $?" >> $out/bench_plain.err
 python bench.py --workload survey-verbatim > $out/bench_survey_verbatim_plain.json 2> $out/bench_survey_verbatim_plain.err; echo "rc $?" >> $out/bench_survey_verbatim_plain.err
 python bench.py --workload survey-verbatim --model usv_model_guidance_ca1 --cpu-sample 0 > $out/bench_survey_verbatim_m1_plain.json 2>/dev/null
-python bench.py --oracle-opt itref_corr_max=2 --oracle-opt cond_pred_corr=1 > $out/bench_oracle_itref2_cpc_plain.json 2>/dev/null
+python bench.py --oracle-opt itref_corr_max=2 > $out/bench_oracle_itref2_plain.json 2>/dev/null
+python bench.py --oracle-opt cond_pred_corr=1 > $out/bench_oracle_cpc_device_plain_plain.json 2>/dev/null   # (exits 4: the option on ONE side only - the size of the unpinned-parity uncertainty)
+python bench.py --option cond_pred_corr=1 --oracle-opt cond_pred_corr=1 > $out/bench_cpc_both_sides_plain.json 2>/dev/null
 python bench.py --cpu-sample 0 --model usv_model_guidance_ca1 > $out/bench_m1_plain.json 2>/dev/null
 python bench.py --cpu-sample 0 --model usv_model --horizon 20 > $out/bench_m0_plain.json 2>/dev/null
 python bench.py --cpu-sample 0 --batch 1024 --horizon 20 --obstacles 3 > $out/bench_cfg1_plain.json 2>/dev/null

@@ -161,8 +161,9 @@ int usvmpc_pipeline_stats(usvmpc_handle *h, long *used, long *discarded);
  * instance per wavefront (option "wide": the latency mapping north_star names - the four rows of the wave share out the stage-local
  * constraint-row work of four consecutive stages), 4 = one instance per workgroup of FOUR wavefronts (option "wide_waves": a whole CU
  * shares out the row work of 16 consecutive stages; default for soft-row OCPs in batches of at most one instance per CU).  The latency
- * mapping is taken by default for batches that leave SIMDs idle, when the OCP's layout allows: one obstacle chunk (K <= 16) with packed
- * box rows, or no obstacle rows; no soft state bounds; the planes live in the CU's LDS when the horizon fits, else in HBM.
+ * mapping is taken by default for batches that leave SIMDs idle (RTI solves and the launches of a full SQP; every layout with a diagonal
+ * Hessian - i.e. every OCP of the reference: up to 32 obstacle rows, soft state bounds); the planes live in the CU's LDS when the horizon
+ * fits, else - and for a full SQP - in HBM.
  * WHICH mapping ran does not show in the results: all of them take every sum in the same order and contract multiply-adds the same way
  * (qp_ipm.hpp: #pragma clang fp contract(on)), so statuses, iteration counts, iterates and multipliers are the same BITS - an instance
  * solved in a handle of 1, of 512 or of 65 536 returns the same answer (tests/test_gpu_wide.py, test_gpu_closed_loop.py::

@@ -115,8 +115,18 @@ struct MatPack {
 // and wrapped the loads in waterfall loops).
 // planes of the exchange area of the wide mapping (qp_ipm.hpp, WIDE: [4 rows][WIDE_EX_PLANES][16 lanes] behind the instance's planes in LDS)
 // (kch obstacle chunks per stage: the complementarity sums of a stage are handed over chunk by chunk - qp_ipm.hpp EX_*)
-constexpr int wide_ex_planes(int kch) { return kch <= 1 ? 7 : 10; }      // ... with the solver's planes in LDS
-constexpr int wide_ex_planes_hbm(int kch) { return kch <= 1 ? 9 : 11; }  // ... in HBM (two more: qp_ipm.hpp)
+// (softbox: soft state bounds - their slack pairs' sums travel in planes of their own)
+constexpr int wide_ex_fwd(int kch, bool softbox) { return 4 * (kch > 1 ? kch : 1) + 2 + (softbox ? 2 : 0); }
+constexpr int wide_ex_planes(int kch, bool softbox = false)      // ... with the solver's planes in LDS
+{
+    const int z = 4 + 2 * (kch > 1 ? kch : 1) + 1 + (softbox ? 1 : 0);
+    return z > wide_ex_fwd(kch, softbox) ? z : wide_ex_fwd(kch, softbox);
+}
+constexpr int wide_ex_planes_hbm(int kch, bool softbox = false)  // ... in HBM (two more: qp_ipm.hpp)
+{
+    const int a = 4 + 2 * (kch > 1 ? kch : 1) + 1 + (softbox ? 1 : 0) + 2;
+    return a > wide_ex_fwd(kch, softbox) ? a : wide_ex_fwd(kch, softbox);
+}
 
 template <class M, int KCH, bool SOFT, bool SOFTBOX = false>
 struct WsLayout {

@@ -214,8 +214,9 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 // per stage) lives in the wave's LDS for the whole launch instead of being streamed with the planes: 4 reads + 2 writes of the
 // 59 + 13 plane accesses per stage and IPM iteration go (the kernel streams at the HBM ceiling: profiles/r03_bound_experiment.txt).
 // RTI launches whose horizon fits (host: usvmpc.hip); finish() leaves a copy in the HBM plane for the read-back paths.
-// WIDE (one obstacle chunk with packed box rows - either row-pass form -, or no obstacle rows at all; the solver's planes in LDS, LDSWS, or
-// for horizons that do not fit there in HBM): the latency mapping - ONE instance per wave.  The four rows of the wave are given the
+// WIDE (packed box rows beside one or two obstacle chunks - either row-pass form -, no obstacle rows at all, or soft state bounds with
+// their rows in planes of their own; the solver's planes in LDS, LDSWS, or - horizons that do not fit there, the launches of a full SQP -
+// in HBM): the latency mapping - ONE instance per wave.  The four rows of the wave are given the
 // same instance and hold the same values; what a lone row spends most of a sweep on, the chains of a stage's box / obstacle rows
 // (stage-local: they depend on nothing outside their stage), the rows do for FOUR CONSECUTIVE STAGES at once - row r takes stage
 // kb -+ r of a block - and leave each stage's terms (Gamma, gamma, S_xx ...) in an exchange area of the workgroup's LDS; the
@@ -234,8 +235,8 @@ template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = fal
 struct QpIpm {
     static_assert(!CPC || (!WIDE && !LDSWS), "the conditional predictor-corrector is built into the throughput sweeps over planes in HBM");
     static_assert(WW == 1 || (WIDE && (WW == 2 || WW == 4)), "several waves per instance: the wide mapping only");
-    static_assert(!WIDE || (((PACK && KCH >= 1) || (!PACK && KCH == 0)) && HDIAG && !SOFTBOX && !AUXLDS),
-                  "the wide mapping works on the packed layouts and on the layout without obstacle rows");
+    static_assert(!WIDE || (((PACK && KCH >= 1) || (!PACK && (KCH == 0 || SOFTBOX))) && HDIAG && !AUXLDS),
+                  "the wide mapping works on the packed layouts, on the layout without obstacle rows and on the soft-state-bound layouts");
     static_assert(!MERGE || PACK, "merged row pass works on the packed layout");
     static_assert(!(AUXLDS && LDSWS), "with the whole workspace in LDS the aux plane is there already");
     static_assert(!PACK || KCH > 0, "box rows are packed into obstacle planes");
@@ -309,11 +310,12 @@ struct QpIpm {
     struct WideMap {
         static constexpr int at(int plane)
         {
-            if (!PACK) return plane < WL::P_RB0 ? plane : -1; // (no obstacle rows: the box planes are in use)
+            // (box rows in planes of their own - no obstacle rows, or soft state bounds, whose six slack planes sit behind the lineariser's)
+            if (!PACK) return plane < WL::P_RB0 ? plane : ((SOFTBOX && plane >= WL::P_BS && plane < WL::P_BS + 6) ? WL::P_RB0 + (plane - WL::P_BS) : -1);
             return plane < WL::P_BLL ? plane : (plane >= WL::P_OBS && plane < WL::P_RB0 ? plane - 4 : -1);
         }
     };
-    static constexpr int NPLW = (WIDE && LDSWS) ? WL::P_RB0 - (PACK ? 4 : 0) : WL::NPT; // planes per stage of an LDS region
+    static constexpr int NPLW = (WIDE && LDSWS) ? WL::P_RB0 - (PACK ? 4 : 0) + (SOFTBOX ? 6 : 0) : WL::NPT; // planes per stage of an LDS region
     using Planes = std::conditional_t<WIDE && LDSWS, lanes::PlanesLdsMapped<WideMap>, std::conditional_t<LDSWS, lanes::PlanesLds, lanes::Planes>>;
 
     const DevPtrs &P;
@@ -1312,10 +1314,11 @@ struct QpIpm {
     // the recursion reads back from the planes the row phase has just written.
     // (EX_MU1 + c, EX_MU2 + c: the complementarity sums of obstacle chunk c - hard pairs, slack pairs -, EX_MU3: of the box rows of the two-pass
     // form; the forward sweeps reuse the area for the sums of mu_aff: chunk c in planes 4 c .. 4 c + 3, the box rows in 4 KC, 4 KC + 1)
-    enum : int { EX_GHB = 0, EX_GAMB, EX_DLB, EX_SC, EX_MU1, EX_MU2 = EX_MU1 + KC, EX_MU3 = EX_MU2 + KC, EX_Z, EX_DV, EX_ALL };
-    static constexpr int EX_FWD = 4 * KC + 2;
+    // (EX_MU4, soft state bounds only: the sums of the box rows' slack pairs)
+    enum : int { EX_GHB = 0, EX_GAMB, EX_DLB, EX_SC, EX_MU1, EX_MU2 = EX_MU1 + KC, EX_MU3 = EX_MU2 + KC, EX_MU4 = EX_MU3 + (SOFTBOX ? 1 : 0), EX_Z, EX_DV, EX_ALL };
+    static constexpr int EX_FWD = 4 * KC + 2 + (SOFTBOX ? 2 : 0);
     static constexpr int EX_N = LDSWS ? ((int)EX_Z > EX_FWD ? (int)EX_Z : EX_FWD) : ((int)EX_ALL > EX_FWD ? (int)EX_ALL : EX_FWD);
-    static_assert(!WIDE || EX_N == (LDSWS ? wide_ex_planes(KCH) : wide_ex_planes_hbm(KCH)), "host-side size of the exchange area");
+    static_assert(!WIDE || EX_N == (LDSWS ? wide_ex_planes(KCH, SOFTBOX) : wide_ex_planes_hbm(KCH, SOFTBOX)), "host-side size of the exchange area");
     static constexpr int BS = 4 * WW; // stages per block = rows of the workgroup
     static constexpr int wide_lds_doubles(int N_) { return (LDSWS ? (N_ + 1) * NPLW * LANES : 0) + BS * EX_N * LANES + (WW > 1 ? LANES : 0); }
     // phases of a sweep hand values from row to row through LDS (or, WW > 1, from wave to wave: a workgroup barrier)
@@ -1424,7 +1427,10 @@ struct QpIpm {
                 if (!pstat) obs_raw<c>(k, in.raw[c]);
             });
         }
-        if constexpr (!PACK) { in.box[0] = W.ld(P_BLL); in.box[1] = W.ld(P_BLU); in.box[2] = W.ld(P_BTL); in.box[3] = W.ld(P_BTU); }
+        if constexpr (!PACK) {
+            in.box[0] = W.ld(P_BLL); in.box[1] = W.ld(P_BLU); in.box[2] = W.ld(P_BTL); in.box[3] = W.ld(P_BTU);
+            if constexpr (SOFTBOX) sfor<0, 6>([&](auto e) { in.bxs[e] = W.ld(P_BS + e); });
+        }
     }
 
     template <bool FACT>
@@ -1464,7 +1470,7 @@ struct QpIpm {
                 const double zbx = aux_zx(aux), zby = aux_zy(aux);
                 const double psel = pos_sel(zbx, zby);
                 const double znew = (FACT && pend) ? z + a_prev * dzp : z;
-                double Sxx = 0.0, Sxy = 0.0, Syy = 0.0, gx = 0.0, gy = 0.0, lx = 0.0, ly = 0.0, dl_m = 0.0, mu3 = 0.0;
+                double Sxx = 0.0, Sxy = 0.0, Syy = 0.0, gx = 0.0, gy = 0.0, lx = 0.0, ly = 0.0, dl_m = 0.0, mu3 = 0.0, mu4 = 0.0;
                 // the two-pass form (a box row rides in the dense part of the aux plane): the box rows in their variables' lanes first
                 double Ghb = 0.0, gamb = 0.0, dlb = 0.0, pk[4];
                 if constexpr (!MERGE) {
@@ -1495,6 +1501,15 @@ struct QpIpm {
                         rm_r = lanes::vmax(rm_r, lanes::vmax(br.ll * br.tl, br.lu * br.tu));
                         mu3 = br.ll * br.tl + br.lu * br.tu;
                         nan_r = fma(0.0, br.rdl + br.rdu, nan_r);
+                        if constexpr (SOFTBOX) {
+                            if (br.soft) {
+                                rg_r = lanes::vmax(rg_r, lanes::vmax_abs2(br.rsl, br.rsu));
+                                rd_r = lanes::vmax(rd_r, lanes::vmax_abs2(br.rdsl, br.rdsu));
+                                rm_r = lanes::vmax(rm_r, lanes::vmax(br.lsl * br.tsl, br.lsu * br.tsu));
+                                mu4 = br.lsl * br.tsl + br.lsu * br.tsu;
+                                nan_r = fma(0.0, br.rsl + br.rsu + br.rdsl + br.rdsu, nan_r);
+                            }
+                        }
                     }
                 }
                 double mu1[KC], mu2[KC];
@@ -1569,6 +1584,7 @@ struct QpIpm {
                     ex_put(row, EX_GHB, Ghb);
                     ex_put(row, EX_DLB, dlb);
                     if constexpr (!MERGE) ex_put(row, EX_MU3, mu3);
+                    if constexpr (SOFTBOX) ex_put(row, EX_MU4, mu4);
                     sfor<0, KC>([&](auto c) {
                         ex_put(row, EX_MU1 + c, mu1[c]);
                         if constexpr (SOFT) ex_put(row, EX_MU2 + c, mu2[c]);
@@ -1608,6 +1624,7 @@ struct QpIpm {
                         if constexpr (SOFT) nm.musum += ex_get(j, EX_MU2 + c);
                     });
                     if constexpr (!MERGE) nm.musum += ex_get(j, EX_MU3);
+                    if constexpr (SOFTBOX) nm.musum += ex_get(j, EX_MU4);
                 }
                 double bat[NX];
                 if (k < N) mat_unpack(cur.mpk, bat); // wave-uniform
@@ -1823,6 +1840,11 @@ struct QpIpm {
                     if (!FINAL) {
                         ex_put(row, 4 * KC, br.act ? br.ll * br.dtl + br.tl * br.dll + br.lu * br.dtu + br.tu * br.dlu : 0.0);
                         ex_put(row, 4 * KC + 1, br.act ? br.dll * br.dtl + br.dlu * br.dtu : 0.0);
+                        if constexpr (SOFTBOX) {
+                            const bool sb = br.act && br.soft;
+                            ex_put(row, 4 * KC + 2, sb ? br.lsl * br.dtsl + br.tsl * br.dlsl + br.lsu * br.dtsu + br.tsu * br.dlsu : 0.0);
+                            ex_put(row, 4 * KC + 3, sb ? br.dlsl * br.dtsl + br.dlsu * br.dtsu : 0.0);
+                        }
                     }
                 }
                 if constexpr (KCH > 0) {
@@ -1852,6 +1874,7 @@ struct QpIpm {
                 wide_sync();
                 for (int j = 0; j < BS; j++) {
                     if constexpr (!MERGE) { s1 += ex_get(j, 4 * KC); s2 += ex_get(j, 4 * KC + 1); }
+                    if constexpr (SOFTBOX) { s1 += ex_get(j, 4 * KC + 2); s2 += ex_get(j, 4 * KC + 3); }
                     if constexpr (KCH > 0) {
                         sfor<0, KCH>([&](auto c) {
                             s1 += ex_get(j, 4 * c); s2 += ex_get(j, 4 * c + 1);

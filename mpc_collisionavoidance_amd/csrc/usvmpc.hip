@@ -79,13 +79,17 @@ __global__ void __launch_bounds__(64 * WW, ((LDSWS || WIDE) ? 1 : qp_waves<KCH, 
     QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, LDSWS, MERGE, AUXLDS, WIDE, WW, CPC> q(P, has ? g0 + row : g0, has ? row : -1);
     q.solve(phase, queue0);
 }
-// (the wide instantiation exists for the one-chunk layouts only)
-// (LDSWS: the solver's planes in LDS - false: in HBM, for horizons that do not fit a CU's LDS)
-template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS = true, int WW = 1>
+// The wide instantiations: packed layouts with one or two obstacle chunks, the layout without obstacle rows, and (SOFTBOX) the layouts with
+// soft state bounds - box rows in planes of their own, with or without obstacle rows.
+// (LDSWS: the solver's planes in LDS - false: in HBM, for horizons that do not fit a CU's LDS and for the launches of a full SQP)
+template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS = true, int WW = 1, bool SOFTBOX = false>
 constexpr auto wide_kernel()
 {
-    // (two obstacle chunks, K = 17 .. 32 - BASELINE configs[4]'s OCP: one wave per instance; four waves are built for one chunk only)
-    if constexpr (KCH == 1 || (KCH == 2 && WW == 1)) return &usv_qp_rti<M, KCH, SOFT, true, true, false, LDSWS, MERGE, false, true, WW>;
+    // (two obstacle chunks, K = 17 .. 32 - BASELINE configs[4]'s OCP - and soft state bounds: one wave per instance; four waves are built for one chunk only)
+    if constexpr (SOFTBOX) {
+        if constexpr (WW == 1 && !MERGE) return &usv_qp_rti<M, KCH, SOFT, true, false, true, LDSWS, false, false, true, 1>;
+        else return (decltype(&usv_qp_rti<M, KCH, SOFT, true, false, true, true, false>))nullptr;
+    } else if constexpr (KCH == 1 || (KCH == 2 && WW == 1)) return &usv_qp_rti<M, KCH, SOFT, true, true, false, LDSWS, MERGE, false, true, WW>;
     else if constexpr (KCH == 0 && !MERGE) return &usv_qp_rti<M, KCH, SOFT, true, false, false, LDSWS, false, false, true, WW>; // (no obstacle rows: box rows in their own planes)
     else return (decltype(&usv_qp_rti<M, KCH, SOFT, true, (KCH > 0), false, true, MERGE>))nullptr;
 }
@@ -109,13 +113,18 @@ constexpr qp_resume_t resume_kernel()
     else return nullptr;
 }
 // the wide kernels of one layout: [planes in LDS, planes in HBM] x [one wave, four waves per instance], and the follow-up kernel
+// (nplw: planes per stage an instance keeps in LDS; ex_lds / ex_hbm: planes of the exchange area - qp_ipm.hpp NPLW, EX_N)
 using qp_kernel_t = void (*)(DevPtrs, long, int, int, int);
-struct WideSet { qp_kernel_t lds1, hbm1, lds4, hbm4; qp_resume_t resume; };
-template <class M, int KCH, bool SOFT, bool MERGE>
+struct WideSet { qp_kernel_t lds1, hbm1, lds4, hbm4; qp_resume_t resume; int nplw, ex_lds, ex_hbm; };
+constexpr WideSet NO_WIDE = WideSet{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+template <class M, int KCH, bool SOFT, bool MERGE, bool SOFTBOX = false>
 constexpr WideSet wide_set()
 {
-    return WideSet{wide_kernel<M, KCH, SOFT, MERGE, true, 1>(), wide_kernel<M, KCH, SOFT, MERGE, false, 1>(),
-                   wide_kernel<M, KCH, SOFT, MERGE, true, 4>(), wide_kernel<M, KCH, SOFT, MERGE, false, 4>(), resume_kernel<M, KCH, SOFT, MERGE>()};
+    using WL = WsLayout<M, KCH, SOFT, SOFTBOX>;
+    return WideSet{wide_kernel<M, KCH, SOFT, MERGE, true, 1, SOFTBOX>(), wide_kernel<M, KCH, SOFT, MERGE, false, 1, SOFTBOX>(),
+                   wide_kernel<M, KCH, SOFT, MERGE, true, 4, SOFTBOX>(), wide_kernel<M, KCH, SOFT, MERGE, false, 4, SOFTBOX>(),
+                   SOFTBOX ? nullptr : resume_kernel<M, KCH, SOFT, MERGE>(),
+                   WL::P_RB0 - ((KCH > 0 && !SOFTBOX) ? 4 : 0) + (SOFTBOX ? 6 : 0), wide_ex_planes(KCH, SOFTBOX), wide_ex_planes_hbm(KCH, SOFTBOX)};
 }
 
 // Multiplier read-back (usvmpc_get "lam" / "t"): the inequality multipliers and slacks of every instance's last QP, from the
@@ -794,7 +803,7 @@ int launch_pair(usvmpc_handle *h, int phase)
     // Small batches: the planes of every instance in flight fit in LDS (160 KB per CU), and a solve whose sweeps wait for
     // HBM at every stage - nothing else runs on the CU to hide it - becomes a solve on LDS.  rows_lds instances per wave
     // (as many whole horizons as fit), one wave per CU at a time; further instances come through the same queue.
-    auto launch_qp = [&](auto kern, decltype(kern) kern_lds, decltype(kern) kern_aux = nullptr, WideSet wide = WideSet{nullptr, nullptr, nullptr, nullptr, nullptr}) -> int {
+    auto launch_qp = [&](auto kern, decltype(kern) kern_lds, decltype(kern) kern_aux = nullptr, WideSet wide = NO_WIDE) -> int {
         const long lds_inst = (long)(h->N + 1) * h->spec.npt * 128;
         h->last_wide = 0;
         h->ptrs.susp_count = nullptr; h->ptrs.susp_list = nullptr; h->ptrs.susp_rec = nullptr; h->ptrs.handover_iter = 0; // (set by the path that hands over)
@@ -803,8 +812,8 @@ int launch_pair(usvmpc_handle *h, int phase)
         // single instance and batches of at most one instance per CU.
         const bool plain = h->spec.cpc != 0; // option "cond_pred_corr": built into the throughput kernels over planes in HBM only
         if (wide.lds4 != nullptr && phase == 0 && h->wide_mode != 0 && h->wide_waves != 1 && h->ncu > 0 && !plain) {
-            const size_t pl = (size_t)(h->N + 1) * (size_t)(WsLayout<M, KCH, SOFT>::P_RB0 - (KCH > 0 ? 4 : 0)) * 128;
-            const size_t b4 = pl + (size_t)16 * wide_ex_planes(KCH) * 128 + 128, x4 = (size_t)16 * wide_ex_planes_hbm(KCH) * 128 + 128;
+            const size_t pl = (size_t)(h->N + 1) * (size_t)wide.nplw * 128;
+            const size_t b4 = pl + (size_t)16 * wide.ex_lds * 128 + 128, x4 = (size_t)16 * wide.ex_hbm * 128 + 128;
             const long win_bytes = (long)std::min(h->N + 1, 16) * h->Bp * h->spec.npt * 128; // (the window of a block of 16 stages: 32-bit offsets)
             if (h->wide4_cap == 0) {
                 int nb = 0;
@@ -843,7 +852,7 @@ int launch_pair(usvmpc_handle *h, int phase)
         if (kern_wide != nullptr && h->wide_mode != 0 && h->ncu > 0 && !plain) {
           if (phase == 0) { // (the launches of a full SQP find their multipliers in the group's planes in HBM: the variant over planes in HBM below)
             // (in LDS: the planes the solve writes - WsLayout's up to L_zu less the four box planes the packed layouts leave unused)
-            const size_t bytes = (size_t)(h->N + 1) * (size_t)(WsLayout<M, KCH, SOFT>::P_RB0 - (KCH > 0 ? 4 : 0)) * 128 + (size_t)4 * wide_ex_planes(KCH) * 128;
+            const size_t bytes = (size_t)(h->N + 1) * (size_t)wide.nplw * 128 + (size_t)4 * wide.ex_lds * 128;
             if (h->wide_cap == 0) {
                 int nb = 0;
                 hipFuncAttributes fa;
@@ -873,7 +882,7 @@ int launch_pair(usvmpc_handle *h, int phase)
             // window, the next block's row planes and the next stage's recursion planes are in flight ahead of their use.
             const long win_bytes = (long)std::min(h->N + 1, 4) * h->Bp * h->spec.npt * 128; // (the window of a block of four stages: 32-bit offsets)
             if ((h->wide_cap < 0 || phase != 0) && kern_wide_hbm != nullptr && win_bytes < (1L << 32)) {
-                const size_t xbytes = (size_t)4 * wide_ex_planes_hbm(KCH) * 128;
+                const size_t xbytes = (size_t)4 * wide.ex_hbm * 128;
                 if (h->wide_hbm_cap == 0) {
                     int nb = 0;
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern_wide_hbm, qp_block, xbytes) == hipSuccess && nb > 0)
@@ -958,7 +967,7 @@ int launch_pair(usvmpc_handle *h, int phase)
         // instances of 30 - 50 iterations on an idling device; past "handover_iter" iterations those go to a follow-up launch on the
         // latency mapping (one instance per wave over the same planes: 1.6x per pass for usv_model_pf_ca at N = 40).  Scheduling only.
         bool hand = false;
-        const size_t xbytes = (size_t)4 * wide_ex_planes_hbm(KCH) * 128;
+        const size_t xbytes = (size_t)4 * wide.ex_hbm * 128;
         if (q0 >= 0 && h->handover_iter > 0 && !plain && wide.resume != nullptr && (long)std::min(h->N + 1, 4) * h->Bp * h->spec.npt * 128 < (1L << 32)) {
             if (h->resume_cap == 0) {
                 int nb = 0;
@@ -1005,7 +1014,8 @@ int launch_pair(usvmpc_handle *h, int phase)
                         &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>);
 #else
     if (h->spec.any_bsoft) { // soft state bounds: rows with slacks, ten planes of their own
-        rcq = h->spec.hdiag ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, true>, nullptr) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, true>, nullptr);
+        rcq = h->spec.hdiag ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, true>, nullptr, nullptr, wide_set<M, KCH, SOFT, false, true>())
+                            : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, true>, nullptr);
     } else if (h->spec.hdiag) { // (every OCP of the reference: the only instantiations that also come with the workspace in LDS)
         // (one row pass when every box row rides in a slot lane: qp_ipm.hpp, MERGE)
         // (the packed layouts - every OCP of the reference, the bench workloads - also come with the aux plane in LDS)
@@ -1016,7 +1026,7 @@ int launch_pair(usvmpc_handle *h, int phase)
             rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>,
                                    &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>, wide_set<M, KCH, SOFT, false>())
                        : launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, false>, &usv_qp_rti<M, KCH, SOFT, true, false, false, true>, nullptr,
-                                   KCH == 0 ? wide_set<M, KCH, SOFT, false>() : WideSet{nullptr, nullptr, nullptr, nullptr, nullptr});
+                                   KCH == 0 ? wide_set<M, KCH, SOFT, false>() : NO_WIDE);
     } else {
         rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, false, CANPACK, false>, nullptr) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, false>, nullptr);
     }

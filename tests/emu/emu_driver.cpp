@@ -162,6 +162,14 @@ void qp_wide_body(void *a)
         q.solve(j->qp_phase, j->queue0);
     }
 }
+// ... with soft state bounds (box rows in planes of their own, with or without obstacle rows)
+template <class M, int KCH, bool SOFT, bool LDSWS, int WW = 1>
+void qp_wide_softbox_body(void *a)
+{
+    Job *j = (Job *)a;
+    QpIpm<M, KCH, SOFT, true, false, true, LDSWS, false, false, true, WW> q(*j->P, j->gid, lanes::block_row() == 0 ? 0 : -1);
+    q.solve(j->qp_phase, j->queue0);
+}
 template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS>
 void run_wide(long g, Job &j, int ww)
 {
@@ -276,6 +284,14 @@ void run_all(const DevPtrs &P_, const DevSpec &S, int phase, int qp_phase)
             Job j{&P, g, qp_phase, queue ? (int)nrows : -1};
             constexpr bool CANPACK = KCH > 0;
             const bool pack = CANPACK && S.boxpack != 0;
+            if (S.any_bsoft && S.hdiag && g_emu_wide && (qp_phase == 0 || !g_emu_lds_mode)) { // the WIDE mapping, one emulated wave per instance
+                lds.assign((size_t)QpIpm<M, KCH, SOFT, true, false, true, true, false, false, true, 1>::wide_lds_doubles(S.N) + 16 * 2 * LANES, 0.0);
+                lanes::g_emu_lds = lds.data();
+                if (g_emu_lds_mode) lanes::run_group(g, &qp_wide_softbox_body<M, KCH, SOFT, true>, &j, 4);
+                else lanes::run_group(g, &qp_wide_softbox_body<M, KCH, SOFT, false>, &j, 4);
+                g_emu_wide_runs++;
+                continue;
+            }
             if (S.any_bsoft) {
                 if (S.hdiag) lanes::run_group(g, &qp_body<M, KCH, SOFT, true, false, true>, &j);
                 else lanes::run_group(g, &qp_body<M, KCH, SOFT, false, false, true>, &j);

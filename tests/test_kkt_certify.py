@@ -149,7 +149,7 @@ def _device_tick(s, oracle, spec, wl, x0, soft):
     return res, ok, xn, un, xb, ub
 
 
-def _certify_closed_loop(oracle, name, N, K, B, ticks, options=()):
+def _certify_closed_loop(oracle, name, N, K, B, ticks, options=(), min_ok=0.97):
     from mpc_collisionavoidance_amd import BatchOcpSolver
     wl = scenario.make_bench_batch(name, N, K, B, seed=1234)
     dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
@@ -168,7 +168,7 @@ def _certify_closed_loop(oracle, name, N, K, B, ticks, options=()):
     worst = dict(stat=0.0, eq=0.0, ineq=0.0, comp=0.0)
     for tk in range(ticks):
         res, ok, xn, un, xb, ub = _device_tick(s, oracle, spec, wl, x0, soft)
-        assert ok.mean() >= 0.97, (name, tk, ok.mean())
+        assert ok.mean() >= min_ok, (name, tk, ok.mean())
         cert = kkt.certified(res, 1e-6 * SLACK, 1e-8 * SLACK, 1e-8 * SLACK, 1e-8 * SLACK)
         n_ok += int(ok.sum())
         n_cert += int((ok & cert).sum())
@@ -206,3 +206,12 @@ def test_device_solutions_certified_config1_full_size(oracle):
 def test_device_solutions_certified_soft_rows(oracle):
     r = _certify_closed_loop(oracle, "usv_model_guidance_ca1", 40, 10, 512, 5)
     assert r["kkt_certified_frac"] == 1.0 and r["active_row_frac"] >= 0.5, r
+
+
+@pytest.mark.gpu
+def test_device_solutions_certified_two_chunks_on_the_latency_mapping(oracle):
+    """K = 20 (two obstacle chunks: BASELINE configs[4]'s OCP) on the one-instance-per-wave mapping, its default for small batches since round 5
+    (VERDICT r04 next 4): every converged solve KKT-certified - planes in LDS (N = 40) and in HBM (N = 80), hard and soft rows."""
+    for name, N, B in (("usv_model_pf_ca", 40, 200), ("usv_model_pf_ca", 80, 96), ("usv_model_guidance_ca1", 40, 128)):
+        r = _certify_closed_loop(oracle, name, N, 20, B, 3, options=(("wide", 1), ("wide_waves", 1)), min_ok=0.9)
+        assert r["kkt_certified_frac"] == 1.0, r

@@ -243,6 +243,46 @@ def _soft_bx_ocp(name, N, K, pos, zl=50.0, Zl=10.0):
     return ocp
 
 
+@pytest.mark.parametrize("name,N,K,pos", [("usv_model", 6, 0, [0, 2]), ("usv_model_pf_ca", 7, 3, [0]), ("usv_model_pf_ca", 5, 20, [0, 1]),
+                                          ("usv_model_pf_ca", 6, 10, [0, 1, 2])])   # (usv_model_guidance_ca1 has no state bounds)
+@pytest.mark.parametrize("lds", [1, 0])
+def test_soft_state_bounds_on_the_latency_mapping_equal_the_16_lane_sweeps(emu, name, N, K, pos, lds):
+    """Soft state bounds (acados idxsbx: S/race_cars/acados_settings_dev.py:107-127; box rows with slacks, in planes of their own) on the
+    one-instance-per-wave sweeps - the last layout the latency mapping skipped (VERDICT r04 missing 4): every output equals the 16-lane
+    sweeps' bit for bit, planes in LDS and in HBM, RTI and full SQP, without obstacle rows and with one and two chunks of them."""
+    B = 4
+    wl = scenario.make_batch(name, N, K, B, seed=33)
+    ocp = _soft_bx_ocp(name, N, K, pos)
+    j, ub = int(ocp.constraints.idxbx[pos[0]]), float(ocp.constraints.ubx[pos[0]])
+    wl["x0"][0, j] = ub + 0.3; wl["x_init"][0, :, j] = ub + 0.3             # instance 0 starts outside the (soft) bound
+    desc = _capi.desc_from_ocp(ocp, batch=B)
+    dsqp = _capi.desc_from_ocp(_soft_bx_ocp(name, N, K, pos), batch=B)
+    dsqp.nlp_max_iter = 12
+    emu.usv_emu_set_wide.argtypes = [C.c_int]
+    emu.usv_emu_set_mode.argtypes = [C.c_int, C.c_long]
+    emu.usv_emu_wide_runs.restype = C.c_long
+    out = []
+    try:
+        emu.usv_emu_set_mode(lds, 2)
+        for wide in (0, 1):
+            emu.usv_emu_set_wide(wide)
+            r = emu_rti(emu, desc, wl, wl["x_init"], wl["u_init"])
+            r2 = emu_rti(emu, desc, wl, r["x"], r["u"])
+            if wide:
+                assert emu.usv_emu_wide_runs() >= 2
+            o = [r2[f] for f in ("x", "u", "status", "qp_status", "qp_iter", "sl", "su", "pi", "res")]
+            if not lds:   # (a full SQP keeps its multipliers in the group's planes: HBM)
+                q = emu_sqp(emu, dsqp, wl, wl["x_init"], wl["u_init"])
+                o += [q[f] for f in ("x", "u", "status", "sqp_iter", "nlp_res")]
+            out.append(o)
+    finally:
+        emu.usv_emu_set_wide(0)
+        emu.usv_emu_set_mode(0, 2)
+    assert (out[0][2] == 0).any() and out[0][4].max() >= 3
+    for n, (a, b) in enumerate(zip(out[0], out[1])):
+        assert np.array_equal(a, b), (n, np.abs(np.asarray(a, float) - np.asarray(b, float)).max())
+
+
 @pytest.mark.parametrize("name,K,pos", [("usv_model", 0, [0, 2]), ("usv_model_pf_ca", 3, [0])])
 def test_soft_state_bounds_kernels_match_oracle(oracle, emu, name, K, pos):
     N, B = 6, 3
@@ -337,3 +377,40 @@ def test_gpu_sqp_after_rti_finds_the_last_qps_multipliers(name, K, B):
         assert np.abs(r[1] - runs[0][1])[ok].max() <= 1 and (r[1] == runs[0][1])[ok].mean() > 0.9
         assert util.rel_err(r[3][ok], runs[0][3][ok]) < 1e-4   # (converged to nlp_tol 1e-6 on each side)
         assert (r[5][ok] == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,N,K,pos,B", [("usv_model", 20, 0, [0, 2], 64), ("usv_model_pf_ca", 20, 10, [0, 3], 64), ("usv_model_pf_ca", 40, 20, [0, 1], 48),
+                                             ("usv_model_pf_ca", 100, 4, [0], 8), ("usv_model_pf_ca", 20, 3, [0], 1)])
+def test_gpu_soft_state_bounds_on_the_latency_mapping(name, N, K, pos, B):
+    """Soft state bounds on the one-instance-per-wave mapping (its default for small batches since round 5; planes in LDS or, N = 100 and
+    the launches of the full SQP, in HBM): RTI closed loop and a full SQP return what the throughput mapping returns, bit for bit."""
+    from mpc_collisionavoidance_amd import BatchOcpSolver
+    wl = scenario.make_batch(name, N, K, B, seed=3)
+    j0 = None
+    out = []
+    for wide in (0, -1):
+        ocp = _soft_bx_ocp(name, N, K, pos)
+        ocp.solver_options.nlp_solver_max_iter = 25
+        if j0 is None:
+            j0, ub = int(ocp.constraints.idxbx[pos[0]]), float(ocp.constraints.ubx[pos[0]])
+            n0 = max(1, B // 8)
+            wl["x0"][:n0, j0] = ub + 0.3; wl["x_init"][:n0, :, j0] = ub + 0.3      # some instances start outside the (soft) bound
+        s = BatchOcpSolver(ocp, B)
+        scenario.load_into(s, wl)
+        s.set_option("wide", wide)
+        maps, o = [], []
+        for t in range(3):
+            st = s.solve()
+            maps.append(s.last_mapping())
+            o += [st.copy(), s.get_int("qp_iter").copy(), s.get_all("x"), s.get_all("u"), s.get_all("pi"), s.get_all("lam"), s.get_all("t")]
+            s.advance(0.0)
+        st = s.solve_sqp()
+        maps.append(s.last_mapping())
+        o += [st.copy(), s.get_int("sqp_iter").copy(), s.get("nlp_res", 0).copy(), s.get_all("x"), s.get_all("u")]
+        out.append((o, maps))
+        s.close()
+    assert set(out[0][1]) == {0} and set(out[1][1]) == {1}, (out[0][1], out[1][1])
+    assert (out[0][0][0] == 0).mean() > 0.8
+    for i, (a, b) in enumerate(zip(out[0][0], out[1][0])):
+        assert np.array_equal(a, b, equal_nan=True), i

@@ -157,7 +157,7 @@ int usvmpc_handover_counts(usvmpc_handle *h, int n, int *counts);
  * were used by the following solve / discarded because the caller wrote x, u or yref in between.  The lineariser only runs ahead after
  * two solves in a row without such a write, so a caller that sets yref every tick (the reference's protocol) discards none. */
 int usvmpc_pipeline_stats(usvmpc_handle *h, long *used, long *discarded);
-/* Which mapping the last RTI solve ran on: 0 = four instances per wavefront (one per 16-lane row: the throughput mapping), 1 = ONE
+/* Which mapping the last solve (RTI, or the last launch of a full SQP) ran on: 0 = four instances per wavefront (one per 16-lane row: the throughput mapping), 1 = ONE
  * instance per wavefront (option "wide": the latency mapping north_star names - the four rows of the wave share out the stage-local
  * constraint-row work of four consecutive stages), 4 = one instance per workgroup of FOUR wavefronts (option "wide_waves": a whole CU
  * shares out the row work of 16 consecutive stages; default for soft-row OCPs in batches of at most one instance per CU).  The latency

@@ -2131,9 +2131,10 @@ struct QpIpm {
     }
 
     // ------------------------------------------------------------------ hand-over of long runners
-    // A persistent launch ends with a handful of rows finishing instances that need 30 - 50 IPM iterations and were handed out late,
-    // while the rest of the device idles (profiles/r03_tail.txt).  What shortens that tail is a faster pass for ONE instance - the
-    // latency mapping.  Once every instance of the launch has been handed out (the queue counter has passed the batch), a row whose
+    // A persistent launch ends with a drain: the instances in flight when its queue runs dry finish one by one while more and more of the
+    // device idles (profiles/r03_tail.txt, r05_handover.txt).  The idea: a faster pass for ONE instance - the latency mapping - for the ones
+    // that run longest.  (Built and measured in round 5: it does not pay - the one-instance-per-wave sweeps over COLD planes in HBM are
+    // slower per pass than the lone row they relieve - and stays off; option "handover_iter".)  Once every instance of the launch has been handed out (the queue counter has passed the batch), a row whose
     // instance has done handover_iter iterations leaves it where it stands: everything an iteration hands to the next is in the
     // workspace planes already (the pending step in P_DZ / P_DZA, multipliers and slacks in the row planes, the iterate in P_Z); what
     // lives in registers - step length and centring target of the pending step, the residual scale, the iteration count - goes into
@@ -2291,7 +2292,7 @@ struct QpIpm {
             }
             bool cpc_done = false;
             if constexpr (HAS_CPC) {
-                if (cpc) { // wave-uniform (DevSpec)
+                if (cpc) { // (compile-time: the CPC instantiations)
                     // HPIPM's conditional predictor-corrector (d_ocp_qp_ipm_arg.cond_pred_corr, on in its SPEED / BALANCE / ROBUST modes; as
                     // recalled - DESIGN.md section 2): a corrected step that leaves the duality measure above cpc_factor x the predictor's
                     // mu_aff is refused and the centring-only step (the corrector's target without its second-order term) taken instead.

@@ -214,9 +214,9 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 // per stage) lives in the wave's LDS for the whole launch instead of being streamed with the planes: 4 reads + 2 writes of the
 // 59 + 13 plane accesses per stage and IPM iteration go (the kernel streams at the HBM ceiling: profiles/r03_bound_experiment.txt).
 // RTI launches whose horizon fits (host: usvmpc.hip); finish() leaves a copy in the HBM plane for the read-back paths.
-// WIDE (packed box rows beside one or two obstacle chunks - either row-pass form -, no obstacle rows at all, or soft state bounds with
-// their rows in planes of their own; the solver's planes in LDS, LDSWS, or - horizons that do not fit there, the launches of a full SQP -
-// in HBM): the latency mapping - ONE instance per wave.  The four rows of the wave are given the
+// WIDE (every row layout: packed box rows beside one or two obstacle chunks - either row-pass form -, box rows in planes of their own - no
+// obstacle rows, obstacle rows that leave no idle lanes, soft state bounds -; the solver's planes in LDS, LDSWS, or - horizons that do not
+// fit there, the launches of a full SQP - in HBM): the latency mapping - ONE instance per wave.  The four rows of the wave are given the
 // same instance and hold the same values; what a lone row spends most of a sweep on, the chains of a stage's box / obstacle rows
 // (stage-local: they depend on nothing outside their stage), the rows do for FOUR CONSECUTIVE STAGES at once - row r takes stage
 // kb -+ r of a block - and leave each stage's terms (Gamma, gamma, S_xx ...) in an exchange area of the workgroup's LDS; the
@@ -235,8 +235,7 @@ template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = fal
 struct QpIpm {
     static_assert(!CPC || (!WIDE && !LDSWS), "the conditional predictor-corrector is built into the throughput sweeps over planes in HBM");
     static_assert(WW == 1 || (WIDE && (WW == 2 || WW == 4)), "several waves per instance: the wide mapping only");
-    static_assert(!WIDE || (((PACK && KCH >= 1) || (!PACK && (KCH == 0 || SOFTBOX))) && HDIAG && !AUXLDS),
-                  "the wide mapping works on the packed layouts, on the layout without obstacle rows and on the soft-state-bound layouts");
+    static_assert(!WIDE || (HDIAG && !AUXLDS), "the wide mapping works on every row layout of an OCP with a diagonal Hessian");
     static_assert(!MERGE || PACK, "merged row pass works on the packed layout");
     static_assert(!(AUXLDS && LDSWS), "with the whole workspace in LDS the aux plane is there already");
     static_assert(!PACK || KCH > 0, "box rows are packed into obstacle planes");

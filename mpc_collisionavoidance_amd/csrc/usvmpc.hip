@@ -79,16 +79,17 @@ __global__ void __launch_bounds__(64 * WW, ((LDSWS || WIDE) ? 1 : qp_waves<KCH, 
     QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, LDSWS, MERGE, AUXLDS, WIDE, WW, CPC> q(P, has ? g0 + row : g0, has ? row : -1);
     q.solve(phase, queue0);
 }
-// The wide instantiations: packed layouts with one or two obstacle chunks, the layout without obstacle rows, and (SOFTBOX) the layouts with
-// soft state bounds - box rows in planes of their own, with or without obstacle rows.
+// The wide instantiations: packed layouts with one or two obstacle chunks, and the layouts with the box rows in planes of their own (UNPACKED:
+// no obstacle rows, obstacle rows that leave the box rows no idle lanes, or - SOFTBOX - soft state bounds).
 // (LDSWS: the solver's planes in LDS - false: in HBM, for horizons that do not fit a CU's LDS and for the launches of a full SQP)
-template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS = true, int WW = 1, bool SOFTBOX = false>
+template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS = true, int WW = 1, bool SOFTBOX = false, bool UNPACKED = false>
 constexpr auto wide_kernel()
 {
-    // (two obstacle chunks, K = 17 .. 32 - BASELINE configs[4]'s OCP - and soft state bounds: one wave per instance; four waves are built for one chunk only)
-    if constexpr (SOFTBOX) {
-        if constexpr (WW == 1 && !MERGE) return &usv_qp_rti<M, KCH, SOFT, true, false, true, LDSWS, false, false, true, 1>;
-        else return (decltype(&usv_qp_rti<M, KCH, SOFT, true, false, true, true, false>))nullptr;
+    // (two obstacle chunks, K = 17 .. 32 - BASELINE configs[4]'s OCP -, unpacked rows beside obstacle rows and soft state bounds: one wave per
+    // instance; four waves are built for the packed one-chunk layouts and the layout without obstacle rows)
+    if constexpr (SOFTBOX || (UNPACKED && KCH > 0)) {
+        if constexpr (WW == 1 && !MERGE) return &usv_qp_rti<M, KCH, SOFT, true, false, SOFTBOX, LDSWS, false, false, true, 1>;
+        else return (decltype(&usv_qp_rti<M, KCH, SOFT, true, false, SOFTBOX, true, false>))nullptr;
     } else if constexpr (KCH == 1 || (KCH == 2 && WW == 1)) return &usv_qp_rti<M, KCH, SOFT, true, true, false, LDSWS, MERGE, false, true, WW>;
     else if constexpr (KCH == 0 && !MERGE) return &usv_qp_rti<M, KCH, SOFT, true, false, false, LDSWS, false, false, true, WW>; // (no obstacle rows: box rows in their own planes)
     else return (decltype(&usv_qp_rti<M, KCH, SOFT, true, (KCH > 0), false, true, MERGE>))nullptr;
@@ -117,14 +118,15 @@ constexpr qp_resume_t resume_kernel()
 using qp_kernel_t = void (*)(DevPtrs, long, int, int, int);
 struct WideSet { qp_kernel_t lds1, hbm1, lds4, hbm4; qp_resume_t resume; int nplw, ex_lds, ex_hbm; };
 constexpr WideSet NO_WIDE = WideSet{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-template <class M, int KCH, bool SOFT, bool MERGE, bool SOFTBOX = false>
+template <class M, int KCH, bool SOFT, bool MERGE, bool SOFTBOX = false, bool UNPACKED = false>
 constexpr WideSet wide_set()
 {
     using WL = WsLayout<M, KCH, SOFT, SOFTBOX>;
-    return WideSet{wide_kernel<M, KCH, SOFT, MERGE, true, 1, SOFTBOX>(), wide_kernel<M, KCH, SOFT, MERGE, false, 1, SOFTBOX>(),
-                   wide_kernel<M, KCH, SOFT, MERGE, true, 4, SOFTBOX>(), wide_kernel<M, KCH, SOFT, MERGE, false, 4, SOFTBOX>(),
-                   SOFTBOX ? nullptr : resume_kernel<M, KCH, SOFT, MERGE>(),
-                   WL::P_RB0 - ((KCH > 0 && !SOFTBOX) ? 4 : 0) + (SOFTBOX ? 6 : 0), wide_ex_planes(KCH, SOFTBOX), wide_ex_planes_hbm(KCH, SOFTBOX)};
+    constexpr bool packed = KCH > 0 && !SOFTBOX && !UNPACKED; // (the packed layouts leave the four box planes out of the LDS map)
+    return WideSet{wide_kernel<M, KCH, SOFT, MERGE, true, 1, SOFTBOX, UNPACKED>(), wide_kernel<M, KCH, SOFT, MERGE, false, 1, SOFTBOX, UNPACKED>(),
+                   wide_kernel<M, KCH, SOFT, MERGE, true, 4, SOFTBOX, UNPACKED>(), wide_kernel<M, KCH, SOFT, MERGE, false, 4, SOFTBOX, UNPACKED>(),
+                   (SOFTBOX || (UNPACKED && KCH > 0)) ? nullptr : resume_kernel<M, KCH, SOFT, MERGE>(),
+                   WL::P_RB0 - (packed ? 4 : 0) + (SOFTBOX ? 6 : 0), wide_ex_planes(KCH, SOFTBOX), wide_ex_planes_hbm(KCH, SOFTBOX)};
 }
 
 // Multiplier read-back (usvmpc_get "lam" / "t"): the inequality multipliers and slacks of every instance's last QP, from the
@@ -1026,7 +1028,7 @@ int launch_pair(usvmpc_handle *h, int phase)
             rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false>, &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, true>,
                                    &usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, true>, wide_set<M, KCH, SOFT, false>())
                        : launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, false>, &usv_qp_rti<M, KCH, SOFT, true, false, false, true>, nullptr,
-                                   KCH == 0 ? wide_set<M, KCH, SOFT, false>() : NO_WIDE);
+                                   wide_set<M, KCH, SOFT, false, false, true>());   // (box rows in planes of their own)
     } else {
         rcq = pack ? launch_qp(&usv_qp_rti<M, KCH, SOFT, false, CANPACK, false>, nullptr) : launch_qp(&usv_qp_rti<M, KCH, SOFT, false, false, false>, nullptr);
     }

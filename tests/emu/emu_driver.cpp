@@ -163,11 +163,11 @@ void qp_wide_body(void *a)
     }
 }
 // ... with soft state bounds (box rows in planes of their own, with or without obstacle rows)
-template <class M, int KCH, bool SOFT, bool LDSWS, int WW = 1>
+template <class M, int KCH, bool SOFT, bool LDSWS, bool SOFTBOX = true, int WW = 1>
 void qp_wide_softbox_body(void *a)
 {
     Job *j = (Job *)a;
-    QpIpm<M, KCH, SOFT, true, false, true, LDSWS, false, false, true, WW> q(*j->P, j->gid, lanes::block_row() == 0 ? 0 : -1);
+    QpIpm<M, KCH, SOFT, true, false, SOFTBOX, LDSWS, false, false, true, WW> q(*j->P, j->gid, lanes::block_row() == 0 ? 0 : -1);
     q.solve(j->qp_phase, j->queue0);
 }
 template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS>
@@ -298,6 +298,16 @@ void run_all(const DevPtrs &P_, const DevSpec &S, int phase, int qp_phase)
                 continue;
             }
             // (the launches of a full SQP - qp_phase 1 / 2 - on the WIDE mapping: over the planes in HBM, where the multipliers persist)
+            if constexpr (KCH >= 1) {
+                if (!pack && g_emu_wide && (qp_phase == 0 || !g_emu_lds_mode) && S.hdiag) { // box rows in planes of their own beside obstacle rows
+                    lds.assign((size_t)QpIpm<M, KCH, SOFT, true, false, false, true, false, false, true, 1>::wide_lds_doubles(S.N) + 16 * 2 * LANES, 0.0);
+                    lanes::g_emu_lds = lds.data();
+                    if (g_emu_lds_mode) lanes::run_group(g, &qp_wide_softbox_body<M, KCH, SOFT, true, false>, &j, 4);
+                    else lanes::run_group(g, &qp_wide_softbox_body<M, KCH, SOFT, false, false>, &j, 4);
+                    g_emu_wide_runs++;
+                    continue;
+                }
+            }
             if (((KCH >= 1 && pack) || KCH == 0) && g_emu_wide && (qp_phase == 0 || !g_emu_lds_mode) && S.hdiag) {
                 lds.assign(wide_lds<M, KCH, SOFT>(S.N), 0.0);
                 lanes::g_emu_lds = lds.data();

@@ -72,6 +72,8 @@ def _compare(name, N, K, B, ticks, opts_a=(("wide", 1), ("wide_waves", 1)), opts
                                                ("usv_model_pf_ca", 80, 20, 64, 3), ("usv_model_pf_ca", 80, 20, 1, 3), ("usv_model_pf_ca", 40, 20, 200, 3),
                                                ("usv_model_pf_ca", 20, 26, 100, 2), ("usv_model_guidance_ca1", 30, 20, 100, 3),
                                                ("usv_model_guidance_ca1", 100, 32, 8, 2),
+                                               # obstacle rows that leave the box rows no idle lanes: box rows in planes of their own (unpacked)
+                                               ("usv_model_pf_ca", 20, 15, 100, 3), ("usv_model_pf_ca", 30, 32, 40, 2), ("usv_model_guidance_ca1", 20, 32, 64, 2),
                                                ("usv_model", 20, 0, 1, 4),                    # BASELINE configs[0]'s shape: no obstacle rows
                                                ("usv_model", 20, 0, 500, 3), ("usv_model", 150, 0, 6, 2)])
 def test_wide_mapping_equals_the_throughput_mapping(name, N, K, B, ticks):

@@ -20,7 +20,9 @@ from tests.test_emu_kernels import emu_rti, _d
                                            # two obstacle chunks (K = 17 .. 32; BASELINE configs[4]'s OCP has K = 20): one row pass (K = 20 + 4 box rows ride in
                                            # the second chunk's idle lanes) and two (usv_model_pf_ca at K = 26: 10 + 7 rows do not fit)
                                            ("usv_model_pf_ca", 6, 20, 2), ("usv_model_pf_ca", 5, 26, 0), ("usv_model_guidance_ca1", 6, 20, 2),
-                                           ("usv_model_guidance_ca1", 5, 32, 0), ("usv_model_pf_ca", 9, 17, 1)])
+                                           ("usv_model_guidance_ca1", 5, 32, 0), ("usv_model_pf_ca", 9, 17, 1),
+                                           # obstacle rows that leave the box rows no idle lanes: box rows in planes of their own (unpacked)
+                                           ("usv_model_pf_ca", 6, 15, 2), ("usv_model_pf_ca", 5, 32, 0), ("usv_model_guidance_ca1", 6, 16, 1)])
 @pytest.mark.parametrize("lds,ww", [(1, 1), (0, 1), (1, 4), (0, 2), (1, 2), (0, 4)])
 def test_wide_mapping_equals_the_16_lane_sweeps_bit_for_bit(emu, name, N, K, rows, lds, ww):
     """lds = 1: the solver's planes in (emulated) LDS; 0: in HBM - the variant for horizons that do not fit a CU's LDS (the row planes

@@ -290,7 +290,7 @@ def test_conditional_predictor_corrector_kernel_bodies_match_oracle(oracle, emu)
     fallback does fire (it moves 5 % of the instances by up to 1e-2: another path into the tolerance ball of a QP with control weight R = 0) -
     statuses equal, iteration counts equal on all but a handful, iterates as close as without the option; a factor nothing can exceed
     leaves the plain iteration's bits."""
-    name, N, K, B = "usv_model_pf_ca", 20, 4, 48
+    name, N, K, B = "usv_model_pf_ca", 20, 4, 40
     wl = scenario.make_bench_batch(name, N, K, B, seed=1234)
     dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
     ocp = usv_models.make_ocp(name, N * dt, N, K)
@@ -304,7 +304,7 @@ def test_conditional_predictor_corrector_kernel_bodies_match_oracle(oracle, emu)
     rng = np.random.default_rng(5)
     moved = agree = total = 0
     try:
-        for t in range(4):
+        for t in range(3):
             emu.usv_emu_set_cpc(0, 2.0)
             e0 = emu_rti(emu, desc, w, x, u)
             emu.usv_emu_set_cpc(1, 1e30)

@@ -222,8 +222,8 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 // kb -+ r of a block - and leave each stage's terms (Gamma, gamma, S_xx ...) in an exchange area of the workgroup's LDS; the
 // Riccati / forward recursion then runs over the block's stages in all four rows alike (a wave64 instruction costs the same for
 // one active row as for four: profiles/r03_exec16_microbench.txt).  Every sum is taken in the order of the 16-lane sweeps, so
-// the results equal theirs bit for bit (lane emulator; on the device to rounding: the compiler contracts the two instantiations
-// differently); only row 0 writes results.
+// the results equal theirs bit for bit - on the lane emulator and, with the contraction rule below, on the device; only row 0 writes
+// results.
 // WW (with WIDE): waves per instance.  The row phase scales on: a workgroup of WW waves shares out the row work of 4 WW consecutive stages
 // (wave w, row r: stage kb -+ (4 w + r)), every wave runs the recursion over the block; the exchange area, the planes in LDS and the
 // parked constants are the workgroup's, phases are separated by workgroup barriers, wave 0 / row 0 writes.  For the single instance and

@@ -85,12 +85,12 @@ __global__ void __launch_bounds__(64 * WW, ((LDSWS || WIDE) ? 1 : qp_waves<KCH, 
 template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS = true, int WW = 1, bool SOFTBOX = false, bool UNPACKED = false>
 constexpr auto wide_kernel()
 {
-    // (two obstacle chunks, K = 17 .. 32 - BASELINE configs[4]'s OCP -, unpacked rows beside obstacle rows and soft state bounds: one wave per
-    // instance; four waves are built for the packed one-chunk layouts and the layout without obstacle rows)
+    // (unpacked rows beside obstacle rows and soft state bounds: one wave per instance; four waves are built for the packed layouts - one or two
+    // obstacle chunks, K = 17 .. 32 being BASELINE configs[4]'s OCP - and the layout without obstacle rows)
     if constexpr (SOFTBOX || (UNPACKED && KCH > 0)) {
         if constexpr (WW == 1 && !MERGE) return &usv_qp_rti<M, KCH, SOFT, true, false, SOFTBOX, LDSWS, false, false, true, 1>;
         else return (decltype(&usv_qp_rti<M, KCH, SOFT, true, false, SOFTBOX, true, false>))nullptr;
-    } else if constexpr (KCH == 1 || (KCH == 2 && WW == 1)) return &usv_qp_rti<M, KCH, SOFT, true, true, false, LDSWS, MERGE, false, true, WW>;
+    } else if constexpr (KCH == 1 || KCH == 2) return &usv_qp_rti<M, KCH, SOFT, true, true, false, LDSWS, MERGE, false, true, WW>;
     else if constexpr (KCH == 0 && !MERGE) return &usv_qp_rti<M, KCH, SOFT, true, false, false, LDSWS, false, false, true, WW>; // (no obstacle rows: box rows in their own planes)
     else return (decltype(&usv_qp_rti<M, KCH, SOFT, true, (KCH > 0), false, true, MERGE>))nullptr;
 }
@@ -330,7 +330,7 @@ struct usvmpc_handle {
     int wide_mode;            // the latency mapping (one instance per wave, QpIpm WIDE): -1 for small batches (default), 0 never, 1 whenever it applies
     long wide_cap;            // waves a launch of the wide kernel holds at once (0: not yet known, -1: does not fit)
     long wide_hbm_cap;        // the same for the wide kernel over planes in HBM (horizons that do not fit LDS)
-    int wide_waves;           // waves per instance of the latency mapping: -1 (default) four for soft-row OCPs while the batch is at most one instance per CU, else one; 1; 4
+    int wide_waves;           // waves per instance of the latency mapping: -1 (default) four for soft-row OCPs and two obstacle chunks while the batch is at most one instance per CU, else one; 1; 4
     long wide4_cap, wide4_hbm_cap; // workgroups of four waves a launch holds at once (0: not yet known, -1: does not fit)
     int last_wide;            // the last RTI launch ran on the wide kernel
     int handover_iter;        // option "handover_iter": IPM iterations after which a row of a drained launch hands its instance to the follow-up launch (0: never)
@@ -835,10 +835,11 @@ int launch_pair(usvmpc_handle *h, int phase)
             const bool lds = h->wide4_cap > 0;
             long cap = lds ? h->wide4_cap : h->wide4_hbm_cap;
             if (cap > 0 && h->max_waves > 0) cap = std::max<long>(1, std::min(cap, h->max_waves / 4)); // option "max_waves" counts wavefronts
-            // default: for the soft-row OCPs only - their row work is the larger share (measured, one instance / 256 instances per tick:
-            // usv_model_guidance_ca1 N = 100 1.78 -> 1.59 / 5.6 -> 5.0 ms, N = 40 0.94 -> 0.86 / 2.05 -> 1.87; usv_model_pf_ca 3 - 7 % SLOWER:
-            // its recursion dominates and pays the barriers)
-            if (cap > 0 && (h->wide_waves == 4 || (SOFT && (long)h->B <= cap))) {
+            // default: where the row work is the larger share - the soft-row OCPs and two obstacle chunks (measured, one instance / 256 instances
+            // per tick: usv_model_guidance_ca1 N = 100 / K = 8 1.78 -> 1.59 / 5.6 -> 5.0 ms, N = 40 / K = 10 0.94 -> 0.86 / 2.05 -> 1.87, N = 80 / K = 20
+            // 4.00 -> 3.00 / 8.1 -> 6.2; usv_model_pf_ca N = 80 / K = 20 6.95 -> 6.22 / 10.4 -> 9.6, with ONE chunk of hard rows 0 - 7 % SLOWER: there
+            // the recursion dominates and pays the barriers)
+            if (cap > 0 && (h->wide_waves == 4 || ((SOFT || KCH == 2) && (long)h->B <= cap))) {
                 long nw = (long)h->B;
                 int q0 = -1;
                 if (h->dynamic_rows && nw > cap) { nw = cap; q0 = (int)nw; }
@@ -1741,7 +1742,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         reset_caps(h);
         return 0;
     }
-    if (s == "wide_waves") { // waves per instance of the latency mapping: -1 (default) four for soft-row OCPs up to one instance per CU, else one; 1; 4
+    if (s == "wide_waves") { // waves per instance of the latency mapping: -1 (default) four for soft-row OCPs / two obstacle chunks up to one instance per CU, else one; 1; 4
         h->wide_waves = value < 0.0 ? -1 : (value >= 4.0 ? 4 : 1);
         reset_caps(h);
         return 0;

@@ -85,6 +85,8 @@ def test_wide_mapping_equals_the_throughput_mapping(name, N, K, B, ticks):
                                                ("usv_model_pf_ca", 21, 9, 5, 3), ("usv_model_guidance_ca1", 100, 8, 1, 4),
                                                ("usv_model_guidance_ca1", 100, 8, 30, 2), ("usv_model_pf_ca", 99, 10, 8, 2),
                                                ("usv_model_pf_ca", 20, 3, 600, 2),      # (more instances than CUs: the rest through the queue)
+                                               ("usv_model_guidance_ca1", 40, 20, 64, 3), ("usv_model_guidance_ca1", 100, 24, 4, 2),   # two obstacle chunks
+                                               ("usv_model_pf_ca", 40, 20, 64, 3), ("usv_model_pf_ca", 80, 20, 16, 2),
                                                ("usv_model", 20, 0, 3, 3)])
 def test_four_waves_per_instance_equal_the_throughput_mapping(name, N, K, B, ticks):
     """Option wide_waves = 4 (usvmpc_last_mapping = 4): a workgroup of four wavefronts - a whole CU - per instance, the row work of 16
@@ -120,8 +122,9 @@ def test_default_takes_the_wide_mapping_for_small_batches_only():
         s.solve()
         assert s.last_mapping() == want, (B, s.last_mapping())
         s.close()
-    # two obstacle chunks (K = 17 .. 32, BASELINE configs[4]'s OCP has K = 20): one wave per instance since round 5, by default for small batches
-    for B, want in ((64, 1), (20000, 0)):
+    # two obstacle chunks (K = 17 .. 32, BASELINE configs[4]'s OCP has K = 20): on the latency mapping since round 5, by default for small
+    # batches - four waves per instance up to one instance per CU (the row work of two chunks is the larger share for hard rows too)
+    for B, want in ((64, 4), (300, 1), (20000, 0)):
         s = _make(name, 20, 20, B, 5, ())
         s.solve()
         assert s.last_mapping() == want, (B, s.last_mapping())

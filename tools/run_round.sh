@@ -25,6 +25,7 @@ python tools/latency_probe.py usv_model_guidance_ca1 100 8 1,16,128,1024 >> $out
 python tools/latency_probe.py usv_model_pf_ca 100 4 1,128,1024 >> $out/latency_probe.txt 2>&1
 python tools/latency_probe.py usv_model 20 0 1,64,1024,2048 >> $out/latency_probe.txt 2>&1   # BASELINE configs[0]'s OCP (one instance) and batches of it
 python tools/latency_probe.py usv_model_pf_ca 80 20 1,64,256,512 >> $out/latency_probe.txt 2>&1   # BASELINE configs[4]'s OCP (two obstacle chunks)
+python tools/latency_probe.py usv_model_guidance_ca1 80 20 1,64,256 >> $out/latency_probe.txt 2>&1   # (two chunks of soft rows)
 # (the single-instance figures the docs quote: a second take, the worse of the two is what gets quoted - VERDICT r04 next 8)
 for m in usv_model_pf_ca usv_model_guidance_ca1; do python tools/latency_probe.py $m 20 3 1; python tools/latency_probe.py $m 40 10 1; done > $out/latency_probe_take2.txt 2>&1
 python tools/latency_probe.py usv_model_guidance_ca1 100 8 1 >> $out/latency_probe_take2.txt 2>&1

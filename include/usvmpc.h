@@ -56,7 +56,7 @@ enum { USVMPC_E_ARG = -1, USVMPC_E_FIELD = -2, USVMPC_E_STAGE = -3, USVMPC_E_SIZ
  * actual dimensions: W ny x ny, W_e nx x nx, Vx ny x nx, Vu ny x nu, Vx_e nx x nx. */
 typedef struct usvmpc_desc {
     int model;
-    int N;
+    int N;                 /* shooting intervals, >= 2 (the reference's OCPs: 20 .. 100); usvmpc_create refuses less */
     double Tf;
     int K;                 /* circular obstacles: nh = K, np = 2K */
     int batch;

@@ -12,7 +12,7 @@ cases = []
 for name in ("usv_model", "usv_model_guidance_ca1", "usv_model_pf_ca"):
     Ks = [0] if name == "usv_model" else [1, 2, 6, 9, 10, 12, 15, 16, 17, 25, 31, 32]
     for K in Ks:
-        for N, B in ((1, 3), (2, 5), (3, 1), (17, 7), (60, 4)):
+        for N, B in ((2, 5), (3, 1), (17, 7), (60, 4)):   # (N = 1 is refused by usvmpc_create: include/usvmpc.h)
             cases.append((name, N, K, B, False))
     if name != "usv_model":
         cases.append((name, 12, 20, 6, True))

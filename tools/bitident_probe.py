@@ -16,7 +16,10 @@ VARIANTS = [("hbm16", (("wide", 0), ("lds_workspace", 0))),
             ("wide4", (("wide", 1), ("wide_waves", 4)))]
 SHAPES = [("usv_model_pf_ca", 20, 3, 256, 4), ("usv_model_pf_ca", 40, 10, 128, 3), ("usv_model_guidance_ca1", 20, 3, 256, 3),
           ("usv_model_guidance_ca1", 40, 10, 64, 3), ("usv_model", 20, 0, 128, 3), ("usv_model_guidance_ca1", 100, 8, 16, 2),
-          ("usv_model_pf_ca", 100, 4, 8, 2)]
+          ("usv_model_pf_ca", 100, 4, 8, 2),
+          # two obstacle chunks (K = 17 .. 32; the four-wave form since r05_e)
+          ("usv_model_pf_ca", 80, 20, 64, 2), ("usv_model_guidance_ca1", 40, 20, 128, 3), ("usv_model_pf_ca", 24, 32, 32, 3),
+          ("usv_model_guidance_ca1", 60, 17, 16, 3)]
 if len(sys.argv) > 1 and sys.argv[1] == "quick":
     SHAPES = SHAPES[:3]
 

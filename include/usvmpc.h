@@ -204,8 +204,8 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  *       sums is added in another lane, so statuses and iteration counts are equal and iterates agree to rounding, not to the bit;
  *       a handle keeps one setting for its lifetime unless the caller changes it;
  *   "wide_waves" (default -1) - wavefronts per instance of the latency mapping: -1 four for OCPs with soft obstacle rows or two obstacle
- *       chunks (K > 16) while the batch is at most one instance per CU (their row work is the larger share: 6 - 25 % per tick), one
- *       otherwise; 1; 4 (built for the packed row layouts and the one without obstacle rows; the others stay at one);
+ *       chunks (K > 16) while the batch is at most one instance per CU - two from N = 40 - (their row work is the larger share: 6 - 25 % per
+ *       tick), one otherwise; 1; 4 (built for the packed row layouts and the one without obstacle rows; the others stay at one);
  *   "wide" (default -1) - the latency mapping, ONE instance per wavefront (usvmpc_last_mapping): -1 while the batch fits the device's
  *       SIMDs twice over, 0 never, 1 whenever the OCP's layout allows it; results do not change by a bit;
  *   "aux_in_lds" (default 1) - an RTI solve keeps the per-stage aux plane (dense box rows, linearisation point, r_g, l_u) in the

@@ -839,7 +839,10 @@ int launch_pair(usvmpc_handle *h, int phase)
             // per tick: usv_model_guidance_ca1 N = 100 / K = 8 1.78 -> 1.59 / 5.6 -> 5.0 ms, N = 40 / K = 10 0.94 -> 0.86 / 2.05 -> 1.87, N = 80 / K = 20
             // 4.00 -> 3.00 / 8.1 -> 6.2; usv_model_pf_ca N = 80 / K = 20 6.95 -> 6.22 / 10.4 -> 9.6, with ONE chunk of hard rows 0 - 7 % SLOWER: there
             // the recursion dominates and pays the barriers)
-            if (cap > 0 && (h->wide_waves == 4 || ((SOFT || KCH == 2) && (long)h->B <= cap))) {
+            // Up to one instance per CU; with the queue and a horizon of 40 or more up to two (tools/latency_probe.py over 13 shapes x 7 batch sizes,
+            // profiles/r05_f_policy_audit.txt: 512 instances 6 - 8 % under one wave each; at N = 20 the second round costs more than the row work saves)
+            const long reach = (h->dynamic_rows && h->N >= 40) ? 2 * cap : cap;
+            if (cap > 0 && (h->wide_waves == 4 || ((SOFT || KCH == 2) && (long)h->B <= reach))) {
                 long nw = (long)h->B;
                 int q0 = -1;
                 if (h->dynamic_rows && nw > cap) { nw = cap; q0 = (int)nw; }
@@ -894,7 +897,10 @@ int launch_pair(usvmpc_handle *h, int phase)
                         h->wide_hbm_cap = -1;
                     if (h->wide_hbm_cap > 0 && h->max_waves > 0) h->wide_hbm_cap = std::min(h->wide_hbm_cap, h->max_waves);
                 }
-                if (h->wide_hbm_cap > 0 && (h->wide_mode > 0 || (long)h->B <= h->wide_hbm_cap)) {
+                // default: an RTI solve while the batch fits the resident waves twice over, as with the planes in LDS (measured at 2 048 instances, N = 80 / 100:
+                // 1.2 - 1.3x the throughput mapping; at 4 096 the throughput mapping is ahead); the launches of a full SQP once (no queue there)
+                const long reach = (phase == 0 && h->dynamic_rows) ? 2 * h->wide_hbm_cap : h->wide_hbm_cap;
+                if (h->wide_hbm_cap > 0 && (h->wide_mode > 0 || (long)h->B <= reach)) {
                     long nw = (long)h->B;
                     int q0 = -1;
                     // (full SQP: one group per workgroup for the whole call - its multipliers persist in the group's planes)

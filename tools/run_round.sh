@@ -26,6 +26,9 @@ python tools/latency_probe.py usv_model_pf_ca 100 4 1,128,1024 >> $out/latency_p
 python tools/latency_probe.py usv_model 20 0 1,64,1024,2048 >> $out/latency_probe.txt 2>&1   # BASELINE configs[0]'s OCP (one instance) and batches of it
 python tools/latency_probe.py usv_model_pf_ca 80 20 1,64,256,512 >> $out/latency_probe.txt 2>&1   # BASELINE configs[4]'s OCP (two obstacle chunks)
 python tools/latency_probe.py usv_model_guidance_ca1 80 20 1,64,256 >> $out/latency_probe.txt 2>&1   # (two chunks of soft rows)
+# policy audit: what the library picks by default against the forced placements (last column), 13 shapes x 7 batch sizes
+for m in usv_model_pf_ca usv_model_guidance_ca1; do for a in "20 3" "40 10" "40 20" "80 20" "100 8" "60 4"; do python tools/latency_probe.py $m $a 64,256,512,1024,2048,4096,8192; done; done > $out/policy_audit.txt 2>&1
+python tools/latency_probe.py usv_model 20 0 64,256,1024,2048,4096,8192 >> $out/policy_audit.txt 2>&1
 # (the single-instance figures the docs quote: a second take, the worse of the two is what gets quoted - VERDICT r04 next 8)
 for m in usv_model_pf_ca usv_model_guidance_ca1; do python tools/latency_probe.py $m 20 3 1; python tools/latency_probe.py $m 40 10 1; done > $out/latency_probe_take2.txt 2>&1
 python tools/latency_probe.py usv_model_guidance_ca1 100 8 1 >> $out/latency_probe_take2.txt 2>&1

@@ -122,6 +122,14 @@ def test_default_takes_the_wide_mapping_for_small_batches_only():
         s.solve()
         assert s.last_mapping() == want, (B, s.last_mapping())
         s.close()
+    # the reaches the policy audit moved (profiles/r05_f_policy_audit.txt): four waves up to TWO instances per CU from N = 40; the latency
+    # mapping over planes in HBM (long horizons) while the batch fits the resident waves twice over
+    for nm, N2, K2, B, want in (("usv_model_guidance_ca1", 40, 10, 400, 4), ("usv_model_guidance_ca1", 40, 10, 600, 0),
+                                ("usv_model_guidance_ca1", 100, 8, 1500, 1), ("usv_model_guidance_ca1", 100, 8, 3000, 0)):
+        s = _make(nm, N2, K2, B, 5, ())
+        s.solve()
+        assert s.last_mapping() == want, (nm, N2, K2, B, s.last_mapping())
+        s.close()
     # two obstacle chunks (K = 17 .. 32, BASELINE configs[4]'s OCP has K = 20): on the latency mapping since round 5, by default for small
     # batches - four waves per instance up to one instance per CU (the row work of two chunks is the larger share for hard rows too)
     for B, want in ((64, 4), (300, 1), (20000, 0)):
@@ -129,3 +137,9 @@ def test_default_takes_the_wide_mapping_for_small_batches_only():
         s.solve()
         assert s.last_mapping() == want, (B, s.last_mapping())
         s.close()
+
+
+@pytest.mark.parametrize("name,N,K,B,want", [("usv_model_guidance_ca1", 40, 10, 400, 4),     # four waves each, the second round through the queue
+                                              ("usv_model_pf_ca", 100, 8, 1500, 1)])          # planes in HBM, more instances than resident waves
+def test_default_mapping_past_one_round_equals_the_throughput_mapping(name, N, K, B, want):
+    _compare(name, N, K, B, 2, opts_a=(), map_a=want)

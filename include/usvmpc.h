@@ -153,6 +153,9 @@ int usvmpc_fail_counts(usvmpc_handle *h, int n, int *counts);
 int usvmpc_unconverged_counts(usvmpc_handle *h, int n, int *counts);
 /* option "handover_iter": how many instances each of the last n RTI launches handed over to its follow-up launch (oldest first, n <= 64) */
 int usvmpc_handover_counts(usvmpc_handle *h, int n, int *counts);
+/* ... and how long that follow-up launch (kernel usv_qp_resume) took, in ms, for each of the last n solves - part of usvmpc_kernel_ms' qp_ms;
+ * 0 for a solve without one */
+int usvmpc_followup_ms(usvmpc_handle *h, int n, float *ms);
 /* option "pipeline_linearize": how many linearisations made ahead of time (on the second stream, beside the previous tick's QP launch)
  * were used by the following solve / discarded because the caller wrote x, u or yref in between.  The lineariser only runs ahead after
  * two solves in a row without such a write, so a caller that sets yref every tick (the reference's protocol) discards none. */
@@ -226,11 +229,13 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  *       switch on and this library leaves off by default (DESIGN.md section 2 lists every HPIPM argument, adopted or not): an IPM iteration whose
  *       corrected step leaves the duality measure above cpc_factor x the predictor's is redone with the centring-only step.  THE option that
  *       changes results beyond rounding (another iteration path to the same tolerance); throughput mapping only;
- *   "handover_iter" (default 0 = off) - RTI launches that pull instances from the queue: once every instance has been handed out, a row
- *       whose instance has passed this many IPM iterations leaves it to a follow-up launch on the latency mapping (one instance per
- *       wavefront over the same workspace planes), which finishes it 1.6x faster per iteration than a lone 16-lane row - the tail of a
- *       65 536-instance launch is a handful of 30 - 50 iteration instances on an otherwise idle device.  Scheduling only: the mappings
- *       return the same bits.  Layouts with a latency mapping (one obstacle chunk / no obstacle rows, no soft state bounds);
+ *   "handover_iter" (default -1) - RTI launches on the throughput mapping: once every instance of the launch has been handed out, a row
+ *       whose instance has passed this many IPM iterations leaves it to a follow-up launch on the latency mapping (kernel usv_qp_resume: one
+ *       instance per wavefront, the suspended solve's planes copied into LDS first), which finishes it at half the time per iteration of a lone
+ *       16-lane row - a launch ends with its 30 - 50 iteration instances on an otherwise idle device.  Scheduling only: the mappings return the
+ *       same bits.  -1: past 24 iterations where the horizon's planes fit a CU's LDS (+1 % at 65 536 instances, +5 ... 15 % at 4 096 ... 12 288),
+ *       never otherwise; 0: never; n > 0: past n.  Layouts: one obstacle chunk / no obstacle rows, packed box rows, no soft state bounds;
+ *   "handover_lds" (default 1) - 0: the follow-up launch works over the planes in HBM whatever the horizon (measured: a loss);
  *   "disturbance_mask" (default all ones) - bit j set: usvmpc_advance adds its noise to state j (the reference's commented
  *       hooks disturb x0[3] and x0[5] only: catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/main.py:181-183). */
 int usvmpc_set_option(usvmpc_handle *h, const char *name, double value);

@@ -351,6 +351,13 @@ class BatchOcpSolver:
         self._check(self._lib.usvmpc_unconverged_counts(self._h, n, a))
         return np.array(a[:])
 
+    def followup_ms(self, n):
+        """Duration (ms) of the follow-up launch of each of the last n RTI solves (kernel usv_qp_resume: the instances the main launch
+        handed over, option "handover_iter"), oldest first; 0 for a solve without one.  Part of kernel_ms' QP time."""
+        a = (C.c_float * n)()
+        self._check(self._lib.usvmpc_followup_ms(self._h, n, a))
+        return np.array(a[:])
+
     def handover_counts(self, n):
         """Instances each of the last n RTI launches handed over to its follow-up launch (option "handover_iter"), oldest first."""
         a = (C.c_int * n)()

@@ -2140,6 +2140,21 @@ struct QpIpm {
     // the instance's record, the group into the list.  The follow-up launch (usvmpc.hip: usv_qp_resume) picks the list up one instance
     // per wave and carries on from exactly that state, on the same planes: the mappings return the same bits, so WHERE an instance
     // is finished does not show in its result (scheduling only; tests/test_gpu_handover.py, emulator tests/test_wide_emu.py).
+    // The resuming wave with its planes in LDS: everything the suspended solve has left in the group's planes in HBM comes in first (the planes of
+    // the LDS map, stage by stage; all rows load, row 0 stores) - one pass over cold planes, after which a pass costs what it costs in LDS.
+    USV_DEV void copy_in() const
+    {
+        if constexpr (WIDE && LDSWS) {
+            for (int k = 0; k <= N; k++) {
+                const lanes::Planes G = wsg(k);
+                const Planes W = ws(k);
+                double v[WL::NPT];
+                sfor<0, WL::NPT>([&](auto p) { if constexpr (WideMap::at(p) >= 0) v[p] = G.ld(p); });
+                sfor<0, WL::NPT>([&](auto p) { if constexpr (WideMap::at(p) >= 0) W.st(p, v[p]); });
+            }
+            wide_sync();
+        }
+    }
     static constexpr bool HAS_CPC = CPC;
     static constexpr bool CAN_SUSPEND = !WIDE && !LDSWS && HDIAG && !SOFTBOX && ((PACK && KCH == 1) || (!PACK && KCH == 0));
     USV_DEV void suspend(bool sel, int it, double a_prev, double sig_prev)
@@ -2207,8 +2222,9 @@ struct QpIpm {
         const bool refill = phase == 0 && queue0 >= 0; // wave-uniform
         constexpr bool cpc = CPC; // option "cond_pred_corr": the host launches this instantiation
         if constexpr (HAS_CPC) { if (cpc) { so_prv = 1.0; so_cur = 1.0; } }
-        if constexpr (WIDE && !LDSWS) {
+        if constexpr (WIDE) {
             if (resume) { // the state the suspending row left (all rows of the wave read the same record)
+                copy_in();
                 const double *r = P.susp_rec + 4 * b;
                 a_prev = r[0]; sig_prev = r[1]; rbscale = r[2]; it = (int)r[3];
                 iters = it;
@@ -2216,7 +2232,7 @@ struct QpIpm {
             }
         }
         // (hand-over: kernel argument, wave-uniform; only launches that refill from a queue have a tail worth handing over)
-        const int hand_it = (CAN_SUSPEND && refill && P.susp_count != nullptr) ? P.handover_iter : 0;
+        const int hand_it = (CAN_SUSPEND && phase == 0 && P.susp_count != nullptr) ? P.handover_iter : 0;
         for (;;) {
             backward<true>(nm, 0.0, pend && !done, a_prev, sig_prev);
             bool fin = late;
@@ -2325,7 +2341,8 @@ struct QpIpm {
             fresh = false;
             if constexpr (CAN_SUSPEND) {
                 if (hand_it > 0) { // wave-uniform
-                    const bool drained = lanes::observe(P.queue) >= nB - queue0; // every instance of the launch has been handed out
+                    // every instance of the launch has been handed out (a launch without a queue: from the start)
+                    const bool drained = !refill || lanes::observe(P.queue) >= nB - queue0;
                     const bool sus = drained && !done && real && it >= hand_it;
                     if (lanes::wave_any(sus)) { // wave-uniform
                         suspend(sus, it, a_prev, sig_prev);

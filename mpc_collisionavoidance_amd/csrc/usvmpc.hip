@@ -95,29 +95,29 @@ constexpr auto wide_kernel()
     else return (decltype(&usv_qp_rti<M, KCH, SOFT, true, (KCH > 0), false, true, MERGE>))nullptr;
 }
 // The follow-up of a launch that handed long runners over (QpIpm::suspend, option "handover_iter"): one wave per suspended instance,
-// on the latency mapping over the planes in HBM - the planes the suspending row was working on.  Workgroup i takes entries i,
-// i + gridDim, ... of the list; with an empty list the launch is a few microseconds.
-template <class M, int KCH, bool SOFT, bool MERGE>
+// on the latency mapping - over the planes in HBM the suspending row was working on, or (LDSWS, horizons that fit) after copying them into
+// LDS, where a pass costs half.  Workgroup i takes entries i, i + gridDim, ... of the list; with an empty list the launch is a few microseconds.
+template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS>
 __global__ void __launch_bounds__(64, 1) usv_qp_resume(DevPtrs P)
 {
     const int n = lanes::uniform(*P.susp_count);
     for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
-        QpIpm<M, KCH, SOFT, true, (KCH > 0), false, false, MERGE, false, true, 1> q(P, (long)P.susp_list[i], (threadIdx.x >> 4) == 0 ? 0 : -1);
+        QpIpm<M, KCH, SOFT, true, (KCH > 0), false, LDSWS, MERGE, false, true, 1> q(P, (long)P.susp_list[i], (threadIdx.x >> 4) == 0 ? 0 : -1);
         q.solve(3, -1);
     }
 }
 using qp_resume_t = void (*)(DevPtrs);
-template <class M, int KCH, bool SOFT, bool MERGE>
+template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS = false>
 constexpr qp_resume_t resume_kernel()
 {
-    if constexpr (KCH == 1 || (KCH == 0 && !MERGE)) return &usv_qp_resume<M, KCH, SOFT, MERGE>;
+    if constexpr (KCH == 1 || (KCH == 0 && !MERGE)) return &usv_qp_resume<M, KCH, SOFT, MERGE, LDSWS>;
     else return nullptr;
 }
 // the wide kernels of one layout: [planes in LDS, planes in HBM] x [one wave, four waves per instance], and the follow-up kernel
 // (nplw: planes per stage an instance keeps in LDS; ex_lds / ex_hbm: planes of the exchange area - qp_ipm.hpp NPLW, EX_N)
 using qp_kernel_t = void (*)(DevPtrs, long, int, int, int);
-struct WideSet { qp_kernel_t lds1, hbm1, lds4, hbm4; qp_resume_t resume; int nplw, ex_lds, ex_hbm; };
-constexpr WideSet NO_WIDE = WideSet{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+struct WideSet { qp_kernel_t lds1, hbm1, lds4, hbm4; qp_resume_t resume, resume_lds; int nplw, ex_lds, ex_hbm; };
+constexpr WideSet NO_WIDE = WideSet{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
 template <class M, int KCH, bool SOFT, bool MERGE, bool SOFTBOX = false, bool UNPACKED = false>
 constexpr WideSet wide_set()
 {
@@ -126,6 +126,7 @@ constexpr WideSet wide_set()
     return WideSet{wide_kernel<M, KCH, SOFT, MERGE, true, 1, SOFTBOX, UNPACKED>(), wide_kernel<M, KCH, SOFT, MERGE, false, 1, SOFTBOX, UNPACKED>(),
                    wide_kernel<M, KCH, SOFT, MERGE, true, 4, SOFTBOX, UNPACKED>(), wide_kernel<M, KCH, SOFT, MERGE, false, 4, SOFTBOX, UNPACKED>(),
                    (SOFTBOX || (UNPACKED && KCH > 0)) ? nullptr : resume_kernel<M, KCH, SOFT, MERGE>(),
+                   (SOFTBOX || (UNPACKED && KCH > 0)) ? nullptr : resume_kernel<M, KCH, SOFT, MERGE, true>(),
                    WL::P_RB0 - (packed ? 4 : 0) + (SOFTBOX ? 6 : 0), wide_ex_planes(KCH, SOFTBOX), wide_ex_planes_hbm(KCH, SOFTBOX)};
 }
 
@@ -311,7 +312,7 @@ struct usvmpc_handle {
     hipStream_t stream;
     bool own_stream;
     static constexpr int RING = 64;      // per-solve event triples, newest at (nsolves-1) % RING
-    hipEvent_t ev[RING][3];
+    hipEvent_t ev[RING][4];   // start | lineariser done | QP phase done | main QP launch done (the follow-up launch of a hand-over comes after it)
     long nsolves;
     DevSpec *d_spec;
     int *d_perm, *d_hist, *d_cursor, *d_iter_prev;
@@ -337,6 +338,8 @@ struct usvmpc_handle {
     int *d_susp_count, *d_susp_list; // [RING] instances each of the last launches handed over / [B] their groups
     double *d_susp_rec;       // [B][4] (DevPtrs::susp_rec)
     long resume_cap;          // workgroups of the follow-up launch (0: not yet known, -1: the kernel cannot be launched)
+    bool ev3_set[RING];       // ev[.][3] was recorded for that solve
+    bool resume_lds, handover_lds; // the follow-up launch copies the planes into LDS (chosen with resume_cap) / option "handover_lds"
     long max_waves;           // cap on the persistent waves of the QP kernel (0: as many as the device holds)
     int ncu;                  // compute units of the device
     long qp_cap;              // groups a full-occupancy launch of the QP kernel holds at once (0: not yet known)
@@ -768,6 +771,7 @@ int launch_pair(usvmpc_handle *h, int phase)
     h->ptrs.redo_words = (h->N + 32) / 32;
     h->ptrs.perm_cur = nullptr;
     h->ptrs.tick = (int)h->nsolves;
+    h->ev3_set[h->nsolves % usvmpc_handle::RING] = false;
     HIP_TRY(h, hipEventRecord(ev[0], h->stream));
     if (use_spec) lin_launch(std::integral_constant<int, 2>{}, h->stream, h->ptrs); // only what the speculative pass had to skip
     else lin_launch(std::integral_constant<int, 0>{}, h->stream, h->ptrs);
@@ -976,29 +980,49 @@ int launch_pair(usvmpc_handle *h, int phase)
         // instances of 30 - 50 iterations on an idling device; past "handover_iter" iterations those go to a follow-up launch on the
         // latency mapping (one instance per wave over the same planes: 1.6x per pass for usv_model_pf_ca at N = 40).  Scheduling only.
         bool hand = false;
-        const size_t xbytes = (size_t)4 * wide.ex_hbm * 128;
-        if (q0 >= 0 && h->handover_iter > 0 && !plain && wide.resume != nullptr && (long)std::min(h->N + 1, 4) * h->Bp * h->spec.npt * 128 < (1L << 32)) {
+        size_t xbytes = (size_t)4 * wide.ex_hbm * 128;
+        qp_resume_t kern_resume = wide.resume;
+        int hand_it = 0;
+        if (phase == 0 && h->handover_iter != 0 && !plain && wide.resume != nullptr && (long)std::min(h->N + 1, 4) * h->Bp * h->spec.npt * 128 < (1L << 32)) {
             if (h->resume_cap == 0) {
+                // (planes in LDS when the horizon fits - option "handover_lds", default on -, else over the planes in HBM)
                 int nb = 0;
-                h->resume_cap = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wide.resume, qp_block, xbytes) == hipSuccess && nb > 0 && h->ncu > 0)
-                                    ? (long)std::min(nb, 4) * h->ncu : -1;
+                hipFuncAttributes fa;
+                const size_t lbytes = (size_t)(h->N + 1) * (size_t)wide.nplw * 128 + (size_t)4 * wide.ex_lds * 128;
+                h->resume_lds = false;
+                if (h->handover_lds && wide.resume_lds != nullptr && lbytes <= 160u * 1024u && hipFuncGetAttributes(&fa, (const void *)wide.resume_lds) == hipSuccess &&
+                    fa.sharedSizeBytes + lbytes <= 160u * 1024u &&
+                    hipFuncSetAttribute((const void *)wide.resume_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lbytes) == hipSuccess &&
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wide.resume_lds, qp_block, lbytes) == hipSuccess && nb > 0 && h->ncu > 0) {
+                    h->resume_cap = (long)std::min(nb, 4) * h->ncu;
+                    h->resume_lds = true;
+                } else {
+                    h->resume_cap = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wide.resume, qp_block, xbytes) == hipSuccess && nb > 0 && h->ncu > 0)
+                                        ? (long)std::min(nb, 4) * h->ncu : -1;
+                }
             }
+            if (h->resume_lds) { kern_resume = wide.resume_lds; xbytes = (size_t)(h->N + 1) * (size_t)wide.nplw * 128 + (size_t)4 * wide.ex_lds * 128; }
             if (h->resume_cap > 0 && !h->d_susp_list) {
                 if (dev_alloc(h, &h->d_susp_count, (size_t)usvmpc_handle::RING, true) || dev_alloc(h, &h->d_susp_list, (size_t)h->B, false) ||
                     dev_alloc(h, &h->d_susp_rec, (size_t)h->B * 4, false))
                     return USVMPC_E_HIP;
             }
-            hand = h->resume_cap > 0;
+            // default (-1): past 24 iterations when the follow-up launch works in LDS (measured over sizes and shapes: +1 % at 65 536 instances,
+            // +5 ... 15 % at 4 096 ... 12 288, never a loss), never when it would run over the planes in HBM (a loss: profiles/r05_handover.txt)
+            hand_it = h->handover_iter > 0 ? h->handover_iter : (h->resume_lds ? 24 : 0);
+            hand = h->resume_cap > 0 && hand_it > 0;
         }
         h->ptrs.susp_count = hand ? h->d_susp_count + h->nsolves % usvmpc_handle::RING : nullptr;
         h->ptrs.susp_list = hand ? h->d_susp_list : nullptr;
         h->ptrs.susp_rec = hand ? h->d_susp_rec : nullptr;
-        h->ptrs.handover_iter = hand ? h->handover_iter : 0;
+        h->ptrs.handover_iter = hand ? hand_it : 0;
         const dim3 qg((unsigned)((ng * LANES + qp_block - 1) / qp_block)), qb(qp_block);
         hipLaunchKernelGGL(kern, qg, qb, aux_bytes, h->stream, h->ptrs, ng, phase, q0, 4);
         if (hand) {
+            HIP_TRY(h, hipEventRecord(ev[3], h->stream));
+            h->ev3_set[h->nsolves % usvmpc_handle::RING] = true;
             const long nwg = std::min<long>(h->resume_cap, (long)h->B);
-            hipLaunchKernelGGL(wide.resume, dim3((unsigned)nwg), dim3(qp_block), xbytes, h->stream, h->ptrs);
+            hipLaunchKernelGGL(kern_resume, dim3((unsigned)nwg), dim3(qp_block), xbytes, h->stream, h->ptrs);
         }
         return 0;
     };
@@ -1293,7 +1317,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->lds_cap = 0;
     h->wide_mode = -1; h->wide_cap = 0; h->wide_hbm_cap = 0; h->last_wide = 0;
     h->wide_waves = -1; h->wide4_cap = 0; h->wide4_hbm_cap = 0;
-    h->handover_iter = 0; h->d_susp_count = nullptr; h->d_susp_list = nullptr; h->d_susp_rec = nullptr; h->resume_cap = 0;
+    h->handover_iter = -1; for (bool &e : h->ev3_set) e = false; h->resume_lds = false; h->handover_lds = true; h->d_susp_count = nullptr; h->d_susp_list = nullptr; h->d_susp_rec = nullptr; h->resume_cap = 0;
     h->max_waves = 0;
     {
         hipDeviceProp_t prop;
@@ -1312,7 +1336,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     HIP_C(hipSetDevice(h->device));
     HIP_C(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (int r = 0; r < usvmpc_handle::RING; r++)
-        for (int i = 0; i < 3; i++) HIP_C(hipEventCreate(&h->ev[r][i]));
+        for (int i = 0; i < 4; i++) HIP_C(hipEventCreate(&h->ev[r][i]));
     const size_t B = h->B, N = h->N, K = h->K;
     const size_t stride = (size_t)h->Bp * LANES;
     const size_t kch = h->kch ? h->kch : 1;
@@ -1401,7 +1425,7 @@ int usvmpc_destroy(usvmpc_handle *h)
     for (void *a : h->allocs) (void)hipFree(a);
     if (h->mirror) (void)hipHostFree(h->mirror);
     for (int r = 0; r < usvmpc_handle::RING; r++)
-        for (int i = 0; i < 3; i++) (void)hipEventDestroy(h->ev[r][i]);
+        for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[r][i]);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -1548,6 +1572,21 @@ int usvmpc_kernel_ms(usvmpc_handle *h, int n, float *linearize_ms, float *qp_ms)
         HIP_TRY(h, hipEventElapsedTime(&b, ev[1], ev[2]));
         if (linearize_ms) linearize_ms[i] = a;
         if (qp_ms) qp_ms[i] = b;
+    }
+    return 0;
+}
+
+int usvmpc_followup_ms(usvmpc_handle *h, int n, float *ms)
+{
+    if (!h || n < 1 || !ms) return USVMPC_E_ARG;
+    if (h->nsolves < n || n > usvmpc_handle::RING) { h->err = "fewer solves recorded than requested"; return USVMPC_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (int i = 0; i < n; i++) { // oldest of the last n first
+        const int r = (h->nsolves - n + i) % usvmpc_handle::RING;
+        ms[i] = 0.0f;
+        if (!h->ev3_set[r]) continue;
+        HIP_TRY(h, hipEventSynchronize(h->ev[r][2]));
+        HIP_TRY(h, hipEventElapsedTime(&ms[i], h->ev[r][3], h->ev[r][2]));
     }
     return 0;
 }
@@ -1775,10 +1814,11 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         return 0;
     }
     if (s == "handover_iter") { // IPM iterations after which a row of a drained launch hands its instance over to the follow-up launch; 0: never
-        if (value < 0.0 || value > 1e6) { h->err = "handover_iter must be >= 0"; return USVMPC_E_ARG; }
-        h->handover_iter = (int)value;
+        if (value > 1e6) { h->err = "handover_iter out of range"; return USVMPC_E_ARG; }
+        h->handover_iter = value < 0.0 ? -1 : (int)value;   // (-1: the default - 24 when the follow-up launch works in LDS, else never)
         return 0;
     }
+    if (s == "handover_lds") { h->handover_lds = value != 0.0; reset_caps(h); return 0; } // the follow-up launch with the planes copied into LDS when the horizon fits (default), or always over the planes in HBM
     if (s == "disturbance_mask") { // bit j: usvmpc_advance adds its noise to state j
         h->noise_mask = (unsigned)value;
         return 0;

@@ -115,6 +115,7 @@ int g_emu_merge = 1;    // 1: box rows processed in their slot lanes when all of
 int g_emu_aux = 0;      // 1: RTI solves of the packed one-chunk layouts keep the aux plane in (emulated) LDS (AUXLDS instantiations)
 int g_emu_wide = 0;     // 1 / 2 / 4: RTI solves of the packed one-chunk layouts on the WIDE mapping, that many emulated waves per instance
 long g_emu_wide_runs = 0; // rows started on the WIDE mapping since the switch was set
+int g_emu_handover_lds = 0; // the follow-up launch copies the planes into LDS (QpIpm::copy_in)
 int g_emu_handover = 0; // > 0: RTI solves on the 16-lane mapping hand instances past this many iterations over once the queue is empty (QpIpm::suspend);
                         // the follow-up pass resumes them on the WIDE mapping over the planes in "HBM" (usv_qp_resume on the device)
 long g_emu_handed = 0;  // instances handed over since the switch was set
@@ -273,7 +274,7 @@ void run_all(const DevPtrs &P_, const DevSpec &S, int phase, int qp_phase)
     std::vector<double> susp_rec((size_t)S.B * 4 + 4, 0.0);
     int susp_count = 0;
     DevPtrs Ph = P_;
-    const bool hand = queue && g_emu_handover > 0 && !g_emu_wide && !g_emu_lds_mode && S.hdiag && !S.any_bsoft && ((KCH == 1 && S.boxpack != 0) || KCH == 0);
+    const bool hand = g_emu_handover > 0 && !g_emu_wide && !g_emu_lds_mode && S.hdiag && !S.any_bsoft && ((KCH == 1 && S.boxpack != 0) || KCH == 0);
     if (hand) { Ph.susp_count = &susp_count; Ph.susp_list = susp_list.data(); Ph.susp_rec = susp_rec.data(); Ph.handover_iter = g_emu_handover; }
     const DevPtrs &P = Ph;
     if (phase & 2)
@@ -330,7 +331,10 @@ void run_all(const DevPtrs &P_, const DevSpec &S, int phase, int qp_phase)
                 lanes::g_emu_lds = lds.data();
                 Job j{&P, (long)susp_list[i], 3, -1};
                 const bool mg = KCH == 1 && g_emu_merge && !S.box_dense;
-                if (mg) run_wide<M, KCH, SOFT, true, false>((long)susp_list[i], j, 1);
+                if (g_emu_handover_lds) {
+                    if (mg) run_wide<M, KCH, SOFT, true, true>((long)susp_list[i], j, 1);
+                    else run_wide<M, KCH, SOFT, false, true>((long)susp_list[i], j, 1);
+                } else if (mg) run_wide<M, KCH, SOFT, true, false>((long)susp_list[i], j, 1);
                 else run_wide<M, KCH, SOFT, false, false>((long)susp_list[i], j, 1);
             }
             g_emu_handed += susp_count;
@@ -444,6 +448,7 @@ extern "C" void usv_emu_set_wide(int wide) { g_emu_wide = wide; g_emu_wide_runs 
 extern "C" long usv_emu_wide_runs() { return g_emu_wide_runs; }
 extern "C" void usv_emu_set_cpc(int on, double factor) { g_emu_cpc = on; g_emu_cpc_factor = factor; }
 extern "C" void usv_emu_set_handover(int iters) { g_emu_handover = iters; g_emu_handed = 0; }
+extern "C" void usv_emu_set_handover_lds(int on) { g_emu_handover_lds = on; }
 extern "C" long usv_emu_handed() { return g_emu_handed; }
 // the next solves also deliver the multipliers / slacks of their QPs (the device's usvmpc_get "lam" / "t"); NULL switches it off
 extern "C" void usv_emu_set_export(double *lam, double *t) { g_emu_lam = lam; g_emu_t = t; }

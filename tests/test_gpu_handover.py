@@ -34,9 +34,15 @@ def _make(name, N, K, B, seed, opts):
     ("usv_model_guidance_ca1", 40, 16, 9000, 6, ()),                   # soft rows, two row passes
     ("usv_model", 20, 0, 12000, 5, (("max_waves", 1024),)),            # no obstacle rows (three waves per SIMD hold 12 288 rows: fewer, so that the queue is used)
     ("usv_model_pf_ca", 20, 3, 12000, 8, (("max_waves", 512),)),       # a quarter of the rows: most of the batch through the queue
+    # (above: the follow-up launch copies the planes into LDS - its default where the horizon fits; below: over the planes in HBM)
+    ("usv_model_pf_ca", 40, 10, 10000, 12, (("handover_lds", 0),)),
+    ("usv_model_guidance_ca1", 20, 8, 12000, 6, (("handover_lds", 0),)),
+    ("usv_model_guidance_ca1", 100, 8, 3000, 5, ()),                   # a horizon that does not fit LDS; every instance resident from the start (no queue)
+    ("usv_model_pf_ca", 40, 10, 3000, 12, ()),                         # a mid-size batch: no queue, the launch is as long as its hardest instances
+    ("usv_model", 20, 0, 5000, 5, ()),
 ])
 def test_handover_does_not_change_a_bit(name, N, K, B, hand, opts):
-    a = _make(name, N, K, B, 1234, (("wide", 0), ("lds_workspace", 0)) + tuple(opts))
+    a = _make(name, N, K, B, 1234, (("wide", 0), ("lds_workspace", 0), ("handover_iter", 0)) + tuple(opts))
     b = _make(name, N, K, B, 1234, (("wide", 0), ("lds_workspace", 0), ("handover_iter", hand)) + tuple(opts))
     handed = 0
     for t in range(3):
@@ -65,7 +71,7 @@ def test_handover_with_the_pipelined_lineariser():
     """Large handles run the next tick's lineariser in the tail of the QP launch, instance by instance as results become final
     (pipeline_linearize): the follow-up launch publishes its instances' epochs like the main launch does."""
     name, N, K, B = "usv_model_pf_ca", 20, 3, 20000
-    a = _make(name, N, K, B, 7, ())
+    a = _make(name, N, K, B, 7, (("handover_iter", 0),))
     b = _make(name, N, K, B, 7, (("handover_iter", 10),))
     for t in range(6):
         a.solve_async(); a.advance(1e-3, seed=t)
@@ -78,3 +84,18 @@ def test_handover_with_the_pipelined_lineariser():
     assert np.array_equal(a.get_int("qp_iter"), b.get_int("qp_iter")) and np.array_equal(a.get("x0", 0), b.get("x0", 0))
     a.close()
     b.close()
+
+
+def test_default_hands_over_where_the_follow_up_works_in_lds():
+    """Default ("handover_iter" = -1): past 24 iterations when the horizon's planes fit a CU's LDS (the follow-up launch copies them in),
+    never when it would have to work over the planes in HBM; the time of the follow-up launch is reported apart (usvmpc_followup_ms)."""
+    for name, N, K, B, want in (("usv_model_pf_ca", 40, 10, 6000, True), ("usv_model_pf_ca", 100, 4, 3000, False), ("usv_model_pf_ca", 40, 20, 3000, False)):
+        s = _make(name, N, K, B, 11, (("wide", 0), ("lds_workspace", 0)))
+        for t in range(3):
+            s.solve(); s.advance(1e-3, seed=t)
+        s.sync()
+        handed, fu, it = int(s.handover_counts(3).sum()), s.followup_ms(3), s.get_int("qp_iter")
+        assert (handed > 0) == want and (fu.max() > 0.0) == want, (name, N, K, handed, fu)
+        if want:
+            assert handed < B and (it >= 24).any() and fu.max() < s.kernel_ms(3)[1].max()   # (the cold first ticks run longer than the last one)
+        s.close()

@@ -81,14 +81,19 @@ def test_handed_over_instances_finish_with_the_same_bits(emu, name, N, K, aux, h
     emu.usv_emu_set_export.argtypes = [_capi._dp, _capi._dp]
     emu.usv_emu_set_export.restype = None
     emu.usv_emu_set_handover.argtypes = [C.c_int]
+    emu.usv_emu_set_handover_lds.argtypes = [C.c_int]
     emu.usv_emu_handed.restype = C.c_long
     emu.usv_emu_set_aux.argtypes = [C.c_int]
     out = []
     try:
         emu.usv_emu_set_mode(0, 2)          # two persistent rows, the other four instances through the queue
         emu.usv_emu_set_aux(aux if K > 0 else 0)
-        for hand in (0, hand_it):
+        # (plain; hand-over with the follow-up pass over the planes in "HBM"; ... with the planes copied into LDS first - QpIpm::copy_in;
+        # ... and from a launch WITHOUT a queue - every instance resident from the start, the case of mid-size batches)
+        for hand, lds, rows in ((0, 0, 2), (hand_it, 0, 2), (hand_it, 1, 2), (hand_it, 1, 0)):
+            emu.usv_emu_set_mode(0, rows)
             emu.usv_emu_set_handover(hand)
+            emu.usv_emu_set_handover_lds(lds)
             lam, t = np.zeros((B, N + 1, nlam)), np.zeros((B, N + 1, nlam))
             emu.usv_emu_set_export(_d(lam), _d(t))
             r = emu_rti(emu, desc, wl, wl["x_init"], wl["u_init"])
@@ -98,8 +103,11 @@ def test_handed_over_instances_finish_with_the_same_bits(emu, name, N, K, aux, h
             out.append((r2["x"], r2["u"], r2["status"], r2["qp_status"], r2["qp_iter"], r2["sl"], r2["su"], r2["pi"], r2["res"], lam.copy(), t.copy()))
     finally:
         emu.usv_emu_set_handover(0)
+        emu.usv_emu_set_handover_lds(0)
+        emu.usv_emu_set_mode(0, 2)
         emu.usv_emu_set_aux(0)
         emu.usv_emu_set_export(None, None)
     assert (out[0][2] == 0).any() and out[0][4].max() >= hand_it
-    for n, (a, b) in enumerate(zip(out[0], out[1])):
-        assert np.array_equal(a, b), (n, np.abs(np.asarray(a, float) - np.asarray(b, float)).max())
+    for v in (1, 2, 3):
+        for n, (a, b) in enumerate(zip(out[0], out[v])):
+            assert np.array_equal(a, b), (v, n, np.abs(np.asarray(a, float) - np.asarray(b, float)).max())

@@ -22,13 +22,22 @@ kname = None
 cond_N = b["config"].get("qp_solver_cond_N")
 cond_N = int(cond_N) if isinstance(cond_N, int) and cond_N != b["config"]["horizon"] else 0   # (partially condensed solve: kernel usv_qp_cond)
 KERN = "qp_cond" if cond_N else "qp_rti"
+fu = None   # the follow-up launch of a hand-over (usv_qp_resume): its bytes and its time belong to the same solve
 for r in csv.reader(open(src + "/pmc_summary.csv")):
     if KERN in r[0]:
         kname, n, f, wv = r[0], int(r[1]), float(r[2]), float(r[3])
+    if KERN == "qp_rti" and "qp_resume" in r[0]:
+        fu = (int(r[1]), float(r[2]), float(r[3]))
 ms = None
+ms_fu = 0.0
 for r in csv.DictReader(open(src + "/trace/t_kernel_stats.csv")):
     if KERN in r["Name"]:
         ms = float(r["AverageNs"]) / 1e6
+    if KERN == "qp_rti" and "qp_resume" in r["Name"]:
+        ms_fu = float(r["AverageNs"]) / 1e6
+if fu is not None:
+    f, wv, ms = f + fu[1], wv + fu[2], ms + ms_fu
+    kname += " + usv_qp_resume"
 tot = (2 * f + wv) * 1024
 pj = dst + "/pmc_traffic.json"
 J = json.load(open(pj))

@@ -112,7 +112,7 @@ def test_round5_lines_carry_the_median_and_the_survey_verbatim_line_exists():
     """every line reports the median of its step times beside the mean ("report median"), and the survey's
     generator to the letter has a committed line of its own next to the builder's variant."""
     import glob
-    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_f_bench*_plain.json")))
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_g_bench*_plain.json")))
     assert len(lines) >= 8
     for fn in lines:
         d = json.load(open(fn))
@@ -122,17 +122,17 @@ def test_round5_lines_carry_the_median_and_the_survey_verbatim_line_exists():
         total = d["config"]["instances_total"] * d["steps"]
         assert abs(d["value"] - ws["solves_per_s_counting_unconverged_ones"] * (1.0 - ws["unconverged_solves_in_timed_region"] / total)) <= 1e-9 * d["value"]
         assert ws["unconverged_counted_over_steps"] == min(d["steps"], 64)
-    v = json.load(open(os.path.join(ROOT, "profiles", "r05_f_bench_survey_verbatim_plain.json")))
+    v = json.load(open(os.path.join(ROOT, "profiles", "r05_g_bench_survey_verbatim_plain.json")))
     w = v["config"]["workload"]
     assert "survey_verbatim" in w and "no obstacle clip" in w and "x_k = x0" in w and "mask 0x3fff" in w
     assert v["parity"]["above_1e-5_without_kkt_certificate_or_beyond_5e-3"] == 0
     ws = v["workload_stats"]
     assert 0.03 < ws["status_nonzero_frac"] < 0.12 and 0.03 < ws["qp_not_converged_frac"] < 0.12 and len(ws["qp_iter_histogram"]) > 20
-    b = json.load(open(os.path.join(ROOT, "profiles", "r05_f_bench_plain.json")))
+    b = json.load(open(os.path.join(ROOT, "profiles", "r05_g_bench_plain.json")))
     assert "obstacle clip" in b["config"]["workload"] and b["value"] > v["value"]
     # the bench's parity leg against the oracle with HPIPM's options
-    it = json.load(open(os.path.join(ROOT, "profiles", "r05_f_bench_oracle_itref2_plain.json")))["parity"]
+    it = json.load(open(os.path.join(ROOT, "profiles", "r05_g_bench_oracle_itref2_plain.json")))["parity"]
     assert it["oracle_options"] == {"itref_corr_max": 2} and it["count_above_1e-5"] == 0 and it["rel_err_per_instance"]["max"] < 1e-5
-    one = json.load(open(os.path.join(ROOT, "profiles", "r05_f_bench_oracle_cpc_device_plain_plain.json")))["parity"]
-    both = json.load(open(os.path.join(ROOT, "profiles", "r05_f_bench_cpc_both_sides_plain.json")))["parity"]
+    one = json.load(open(os.path.join(ROOT, "profiles", "r05_g_bench_oracle_cpc_device_plain_plain.json")))["parity"]
+    both = json.load(open(os.path.join(ROOT, "profiles", "r05_g_bench_cpc_both_sides_plain.json")))["parity"]
     assert one["count_above_1e-5"] > 20 and both["count_above_1e-5"] <= 3 and both["above_1e-5_without_kkt_certificate_or_beyond_5e-3"] == 0

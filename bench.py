@@ -218,7 +218,11 @@ def main():
         from oracle import binding as ob
         per_solve_ms = {"usv_model": 0.12, "usv_model_guidance_ca1": 1.2, "usv_model_pf_ca": 3.5}[name] * N / 40.0 * (1 + 0.15 * (steps - 1))
         S1 = min(B, int(max(32, min(B, 4000.0 / per_solve_ms))))       # ~4 s per tick on one core (batches below 32: all of them)
-        oopts = {kv.split("=")[0]: (float(kv.split("=")[1]) if kv.split("=")[0] == "cpc_factor" else int(float(kv.split("=")[1]))) for kv in args.oracle_opt}
+        def _oval(k, v):   # hpipm_mode=R04, cpc_factor=2.5, itref_corr_max=0 ...
+            if k == "hpipm_mode":
+                return v
+            return float(v) if k in ("cpc_factor", "mu0", "alpha_min", "thr0") else int(float(v))
+        oopts = {kv.split("=")[0]: _oval(*kv.split("=")[:2]) for kv in args.oracle_opt}
         spec = ob.spec(_ID[name], N, N * dt, K, sim_steps=steps, **oopts)
         x0o = wl["x0"][:S1].copy()
         errs, errs_x, errs_u = [], [], []
@@ -294,7 +298,9 @@ def main():
                   "kkt_certified_frac": n_cert / float(max(1, n_conv_dev)),
                   "kkt": "every solve the device reports converged, checked against the KKT conditions of its QP (stat <= 1e-6, "
                          "eq / ineq / comp <= 1e-8, lam, t >= 0) by tests/kkt.py on the oracle's linearisation: %d of %d" % (n_cert, n_conv_dev),
-                  "oracle_options": oopts or "defaults (oracle/usv_oracle.h: plain Mehrotra iteration, no cond_pred_corr, no iterative refinement)",
+                  "oracle_options": dict({"hpipm_mode": "BALANCE"}, **oopts),
+                  "oracle_profile": "oracle/usv_oracle.c usv_opts_profile: HPIPM mode + acados' overwrites as recalled (BALANCE: mu0 1, alpha_min 1e-8, "
+                                    "cond_pred_corr 1, itref_corr_max 2); the device runs its descriptor's profile (config.hpipm_mode)",
                   "vs": "CPU oracle (port; parity vs acados itself is unpinned); closed loop, every tick from the iterate "
                         "and x0 the device starts it from; error of an instance = max over (x, u) components of |dev - oracle| / "
                         "(that component's max |oracle| over the sample)"}

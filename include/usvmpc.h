@@ -49,6 +49,18 @@ enum { USVMPC_MODEL_USV = 0,             /* `usv_model`              nx 5  nu 2 
        USVMPC_MODEL_GENERATED = 3 };     /* model compiled into THIS library from a symbolic definition
                                             (mpc_collisionavoidance_amd/codegen.py); only in libraries built for it */
 
+/* The QP solver's argument profile.  The reference selects HPIPM through acados (qp_solver = "PARTIAL_CONDENSING_HPIPM":
+ * catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/acados_settings.py:172, usv_guidance_ca1/acados_settings.py:190) and leaves every knob at its default
+ * (the tolerances are there, commented: :183-186 / :198-204), i.e. at what acados' ocp_qp_hpipm_opts_initialize_default produces: one of HPIPM's
+ * modes (d_ocp_qp_ipm_arg_set_default) plus acados' own overwrites.  Neither source tree is in /root/reference; DESIGN.md section 2 lists every
+ * field as recalled.  The modes differ, for this library, in nothing the kernels do (iterative refinement and the LQ fall-back are the checker's
+ * business: oracle/usv_oracle.h); they are kept apart so that a binding can pass acados' `hpipm_mode` through:
+ *   BALANCE / SPEED / ROBUST  cond_pred_corr = 1 (HPIPM, every mode), mu0 = 1, alpha_min = 1e-8, tolerances 1e-6 / 1e-8 / 1e-8 / 1e-8,
+ *                             iter_max = 50 (acados' overwrites of the mode's values)
+ *   R04                       this library's behaviour up to its round 5: cond_pred_corr = 0, mu0 = 10, alpha_min = 1e-12 (HPIPM's own
+ *                             mode values without acados' overwrites) - kept reachable for comparison */
+enum { USVMPC_HPIPM_BALANCE = 0, USVMPC_HPIPM_SPEED = 1, USVMPC_HPIPM_ROBUST = 2, USVMPC_HPIPM_R04 = 3 };
+
 enum { USVMPC_E_ARG = -1, USVMPC_E_FIELD = -2, USVMPC_E_STAGE = -3, USVMPC_E_SIZE = -4,
        USVMPC_E_HIP = -5, USVMPC_E_NODEVICE = -6 };
 
@@ -86,14 +98,23 @@ typedef struct usvmpc_desc {
      * the NLP residuals stat / eq / ineq / comp (0 is read as 1e-6, the acados default) */
     int nlp_max_iter;
     double nlp_tol_stat, nlp_tol_eq, nlp_tol_ineq, nlp_tol_comp;
+    /* QP solver profile (USVMPC_HPIPM_*; usvmpc_hpipm_profile fills the fields it governs: mu0, alpha_min, the tolerances, qp_iter_max and the
+     * two below) and HPIPM's conditional predictor-corrector: 1 = a corrected step that leaves the duality measure above cpc_factor (0 is read
+     * as 2) x the predictor's mu_aff is redone with the centring-only step */
+    int hpipm_mode;
+    int cond_pred_corr;
+    double cpc_factor;
 } usvmpc_desc;
 
 typedef struct usvmpc_handle usvmpc_handle;
 
 /* nx, nu of a model id; returns 0 or USVMPC_E_ARG */
 int usvmpc_model_dims(int model, int *nx, int *nu);
-/* solver option defaults (iter_max 50, mu0 10, thr0 0.1, tolerances 1e-6/1e-8, alpha_min 1e-12) */
+/* solver option defaults: thr0 0.1, one RK4 step per interval, the NLP tolerances, and the QP solver profile USVMPC_HPIPM_BALANCE
+ * (iter_max 50, mu0 1, tolerances 1e-6/1e-8, alpha_min 1e-8, cond_pred_corr 1) */
 void usvmpc_default_options(usvmpc_desc *d);
+/* the fields of d that the QP solver profile `mode` governs (above); returns 0 or USVMPC_E_ARG */
+int usvmpc_hpipm_profile(usvmpc_desc *d, int mode);
 
 int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out);
 int usvmpc_destroy(usvmpc_handle *h);
@@ -224,11 +245,15 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  *       of one synchronising copy per call (the reference issues 3N+4 setters per tick: scripts/usv_guidance_ca1/main.py:
  *       123-130, src/nmpc_guidance_ca1.cpp:567-574); x / u / status come back in one copy and usvmpc_get "x" / "u" is served
  *       from it.  0 switches it off for the handle (it cannot be switched on again);
- *   "cond_pred_corr" (default 0 = off), "cpc_factor" (default 2) - HPIPM's conditional predictor-corrector, an option of the QP solver the
- *       reference selects (qp_solver = PARTIAL_CONDENSING_HPIPM: catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/acados_settings.py:172) that its modes
- *       switch on and this library leaves off by default (DESIGN.md section 2 lists every HPIPM argument, adopted or not): an IPM iteration whose
- *       corrected step leaves the duality measure above cpc_factor x the predictor's is redone with the centring-only step.  THE option that
- *       changes results beyond rounding (another iteration path to the same tolerance); throughput mapping only;
+ *   "hpipm_mode" (USVMPC_HPIPM_*; default: the descriptor's) - re-applies a QP solver profile to the handle: mu0, alpha_min and cond_pred_corr
+ *       as the profile says (tolerances and iter_max are the same in every profile and keep the descriptor's values);
+ *   "cond_pred_corr" (default: the descriptor's, 1 in every profile but R04), "cpc_factor" (default 2) - HPIPM's conditional predictor-corrector,
+ *       an option of the QP solver the reference selects (qp_solver = PARTIAL_CONDENSING_HPIPM: catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/
+ *       acados_settings.py:172) that every mode acados can pick switches on (DESIGN.md section 2 lists every HPIPM argument, adopted or not): an
+ *       IPM iteration whose corrected step leaves the duality measure above cpc_factor x the predictor's is redone with the centring-only step.
+ *       THE option that changes results beyond rounding (another iteration path to the same tolerance).  The test is built into every kernel -
+ *       every mapping, the follow-up launch of the hand-over, the launches of a full SQP, the partially condensed solve; switched off, the same
+ *       kernels return the bits of kernels without it;
  *   "handover_iter" (default -1) - RTI launches on the throughput mapping: once every instance of the launch has been handed out, a row
  *       whose instance has passed this many IPM iterations leaves it to a follow-up launch on the latency mapping (kernel usv_qp_resume: one
  *       instance per wavefront, the suspended solve's planes copied into LDS first), which finishes it at half the time per iteration of a lone

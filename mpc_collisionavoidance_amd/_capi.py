@@ -36,7 +36,12 @@ class Desc(C.Structure):
                 ("zl_bx", C.c_double * NXM), ("zu_bx", C.c_double * NXM), ("Zl_bx", C.c_double * NXM), ("Zu_bx", C.c_double * NXM),
                 ("sim_num_steps", C.c_int), ("nlp_max_iter", C.c_int),
                 ("nlp_tol_stat", C.c_double), ("nlp_tol_eq", C.c_double), ("nlp_tol_ineq", C.c_double),
-                ("nlp_tol_comp", C.c_double)]
+                ("nlp_tol_comp", C.c_double),
+                ("hpipm_mode", C.c_int), ("cond_pred_corr", C.c_int), ("cpc_factor", C.c_double)]
+
+
+# QP solver profiles (include/usvmpc.h, USVMPC_HPIPM_*): acados' `hpipm_mode` names, and this library's behaviour up to round 5
+HPIPM_MODES = {"BALANCE": 0, "SPEED": 1, "ROBUST": 2, "R04": 3}
 
 
 def lib_path():
@@ -49,7 +54,7 @@ def lib_path():
 # leaves torch unable to initialise its device.  Recorded here so the torch helpers can say so.
 loaded_before_torch = False
 
-EXPORTS = ["usvmpc_model_dims", "usvmpc_default_options", "usvmpc_create", "usvmpc_destroy",
+EXPORTS = ["usvmpc_model_dims", "usvmpc_default_options", "usvmpc_hpipm_profile", "usvmpc_create", "usvmpc_destroy",
            "usvmpc_set", "usvmpc_get", "usvmpc_get_int", "usvmpc_solve", "usvmpc_solve_sqp", "usvmpc_solve_async",
            "usvmpc_sync", "usvmpc_get_device_ptr", "usvmpc_last_kernel_ms", "usvmpc_kernel_ms", "usvmpc_tick_ms", "usvmpc_fail_counts", "usvmpc_unconverged_counts", "usvmpc_handover_counts", "usvmpc_followup_ms", "usvmpc_pipeline_stats", "usvmpc_last_mapping",
            "usvmpc_advance", "usvmpc_set_stream", "usvmpc_set_option", "usvmpc_calibrate_traffic", "usvmpc_guidance_reset", "usvmpc_guidance_prepare", "usvmpc_guidance_sense",
@@ -82,6 +87,7 @@ def load(path):
     L.usvmpc_model_dims.argtypes = [C.c_int, _ip, _ip]
     L.usvmpc_default_options.argtypes = [C.POINTER(Desc)]
     L.usvmpc_default_options.restype = None
+    L.usvmpc_hpipm_profile.argtypes = [C.POINTER(Desc), C.c_int]
     L.usvmpc_create.argtypes = [C.POINTER(Desc), C.POINTER(C.c_void_p)]
     L.usvmpc_destroy.argtypes = [C.c_void_p]
     L.usvmpc_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _dp, C.c_size_t]
@@ -143,12 +149,27 @@ def _fill(dst, src, n, what="array"):
         dst[i] = a[i]
 
 
+def hpipm_profile(d, mode):
+    """The fields of the descriptor a QP solver profile governs (mirrors usvmpc_hpipm_profile / host_spec.hpp); mode: a name of
+    HPIPM_MODES or its number."""
+    m = HPIPM_MODES.get(str(mode).upper(), mode) if not isinstance(mode, int) else mode
+    if m not in HPIPM_MODES.values():
+        raise Exception("hpipm_mode must be one of %s" % ", ".join(HPIPM_MODES))
+    r04 = m == HPIPM_MODES["R04"]
+    d.hpipm_mode = m
+    d.qp_iter_max = 50
+    d.tol_stat, d.tol_eq, d.tol_ineq, d.tol_comp = 1e-6, 1e-8, 1e-8, 1e-8
+    d.mu0 = 10.0 if r04 else 1.0
+    d.alpha_min = 1e-12 if r04 else 1e-8
+    d.cond_pred_corr = 0 if r04 else 1
+    d.cpc_factor = 2.0
+    return d
+
+
 def default_options(d):
     """Solver option defaults (mirrors usvmpc_default_options so that it works without the .so)."""
-    d.qp_iter_max = 50
-    d.mu0, d.thr0 = 10.0, 0.1
-    d.tol_stat, d.tol_eq, d.tol_ineq, d.tol_comp = 1e-6, 1e-8, 1e-8, 1e-8
-    d.alpha_min = 1e-12
+    hpipm_profile(d, HPIPM_MODES["BALANCE"])
+    d.thr0 = 0.1
     d.sim_num_steps = 1
     d.nlp_max_iter = 100
     d.nlp_tol_stat = d.nlp_tol_eq = d.nlp_tol_ineq = d.nlp_tol_comp = 1e-6
@@ -261,6 +282,8 @@ def desc_from_ocp(ocp, batch=1, device=0, generated=False):
         raise Exception("usv_model_guidance_ca1 is built with soft obstacle rows")
     if mid == 2 and d.soft:
         raise Exception("usv_model_pf_ca is built with hard obstacle rows")
+    if getattr(opts, "hpipm_mode", None) is not None:   # (before the individual knobs: they override the profile's values)
+        hpipm_profile(d, opts.hpipm_mode)
     if opts.qp_solver_iter_max is not None:
         d.qp_iter_max = int(opts.qp_solver_iter_max)
     for src, dst in (("qp_solver_tol_stat", "tol_stat"), ("qp_solver_tol_eq", "tol_eq"),

@@ -106,6 +106,10 @@ class AcadosOcpOptions:
         self.nlp_solver_type = "SQP_RTI"
         self.hessian_approx = "GAUSS_NEWTON"
         self.integrator_type = "ERK"
+        # acados' `hpipm_mode` ("BALANCE" - its default -, "SPEED", "ROBUST"): the QP solver's argument profile; the reference never sets it
+        # (usv_pf_ca/acados_settings.py:172-186).  "R04" selects this package's behaviour up to its round 5 (include/usvmpc.h, USVMPC_HPIPM_*).
+        # None = "BALANCE".  The knobs below override the profile's values.
+        self.hpipm_mode = None
         self.qp_solver_iter_max = None
         self.qp_solver_tol_stat = None
         self.qp_solver_tol_eq = None

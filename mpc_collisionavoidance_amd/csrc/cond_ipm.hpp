@@ -119,6 +119,8 @@ struct CondIpm {
         const int *box_pos;           // LDS
         int N, K, B, Bp, npt, hdiag, p_static, iter_max, nbu, nbx, nc;
         double thr0, mu0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min;
+        int cpc;            // option "cond_pred_corr" (qp_ipm.hpp, QpIpm::solve: the same rule on the dense stages)
+        double cpc_factor;
     };
     const DevPtrs &P;
     SpecLocal S;
@@ -131,6 +133,9 @@ struct CondIpm {
     double *Gm, *SRm, *Sm, *Sn, *Tm, *BAm, *PBm, *Pn, *BAk, *del, *delo, *dela, *delf, *yxr, *yxg, *wd, *wxy, *yur, *yug, *wu, *obuf, *red;
     double *vw, *vdwa, *vdw, *vr, *vgt, *vrq, *vg0, *vt, *vpi, *vpin, *vxn, *vpv, *vPb, *vrb, *vbt, *vdx, *vdxn, *vtmp, *vlus, *vq, *vgk, *vzb, *vdz, *vcr, *vdg;
     struct Norms { double rg, rb, rd, rm, musum; bool bad; };
+    // second-order factor of the corrector targets of this pass / of the pending step: 0 where the corrected step was refused and the
+    // centring-only one taken (the team holds one instance: a scalar)
+    double so_cur = 1.0, so_prv = 1.0;
 
     USV_CDEV CondIpm(const DevPtrs &P_, const CondDims &Dg, double *scratch, double *lds) : P(P_), cw(scratch)
     {
@@ -141,6 +146,7 @@ struct CondIpm {
         S.iter_max = Sg.iter_max; S.nbu = Sg.nbu; S.nbx = Sg.nbx; S.nc = Sg.nc;
         S.thr0 = Sg.thr0; S.mu0 = Sg.mu0; S.tol_stat = Sg.tol_stat; S.tol_eq = Sg.tol_eq; S.tol_ineq = Sg.tol_ineq; S.tol_comp = Sg.tol_comp;
         S.alpha_min = Sg.alpha_min;
+        S.cpc = Sg.cpc; S.cpc_factor = Sg.cpc_factor;
         D.Mb = Dg.Mb; D.N2 = Dg.N2; D.N1 = Dg.N1; D.R1 = Dg.R1; D.nuh = Dg.nuh; D.nzh = Dg.nzh; D.nxr = Dg.nxr; D.R = Dg.R; D.nrows = Dg.nrows; D.nbu = Dg.nbu; D.nbx = Dg.nbx;
         D.ipx = Dg.ipx; D.ipy = Dg.ipy;
         D.o_SR = (int)Dg.o_SR; D.o_cr = (int)Dg.o_cr; D.o_BA = (int)Dg.o_BA; D.o_bt = (int)Dg.o_bt; D.o_H0 = (int)Dg.o_H0; D.o_g0 = (int)Dg.o_g0;
@@ -598,7 +604,7 @@ struct CondIpm {
                     else if (q < D.nbu + D.nbx) vo = delo[j * nxr + D.xvar[q - D.nbu]];
                     else vo = rw[6 * nrows] * delo[j * nxr + D.ipx] + rw[7 * nrows] * delo[j * nxr + D.ipy];
                     double g0_, g1_;
-                    r.resid(vo); r.targets_pred(); r.reduce(g0_, g1_); r.expand(wa); r.targets_corr(sig_prev); r.reduce(g0_, g1_);
+                    r.resid(vo); r.targets_pred(); r.reduce(g0_, g1_); r.expand(wa); r.template targets_corr<true>(sig_prev, so_prv); r.reduce(g0_, g1_);
                     r.expand(wf); r.apply(a_prev);
                     rw[0] = r.ll; rw[nrows] = r.lu; rw[2 * nrows] = r.tl; rw[3 * nrows] = r.tu;
                     if constexpr (SOFT) {
@@ -759,7 +765,7 @@ struct CondIpm {
             TM::sync();
             row_pass(i, W, true, [&](int, int, int, Row &r, double *, double v, double wa, double, double &yr, double &yg, double &Gh) {
                 double g0_, g1_;
-                r.resid(v); r.targets_pred(); r.reduce(g0_, g1_); r.expand(wa); r.targets_corr(sigmu); r.reduce(Gh, yg);
+                r.resid(v); r.targets_pred(); r.reduce(g0_, g1_); r.expand(wa); r.template targets_corr<true>(sigmu, so_cur); r.reduce(Gh, yg);
                 yr = 0.0;
             });
             rows_transposed(vgt, yxg, yug);
@@ -827,9 +833,9 @@ struct CondIpm {
             row_pass(i, W, false, [&](int, int, int, Row &r, double *, double v, double wa, double wf, double &, double &, double &) {
                 double g0_, g1_;
                 r.resid(v); r.targets_pred(); r.reduce(g0_, g1_); r.expand(wa);
-                if (corr) { r.targets_corr(sigmu); r.reduce(g0_, g1_); r.expand(wf); }
+                if (corr) { r.template targets_corr<true>(sigmu, so_cur); r.reduce(g0_, g1_); r.expand(wf); }
                 qmax = r.blocking(qmax);
-                if (!corr && r.act) {
+                if (r.act) { // (the sums of mu(alpha): of the affine step for sigma, of the corrected step for the conditional test)
                     s1 += r.ll * r.dtl + r.tl * r.dll + r.lu * r.dtu + r.tu * r.dlu;
                     s2 += r.dll * r.dtl + r.dlu * r.dtu;
                     if constexpr (SOFT) {
@@ -849,7 +855,7 @@ struct CondIpm {
         }
         qmax = TM::rmax(qmax, red);
         alpha = 1.0 / qmax;
-        if (!corr) { S1 = TM::rsum(s1, red); S2 = TM::rsum(s2, red); }
+        S1 = TM::rsum(s1, red); S2 = TM::rsum(s2, red);
     }
 
     // ------------------------------------------------------------------ expansion + RTI step + outputs
@@ -985,6 +991,7 @@ struct CondIpm {
         g = group;
         b = P.perm ? (long)P.perm[g] : g;
         const bool bad0 = condense();
+        so_cur = 1.0; so_prv = 1.0;
         int status = bad0 ? 4 : 1, it = 0;
         Norms nm{0.0, 0.0, 0.0, 0.0, 0.0, false};
         bool pend = false;
@@ -998,17 +1005,27 @@ struct CondIpm {
             const double mu = nc > 0.0 ? nm.musum / nc : 0.0;
             double a_aff = 1.0, S1 = 0.0, S2 = 0.0, a = 1.0, d1, d2;
             forward(false, 0.0, a_aff, S1, S2);
-            double sigmu = 0.0;
+            double sigmu = 0.0, mu_aff = 0.0;
             if (nc > 0.0) {
-                const double mu_aff = (nm.musum + a_aff * S1 + a_aff * a_aff * S2) / nc;
+                mu_aff = (nm.musum + a_aff * S1 + a_aff * a_aff * S2) / nc;
                 const double sg = mu_aff / mu;
                 sigmu = sg * sg * sg * mu;
             }
+            so_cur = 1.0;
             backward_rhs(sigmu);
             forward(true, sigmu, a, d1, d2);
+            if (S.cpc && nc > 0.0) { // HPIPM's conditional predictor-corrector (QpIpm::solve): refused -> the centring-only step
+                const double mu_pc = (nm.musum + a * d1 + a * a * d2) / nc;
+                if (mu_pc > S.cpc_factor * mu_aff) {
+                    so_cur = 0.0;
+                    backward_rhs(sigmu);
+                    forward(true, sigmu, a, d1, d2);
+                }
+            }
             if (a < S.alpha_min) { status = 2; break; }
             a_prev = a * ((1.0 - a) * 0.99 + a * 0.9999999);
             sig_prev = sigmu;
+            so_prv = so_cur;
             pend = true;
             it++;
         }

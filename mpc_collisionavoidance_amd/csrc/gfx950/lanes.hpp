@@ -328,6 +328,9 @@ struct Stash {
     }
     USV_DEV static void put(int slot, double v) { area()[slot * WLANES + (threadIdx.x & (unsigned)(WLANES - 1))] = v; }
     USV_DEV static double get(int slot) { return area()[slot * WLANES + (threadIdx.x & (unsigned)(WLANES - 1))]; }
+    // two small values sharing one slot (halves 0 / 1, kept as floats: exact for flags and small integers)
+    USV_DEV static void puth(int slot, int half, double v) { ((float *)area())[2 * (slot * WLANES + (threadIdx.x & (unsigned)(WLANES - 1))) + half] = (float)v; }
+    USV_DEV static double geth(int slot, int half) { return (double)((const float *)area())[2 * (slot * WLANES + (threadIdx.x & (unsigned)(WLANES - 1))) + half]; }
 };
 
 // The same planes held in the CU's LDS instead of HBM (small batches: the whole horizon of an instance's planes fits in

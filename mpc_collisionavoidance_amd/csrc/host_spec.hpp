@@ -156,7 +156,10 @@ inline std::string build_spec(const usvmpc_desc &d, DevSpec &S)
     if (S.iter_max < 1) return "qp_iter_max must be >= 1";
     if (d.sim_num_steps < 0 || d.sim_num_steps > 64) return "sim_num_steps out of range (1..64)";
     S.sim_steps = d.sim_num_steps > 0 ? d.sim_num_steps : 1;
-    S.cpc = 0; S.cpc_factor = 2.0; // (option "cond_pred_corr": off - DESIGN.md section 2)
+    if (d.hpipm_mode < USVMPC_HPIPM_BALANCE || d.hpipm_mode > USVMPC_HPIPM_R04) return "hpipm_mode must be one of USVMPC_HPIPM_*";
+    if (d.cpc_factor < 0.0) return "cpc_factor must be positive (0: the default, 2)";
+    S.cpc = d.cond_pred_corr != 0 ? 1 : 0;
+    S.cpc_factor = d.cpc_factor > 0.0 ? d.cpc_factor : 2.0;
     S.nlp_tol[0] = d.nlp_tol_stat > 0.0 ? d.nlp_tol_stat : 1e-6;
     S.nlp_tol[1] = d.nlp_tol_eq > 0.0 ? d.nlp_tol_eq : 1e-6;
     S.nlp_tol[2] = d.nlp_tol_ineq > 0.0 ? d.nlp_tol_ineq : 1e-6;
@@ -168,12 +171,27 @@ inline std::string build_spec(const usvmpc_desc &d, DevSpec &S)
 // entries per stage of the multiplier vectors usvmpc_get "lam" / "t" return (DevSpec: 2 (nrow + ns))
 inline int lam_len(const DevSpec &S, bool soft) { return 2 * (S.nbu + S.nbx + S.K + S.nsbx + (soft ? S.K : 0)); }
 
+// The fields of the descriptor a QP solver profile governs (include/usvmpc.h, USVMPC_HPIPM_*; DESIGN.md section 2: HPIPM's mode values as set by
+// d_ocp_qp_ipm_arg_set_default and acados' overwrites in ocp_qp_hpipm_opts_initialize_default, as recalled).  The oracle has the same table
+// (oracle/usv_oracle.c, usv_opts_profile) plus the two fields only it implements (itref_corr_max).
+inline bool hpipm_profile(usvmpc_desc &d, int mode)
+{
+    if (mode < USVMPC_HPIPM_BALANCE || mode > USVMPC_HPIPM_R04) return false;
+    const bool r04 = mode == USVMPC_HPIPM_R04;
+    d.hpipm_mode = mode;
+    d.qp_iter_max = 50;                                                                  // acados (HPIPM: 15 / 30 / 100)
+    d.tol_stat = 1e-6; d.tol_eq = 1e-8; d.tol_ineq = 1e-8; d.tol_comp = 1e-8;            // acados (HPIPM: 1e-8 each)
+    d.mu0 = r04 ? 10.0 : 1.0;                                                            // acados: 1 (HPIPM: 10 / 10 / 100)
+    d.alpha_min = r04 ? 1e-12 : 1e-8;                                                    // acados: 1e-8 (HPIPM: 1e-12)
+    d.cond_pred_corr = r04 ? 0 : 1;                                                      // HPIPM: 1 in SPEED, BALANCE and ROBUST
+    d.cpc_factor = 2.0;
+    return true;
+}
+
 inline void default_options(usvmpc_desc &d)
 {
-    d.qp_iter_max = 50;
-    d.mu0 = 10.0; d.thr0 = 0.1;
-    d.tol_stat = 1e-6; d.tol_eq = 1e-8; d.tol_ineq = 1e-8; d.tol_comp = 1e-8;
-    d.alpha_min = 1e-12;
+    hpipm_profile(d, USVMPC_HPIPM_BALANCE);
+    d.thr0 = 0.1;
     d.sim_num_steps = 1;
     d.nlp_max_iter = 100;
     d.nlp_tol_stat = d.nlp_tol_eq = d.nlp_tol_ineq = d.nlp_tol_comp = 1e-6;

@@ -228,12 +228,12 @@ USV_DEV void obs_dist(double dx, double dy, double &d, double &ux, double &uy)
 // (wave w, row r: stage kb -+ (4 w + r)), every wave runs the recursion over the block; the exchange area, the planes in LDS and the
 // parked constants are the workgroup's, phases are separated by workgroup barriers, wave 0 / row 0 writes.  For the single instance and
 // the few dozen: a CU (WW = 4) or half a CU (WW = 2) per instance.
-// CPC: HPIPM's conditional predictor-corrector built in (option "cond_pred_corr"; QpIpm::solve) - instantiations of their own, launched
-// when the option is on: the stock kernels carry none of it.
+// CPC: HPIPM's conditional predictor-corrector built in (option "cond_pred_corr", on in every HPIPM mode acados can select: DESIGN.md
+// section 2; QpIpm::solve) - since round 6 in EVERY kernel (the parameter is kept so that a build without it can be measured against: it
+// costs the sums of mu(alpha) in forward B and one LDS slot); the option switches the test, not the kernel.
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX = false, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false,
-          bool WIDE = false, int WW = 1, bool CPC = false>
+          bool WIDE = false, int WW = 1, bool CPC = true>
 struct QpIpm {
-    static_assert(!CPC || (!WIDE && !LDSWS), "the conditional predictor-corrector is built into the throughput sweeps over planes in HBM");
     static_assert(WW == 1 || (WIDE && (WW == 2 || WW == 4)), "several waves per instance: the wide mapping only");
     static_assert(!WIDE || (HDIAG && !AUXLDS), "the wide mapping works on every row layout of an OCP with a diagonal Hessian");
     static_assert(!MERGE || PACK, "merged row pass works on the packed layout");
@@ -372,7 +372,7 @@ struct QpIpm {
         ST_BSL = ST_QU + (SOFT ? KC : 0), ST_BSU = ST_BSL + (SOFT ? KC : 0), ST_BOX = ST_BSU + (SOFT ? KC : 0),
         ST_SLOT = ST_BOX + (SOFTBOX ? 6 : 0), // MERGE: bounds of the box row a slot lane carries
         ST_CPC = ST_SLOT + (MERGE ? 2 : 0),   // option "cond_pred_corr": second-order factor of this pass's / of the pending step's corrector targets
-        ST_N = ST_CPC + (CPC ? 2 : 0)
+        ST_N = ST_CPC + (CPC ? 1 : 0)         // (0 or 1 each: the two share ONE slot - with the aux plane in LDS a wave at N = 40 has 600 bytes left of its 20 KB)
     };
     using ST = lanes::Stash<ST_N, (WIDE ? 16 : 64)>; // (WIDE: the rows hold the same constants - one row's worth)
     struct CRef {
@@ -389,9 +389,14 @@ struct QpIpm {
         USV_DEV operator double() const { return ST::get(SLOT); }
         USV_DEV void operator=(double v) const { ST::put(SLOT, v); }
     };
+    template <int SLOT, int HALF>
+    struct CHalf {
+        USV_DEV operator double() const { return ST::geth(SLOT, HALF); }
+        USV_DEV void operator=(double v) const { ST::puth(SLOT, HALF, v); }
+    };
     CVal<ST_LB> lbv; CVal<ST_UB> ubv; CVal<ST_HDS> hd_stage; CVal<ST_HDT> hd_term;
     CVal<ST_SLOT> slot_lb; CVal<ST_SLOT + 1> slot_ub;
-    CVal<ST_CPC> so_cur; CVal<ST_CPC + 1> so_prv; // (parked in LDS like the other per-lane constants: they must not cost the sweeps a register)
+    CHalf<ST_CPC, 0> so_cur; CHalf<ST_CPC, 1> so_prv; // (parked in LDS like the other per-lane constants: they must not cost the sweeps a register)
     bool bsoft;                               // SOFTBOX: this lane's state bound is soft
     // its slack penalties (scaled by dt) and slack lower bounds
     CVal<ST_BOX + 0> bzl; CVal<ST_BOX + 1> bzu; CVal<ST_BOX + 2> bZl; CVal<ST_BOX + 3> bZu; CVal<ST_BOX + 4> bbsl; CVal<ST_BOX + 5> bbsu;
@@ -1436,6 +1441,8 @@ struct QpIpm {
     USV_DEV void backward_wide(Norms &nm, double sigmu, bool pend, double a_prev, double sigmu_prev)
     {
         const int row = (int)lanes::block_row();
+        double so_c = 1.0, so_p = 1.0; // (CPC: the same in every row and wave of the workgroup - they hold one instance)
+        if constexpr (CPC) { so_c = so_cur; so_p = so_prv; }
         double Pn[NX], pn = 0.0, pin = 0.0;
         sfor<0, NX>([&](auto c) { Pn[c] = 0.0; });
         double rg_r = 0.0, rd_r = 0.0, rm_r = 0.0, nan_r = 0.0; // what the norms get from the rows this row has processed
@@ -1479,7 +1486,7 @@ struct QpIpm {
                     br.act = br.act && own;
                     if (FACT) {
                         if (pend && br.act) {
-                            chain(br, z, true, dzap, sigmu_prev, Ghb, gamb);
+                            chain<CPC>(br, z, true, dzap, sigmu_prev, Ghb, gamb, so_p);
                             br.expand(dzp);
                             br.apply(a_prev);
                         }
@@ -1493,7 +1500,7 @@ struct QpIpm {
                             if constexpr (!LDSWS) ex_put(row, EX_DV, aux);
                         }
                     }
-                    chain(br, znew, !FACT, dza, sigmu, Ghb, gamb);
+                    chain<CPC>(br, znew, !FACT, dza, sigmu, Ghb, gamb, so_c);
                     dlb = br.act ? br.ll - br.lu : 0.0;
                     if (FACT && br.act) {
                         rd_r = lanes::vmax(rd_r, lanes::vmax_abs2(br.rdl, br.rdu));
@@ -1523,7 +1530,7 @@ struct QpIpm {
                     if (FACT) {
                         const double vo = rowdot<c>(cx, cy, z - psel, z), wp = rowdot<c>(cx, cy, dzp, dzp), wap = rowdot<c>(cx, cy, dzap, dzap);
                         if (pend && o.act) {
-                            chain(o, vo, true, wap, sigmu_prev, Gh, gam);
+                            chain<CPC>(o, vo, true, wap, sigmu_prev, Gh, gam, so_p);
                             o.expand(wp);
                             o.apply(a_prev);
                         }
@@ -1532,7 +1539,7 @@ struct QpIpm {
                     }
                     const double v = rowdot<c>(cx, cy, znew - psel, znew);
                     const double wa = FACT ? 0.0 : rowdot<c>(cx, cy, dza, dza);
-                    chain(o, v, !FACT, wa, sigmu, Gh, gam);
+                    chain<CPC>(o, v, !FACT, wa, sigmu, Gh, gam, so_c);
                     gx += gam * cx; gy += gam * cy;
                     if constexpr (c == KCH - 1) { Gh_m = Gh; gam_m = gam; }
                     if (FACT) {
@@ -1757,6 +1764,9 @@ struct QpIpm {
     USV_DEV void forward_wide(double sigmu, double &alpha, double &S1, double &S2)
     {
         const int row = (int)lanes::block_row();
+        constexpr bool SUMS = !FINAL || CPC; // (CPC: the corrected step delivers the sums too - forward())
+        double so_c = 1.0;
+        if constexpr (CPC) so_c = so_cur;
         double dzx;
         {
             const Planes W0 = ws(0);
@@ -1833,10 +1843,10 @@ struct QpIpm {
                     box_from(in, k, br);
                     br.act = br.act && own;
                     double Gh, gam;
-                    chain(br, z, FINAL, dza, sigmu, Gh, gam);
+                    chain<CPC>(br, z, FINAL, dza, sigmu, Gh, gam, so_c);
                     br.expand(dz);
                     q = br.blocking(q);
-                    if (!FINAL) {
+                    if (SUMS) {
                         ex_put(row, 4 * KC, br.act ? br.ll * br.dtl + br.tl * br.dll + br.lu * br.dtu + br.tu * br.dlu : 0.0);
                         ex_put(row, 4 * KC + 1, br.act ? br.dll * br.dtl + br.dlu * br.dtu : 0.0);
                         if constexpr (SOFTBOX) {
@@ -1855,10 +1865,10 @@ struct QpIpm {
                     const double v = rowdot<c>(cx, cy, z - pos_sel(zbx, zby), z);
                     const double w = rowdot<c>(cx, cy, dz, dz);
                     const double wa = FINAL ? rowdot<c>(cx, cy, dza, dza) : w;
-                    chain(o, v, FINAL, wa, sigmu, Gh2, gam2);
+                    chain<CPC>(o, v, FINAL, wa, sigmu, Gh2, gam2, so_c);
                     o.expand(w);
                     q = o.blocking(q);
-                    if (!FINAL) {
+                    if (SUMS) {
                         ex_put(row, 4 * c, o.act ? o.ll * o.dtl + o.tl * o.dll + o.lu * o.dtu + o.tu * o.dlu : 0.0);
                         ex_put(row, 4 * c + 1, o.act ? o.dll * o.dtl + o.dlu * o.dtu : 0.0);
                         if constexpr (SOFT) {
@@ -1869,7 +1879,7 @@ struct QpIpm {
                 });
                 } // (KCH > 0)
             }
-            if (!FINAL) { // the sums for mu_aff, stage by stage as the 16-lane sweep takes them
+            if (SUMS) { // the sums for mu_aff (CPC: and of the corrected step), stage by stage as the 16-lane sweep takes them
                 wide_sync();
                 for (int j = 0; j < BS; j++) {
                     if constexpr (!MERGE) { s1 += ex_get(j, 4 * KC); s2 += ex_get(j, 4 * KC + 1); }
@@ -1886,7 +1896,7 @@ struct QpIpm {
         }
         if constexpr (!LDSWS) lanes::drain_stores(); // (rows read each other's stores in the next sweep)
         alpha = 1.0 / xwave<true>(lanes::gmax(lanes::xrow_max(q))); // q >= 1: alpha = min(1, min over blocking pairs of -v/dv)
-        if (!FINAL) { S1 = lanes::gsum(s1); S2 = lanes::gsum(s2); }
+        if (SUMS) { S1 = lanes::gsum(s1); S2 = lanes::gsum(s2); }
     }
 
     // ------------------------------------------------------------------ NLP residuals (full SQP only)
@@ -2171,7 +2181,10 @@ struct QpIpm {
             const int slot = lanes::fetch_add(P.susp_count);
             P.susp_list[slot] = (int)g;
             double *r = P.susp_rec + 4 * b;
-            r[0] = a_prev; r[1] = sig_prev; r[2] = rbscale; r[3] = (double)it;
+            // (CPC: whether the pending step is a centring-only one rides in the sign of the iteration count, which is at least 1 here)
+            double itv = (double)it;
+            if constexpr (CPC) itv = ((double)so_prv == 0.0) ? -itv : itv;
+            r[0] = a_prev; r[1] = sig_prev; r[2] = rbscale; r[3] = itv;
         }
     }
 
@@ -2221,13 +2234,16 @@ struct QpIpm {
         double a_prev = 0.0, sig_prev = 0.0;
         const double nc = (double)S.nc;
         const bool refill = phase == 0 && queue0 >= 0; // wave-uniform
-        constexpr bool cpc = CPC; // option "cond_pred_corr": the host launches this instantiation
-        if constexpr (HAS_CPC) { if (cpc) { so_prv = 1.0; so_cur = 1.0; } }
+        // option "cond_pred_corr" (on in every profile but "r04"): the test is built into every kernel, the option switches it (off: no step is
+        // ever refused, every so stays 1 and the sweeps return the bits of sweeps without it)
+        const bool cpc = CPC && lanes::uniform(S.cpc) != 0;
+        if constexpr (HAS_CPC) { so_prv = 1.0; so_cur = 1.0; }
         if constexpr (WIDE) {
             if (resume) { // the state the suspending row left (all rows of the wave read the same record)
                 copy_in();
                 const double *r = P.susp_rec + 4 * b;
-                a_prev = r[0]; sig_prev = r[1]; rbscale = r[2]; it = (int)r[3];
+                a_prev = r[0]; sig_prev = r[1]; rbscale = r[2]; it = (int)fabs(r[3]);
+                if constexpr (CPC) so_prv = (r[3] < 0.0) ? 0.0 : 1.0;
                 iters = it;
                 pend = true;
             }
@@ -2279,7 +2295,7 @@ struct QpIpm {
                         it = take ? 0 : it;
                         iters = take ? 0 : iters;
                         status = take ? (bad ? 4 : 1) : status;
-                        if constexpr (HAS_CPC) { if (cpc) { const double sp = so_prv; so_prv = take ? 1.0 : sp; } }
+                        if constexpr (HAS_CPC) { const double sp = so_prv; so_prv = take ? 1.0 : sp; }
                         // (the freshly started row sits out the three remaining sweeps of this pass: parked meanwhile - see below - so that
                         // it does not stream its new group's planes for nothing; back at the end of the pass)
                         if constexpr (!LDSWS && !WIDE) voff = take ? stage_bytes + (unsigned)(lane * 8) : voff;
@@ -2306,36 +2322,29 @@ struct QpIpm {
                 const double sg = mu_aff / mu;
                 sigmu = sg * sg * sg * mu;
             }
-            bool cpc_done = false;
+            if constexpr (HAS_CPC) so_cur = 1.0;
+            backward<false>(nm, sigmu, false, 0.0, 0.0);
+            forward<true>(sigmu, a, d1, d2);
             if constexpr (HAS_CPC) {
-                if (cpc) { // (compile-time: the CPC instantiations)
-                    // HPIPM's conditional predictor-corrector (d_ocp_qp_ipm_arg.cond_pred_corr, on in its SPEED / BALANCE / ROBUST modes; as
-                    // recalled - DESIGN.md section 2): a corrected step that leaves the duality measure above cpc_factor x the predictor's
-                    // mu_aff is refused and the centring-only step (the corrector's target without its second-order term) taken instead.
-                    // Per row; the sweeps are the wave's, so the rows that keep their step recompute it (so = 1: the same bits).
-                    so_cur = 1.0;
+                // HPIPM's conditional predictor-corrector (d_ocp_qp_ipm_arg.cond_pred_corr, on in its SPEED / BALANCE / ROBUST modes; as
+                // recalled - DESIGN.md section 2): a corrected step that leaves the duality measure above cpc_factor x the predictor's
+                // mu_aff is refused and the centring-only step (the corrector's target without its second-order term) taken instead.
+                // Per row; the sweeps are the wave's, so the rows that keep their step recompute it (so = 1: the same bits).  (WIDE: the
+                // rows and waves of a workgroup hold one instance and the same values - the branch is uniform over the workgroup.)
+                const double mu_pc = nc > 0.0 ? (nm.musum + a * d1 + a * a * d2) / nc : 0.0;
+                const bool refuse = cpc && run && nc > 0.0 && mu_pc > S.cpc_factor * mu_aff;
+                if (lanes::wave_any(refuse)) { // wave-uniform
+                    so_cur = refuse ? 0.0 : 1.0; // (LDS operations of a wave execute in order: the sweeps below read what is written here)
+                    double a2 = 1.0;
                     backward<false>(nm, sigmu, false, 0.0, 0.0);
-                    forward<true>(sigmu, a, d1, d2);
-                    const double mu_pc = nc > 0.0 ? (nm.musum + a * d1 + a * a * d2) / nc : 0.0;
-                    const bool refuse = run && nc > 0.0 && mu_pc > S.cpc_factor * mu_aff;
-                    if (lanes::wave_any(refuse)) { // wave-uniform
-                        so_cur = refuse ? 0.0 : 1.0; // (LDS operations of a wave execute in order: the sweeps below read what is written here)
-                        double a2 = 1.0;
-                        backward<false>(nm, sigmu, false, 0.0, 0.0);
-                        forward<true>(sigmu, a2, d1, d2);
-                        a = refuse ? a2 : a;
-                    }
-                    cpc_done = true;
+                    forward<true>(sigmu, a2, d1, d2);
+                    a = refuse ? a2 : a;
                 }
-            }
-            if (!cpc_done) {
-                backward<false>(nm, sigmu, false, 0.0, 0.0);
-                forward<true>(sigmu, a, d1, d2);
             }
             if (run && a < S.alpha_min) { status = 2; done = true; late = true; iters = it; }
             a_prev = run ? a * ((1.0 - a) * 0.99 + a * 0.9999999) : a_prev;
             sig_prev = run ? sigmu : sig_prev;
-            if constexpr (HAS_CPC) { if (cpc) { const double sp = so_prv, sc = so_cur; so_prv = run ? sc : sp; } }
+            if constexpr (HAS_CPC) { const double sp = so_prv, sc = so_cur; so_prv = run ? sc : sp; }
             pend = run ? true : pend;
             it = run ? it + 1 : it;
             if constexpr (!LDSWS && !WIDE) voff = fresh ? lanes::Planes::lane_offset(g, NPL, lane) : voff;

@@ -67,9 +67,9 @@ constexpr int qp_waves() { return (KCH >= 2 || SOFTBOX) ? 1 : USV_QP_WAVES; }
 // WIDE: the latency mapping - one instance per wave (rows = 1: rows 1 - 3 are handed row 0's group and share its LDS region; in the
 // sweeps they take over the row work of the neighbouring stages: qp_ipm.hpp)
 // WW > 1 (with WIDE): a workgroup of WW waves per instance (qp_ipm.hpp)
-// CPC: with HPIPM's conditional predictor-corrector (option "cond_pred_corr") - instantiations of their own
+// CPC: with HPIPM's conditional predictor-corrector built in (qp_ipm.hpp; option "cond_pred_corr" switches the test) - every kernel of the library
 template <class M, int KCH, bool SOFT, bool HDIAG, bool PACK, bool SOFTBOX, bool LDSWS = false, bool MERGE = false, bool AUXLDS = false, bool WIDE = false,
-          int WW = 1, bool CPC = false>
+          int WW = 1, bool CPC = true>
 __global__ void __launch_bounds__(64 * WW, ((LDSWS || WIDE) ? 1 : qp_waves<KCH, SOFTBOX>())) usv_qp_rti(DevPtrs P, long ngroups, int phase, int queue0, int rows)
 {
     const int row = (int)(threadIdx.x >> 4);
@@ -816,8 +816,7 @@ int launch_pair(usvmpc_handle *h, int phase)
         const qp_kernel_t kern_wide = wide.lds1, kern_wide_hbm = wide.hbm1;
         // Four waves per instance (qp_ipm.hpp, WW): a workgroup = a whole CU shares out the row work of 16 consecutive stages - for the
         // single instance and batches of at most one instance per CU.
-        const bool plain = h->spec.cpc != 0; // option "cond_pred_corr": built into the throughput kernels over planes in HBM only
-        if (wide.lds4 != nullptr && phase == 0 && h->wide_mode != 0 && h->wide_waves != 1 && h->ncu > 0 && !plain) {
+        if (wide.lds4 != nullptr && phase == 0 && h->wide_mode != 0 && h->wide_waves != 1 && h->ncu > 0) {
             const size_t pl = (size_t)(h->N + 1) * (size_t)wide.nplw * 128;
             const size_t b4 = pl + (size_t)16 * wide.ex_lds * 128 + 128, x4 = (size_t)16 * wide.ex_hbm * 128 + 128;
             const long win_bytes = (long)std::min(h->N + 1, 16) * h->Bp * h->spec.npt * 128; // (the window of a block of 16 stages: 32-bit offsets)
@@ -859,7 +858,7 @@ int launch_pair(usvmpc_handle *h, int phase)
         // The latency mapping: ONE instance per wave (qp_ipm.hpp, WIDE) - planes in LDS, the four rows share out the stage-local row
         // work.  A wave then finishes an instance 1.4x (hard rows) to 1.8x (soft rows) sooner and the device holds a quarter of the instances at once: it pays while
         // the batch leaves SIMDs idle anyway (a solve of the batch then lasts as long as its hardest instance on a lone wave).
-        if (kern_wide != nullptr && h->wide_mode != 0 && h->ncu > 0 && !plain) {
+        if (kern_wide != nullptr && h->wide_mode != 0 && h->ncu > 0) {
           if (phase == 0) { // (the launches of a full SQP find their multipliers in the group's planes in HBM: the variant over planes in HBM below)
             // (in LDS: the planes the solve writes - WsLayout's up to L_zu less the four box planes the packed layouts leave unused)
             const size_t bytes = (size_t)(h->N + 1) * (size_t)wide.nplw * 128 + (size_t)4 * wide.ex_lds * 128;
@@ -923,7 +922,7 @@ int launch_pair(usvmpc_handle *h, int phase)
             if (hipFuncGetAttributes(&fa, (const void *)kern_lds) == hipSuccess) lds_static = (long)fa.sharedSizeBytes;
         }
         const int rows_lds = (int)std::min<long>(4, (160L * 1024 - lds_static) / lds_inst);
-        bool use_lds = phase == 0 && h->lds_mode != 0 && kern_lds != nullptr && rows_lds >= 1 && h->ncu > 0 && !plain;
+        bool use_lds = phase == 0 && h->lds_mode != 0 && kern_lds != nullptr && rows_lds >= 1 && h->ncu > 0;
         // by default only while one round of workgroups covers the batch: measured on usv_model_pf_ca, N = 20 / K = 3, the solve
         // of 512 instances takes 5.9 ms with the planes in LDS against 6.5 ms in HBM, at 1024 (two rounds) 7.5 against 7.1
         if (use_lds && h->lds_mode < 0) use_lds = (long)h->B <= (long)rows_lds * h->ncu;
@@ -983,7 +982,7 @@ int launch_pair(usvmpc_handle *h, int phase)
         size_t xbytes = (size_t)4 * wide.ex_hbm * 128;
         qp_resume_t kern_resume = wide.resume;
         int hand_it = 0;
-        if (phase == 0 && h->handover_iter != 0 && !plain && wide.resume != nullptr && (long)std::min(h->N + 1, 4) * h->Bp * h->spec.npt * 128 < (1L << 32)) {
+        if (phase == 0 && h->handover_iter != 0 && wide.resume != nullptr && (long)std::min(h->N + 1, 4) * h->Bp * h->spec.npt * 128 < (1L << 32)) {
             if (h->resume_cap == 0) {
                 // (planes in LDS when the horizon fits - option "handover_lds", default on -, else over the planes in HBM)
                 int nb = 0;
@@ -1029,12 +1028,6 @@ int launch_pair(usvmpc_handle *h, int phase)
     int rcq = 0;
     if (cond) {
         rcq = launch_cond(h);
-    } else if (h->spec.cpc) {
-        // option "cond_pred_corr": instantiations of their own (QpIpm<.., CPC>), planes in HBM, for the layouts of the reference's OCPs
-        if (h->spec.any_bsoft || !h->spec.hdiag) { h->err = "cond_pred_corr is built for diagonal Hessians without soft state bounds (every OCP of the reference)"; return USVMPC_E_ARG; }
-        if (pack && h->merge_rows && !h->spec.box_dense) rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, CANPACK, false, false, 1, true>, nullptr);
-        else if (pack) rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, CANPACK, false, false, false, false, false, 1, true>, nullptr);
-        else rcq = launch_qp(&usv_qp_rti<M, KCH, SOFT, true, false, false, false, false, false, false, 1, true>, nullptr);
     } else {
 #ifdef USV_BENCH_ONLY // development builds (tools/dev_build.sh): only the instantiation the bench workload runs
     if (!(h->spec.hdiag && pack && !h->spec.any_bsoft)) { h->err = "development build: bench instantiation only"; return USVMPC_E_ARG; }
@@ -1249,6 +1242,11 @@ int usvmpc_model_dims(int model, int *nx, int *nu)
 void usvmpc_default_options(usvmpc_desc *d)
 {
     if (d) default_options(*d);
+}
+
+int usvmpc_hpipm_profile(usvmpc_desc *d, int mode)
+{
+    return (d && hpipm_profile(*d, mode)) ? 0 : USVMPC_E_ARG;
 }
 
 int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
@@ -1770,7 +1768,6 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
             // (blocks as HPIPM partitions them: N / N2 stages each, the first N mod N2 one more; one block's variables must fit a wave)
             if (h->nx + ((h->N + want - 1) / want) * h->nu > 64) { h->err = "qp_cond_N: a condensed stage may have at most 64 variables (nx + ceil(N / qp_cond_N) nu)"; return USVMPC_E_ARG; }
             if (h->spec.any_bsoft) { h->err = "partial condensing (qp_cond_N) is not built for soft state bounds"; return USVMPC_E_ARG; }
-            if (h->spec.cpc) { h->err = "partial condensing (qp_cond_N) is not built for cond_pred_corr"; return USVMPC_E_ARG; }
         }
         if (want != h->cond_N2) { cond_release(h); h->cond_N2 = want; h->map_changed = true; }
         return 0;
@@ -1797,17 +1794,19 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         reset_caps(h);
         return 0;
     }
-    if (s == "cond_pred_corr" || s == "cpc_factor") {
-        // HPIPM's conditional predictor-corrector (d_ocp_qp_ipm_arg.cond_pred_corr: on in the modes acados picks from, left off here by default -
-        // DESIGN.md section 2): a corrected step that leaves the duality measure above cpc_factor (2) x the predictor's mu_aff is replaced by the
-        // centring-only step.  Changes the iteration path, i.e. results inside the exit tolerance ball; RTI and SQP solves on the throughput mapping
-        // (the latency mapping, the LDS workspace, the hand-over and partial condensing are not taken while it is on).
+    if (s == "cond_pred_corr" || s == "cpc_factor" || s == "hpipm_mode") {
+        // HPIPM's conditional predictor-corrector (d_ocp_qp_ipm_arg.cond_pred_corr: on in every mode acados picks from - DESIGN.md section 2): a
+        // corrected step that leaves the duality measure above cpc_factor (2) x the predictor's mu_aff is replaced by the centring-only step.
+        // Changes the iteration path, i.e. results inside the exit tolerance ball.  Built into every kernel; the option switches the test.
+        // "hpipm_mode": the profile's values of mu0, alpha_min and cond_pred_corr (host_spec.hpp, hpipm_profile).
         if (s == "cpc_factor") { if (!(value > 0.0)) { h->err = "cpc_factor must be positive"; return USVMPC_E_ARG; } h->spec.cpc_factor = value; }
-        else {
-            if (value != 0.0 && h->cond_N2 > 0) { h->err = "cond_pred_corr is not built for the partially condensed solve (qp_cond_N)"; return USVMPC_E_ARG; }
+        else if (s == "hpipm_mode") {
+            usvmpc_desc d;
+            if (value != (double)(int)value || !hpipm_profile(d, (int)value)) { h->err = "hpipm_mode must be one of USVMPC_HPIPM_*"; return USVMPC_E_ARG; }
+            h->spec.mu0 = d.mu0; h->spec.alpha_min = d.alpha_min; h->spec.cpc = d.cond_pred_corr; h->spec.cpc_factor = d.cpc_factor;
+        } else {
             h->spec.cpc = value != 0.0 ? 1 : 0;
         }
-        reset_caps(h);
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipMemcpyAsync(h->d_spec, &h->spec, sizeof(DevSpec), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -81,6 +81,7 @@ def lib():
         build()
         L = C.CDLL(_LIB)
         L.usv_spec_defaults.argtypes = [C.POINTER(Spec), C.c_int, C.c_int, C.c_double, C.c_int]
+        L.usv_opts_profile.argtypes = [C.POINTER(Opts), C.c_int]
         L.usv_model_dims.argtypes = [C.c_int, _ip, _ip]
         L.usv_model_f.argtypes = [C.c_int, _dp, _dp, _dp]
         L.usv_model_f.restype = None
@@ -135,10 +136,19 @@ def dims(model):
     return nx.value, nu.value
 
 
+HPIPM_MODES = {"BALANCE": 0, "SPEED": 1, "ROBUST": 2, "R04": 3}   # usv_oracle.h USV_HPIPM_*
+
+
 def spec(model, N, Tf, K=0, **opts):
+    """hpipm_mode = "BALANCE" (default) | "SPEED" | "ROBUST" | "R04": the QP solver profile (usv_opts_profile), applied before the other
+    options, which override single fields of it."""
     s = Spec()
     if lib().usv_spec_defaults(C.byref(s), model, N, float(Tf), K) != 0:
         raise ValueError("bad spec")
+    if "hpipm_mode" in opts:
+        m = opts.pop("hpipm_mode")
+        if lib().usv_opts_profile(C.byref(s.opts), HPIPM_MODES.get(str(m).upper(), m) if not isinstance(m, int) else m) != 0:
+            raise ValueError("hpipm_mode must be one of %s" % ", ".join(HPIPM_MODES))
     for k, v in opts.items():
         if k in ("sim_steps", "nlp_max_iter"):
             setattr(s, k, int(v))

@@ -86,7 +86,8 @@ def part_cond(qp, N2):
 
 def solve(cq, opts):
     """Mehrotra IPM of oracle/usv_oracle.c (usv_qp_solve) on the dense-stage QP.  opts: dict(qp_iter_max, mu0, thr0,
-    tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min).  Returns dict(w [per stage], status, iter, res)."""
+    tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min, cond_pred_corr, cpc_factor).  Returns dict(w [per stage], status, iter, res,
+    cpc_fallbacks)."""
     st, nx = cq["stages"], cq["nx"]
     S = len(st)
     w = [np.zeros(s["nu"] + nx) for s in st]
@@ -195,7 +196,7 @@ def solve(cq, opts):
                     a = min(a, float((-v[neg] / dv[neg]).min()))
         return a
 
-    status, it = 1, 0
+    status, it, fallbacks = 1, 0, 0
     cache = dict(Ht=[None] * S, P=[None] * S, Luu=[None] * S, Lxu=[None] * S, Pb=[None] * S)
     rgs, rbs, rdl, rdu, e0, res, mu = residuals()
     for it in range(opts["qp_iter_max"]):
@@ -220,6 +221,17 @@ def solve(cq, opts):
             ml = [ll[k] * tl[k] + dll[k] * dtl[k] - sigma * mu for k in range(S)]
             mu_ = [lu[k] * tu[k] + dlu[k] * dtu[k] - sigma * mu for k in range(S)]
             dw, dpi, dll, dlu, dtl, dtu = kkt_step(rgs, rbs, rdl, rdu, e0, ml, mu_, False, cache)
+            if opts.get("cond_pred_corr", 0):
+                # HPIPM's conditional predictor-corrector as oracle/usv_oracle.c has it: a corrected step that leaves the duality measure
+                # above cpc_factor x the predictor's is replaced by the centring-only one
+                a_pc = step_length(dll, dlu, dtl, dtu)
+                mu_pc = sum(((ll[k] + a_pc * dll[k]) * (tl[k] + a_pc * dtl[k])).sum() +
+                            ((lu[k] + a_pc * dlu[k]) * (tu[k] + a_pc * dtu[k])).sum() for k in range(S)) / nc
+                if mu_pc > opts.get("cpc_factor", 2.0) * mu_aff:
+                    ml = [ll[k] * tl[k] - sigma * mu for k in range(S)]
+                    mu_ = [lu[k] * tu[k] - sigma * mu for k in range(S)]
+                    dw, dpi, dll, dlu, dtl, dtu = kkt_step(rgs, rbs, rdl, rdu, e0, ml, mu_, False, cache)
+                    fallbacks += 1
         a = step_length(dll, dlu, dtl, dtu)
         if a < opts["alpha_min"]:
             status = 2
@@ -236,7 +248,7 @@ def solve(cq, opts):
         it = opts["qp_iter_max"]
         if res[0] <= opts["tol_stat"] and res[1] <= opts["tol_eq"] and res[2] <= opts["tol_ineq"] and res[3] <= opts["tol_comp"]:
             status = 0
-    return dict(w=w, status=status, iter=it, res=res)
+    return dict(w=w, status=status, iter=it, res=res, cpc_fallbacks=fallbacks)
 
 
 def expand(cq, sol):
@@ -273,7 +285,10 @@ def evaluate(cq, dz):
     return obj, viol, eq
 
 
-DEFAULT_OPTS = dict(qp_iter_max=50, mu0=10.0, thr0=0.1, tol_stat=1e-6, tol_eq=1e-8, tol_ineq=1e-8, tol_comp=1e-8, alpha_min=1e-12)
+# (the oracle's default profile - usv_oracle.c usv_opts_profile, BALANCE - less the iterative refinement, which the dense numpy solves do not need)
+DEFAULT_OPTS = dict(qp_iter_max=50, mu0=1.0, thr0=0.1, tol_stat=1e-6, tol_eq=1e-8, tol_ineq=1e-8, tol_comp=1e-8, alpha_min=1e-8,
+                    cond_pred_corr=1, cpc_factor=2.0)
+R04_OPTS = dict(qp_iter_max=50, mu0=10.0, thr0=0.1, tol_stat=1e-6, tol_eq=1e-8, tol_ineq=1e-8, tol_comp=1e-8, alpha_min=1e-12, cond_pred_corr=0)
 
 
 def rti_condensed(binding, spec, x, u, x0, yref, yref_e, p, lh, N2, **opts):

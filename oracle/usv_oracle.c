@@ -334,20 +334,39 @@ void usv_rk4_sens(int model, double dt, const double *x, const double *u, double
 /* ------------------------------------------------------------------------------------------
  * 3. OCP definitions
  * ---------------------------------------------------------------------------------------- */
-void usv_opts_defaults(usv_opts *o)
+/* The QP solver's argument profile: what acados' ocp_qp_hpipm_opts_initialize_default leaves in d_ocp_qp_ipm_arg - HPIPM's
+ * d_ocp_qp_ipm_arg_set_default(mode) followed by acados' overwrites - AS RECALLED (neither tree is under /root/reference: usv_oracle.h,
+ * "PARITY UNPINNED"; DESIGN.md section 2 has the field-by-field table).  The reference selects the solver and touches none of its knobs
+ * (scripts/usv_pf_ca/acados_settings.py:172,183-186; scripts/usv_guidance_ca1/acados_settings.py:190,198-204).
+ *                     SPEED   BALANCE  ROBUST   acados' overwrite      R04 (this restatement up to round 5)
+ *   mu0               10      10       100      1                      10
+ *   alpha_min         1e-12   1e-12    1e-12    1e-8                   1e-12
+ *   res_g/b/d/m_max   1e-8 each                 1e-6, 1e-8, 1e-8, 1e-8 the same
+ *   iter_max          15      30       100      50                     50
+ *   cond_pred_corr    1       1        1        -                      0
+ *   itref_corr_max    0       2        4        -                      0
+ * Returns 0, or -1 for an unknown mode. */
+int usv_opts_profile(usv_opts *o, int mode)
 {
+    if (mode < USV_HPIPM_BALANCE || mode > USV_HPIPM_R04) return -1;
     o->qp_iter_max = 50;
-    o->mu0 = 10.0;
     o->thr0 = 0.1;
     o->tol_stat = 1e-6;
     o->tol_eq = 1e-8;
     o->tol_ineq = 1e-8;
     o->tol_comp = 1e-8;
-    o->alpha_min = 1e-12;
     o->riccati = USV_RICCATI_SQRT;
-    o->cond_pred_corr = 0;
     o->cpc_factor = 2.0;
-    o->itref_corr_max = 0;
+    o->mu0 = mode == USV_HPIPM_R04 ? 10.0 : 1.0;
+    o->alpha_min = mode == USV_HPIPM_R04 ? 1e-12 : 1e-8;
+    o->cond_pred_corr = mode == USV_HPIPM_R04 ? 0 : 1;
+    o->itref_corr_max = mode == USV_HPIPM_BALANCE ? 2 : (mode == USV_HPIPM_ROBUST ? 4 : 0);
+    return 0;
+}
+
+void usv_opts_defaults(usv_opts *o)
+{
+    usv_opts_profile(o, USV_HPIPM_BALANCE);
 }
 
 int usv_spec_defaults(usv_spec *s, int model, int N, double Tf, int K)
@@ -1240,12 +1259,6 @@ int usv_qp_solve(const usv_qp *q, const usv_opts *o, usv_qp_sol *sol)
             reduce_rows(&w, 0);
             riccati_solve(&w);
             expand_rows(&w);
-            if (o->itref_corr_max > 0) {
-                const double tol[4] = {o->tol_stat, o->tol_eq, o->tol_ineq, o->tol_comp};
-                int rr;
-                for (rr = 0; rr < o->itref_corr_max; rr++)
-                    if (!refine_step(&w, tol)) break;
-            }
             if (o->cond_pred_corr) {
                 /* the corrected step must not leave the central path further than the predictor promised: otherwise centring only */
                 const double a_pc = step_length(&w);
@@ -1265,6 +1278,13 @@ int usv_qp_solve(const usv_qp *q, const usv_opts *o, usv_qp_sol *sol)
                     expand_rows(&w);
                     sol->cpc_fallbacks++;
                 }
+            }
+            /* iterative refinement of the direction that will be taken (HPIPM refines after the conditional block, as recalled) */
+            if (o->itref_corr_max > 0) {
+                const double tol[4] = {o->tol_stat, o->tol_eq, o->tol_ineq, o->tol_comp};
+                int rr;
+                for (rr = 0; rr < o->itref_corr_max; rr++)
+                    if (!refine_step(&w, tol)) break;
             }
         }
         a = step_length(&w);

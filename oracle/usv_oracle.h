@@ -31,9 +31,11 @@
  *     (con_h_expr_e / lbx_e never set).  Stage-0 h rows depend on no free variable (D = 0).
  *   - soft h (M1): lh - sl <= h <= uh + su, sl >= lsh, su >= ush, stage cost dt*(zl*sl + zu*su +
  *     Zl/2 sl^2 + Zu/2 su^2); slacks are cold-started inside every QP.
- *   - QP: Mehrotra predictor-corrector IPM, cold start (mu0 = 10, thr0 = 0.1), square-root
- *     backward Riccati, step-length damping alpha*((1-alpha)*0.99 + alpha*0.9999999),
- *     exit on inf-norm residuals (stat 1e-6, eq/ineq/comp 1e-8), iter_max 50.
+ *   - QP: Mehrotra predictor-corrector IPM with HPIPM's conditional predictor-corrector, cold start
+ *     (mu0 = 1, thr0 = 0.1), square-root backward Riccati with two rounds of iterative refinement,
+ *     step-length damping alpha*((1-alpha)*0.99 + alpha*0.9999999), exit on inf-norm residuals
+ *     (stat 1e-6, eq/ineq/comp 1e-8), iter_max 50, alpha_min 1e-8: HPIPM's BALANCE mode with
+ *     acados' overwrites (usv_opts_profile; the other modes and the pre-round-6 defaults by name).
  *   - RTI: one linearisation + one QP + full step; QP max-iter is tolerated (status 0),
  *     NaN / min-step give status 4.
  */
@@ -58,23 +60,26 @@ enum { USV_M0 = 0, USV_M1 = 1, USV_M2 = 2, USV_MGEN = 3 };
 typedef void (*usv_fjvp_fn)(const double *, const double *, const double *, const double *, double *, double *);
 void usv_oracle_register_generated(usv_fjvp_fn fn, int nx, int nu, int ipx, int ipy);
 enum { USV_RICCATI_SQRT = 0, USV_RICCATI_CLASSIC = 1 };
+/* QP solver profiles (usv_opts_profile; the device library has the same names: include/usvmpc.h USVMPC_HPIPM_*): HPIPM's modes with acados'
+ * overwrites, and R04 = this restatement's defaults up to round 5 (HPIPM's SPEED values without acados' overwrites, no conditional
+ * predictor-corrector, no refinement) */
+enum { USV_HPIPM_BALANCE = 0, USV_HPIPM_SPEED = 1, USV_HPIPM_ROBUST = 2, USV_HPIPM_R04 = 3 };
 
+/* (values in the comments: the default profile, USV_HPIPM_BALANCE) */
 typedef struct usv_opts {
     int qp_iter_max;      /* 50 */
-    double mu0;           /* 10 */
+    double mu0;           /* 1 */
     double thr0;          /* 0.1 */
     double tol_stat;      /* 1e-6 */
     double tol_eq;        /* 1e-8 */
     double tol_ineq;      /* 1e-8 */
     double tol_comp;      /* 1e-8 */
-    double alpha_min;     /* 1e-12 */
+    double alpha_min;     /* 1e-8 */
     int riccati;          /* USV_RICCATI_SQRT */
-    /* HPIPM options the mode acados selects (BALANCE) runs with and this restatement does NOT adopt by default - off here, on request for
-     * the experiments of tests/test_parity_outliers.py (DESIGN.md section 2 lists every d_ocp_qp_ipm_arg field, adopted or not): */
-    int cond_pred_corr;   /* 0.  1: conditional predictor-corrector - when the corrected step leaves the duality measure above
+    int cond_pred_corr;   /* 1: conditional predictor-corrector - when the corrected step leaves the duality measure above
                            * cpc_factor x the predictor's mu_aff, the step is replaced by the centring-only one (no second-order term) */
     double cpc_factor;    /* 2.0 */
-    int itref_corr_max;   /* 0.  > 0: that many rounds of iterative refinement of the corrector's KKT solve (residual of the linear
+    int itref_corr_max;   /* 2.  > 0: that many rounds of iterative refinement of the corrector's KKT solve (residual of the linear
                            * system with the step just computed, solved again on the same factorisation, added), each skipped once the
                            * residual is below the exit tolerances */
 } usv_opts;
@@ -112,7 +117,8 @@ typedef struct usv_spec {
 /* Fill `s` with the reference's OCP definition for `model` (weights, selectors, bounds, soft
  * setup exactly as the cited acados_settings.py), generalised to K obstacles. */
 int usv_spec_defaults(usv_spec *s, int model, int N, double Tf, int K);
-void usv_opts_defaults(usv_opts *o);
+void usv_opts_defaults(usv_opts *o);           /* = usv_opts_profile(o, USV_HPIPM_BALANCE) */
+int usv_opts_profile(usv_opts *o, int mode);    /* USV_HPIPM_*; -1 for an unknown mode */
 
 /* ---- model functions (pinned by sympy / known answers in tests) ---- */
 int usv_model_dims(int model, int *nx, int *nu);

@@ -16,6 +16,16 @@
 #include <cstring>
 #include <vector>
 
+// Build parts (tests/emu/build_emu.py): the kernel bodies of one (model, obstacle chunks) pair take minutes to compile on the host compiler
+// too, so the stock emulator library compiles THIS file six times in parallel - -DEMU_PART=0: the fibers, the switches, the C entry points;
+// 1 .. 5: run_all of one pair each (explicit instantiation there, extern template elsewhere).  Without EMU_PART: one translation unit (the
+// generated-model libraries of genbuild.py).
+#ifndef EMU_PART
+#define EMU_PART -1
+#endif
+#define EMU_MAIN (EMU_PART <= 0)
+
+#if EMU_MAIN
 namespace lanes {
 
 Emu g_emu;
@@ -102,23 +112,40 @@ void run_group(long group, void (*body)(void *), void *arg, int rows)
 }
 
 } // namespace lanes
-
-namespace {
+#endif // EMU_MAIN
 
 using namespace usv;
 
+// the test switches (defined in the main part)
+#if EMU_MAIN
+#define EMU_VAR(decl, init) decl = init
+#else
+#define EMU_VAR(decl, init) extern decl
+#endif
+EMU_VAR(int g_emu_cpc, -1);         // option "cond_pred_corr" of the next solves: -1 as the descriptor says (its QP solver profile), 0 / 1 forced
+EMU_VAR(double g_emu_cpc_factor, 2.0);
+EMU_VAR(int g_emu_lds_mode, 0); // 1: run the RTI solves with the workspace in (emulated) LDS
+EMU_VAR(int g_emu_merge, 1);    // 1: box rows processed in their slot lanes when all of them ride there (as the device library does)
+EMU_VAR(int g_emu_aux, 0);      // 1: RTI solves of the packed one-chunk layouts keep the aux plane in (emulated) LDS (AUXLDS instantiations)
+EMU_VAR(int g_emu_wide, 0);     // 1 / 2 / 4: RTI solves of the packed one-chunk layouts on the WIDE mapping, that many emulated waves per instance
+EMU_VAR(long g_emu_wide_runs, 0); // rows started on the WIDE mapping since the switch was set
+EMU_VAR(int g_emu_handover_lds, 0); // the follow-up launch copies the planes into LDS (QpIpm::copy_in)
+EMU_VAR(int g_emu_handover, 0); // > 0: RTI solves on the 16-lane mapping hand instances past this many iterations over once the queue is empty (QpIpm::suspend);
+                                // the follow-up pass resumes them on the WIDE mapping over the planes in "HBM" (usv_qp_resume on the device)
+EMU_VAR(long g_emu_handed, 0);  // instances handed over since the switch was set
+EMU_VAR(double *g_emu_lam, nullptr); // [B][N+1][nlam] each: filled after the solve when set (usv_emu_set_export)
+EMU_VAR(double *g_emu_t, nullptr);
+// inspection copies of the lineariser's output: BAt [N][nx][Bp*16] (the packed planes expanded back to one plane
+// per row), rb0 [N][Bp*16], gq [N+1][Bp*16]
+EMU_VAR(double *g_dbg_BAt, nullptr);
+EMU_VAR(double *g_dbg_rb0, nullptr);
+EMU_VAR(double *g_dbg_gq, nullptr);
+EMU_VAR(long g_emu_rows, 2); // persistent rows of an emulated RTI solve (0: one row per group, no queue)
+EMU_VAR(int g_emu_cond_N2, 0); // > 0: RTI solves condense the QP to this many stages first (cond_ipm.hpp)
+
+namespace {
+
 struct Job { const DevPtrs *P; long gid; int qp_phase; int queue0; };
-int g_emu_cpc = 0;          // option "cond_pred_corr" of the next solves (the CPC instantiations of the 16-lane sweeps)
-double g_emu_cpc_factor = 2.0;
-int g_emu_lds_mode = 0; // 1: run the RTI solves with the workspace in (emulated) LDS
-int g_emu_merge = 1;    // 1: box rows processed in their slot lanes when all of them ride there (as the device library does)
-int g_emu_aux = 0;      // 1: RTI solves of the packed one-chunk layouts keep the aux plane in (emulated) LDS (AUXLDS instantiations)
-int g_emu_wide = 0;     // 1 / 2 / 4: RTI solves of the packed one-chunk layouts on the WIDE mapping, that many emulated waves per instance
-long g_emu_wide_runs = 0; // rows started on the WIDE mapping since the switch was set
-int g_emu_handover_lds = 0; // the follow-up launch copies the planes into LDS (QpIpm::copy_in)
-int g_emu_handover = 0; // > 0: RTI solves on the 16-lane mapping hand instances past this many iterations over once the queue is empty (QpIpm::suspend);
-                        // the follow-up pass resumes them on the WIDE mapping over the planes in "HBM" (usv_qp_resume on the device)
-long g_emu_handed = 0;  // instances handed over since the switch was set
 
 template <class M, int KCH, bool SOFT>
 void lin_body(void *a)
@@ -138,11 +165,6 @@ void qp_body(void *a)
     }
     if constexpr (HDIAG && PACK && !SOFTBOX) if (g_emu_aux && j->qp_phase == 0) {
         QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, false, MERGE, true> q(*j->P, j->gid);
-        q.solve(j->qp_phase, j->queue0);
-        return;
-    }
-    if constexpr (HDIAG && !SOFTBOX) if (g_emu_cpc) { // option "cond_pred_corr": the instantiation with the conditional predictor-corrector
-        QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, false, MERGE, false, false, 1, true> q(*j->P, j->gid);
         q.solve(j->qp_phase, j->queue0);
         return;
     }
@@ -194,13 +216,6 @@ void export_body(void *a)
     QpIpm<M, KCH, SOFT, true, PACK, SOFTBOX> q(*j->P, j->gid);
     q.export_rows();
 }
-double *g_emu_lam = nullptr, *g_emu_t = nullptr; // [B][N+1][nlam] each: filled after the solve when set (usv_emu_set_export)
-
-// inspection copies of the lineariser's output: BAt [N][nx][Bp*16] (the packed planes expanded back to one plane
-// per row), rb0 [N][Bp*16], gq [N+1][Bp*16]
-double *g_dbg_BAt = nullptr, *g_dbg_rb0 = nullptr, *g_dbg_gq = nullptr;
-long g_emu_rows = 2; // persistent rows of an emulated RTI solve (0: one row per group, no queue)
-int g_emu_cond_N2 = 0; // > 0: RTI solves condense the QP to this many stages first (cond_ipm.hpp)
 
 // the condensed solve of every instance, serially (the device runs one team of threads per instance)
 template <class M, int KCH, bool SOFT>
@@ -250,6 +265,9 @@ void expand_packed(const DevPtrs &P, const DevSpec &S)
         }
 }
 
+} // namespace
+
+// (external linkage: a split build defines each instantiation in a translation unit of its own - "Build parts" above)
 template <class M, int KCH, bool SOFT>
 void run_all(const DevPtrs &P_, const DevSpec &S, int phase, int qp_phase)
 {
@@ -351,7 +369,38 @@ void run_all(const DevPtrs &P_, const DevSpec &S, int phase, int qp_phase)
         }
 }
 
-} // namespace
+#if EMU_PART >= 0 && !defined(USV_GEN_ONLY) && !defined(USV_GEN_MODEL_HEADER)
+#define EMU_PAIR(PART, M, KCH, SOFT) EMU_PAIR_##PART(M, KCH, SOFT)
+#define EMU_DEF(M, KCH, SOFT) template void run_all<M, KCH, SOFT>(const DevPtrs &, const DevSpec &, int, int);
+#define EMU_EXT(M, KCH, SOFT) extern template void run_all<M, KCH, SOFT>(const DevPtrs &, const DevSpec &, int, int);
+#if EMU_PART == 1
+EMU_DEF(ModelM0, 0, false)
+#else
+EMU_EXT(ModelM0, 0, false)
+#endif
+#if EMU_PART == 2
+EMU_DEF(ModelM1, 1, true)
+#else
+EMU_EXT(ModelM1, 1, true)
+#endif
+#if EMU_PART == 3
+EMU_DEF(ModelM1, 2, true)
+#else
+EMU_EXT(ModelM1, 2, true)
+#endif
+#if EMU_PART == 4
+EMU_DEF(ModelM2, 1, false)
+#else
+EMU_EXT(ModelM2, 1, false)
+#endif
+#if EMU_PART == 5
+EMU_DEF(ModelM2, 2, false)
+#else
+EMU_EXT(ModelM2, 2, false)
+#endif
+#endif
+
+#if EMU_MAIN
 
 // One RTI iteration (sqp = 0) or a full SQP run (sqp = 1: the host loop of usvmpc_solve_sqp) of every instance
 // on the emulator. Arrays as in include/usvmpc.h (host).
@@ -369,7 +418,7 @@ static int emu_run(const usvmpc_desc *d, int sqp, double *x, double *u, const do
         std::fprintf(stderr, "usv_emu_solve: %s\n", err.c_str());
         return -1;
     }
-    S.cpc = g_emu_cpc; S.cpc_factor = g_emu_cpc_factor;
+    if (g_emu_cpc >= 0) { S.cpc = g_emu_cpc; S.cpc_factor = g_emu_cpc_factor; }
     int nx, nu;
     model_dims(d->model, nx, nu);
     const int N = S.N;
@@ -517,3 +566,4 @@ extern "C" int usv_emu_lin_modes(const usvmpc_desc *d, const double *x, const do
 #endif
     return -3;
 }
+#endif // EMU_MAIN

@@ -181,6 +181,8 @@ struct Stash {
     static double *area() { static double s[4][NSLOT * 16]; return s[WLANES == 16 ? 0 : ((g_emu.cur >> 4) & 3)]; }
     static void put(int slot, double v) { area()[slot * 16 + lane()] = v; }
     static double get(int slot) { return area()[slot * 16 + lane()]; }
+    static void puth(int slot, int half, double v) { ((float *)area())[2 * (slot * 16 + lane()) + half] = (float)v; }
+    static double geth(int slot, int half) { return (double)((const float *)area())[2 * (slot * 16 + lane()) + half]; }
 };
 
 // the workgroup's LDS (one emulated row per "wave")

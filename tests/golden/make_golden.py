@@ -41,6 +41,9 @@ CASES = [  # (tag, model name, N, K, B, seed, RTI iterations, generator)
 ]
 
 
+PROFILE = "BALANCE"   # the QP solver profile the fixtures are made under (oracle/usv_oracle.c usv_opts_profile): the default since round 6
+
+
 def active_rows(name, wl, x, K):
     """[B] bool: some obstacle row of the iterate x sits on its bound (hard rows: h - lh < 1e-3; soft rows, whose slack rests at
     lsh = -0.2: h - lh < 0.2 + 1e-3)."""
@@ -65,8 +68,8 @@ def main():
             dt, steps = scenario.DT[name], 1
         path = os.path.join(out_dir, tag + ".npz")
         if gen != "survey" and os.path.exists(path):
-            continue   # the round-1 fixtures stay byte-for-byte what they were
-        spec = util.oracle_spec(ob, name, N, dt, K, sim_steps=steps)
+            continue   # the round-1 fixtures stay byte-for-byte what they were: made under the QP solver profile "R04" (no `profile` key)
+        spec = util.oracle_spec(ob, name, N, dt, K, sim_steps=steps, hpipm_mode=PROFILE)
         x, u = wl["x_init"].copy(), wl["u_init"].copy()
         xs, us, sts, its, x0s = [], [], [], [], []
         x0 = wl["x0"].copy()
@@ -78,7 +81,7 @@ def main():
             act |= active_rows(name, wl, x, K)
             if gen == "survey":
                 x0 = x[:, 1].copy()
-        np.savez_compressed(path, name=name, N=N, K=K, B=B, dt=dt, seed=seed, sim_steps=steps, generator=gen, active=act,
+        np.savez_compressed(path, name=name, N=N, K=K, B=B, dt=dt, seed=seed, sim_steps=steps, generator=gen, active=act, profile=PROFILE,
                             x0=wl["x0"], yref=wl["yref"], yref_e=wl["yref_e"], p=wl["p"], lh=wl["lh"],
                             x_init=wl["x_init"], u_init=wl["u_init"], x0_in=np.stack(x0s),
                             x_out=np.stack(xs), u_out=np.stack(us), status=np.stack(sts), qp_iter=np.stack(its))

@@ -1,6 +1,9 @@
 """Golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py): the oracle must keep
 reproducing them (CPU), and the HIP path must reproduce them through the C ABI (GPU).
 
+Each fixture records the QP solver profile it was made under (`profile`; the round-1 files carry none: "R04", the defaults up to round 5 - they
+keep that profile under test on the oracle, the emulator and the device).
+
 Two families.  m?_*: the reference's own step sizes, obstacles beside the roll-out (rows mostly inactive), consecutive RTI
 iterations.  m?s_*: the benchmark workloads of SURVEY.md 8(d) - BASELINE configs[1] / configs[2] shapes and a two-chunk shape,
 dt = 0.05 s - run closed loop until the obstacle rows bind (`active` in the fixture: instances with a row on its bound);
@@ -23,6 +26,7 @@ def _load(f):
     wl["K"] = int(g["K"])
     steps = int(g["sim_steps"]) if "sim_steps" in g.files else 1
     closed = "generator" in g.files and str(g["generator"]) == "survey"
+    wl["profile"] = str(g["profile"]) if "profile" in g.files else "R04"
     return g, wl, steps, closed
 
 
@@ -50,7 +54,7 @@ def test_fixtures_exist():
 def test_oracle_reproduces_golden(oracle, f):
     g, wl, steps, closed = _load(f)
     name, N, K = str(g["name"]), int(g["N"]), int(g["K"])
-    spec = util.oracle_spec(oracle, name, N, float(g["dt"]), K, sim_steps=steps)
+    spec = util.oracle_spec(oracle, name, N, float(g["dt"]), K, sim_steps=steps, hpipm_mode=wl["profile"])
     for it in range(g["x_out"].shape[0]):
         x, u, x0 = _inputs(g, wl, it, closed)
         x, u, st, qi = util.oracle_rti(oracle, spec, wl, x, u, x0=x0)
@@ -71,6 +75,7 @@ def test_kernel_bodies_reproduce_survey_golden_on_the_emulator(emu, f):
     name, N, K, B = str(g["name"]), int(g["N"]), int(g["K"]), int(g["B"])
     ocp = usv_models.make_ocp(name, N * float(g["dt"]), N, K)
     ocp.solver_options.sim_method_num_steps = steps
+    ocp.solver_options.hpipm_mode = wl["profile"]
     desc = _capi.desc_from_ocp(ocp, batch=B)
     for it in range(g["x_out"].shape[0]):
         x, u, x0 = _inputs(g, wl, it, closed)
@@ -89,6 +94,7 @@ def test_hip_path_reproduces_golden(f):
     name, N, K, B = str(g["name"]), int(g["N"]), int(g["K"]), int(g["B"])
     ocp = usv_models.make_ocp(name, N * float(g["dt"]), N, None if name == "usv_model" else K)
     ocp.solver_options.sim_method_num_steps = steps
+    ocp.solver_options.hpipm_mode = wl["profile"]
     s = BatchOcpSolver(ocp, B)
     scenario.load_into(s, wl)
     for it in range(g["x_out"].shape[0]):

@@ -50,9 +50,23 @@ def test_desc_struct_matches_header_layout():
     assert lib.usvmpc_model_dims(7, C.byref(nx), C.byref(nu)) == -1
     d = _capi.Desc()
     lib.usvmpc_default_options(C.byref(d))  # writes the LAST fields of the struct: checks its size/offsets
-    assert (d.qp_iter_max, d.mu0, d.thr0, d.tol_stat, d.tol_eq, d.alpha_min) == (50, 10.0, 0.1, 1e-6, 1e-8, 1e-12)
+    # (the QP solver profile BALANCE = HPIPM's mode + acados' overwrites: include/usvmpc.h)
+    assert (d.qp_iter_max, d.mu0, d.thr0, d.tol_stat, d.tol_eq, d.alpha_min) == (50, 1.0, 0.1, 1e-6, 1e-8, 1e-8)
+    assert (d.hpipm_mode, d.cond_pred_corr, d.cpc_factor) == (_capi.HPIPM_MODES["BALANCE"], 1, 2.0)   # the struct's last fields
     e = _capi.default_options(_capi.Desc())
-    assert (e.qp_iter_max, e.mu0, e.tol_comp) == (d.qp_iter_max, d.mu0, d.tol_comp)
+    fields = ("qp_iter_max", "mu0", "thr0", "tol_stat", "tol_eq", "tol_ineq", "tol_comp", "alpha_min", "hpipm_mode", "cond_pred_corr", "cpc_factor",
+              "sim_num_steps", "nlp_max_iter", "nlp_tol_stat")
+    assert all(getattr(e, f) == getattr(d, f) for f in fields)
+    # every profile: the library's table and the Python mirror agree; R04 is the behaviour up to round 5
+    for mode in _capi.HPIPM_MODES.values():
+        a, b = _capi.Desc(), _capi.Desc()
+        assert lib.usvmpc_hpipm_profile(C.byref(a), mode) == 0
+        _capi.hpipm_profile(b, mode)
+        assert all(getattr(a, f) == getattr(b, f) for f in fields[:11] if f != "thr0")
+    assert lib.usvmpc_hpipm_profile(C.byref(d), 9) == -1
+    assert (a.mu0, a.alpha_min, a.cond_pred_corr) == (10.0, 1e-12, 0)   # (R04 is the last mode)
+    with pytest.raises(Exception):
+        _capi.hpipm_profile(_capi.Desc(), "FAST")
 
 
 @pytest.mark.parametrize("name,nx,nu,K", [("usv_model", 5, 2, 0), ("usv_model_guidance_ca1", 8, 1, 8), ("usv_model_pf_ca", 14, 2, 4)])

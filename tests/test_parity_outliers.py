@@ -12,6 +12,12 @@ What they show (CPU suite):
   and differ from the device by 1e-6 .. 5e-5 on every other outlier / near instance (1e-13 on ordinary ones): these QPs amplify
   rounding by ten orders of magnitude whoever solves them, so bit-for-bit equality of two builds of one source does not exist here.
 GPU suite: the device run again on the fixture's inputs against its own emulator and its stored outputs.
+
+The fixture was taken under the QP solver profile "R04" (the defaults up to round 5: no conditional predictor-corrector, mu0 = 10, no iterative
+refinement in the oracle - include/usvmpc.h USVMPC_HPIPM_R04) and every side below runs that profile: it is the record of what the unpinned
+profile choice was worth, and it keeps R04 reachable bit for bit.  Under the default profile since round 6 (BALANCE: acados' overwrites,
+cond_pred_corr, the oracle with HPIPM's two rounds of iterative refinement) the same closed loop has NO instance above 1e-5
+(tests/golden/parity_tail_balance.npz, tests/test_parity_tail_balance.py).
 """
 import os
 
@@ -41,7 +47,7 @@ def _err(f, xa, ua, xb, ub):
 
 
 def _oracle(ob, f, **opts):
-    spec = ob.spec(2, f["N"], f["N"] * f["dt"], f["K"], sim_steps=f["steps"], **opts)
+    spec = ob.spec(2, f["N"], f["N"] * f["dt"], f["K"], sim_steps=f["steps"], hpipm_mode="R04", **opts)
     x, u = f["x_in"].copy(), f["u_in"].copy()
     st, it = ob.rti_batch(spec, x, u, *[np.ascontiguousarray(f[k]) for k in ("x0", "yref", "yref_e", "p", "lh")], threads=0)
     return x, u, st, it
@@ -50,6 +56,7 @@ def _oracle(ob, f, **opts):
 def _ocp(f):
     ocp = usv_models.make_ocp("usv_model_pf_ca", f["N"] * f["dt"], f["N"], f["K"])
     ocp.solver_options.sim_method_num_steps = f["steps"]
+    ocp.solver_options.hpipm_mode = "R04"
     return ocp
 
 

@@ -65,6 +65,45 @@ def usable_cores():
     return n
 
 
+def bind_to_gpu_numa(local_rank, world, mode="auto"):
+    """Pin this rank's host threads to the CPUs of its GPU's NUMA node (each rank's host thread feeds a persistent-kernel stream and polls
+    events: eight of them on one socket's cores - or migrating - cost launch latency).  The node comes from the GPU's PCI device in sysfs
+    (/sys/bus/pci/devices/<bdf>/numa_node, the figure `rocm-smi --showtoponuma` prints); without it (no NUMA information, one node) the
+    usable CPUs are split evenly among the ranks.  mode: "auto" (only under a multi-rank launch), "on", "off".  Returns what was done."""
+    if mode == "off" or (mode == "auto" and world <= 1) or not hasattr(os, "sched_setaffinity"):
+        return "not bound"
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except Exception:
+        return "not bound (no affinity interface)"
+    node, cpus = None, None
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node >= 0:
+            cpus = []
+            for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus += list(range(int(a), int(b or a) + 1))
+            cpus = [c for c in cpus if c in allowed]
+    except Exception:
+        node, cpus = None, None
+    if not cpus:   # no NUMA information: an even share of the usable CPUs
+        n = max(1, len(allowed) // max(1, world))
+        cpus = allowed[local_rank * n:(local_rank + 1) * n] or allowed
+        how = "even share of the %d usable CPUs (no NUMA node for the GPU in sysfs)" % len(allowed)
+    else:
+        # the ranks of one node share its CPUs evenly too
+        how = "NUMA node %d of GPU %d" % (node, local_rank)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except Exception as ex:
+        return "not bound (%r)" % (ex,)
+    return "%s: %d CPUs (%d..%d)" % (how, len(cpus), cpus[0], cpus[-1])
+
+
 def baseline_config(name, B, world, N, K, moving):
     """Which BASELINE.json config this run is (the line must name itself, whatever the flags)."""
     total = B * world
@@ -104,6 +143,86 @@ def make_workload(name, N, K, batch, global_batch, workload, moving, rank, world
         wl = sharding.split_workload(wl, world, rank)
         batch = hi - lo
     return wl, batch, dt, steps, sigma, mask
+
+
+def survey_verbatim_leg(args, name, N, K, B, device, parity_sample):
+    """A second, shorter timed region of the same run on SURVEY.md 8(d)'s generator TO THE LETTER (scenario.make_batch "survey_verbatim": no
+    obstacle clip, acados' own initial guess x_k = x0, disturbance on every state; `--workload survey-verbatim` is the full-length line): the
+    figure the survey's own wording gives, beside the headline's stated departures.  Warm-up of 3 ticks with the parity leg on the first
+    `parity_sample` instances (0: none), then min(steps, 10) timed ticks.  Returns the `survey_verbatim` object of the line."""
+    from mpc_collisionavoidance_amd import BatchOcpSolver, scenario, usv_models
+    dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
+    wl = scenario.make_bench_batch(name, N, K, B, seed=1234, verbatim=True)
+    ocp = usv_models.make_ocp(name, N * dt, N, None if name == "usv_model" else K)
+    ocp.solver_options.sim_method_num_steps = steps
+    ocp.solver_options.hpipm_mode = args.hpipm_mode
+    s = BatchOcpSolver(ocp, B, device=device)
+    scenario.load_into(s, wl)
+    s.set_option("disturbance_mask", scenario.ALL_STATES_MASK)
+    for kv in args.option:
+        s.set_option(kv.split("=")[0], float(kv.split("=")[1]))
+    if K > 0:
+        s.set_option("static_obstacles", 1)
+    par = None
+    S1 = int(parity_sample)
+    if S1 > 0:
+        from oracle import binding as ob
+        from tests import parity_rule, util
+        spec = ob.spec(_ID[name], N, N * dt, K, sim_steps=steps, hpipm_mode=args.hpipm_mode)
+        data = tuple(wl[k][:S1] for k in ("yref", "yref_e", "p", "lh"))
+        x0o = wl["x0"][:S1].copy()
+        errs, n_same, n_above, n_bad, n_ok = [], 0, 0, 0, 0
+    for w in range(3):
+        if S1 > 0:
+            s.sync()
+            xin, uin = s.get_all("x")[:S1].copy(), s.get_all("u")[:S1].copy()
+        s.solve_async()
+        if S1 > 0:
+            s.sync()
+            xo, uo = xin.copy(), uin.copy()
+            sto, ito = ob.rti_batch(spec, xo, uo, x0o, *data, threads=usable_cores())
+            stg, qsg = s.get_int("status")[:S1], s.get_int("qp_status")[:S1]
+            n_same += int((stg == sto).sum())
+            ok = (sto == 0) & (ito < spec.opts.qp_iter_max) & (qsg == 0)
+            n_ok += int(ok.sum())
+            if ok.any():
+                e = np.maximum(util.rel_err_per_instance(s.get_all("x")[:S1][ok], xo[ok]), util.rel_err_per_instance(s.get_all("u")[:S1][ok], uo[ok]))
+                errs.append(e)
+                # (the rule of tests/parity_rule.py on the sample: its indices are the first S1 of the batch)
+                r = parity_rule.check(ob, spec, s, ok, e, xin, uin, x0o, data, soft=(name == "usv_model_guidance_ca1" and K > 0), max_frac=1.0)
+                n_above += r["above"]
+                n_bad += len(r["violations"])
+        s.advance(1e-3, seed=3000 + w)
+        if S1 > 0:
+            s.sync()
+            x0o = s.get("x0", 0)[:S1].copy()
+    if S1 > 0 and errs:
+        ee = np.concatenate(errs)
+        par = {"ticks": 3, "instances": S1, "compared": int(ee.size), "status_agreement_frac": n_same / float(3 * S1),
+               "converged_on_both_sides_frac": n_ok / float(3 * S1),
+               "rel_err_per_instance": {"p50": float(np.percentile(ee, 50)), "p99": float(np.percentile(ee, 99)), "max": float(ee.max())},
+               "count_above_1e-5": n_above, "rule_violations": n_bad}
+    s.sync()
+    nst = max(1, min(args.steps, 10))
+    unconv0 = s.unconverged_total()
+    t0 = time.perf_counter()
+    for k in range(nst):
+        s.solve_async()
+        s.advance(1e-3, seed=4000 + k)
+    s.sync()
+    el = time.perf_counter() - t0
+    unconv = s.unconverged_total() - unconv0
+    qs, st, qi = s.get_int("qp_status"), s.get_int("status"), s.get_int("qp_iter")
+    tmin = s.get("obs_tmin", 0) if K > 0 else np.full(B, 1e300)
+    out = {"value": (B * nst - unconv) / el, "unit": "converged solves/s", "ms_per_step": el / nst * 1e3, "steps": nst, "warmup": 3,
+           "solves_per_s_counting_unconverged_ones": B * nst / el,
+           "qp_not_converged_frac": float((qs != 0).mean()), "status_nonzero_frac": float((st != 0).mean()),
+           "qp_iter_mean": float(qi.mean()), "active_row_frac": float((tmin < 1e-3).mean()) if K > 0 else 0.0,
+           "generator": "SURVEY.md 8(d) to the letter (scenario 'survey_verbatim': no obstacle clip, initial guess x_k = x0, disturbance on every state; "
+                        "%d RK4 step(s) per interval); same batch size, seed and profile as the headline; the full-length line: --workload survey-verbatim" % steps,
+           "parity": par}
+    s.close()
+    return out
 
 
 def self_launch(args):
@@ -147,6 +266,14 @@ def main():
     ap.add_argument("--oracle-opt", action="append", default=[], metavar="NAME=VALUE",
                     help="option of the CPU oracle in the un-timed parity leg (oracle/usv_oracle.h usv_opts), e.g. itref_corr_max=2 or "
                          "cond_pred_corr=1: HPIPM options the restatement leaves off by default; may be repeated")
+    ap.add_argument("--hpipm-mode", default="BALANCE", choices=["BALANCE", "SPEED", "ROBUST", "R04"],
+                    help="QP solver profile of the device AND of the oracle of the parity leg (include/usvmpc.h USVMPC_HPIPM_*; --oracle-opt overrides the oracle's)")
+    ap.add_argument("--spread-mode", default="R04", choices=["BALANCE", "SPEED", "ROBUST", "R04", "none"],
+                    help="second profile for parity.profile_spread: the device under --hpipm-mode against the device under this profile on the parity sample")
+    ap.add_argument("--no-survey-verbatim", action="store_true",
+                    help="skip the second timed region on SURVEY 8(d)'s generator to the letter (the `survey_verbatim` key of the default line)")
+    ap.add_argument("--bind-numa", default="auto", choices=["auto", "on", "off"],
+                    help="pin each rank's host threads to its GPU's NUMA node (auto: under a multi-rank launch)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="solver run-time option (usvmpc_set_option), e.g. dynamic_rows=0; may be repeated")
     args = ap.parse_args()
@@ -166,6 +293,7 @@ def main():
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d has no GPU (visible: %d)" % (local_rank, torch.cuda.device_count()))
     from mpc_collisionavoidance_amd import BatchOcpSolver, scenario, sharding, usv_models
+    binding = bind_to_gpu_numa(local_rank, world, args.bind_numa)
 
     dist = None
     ranks_seen = 1
@@ -190,6 +318,7 @@ def main():
     ocp.solver_options.sim_method_num_steps = steps
     if args.cond_N:
         ocp.solver_options.qp_solver_cond_N = args.cond_N
+    ocp.solver_options.hpipm_mode = args.hpipm_mode
     solver = BatchOcpSolver(ocp, B, device=local_rank)
     cond_applied = bool(args.cond_N and args.cond_N != N)   # the QP is condensed to cond_N dense stages on the device (csrc/cond_ipm.hpp)
     scenario.load_into(solver, wl)
@@ -222,7 +351,7 @@ def main():
             if k == "hpipm_mode":
                 return v
             return float(v) if k in ("cpc_factor", "mu0", "alpha_min", "thr0") else int(float(v))
-        oopts = {kv.split("=")[0]: _oval(*kv.split("=")[:2]) for kv in args.oracle_opt}
+        oopts = dict({"hpipm_mode": args.hpipm_mode}, **{kv.split("=")[0]: _oval(*kv.split("=")[:2]) for kv in args.oracle_opt})
         spec = ob.spec(_ID[name], N, N * dt, K, sim_steps=steps, **oopts)
         x0o = wl["x0"][:S1].copy()
         errs, errs_x, errs_u = [], [], []
@@ -232,6 +361,17 @@ def main():
         soft_rows = name == "usv_model_guidance_ca1" and K > 0
         if cond_applied:
             solver.set_option("keep_multipliers", 1)   # (the condensed solve writes "lam" / "t" itself, into buffers that must exist)
+        # parity.profile_spread: what the profile choice - the part of "parity unpinned" that is a choice - is worth on THIS sample: the same
+        # instances, from the same inputs every tick, on the device under a second profile
+        spread_solver, spread = None, []
+        if args.spread_mode not in ("none", args.hpipm_mode) and not cond_applied:
+            ocp2 = usv_models.make_ocp(name, N * dt, N, None if name == "usv_model" else K)
+            ocp2.solver_options.sim_method_num_steps = steps
+            ocp2.solver_options.hpipm_mode = args.spread_mode
+            spread_solver = BatchOcpSolver(ocp2, S1, device=local_rank)
+            scenario.load_into(spread_solver, {k: (v[:S1] if isinstance(v, np.ndarray) else v) for k, v in wl.items()})
+            if static:
+                spread_solver.set_option("static_obstacles", 1)
     for w in range(args.warmup):
         if check:   # the oracle starts every tick from the iterate and x0 the device starts it from ("same inputs")
             solver.sync()
@@ -245,6 +385,15 @@ def main():
                                     threads=usable_cores())
             xg, ug = solver.get_all("x")[:S1], solver.get_all("u")[:S1]
             stg, qsg = solver.get_int("status")[:S1], solver.get_int("qp_status")[:S1]
+            if spread_solver is not None:
+                spread_solver.set_all("x", xo_in); spread_solver.set_all("u", uo_in); spread_solver.set("x0", 0, x0o)
+                spread_solver.solve()
+                both = (qsg == 0) & (spread_solver.get_int("qp_status") == 0)
+                if both.any():
+                    xs2, us2 = spread_solver.get_all("x"), spread_solver.get_all("u")
+                    scx = np.maximum(1e-2, np.abs(xg[both]).max(axis=(0, 1))); scu = np.maximum(1e-2, np.abs(ug[both]).max(axis=(0, 1)))
+                    spread.append(np.maximum((np.abs(xs2[both] - xg[both]) / scx).reshape(int(both.sum()), -1).max(axis=1),
+                                             (np.abs(us2[both] - ug[both]) / scu).reshape(int(both.sum()), -1).max(axis=1)))
             # every solve the DEVICE calls converged must satisfy the KKT conditions of its QP (stat <= 1e-6, eq / ineq / comp
             # <= 1e-8), evaluated in numpy on the oracle's linearisation - independent of anybody's iteration path
             qpd = kkt_check.linearize_batch(ob, spec, xo_in, uo_in, x0o, wl["yref"][:S1], wl["yref_e"][:S1], wl["p"][:S1], wl["lh"][:S1])
@@ -298,13 +447,24 @@ def main():
                   "kkt_certified_frac": n_cert / float(max(1, n_conv_dev)),
                   "kkt": "every solve the device reports converged, checked against the KKT conditions of its QP (stat <= 1e-6, "
                          "eq / ineq / comp <= 1e-8, lam, t >= 0) by tests/kkt.py on the oracle's linearisation: %d of %d" % (n_cert, n_conv_dev),
-                  "oracle_options": dict({"hpipm_mode": "BALANCE"}, **oopts),
+                  "profile_spread": ({"device_profile": args.hpipm_mode, "against_device_profile": args.spread_mode,
+                                      "compared": int(sum(len(e) for e in spread)),
+                                      "p50": float(np.percentile(np.concatenate(spread), 50)), "p99": float(np.percentile(np.concatenate(spread), 99)),
+                                      "max": float(np.concatenate(spread).max()), "count_above_1e-5": int((np.concatenate(spread) > 1e-5).sum()),
+                                      "note": "the SAME kernels under two QP solver profiles (include/usvmpc.h USVMPC_HPIPM_*), same instances, same inputs "
+                                              "every tick: what the recalled-not-read part of acados' defaults (mu0, alpha_min, cond_pred_corr) moves the "
+                                              "solution inside the IPM's exit tolerance ball - the measured size of 'parity unpinned' beyond rounding"}
+                                     if spread else None),
+                  "oracle_options": oopts,
                   "oracle_profile": "oracle/usv_oracle.c usv_opts_profile: HPIPM mode + acados' overwrites as recalled (BALANCE: mu0 1, alpha_min 1e-8, "
                                     "cond_pred_corr 1, itref_corr_max 2); the device runs its descriptor's profile (config.hpipm_mode)",
                   "vs": "CPU oracle (port; parity vs acados itself is unpinned); closed loop, every tick from the iterate "
                         "and x0 the device starts it from; error of an instance = max over (x, u) components of |dev - oracle| / "
                         "(that component's max |oracle| over the sample)"}
+    if check and spread_solver is not None:
+        spread_solver.close()
     barrier()
+    unconv_before = solver.unconverged_total()
 
     # ---- timed region: exactly K steps
     t0 = time.perf_counter()
@@ -313,7 +473,12 @@ def main():
         solver.advance(sigma, seed=2000 + k)
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
+        mine = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        every = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(v.item()) / args.steps * 1e3 for v in every]   # (each rank's own clock around the same K steps)
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -323,9 +488,9 @@ def main():
     fu_ms = solver.followup_ms(nk)   # (the follow-up launch of the hand-over, usv_qp_resume: part of qp_ms)
     # per-step times on the device clock ("report median"): start of tick i to start of tick i + 1 on the solver's stream;
     # the last step closes with the wall-clock remainder of the timed region
+    # (device event deltas only - one fewer than steps: the last step has no following tick to close it, and the wall-clock remainder
+    # would mix the host's launch offset and the final synchronisation into one sample)
     tick_ms = [float(v) for v in solver.tick_ms(nk)]
-    if nk == args.steps:
-        tick_ms.append(max(0.0, elapsed * 1e3 - sum(tick_ms)))
     mapping = solver.last_mapping()
     pipelined = B >= 16384 and not any(kv.split("=")[0] == "pipeline_linearize" and float(kv.split("=")[1]) == 0.0 for kv in args.option)
     fails = solver.fail_counts(nk)
@@ -352,7 +517,7 @@ def main():
 
     # a solve = one RTI iteration of one instance whose IPM converged to the stated tolerance - counted on the device by
     # every launch (usvmpc_unconverged_counts: qp_status != 0)
-    unconv = float(solver.unconverged_counts(nk).sum()) * (args.steps / float(nk))
+    unconv = float(solver.unconverged_total() - unconv_before)   # (a device-side running sum: exact for any number of steps)
     solves_here = float(B * args.steps)
     b_min = b_max = B
     if dist is not None:
@@ -426,6 +591,12 @@ def main():
                                   % (S, "-O3 -march=native on this host" if native else "with the checker's flags (-O2)",
                                      cores, csec, S1t, c1sec)}
 
+    # ---- the survey's generator to the letter, as a second short timed region of the same run (single-GPU default-workload lines)
+    survey_verbatim = None
+    if rank == 0 and args.gpus == 1 and args.workload == "survey" and not args.no_survey_verbatim and not cond_applied and not args.moving and K > 0:
+        solver.sync()
+        survey_verbatim = survey_verbatim_leg(args, name, N, K, B, local_rank, min(S1, 128) if check else 0)
+
     departures = "none"
     if args.workload == "survey" and name == "usv_model_pf_ca":
         departures = ("(1) %d RK4 steps per interval (the model cannot take one 0.05 s step); (2) obstacle clip: an obstacle whose keep-out circle "
@@ -472,8 +643,15 @@ def main():
                 "mapping": ("one OCP instance per wavefront (option 'wide': the rows of the wave share out the stage-local row work)" if mapping == 1
                             else "one OCP instance per workgroup of four wavefronts (options 'wide' / 'wide_waves')" if mapping == 4
                             else "four OCP instances per wavefront (one per 16-lane row)"),
+                "hpipm_mode": "%s (QP solver profile of the device, include/usvmpc.h: %s)"
+                              % (args.hpipm_mode, "HPIPM's values without acados' overwrites, no cond_pred_corr - the library's behaviour up to round 5"
+                                 if args.hpipm_mode == "R04" else "acados' overwrites mu0 1 / alpha_min 1e-8 / tolerances 1e-6, 1e-8 / iter_max 50, cond_pred_corr 1"),
                 "lib_sha256": lib_hash,
                 "sharding": "batch-sharded x%d, no data-path collective" % world, "ranks_seen": ranks_seen,
+                "per_rank_ms_per_step": per_rank_ms, "per_rank_ms_per_step_min_max": [min(per_rank_ms), max(per_rank_ms)],
+                "host_binding_rank0": binding,
+                "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "NCCL_SOCKET_IFNAME", "HIP_VISIBLE_DEVICES",
+                                                       "ROCR_VISIBLE_DEVICES", "OMP_NUM_THREADS") if os.environ.get(k) is not None},
             },
             "roofline": {
                 "bound": "hbm", "kernel": "usv_qp_cond" if cond_applied else ("usv_qp_rti + usv_qp_resume" if float(fu_ms.mean()) > 0.0 else "usv_qp_rti"),
@@ -505,13 +683,14 @@ def main():
                 "qp_not_converged_frac": float((qs != 0).mean()),
                 "solves_per_s_counting_unconverged_ones": value_all,
                 "unconverged_solves_in_timed_region": unconv,
-                "unconverged_counted_over_steps": nk,   # (the device keeps the last 64 launches' counts: beyond that the figure is scaled up)
+                "unconverged_counted_over_steps": args.steps,   # (device-side running sum over the whole timed region)
                 "active_row_frac": float((tmin < 1e-3).mean()) if K > 0 else 0.0,
                 "qp_iter_mean": float(qi.mean()), "qp_iter_p50": float(np.percentile(qi, 50)),
                 "qp_iter_p99": float(np.percentile(qi, 99)), "qp_iter_max": int(qi.max()),
                 "qp_iter_histogram": np.bincount(np.clip(qi, 0, None)).tolist(),
             },
             "parity": parity,
+            "survey_verbatim": survey_verbatim,
             "allgather": gather,
         }
         print(json.dumps(out))

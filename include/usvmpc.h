@@ -172,11 +172,16 @@ int usvmpc_fail_counts(usvmpc_handle *h, int n, int *counts);
  * a hard keep-out circle), per solve likewise: solves minus this = "solves" as SURVEY.md 8(d) counts them (IPM converged to the stated
  * tolerance).  RTI solves (usvmpc_solve / usvmpc_solve_async); counted by a small kernel behind the QP launch. */
 int usvmpc_unconverged_counts(usvmpc_handle *h, int n, int *counts);
+/* ... and their sum over every RTI solve since the handle was created (a device-side running sum: no limit of 64 solves) */
+int usvmpc_unconverged_total(usvmpc_handle *h, long long *total);
 /* option "handover_iter": how many instances each of the last n RTI launches handed over to its follow-up launch (oldest first, n <= 64) */
 int usvmpc_handover_counts(usvmpc_handle *h, int n, int *counts);
 /* ... and how long that follow-up launch (kernel usv_qp_resume) took, in ms, for each of the last n solves - part of usvmpc_kernel_ms' qp_ms;
  * 0 for a solve without one */
 int usvmpc_followup_ms(usvmpc_handle *h, int n, float *ms);
+/* option "handover_co": of those, how many the follow-up kernel running BESIDE the launch (usv_qp_resume_co) finished, and how many of its
+ * waits for a list entry ran into the spin limit (left to the follow-up launch behind the main one; timeouts may be NULL) */
+int usvmpc_handover_co_counts(usvmpc_handle *h, int n, int *finished, int *timeouts);
 /* option "pipeline_linearize": how many linearisations made ahead of time (on the second stream, beside the previous tick's QP launch)
  * were used by the following solve / discarded because the caller wrote x, u or yref in between.  The lineariser only runs ahead after
  * two solves in a row without such a write, so a caller that sets yref every tick (the reference's protocol) discards none. */
@@ -261,6 +266,11 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  *       same bits.  -1: past 24 iterations where the horizon's planes fit a CU's LDS (+1 % at 65 536 instances, +5 ... 15 % at 4 096 ... 12 288),
  *       never otherwise; 0: never; n > 0: past n.  Layouts: one obstacle chunk / no obstacle rows, packed box rows, no soft state bounds;
  *   "handover_lds" (default 1) - 0: the follow-up launch works over the planes in HBM whatever the horizon (measured: a loss);
+ *   "handover_co" (default -1 = on where the follow-up works in LDS and the handle owns its stream; 0: off) - the follow-up kernel also runs
+ *       BESIDE the draining launch (kernel usv_qp_resume_co on a stream of its own): its workgroups come onto the device as wavefronts of the
+ *       main launch leave, wait - a bounded wait, "handover_co_spin" polls - for list entries to appear and finish those instances while the
+ *       main launch is still draining; what they do not get to is done by the launch behind it (every entry is taken by exactly one of the
+ *       two).  Scheduling only.  "handover_co_wgs": workgroups of that kernel (0 = as many as the follow-up launch may hold);
  *   "disturbance_mask" (default all ones) - bit j set: usvmpc_advance adds its noise to state j (the reference's commented
  *       hooks disturb x0[3] and x0[5] only: catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/main.py:181-183). */
 int usvmpc_set_option(usvmpc_handle *h, const char *name, double value);

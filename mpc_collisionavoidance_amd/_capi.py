@@ -56,7 +56,7 @@ loaded_before_torch = False
 
 EXPORTS = ["usvmpc_model_dims", "usvmpc_default_options", "usvmpc_hpipm_profile", "usvmpc_create", "usvmpc_destroy",
            "usvmpc_set", "usvmpc_get", "usvmpc_get_int", "usvmpc_solve", "usvmpc_solve_sqp", "usvmpc_solve_async",
-           "usvmpc_sync", "usvmpc_get_device_ptr", "usvmpc_last_kernel_ms", "usvmpc_kernel_ms", "usvmpc_tick_ms", "usvmpc_fail_counts", "usvmpc_unconverged_counts", "usvmpc_handover_counts", "usvmpc_followup_ms", "usvmpc_pipeline_stats", "usvmpc_last_mapping",
+           "usvmpc_sync", "usvmpc_get_device_ptr", "usvmpc_last_kernel_ms", "usvmpc_kernel_ms", "usvmpc_tick_ms", "usvmpc_fail_counts", "usvmpc_unconverged_counts", "usvmpc_unconverged_total", "usvmpc_handover_counts", "usvmpc_handover_co_counts", "usvmpc_followup_ms", "usvmpc_pipeline_stats", "usvmpc_last_mapping",
            "usvmpc_advance", "usvmpc_set_stream", "usvmpc_set_option", "usvmpc_calibrate_traffic", "usvmpc_guidance_reset", "usvmpc_guidance_prepare", "usvmpc_guidance_sense",
            "usvmpc_guidance_publish", "usvmpc_guidance_state", "usvmpc_device_bytes", "usvmpc_last_error",
            "usvmpc_debug_model_eval", "usvmpc_debug_obstacle_eval"]
@@ -104,6 +104,8 @@ def load(path):
     L.usvmpc_fail_counts.argtypes = [C.c_void_p, C.c_int, _ip]
     L.usvmpc_unconverged_counts.argtypes = [C.c_void_p, C.c_int, _ip]
     L.usvmpc_handover_counts.argtypes = [C.c_void_p, C.c_int, _ip]
+    L.usvmpc_unconverged_total.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    L.usvmpc_handover_co_counts.argtypes = [C.c_void_p, C.c_int, _ip, _ip]
     L.usvmpc_followup_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.usvmpc_pipeline_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
     L.usvmpc_last_mapping.argtypes = [C.c_void_p, C.POINTER(C.c_int)]

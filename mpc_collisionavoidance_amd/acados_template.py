@@ -368,6 +368,19 @@ class BatchOcpSolver:
         self._check(self._lib.usvmpc_handover_counts(self._h, n, a))
         return np.array(a[:])
 
+    def unconverged_total(self):
+        """Instances whose QP did not converge to the IPM tolerances, summed over every RTI solve of this handle (device-side running sum)."""
+        v = C.c_longlong(0)
+        self._check(self._lib.usvmpc_unconverged_total(self._h, C.byref(v)))
+        return int(v.value)
+
+    def handover_co_counts(self, n):
+        """(finished, timeouts) of the follow-up kernel that runs BESIDE the launch (option "handover_co") for each of the last n solves:
+        instances it finished, and waits of its workgroups that ran into the spin limit."""
+        a, b = (C.c_int * n)(), (C.c_int * n)()
+        self._check(self._lib.usvmpc_handover_co_counts(self._h, n, a, b))
+        return np.array(a[:]), np.array(b[:])
+
     def advance(self, sigma=0.0, seed=0):
         """Closed-loop hand-over on the device: x0 <- x_1 (+ sigma N(0,1)); asynchronous."""
         self._check(self._lib.usvmpc_advance(self._h, float(sigma), int(seed)))

@@ -223,6 +223,12 @@ USV_DEV void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 USV_DEV void publish(int *flag, int v) { __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 USV_DEV int observe(const int *flag) { return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 USV_DEV void set_bits(int *word, int bits) { atomicOr(word, bits); }
+// Plain stores of this wave handed to a wave on another CU / XCD while both kernels run (hand-over to the co-resident follow-up kernel): the
+// producer writes its XCD's L2 back before the flag goes out (the asm wait is the one the compiler must not drop: MI355X_MICROARCH.md,
+// "Compiler hazard"), the consumer invalidates its L1 / non-local L2 lines after it has seen the flag.
+USV_DEV void release_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+USV_DEV void acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+USV_DEV bool claim(int *entry, int seen) { return atomicCAS(entry, seen, -2 - seen) == seen; }
 
 // lane index inside the wave (a wave carries four 16-lane groups)
 USV_DEV unsigned wave_lane() { return threadIdx.x & 63u; }

@@ -194,6 +194,13 @@ struct DevPtrs {
     int *susp_list;       // [B]     their groups
     double *susp_rec;     // [B][4]  per instance: step length and centring target of the pending step, residual scale, iterations done
     int handover_iter;
+    // ... with the follow-up kernel running BESIDE the draining launch (usvmpc.hip usv_qp_resume_co, option "handover_co"): entries are
+    // published one by one (susp_list starts at -1 everywhere; a consumer claims entry i by compare-and-swap to -2 - group), the planes and
+    // the record go out past the suspending wave's L2 first (the XCDs' L2s are not coherent: agent-scope release before the entry appears,
+    // agent-scope acquire in the consumer).  co_ctl: [0] tickets taken, [1] the main launch has ended, [2] main workgroups that have started,
+    // [3] entries the co-resident kernel finished, [4] polls that ran into the spin limit (a bounded wait: what it leaves is done by the
+    // launch behind the main one); nullptr: entries are only read after the launch has ended.
+    int *co_ctl;
 };
 
 } // namespace usv

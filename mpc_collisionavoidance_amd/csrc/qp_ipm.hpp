@@ -2178,13 +2178,20 @@ struct QpIpm {
             }
         }
         if (sel && lane == 0) {
-            const int slot = lanes::fetch_add(P.susp_count);
-            P.susp_list[slot] = (int)g;
             double *r = P.susp_rec + 4 * b;
             // (CPC: whether the pending step is a centring-only one rides in the sign of the iteration count, which is at least 1 here)
             double itv = (double)it;
             if constexpr (CPC) itv = ((double)so_prv == 0.0) ? -itv : itv;
             r[0] = a_prev; r[1] = sig_prev; r[2] = rbscale; r[3] = itv;
+        }
+        // With the follow-up kernel running beside this launch (co_ctl) the consumer may sit on another XCD and starts as soon as the entry
+        // appears: everything this wave has stored for the instance - planes, record - leaves its L2 first.  (Wave-uniform: kernel argument.)
+        const bool co = P.co_ctl != nullptr;
+        if (co) lanes::release_agent();
+        if (sel && lane == 0) {
+            const int slot = lanes::fetch_add(P.susp_count);
+            if (co) lanes::publish(P.susp_list + slot, (int)g);
+            else P.susp_list[slot] = (int)g;
         }
     }
 
@@ -2242,8 +2249,10 @@ struct QpIpm {
             if (resume) { // the state the suspending row left (all rows of the wave read the same record)
                 copy_in();
                 const double *r = P.susp_rec + 4 * b;
-                a_prev = r[0]; sig_prev = r[1]; rbscale = r[2]; it = (int)fabs(r[3]);
-                if constexpr (CPC) so_prv = (r[3] < 0.0) ? 0.0 : 1.0;
+                const double r3 = r[3];
+                a_prev = r[0]; sig_prev = r[1]; rbscale = r[2];
+                it = (int)fabs(r3);
+                if constexpr (CPC) so_prv = (r3 < 0.0) ? 0.0 : 1.0;
                 iters = it;
                 pend = true;
             }

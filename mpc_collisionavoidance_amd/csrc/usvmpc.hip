@@ -75,6 +75,8 @@ __global__ void __launch_bounds__(64 * WW, ((LDSWS || WIDE) ? 1 : qp_waves<KCH, 
     const int row = (int)(threadIdx.x >> 4);
     const long g0 = (long)blockIdx.x * rows;
     if (g0 >= ngroups) return;
+    // (hand-over with a co-resident follow-up kernel: that kernel goes to work only once every workgroup of THIS launch is on the device)
+    if constexpr (!WIDE && !LDSWS) { if (P.co_ctl != nullptr && threadIdx.x == 0) lanes::count_one(P.co_ctl + 2); }
     const bool has = row < rows;
     QpIpm<M, KCH, SOFT, HDIAG, PACK, SOFTBOX, LDSWS, MERGE, AUXLDS, WIDE, WW, CPC> q(P, has ? g0 + row : g0, has ? row : -1);
     q.solve(phase, queue0);
@@ -101,23 +103,87 @@ template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS>
 __global__ void __launch_bounds__(64, 1) usv_qp_resume(DevPtrs P)
 {
     const int n = lanes::uniform(*P.susp_count);
+    const bool co = P.co_ctl != nullptr; // (the co-resident kernel may have taken the entry - or be about to: one compare-and-swap decides)
     for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
-        QpIpm<M, KCH, SOFT, true, (KCH > 0), false, LDSWS, MERGE, false, true, 1> q(P, (long)P.susp_list[i], (threadIdx.x >> 4) == 0 ? 0 : -1);
+        int g = P.susp_list[i];
+        if (co) {
+            if (threadIdx.x == 0) g = (g >= 0 && lanes::claim(P.susp_list + i, g)) ? g : -1;
+            g = lanes::wave_first_i(g);
+            if (g < 0) continue;
+        }
+        QpIpm<M, KCH, SOFT, true, (KCH > 0), false, LDSWS, MERGE, false, true, 1> q(P, (long)g, (threadIdx.x >> 4) == 0 ? 0 : -1);
         q.solve(3, -1);
     }
 }
+// The same follow-up BESIDE the draining launch (option "handover_co"): enqueued on a stream of its own together with the main launch, its
+// workgroups come onto the device as main wavefronts leave it (75 KB of LDS and a SIMD's registers each), take a ticket each and wait - a
+// bounded wait - for the list entry of that number to appear; the instance behind it is finished here while the main launch is still
+// draining, instead of behind it.  A workgroup leaves when the main launch has ended and its ticket's entry never came (the list is
+// complete then), when its wait runs into the spin limit, or - at once - when it finds itself on the device before every workgroup of the
+// main launch is (it must not hold what a persistent launch still waits for).  Whatever is left is done by usv_qp_resume behind the main
+// launch; an entry is taken by one of the two (compare-and-swap).  Scheduling only: the same sweeps over the same planes.
+template <class M, int KCH, bool SOFT, bool MERGE>
+__global__ void __launch_bounds__(64, 1) usv_qp_resume_co(DevPtrs P, int main_wgs, int cap, int spin_limit)
+{
+    int *ctl = P.co_ctl;
+    {
+        int ok = 0;
+        if (threadIdx.x == 0) ok = lanes::observe(ctl + 2) >= main_wgs;
+        if (!lanes::wave_first_i(ok)) return;
+    }
+    for (;;) {
+        int t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(ctl, 1);
+        t = lanes::wave_first_i(t);
+        if (t >= cap) return;
+        // Every lane polls the same word: one access for the wave, and NO loop inside a single-lane region.  (The first form of this kernel had
+        // lane 0 alone run the ticket / poll / claim loops: on this toolchain every instance a workgroup finished after its first came out
+        // wrong - with or without the main launch beside it, with or without the fences; the sweeps' code was the follow-up launch's.  The
+        // single-lane regions left are an atomic each.)
+        int e, spins = 0;
+        for (;;) {
+            e = lanes::observe(P.susp_list + t);
+            if (e != -1) break;
+            if (lanes::observe(ctl + 1) != 0) { e = lanes::observe(P.susp_list + t); break; } // (the main launch has ended: the list is final)
+            if (++spins > spin_limit) break;
+            __builtin_amdgcn_s_sleep(64);
+        }
+        e = lanes::wave_first_i(e);
+        if (e == -1) { // nothing will come for this number (entries are dense), or the wait was given up: what is left is the launch's behind the main one
+            if (spins > spin_limit && threadIdx.x == 0) lanes::count_one(ctl + 4);
+            return;
+        }
+        int mine = 0;
+        if (threadIdx.x == 0) mine = (e >= 0 && lanes::claim(P.susp_list + t, e)) ? 1 : 0;
+        if (!lanes::wave_first_i(mine)) continue;
+        lanes::acquire_agent(); // (the suspending wave released at agent scope before the entry went out)
+        {
+            QpIpm<M, KCH, SOFT, true, (KCH > 0), false, true, MERGE, false, true, 1> q(P, (long)e, (threadIdx.x >> 4) == 0 ? 0 : -1);
+            q.solve(3, -1);
+        }
+        if (threadIdx.x == 0) lanes::count_one(ctl + 3);
+    }
+}
+static __global__ void usv_co_done(int *ctl) { lanes::publish(ctl + 1, 1); }
 using qp_resume_t = void (*)(DevPtrs);
+using qp_resume_co_t = void (*)(DevPtrs, int, int, int);
 template <class M, int KCH, bool SOFT, bool MERGE, bool LDSWS = false>
 constexpr qp_resume_t resume_kernel()
 {
     if constexpr (KCH == 1 || (KCH == 0 && !MERGE)) return &usv_qp_resume<M, KCH, SOFT, MERGE, LDSWS>;
     else return nullptr;
 }
+template <class M, int KCH, bool SOFT, bool MERGE>
+constexpr qp_resume_co_t resume_co_kernel()
+{
+    if constexpr (KCH == 1 || (KCH == 0 && !MERGE)) return &usv_qp_resume_co<M, KCH, SOFT, MERGE>;
+    else return nullptr;
+}
 // the wide kernels of one layout: [planes in LDS, planes in HBM] x [one wave, four waves per instance], and the follow-up kernel
 // (nplw: planes per stage an instance keeps in LDS; ex_lds / ex_hbm: planes of the exchange area - qp_ipm.hpp NPLW, EX_N)
 using qp_kernel_t = void (*)(DevPtrs, long, int, int, int);
-struct WideSet { qp_kernel_t lds1, hbm1, lds4, hbm4; qp_resume_t resume, resume_lds; int nplw, ex_lds, ex_hbm; };
-constexpr WideSet NO_WIDE = WideSet{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+struct WideSet { qp_kernel_t lds1, hbm1, lds4, hbm4; qp_resume_t resume, resume_lds; qp_resume_co_t resume_co; int nplw, ex_lds, ex_hbm; };
+constexpr WideSet NO_WIDE = WideSet{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
 template <class M, int KCH, bool SOFT, bool MERGE, bool SOFTBOX = false, bool UNPACKED = false>
 constexpr WideSet wide_set()
 {
@@ -127,6 +193,7 @@ constexpr WideSet wide_set()
                    wide_kernel<M, KCH, SOFT, MERGE, true, 4, SOFTBOX, UNPACKED>(), wide_kernel<M, KCH, SOFT, MERGE, false, 4, SOFTBOX, UNPACKED>(),
                    (SOFTBOX || (UNPACKED && KCH > 0)) ? nullptr : resume_kernel<M, KCH, SOFT, MERGE>(),
                    (SOFTBOX || (UNPACKED && KCH > 0)) ? nullptr : resume_kernel<M, KCH, SOFT, MERGE, true>(),
+                   (SOFTBOX || (UNPACKED && KCH > 0)) ? nullptr : resume_co_kernel<M, KCH, SOFT, MERGE>(),
                    WL::P_RB0 - (packed ? 4 : 0) + (SOFTBOX ? 6 : 0), wide_ex_planes(KCH, SOFTBOX), wide_ex_planes_hbm(KCH, SOFTBOX)};
 }
 
@@ -145,7 +212,7 @@ __global__ void __launch_bounds__(64) usv_qp_export(DevPtrs P, long ngroups)
 // launch, per workgroup in LDS and one atomic per workgroup (usvmpc_unconverged_counts; SURVEY.md 8(d) counts converged solves).  Not inside
 // QpIpm::finish(): one more counter there moved the headline kernel's register allocation (12 -> 17 spilled registers, +1.3 % per launch in a
 // same-box A/B).
-static __global__ void __launch_bounds__(256) usv_count_unconverged(const int *qp_status, int B, int *count)
+static __global__ void __launch_bounds__(256) usv_count_unconverged(const int *qp_status, int B, int *count, unsigned long long *total)
 {
     __shared__ int loc;
     if (threadIdx.x == 0) loc = 0;
@@ -153,7 +220,7 @@ static __global__ void __launch_bounds__(256) usv_count_unconverged(const int *q
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B && qp_status[i] != 0) atomicAdd(&loc, 1);
     __syncthreads();
-    if (threadIdx.x == 0 && loc != 0) atomicAdd(count, loc);
+    if (threadIdx.x == 0 && loc != 0) { atomicAdd(count, loc); atomicAdd(total, (unsigned long long)loc); } // (total: the handle's running sum)
 }
 
 #if USV_MAIN
@@ -338,6 +405,13 @@ struct usvmpc_handle {
     int *d_susp_count, *d_susp_list; // [RING] instances each of the last launches handed over / [B] their groups
     double *d_susp_rec;       // [B][4] (DevPtrs::susp_rec)
     long resume_cap;          // workgroups of the follow-up launch (0: not yet known, -1: the kernel cannot be launched)
+    // the follow-up kernel beside the draining launch (usv_qp_resume_co; option "handover_co": -1 = when the follow-up works in LDS, 0 never, 1 the same)
+    int handover_co;
+    int co_spin_limit;        // polls of ~1 us a co-resident workgroup waits for its entry before it gives up (option "handover_co_spin")
+    long co_wgs;              // workgroups of the co-resident launch (option "handover_co_wgs"; 0: as many as the follow-up launch may hold)
+    hipStream_t co_stream;    // nullptr until first used
+    hipEvent_t ev_co_pre, ev_co_end;
+    int *d_co_ctl;            // [RING][8] DevPtrs::co_ctl of the last launches
     bool ev3_set[RING];       // ev[.][3] was recorded for that solve
     bool resume_lds, handover_lds; // the follow-up launch copies the planes into LDS (chosen with resume_cap) / option "handover_lds"
     long max_waves;           // cap on the persistent waves of the QP kernel (0: as many as the device holds)
@@ -349,6 +423,7 @@ struct usvmpc_handle {
     unsigned noise_mask;      // states usvmpc_advance disturbs (option "disturbance_mask"; default: all)
     int *d_fail_ring;         // [RING] instances with status != 0, one slot per solve
     int *d_unconv_ring;       // [RING] instances whose QP did not converge to the tolerances (qp_status != 0), one slot per solve
+    unsigned long long *d_unconv_total; // [1] ... summed over every RTI solve of the handle (usvmpc_unconverged_total)
     // Caller-visible arrays live in ONE device arena, in the order [x | u | status | x0 | yref | yref_e | p | lh] (256-byte aligned
     // pieces).  Small handles (the single-instance drop-in faces: AcadosOcpSolver, the acados C shim) also keep a pinned host
     // MIRROR of it: usvmpc_set then writes the mirror and marks the field dirty - no HIP call, no synchronisation - and the next
@@ -812,7 +887,7 @@ int launch_pair(usvmpc_handle *h, int phase)
     auto launch_qp = [&](auto kern, decltype(kern) kern_lds, decltype(kern) kern_aux = nullptr, WideSet wide = NO_WIDE) -> int {
         const long lds_inst = (long)(h->N + 1) * h->spec.npt * 128;
         h->last_wide = 0;
-        h->ptrs.susp_count = nullptr; h->ptrs.susp_list = nullptr; h->ptrs.susp_rec = nullptr; h->ptrs.handover_iter = 0; // (set by the path that hands over)
+        h->ptrs.susp_count = nullptr; h->ptrs.susp_list = nullptr; h->ptrs.susp_rec = nullptr; h->ptrs.handover_iter = 0; h->ptrs.co_ctl = nullptr; // (set by the path that hands over)
         const qp_kernel_t kern_wide = wide.lds1, kern_wide_hbm = wide.hbm1;
         // Four waves per instance (qp_ipm.hpp, WW): a workgroup = a whole CU shares out the row work of 16 consecutive stages - for the
         // single instance and batches of at most one instance per CU.
@@ -1016,13 +1091,41 @@ int launch_pair(usvmpc_handle *h, int phase)
         h->ptrs.susp_rec = hand ? h->d_susp_rec : nullptr;
         h->ptrs.handover_iter = hand ? hand_it : 0;
         const dim3 qg((unsigned)((ng * LANES + qp_block - 1) / qp_block)), qb(qp_block);
+        // The follow-up kernel BESIDE the draining launch (usv_qp_resume_co): on a stream of its own, eligible together with the main launch;
+        // what it does not get to is done by the follow-up launch behind the main one.  With the planes copied into LDS only (the form that pays).
+        const bool co = hand && h->handover_co > 0 && h->resume_lds && wide.resume_co != nullptr && h->own_stream;
+        h->ptrs.co_ctl = nullptr;
+        if (co) {
+            if (!h->co_stream) {
+                int prio_least = 0, prio_greatest = 0;
+                HIP_TRY(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+                HIP_TRY(h, hipStreamCreateWithPriority(&h->co_stream, hipStreamNonBlocking, prio_least));
+                HIP_TRY(h, hipEventCreateWithFlags(&h->ev_co_pre, hipEventDisableTiming));
+                HIP_TRY(h, hipEventCreateWithFlags(&h->ev_co_end, hipEventDisableTiming));
+                if (dev_alloc(h, &h->d_co_ctl, (size_t)usvmpc_handle::RING * 8, true)) return USVMPC_E_HIP;
+            }
+            HIP_TRY(h, hipFuncSetAttribute((const void *)wide.resume_co, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xbytes)); // (per kernel, not per handle: handles differ in horizon)
+            h->ptrs.co_ctl = h->d_co_ctl + 8 * (h->nsolves % usvmpc_handle::RING);
+            HIP_TRY(h, hipMemsetAsync(h->ptrs.co_ctl, 0, 8 * sizeof(int), h->stream));
+            HIP_TRY(h, hipMemsetAsync(h->d_susp_list, 0xff, (size_t)h->B * sizeof(int), h->stream)); // (-1: no entry yet)
+            HIP_TRY(h, hipEventRecord(h->ev_co_pre, h->stream));
+        }
         hipLaunchKernelGGL(kern, qg, qb, aux_bytes, h->stream, h->ptrs, ng, phase, q0, 4);
+        if (co) {
+            hipLaunchKernelGGL(usv_co_done, dim3(1), dim3(1), 0, h->stream, h->ptrs.co_ctl);
+            HIP_TRY(h, hipStreamWaitEvent(h->co_stream, h->ev_co_pre, 0));
+            long nco = std::min<long>(h->resume_cap, (long)h->B);
+            if (h->co_wgs > 0) nco = std::min<long>(nco, h->co_wgs);
+            hipLaunchKernelGGL(wide.resume_co, dim3((unsigned)nco), dim3(qp_block), xbytes, h->co_stream, h->ptrs, (int)qg.x, (int)h->B, h->co_spin_limit);
+            HIP_TRY(h, hipEventRecord(h->ev_co_end, h->co_stream));
+        }
         if (hand) {
             HIP_TRY(h, hipEventRecord(ev[3], h->stream));
             h->ev3_set[h->nsolves % usvmpc_handle::RING] = true;
             const long nwg = std::min<long>(h->resume_cap, (long)h->B);
             hipLaunchKernelGGL(kern_resume, dim3((unsigned)nwg), dim3(qp_block), xbytes, h->stream, h->ptrs);
         }
+        if (co) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_co_end, 0)); // (the tick's QPs are solved when both kernels are through)
         return 0;
     };
     int rcq = 0;
@@ -1063,7 +1166,7 @@ int launch_pair(usvmpc_handle *h, int phase)
     HIP_TRY(h, hipEventRecord(ev[2], h->stream));
     if (phase == 0) { // (an RTI solve: one QP per instance)
         hipLaunchKernelGGL(usv_count_unconverged, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->ptrs.qp_status, B,
-                           h->d_unconv_ring + h->nsolves % usvmpc_handle::RING);
+                           h->d_unconv_ring + h->nsolves % usvmpc_handle::RING, h->d_unconv_total);
         HIP_TRY(h, hipGetLastError());
     }
     if (spec_next) {
@@ -1315,6 +1418,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->lds_cap = 0;
     h->wide_mode = -1; h->wide_cap = 0; h->wide_hbm_cap = 0; h->last_wide = 0;
     h->wide_waves = -1; h->wide4_cap = 0; h->wide4_hbm_cap = 0;
+    h->handover_co = 0; h->co_spin_limit = 200000; h->co_wgs = 0; h->co_stream = nullptr; h->ev_co_pre = nullptr; h->ev_co_end = nullptr; h->d_co_ctl = nullptr;
     h->handover_iter = -1; for (bool &e : h->ev3_set) e = false; h->resume_lds = false; h->handover_lds = true; h->d_susp_count = nullptr; h->d_susp_list = nullptr; h->d_susp_rec = nullptr; h->resume_cap = 0;
     h->max_waves = 0;
     {
@@ -1387,6 +1491,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     TRY_C(dev_alloc(h, &P.obs_tmin, B, true));
     TRY_C(dev_alloc(h, &h->d_fail_ring, usvmpc_handle::RING, true));
     TRY_C(dev_alloc(h, &h->d_unconv_ring, usvmpc_handle::RING, true));
+    TRY_C(dev_alloc(h, &h->d_unconv_total, 1, true));
     TRY_C(dev_alloc(h, &P.queue, 1, true));
     TRY_C(dev_alloc(h, &P.nlp_res, B * 4, true));
     TRY_C(dev_alloc(h, &P.sqp_iter, B, true));
@@ -1419,6 +1524,12 @@ int usvmpc_destroy(usvmpc_handle *h)
         (void)hipStreamDestroy(h->aux_stream);
         (void)hipEventDestroy(h->ev_pre);
         (void)hipEventDestroy(h->ev_spec);
+    }
+    if (h->co_stream) {
+        (void)hipStreamSynchronize(h->co_stream);
+        (void)hipStreamDestroy(h->co_stream);
+        (void)hipEventDestroy(h->ev_co_pre);
+        (void)hipEventDestroy(h->ev_co_end);
     }
     for (void *a : h->allocs) (void)hipFree(a);
     if (h->mirror) (void)hipHostFree(h->mirror);
@@ -1685,6 +1796,17 @@ int usvmpc_unconverged_counts(usvmpc_handle *h, int n, int *counts)
     return 0;
 }
 
+int usvmpc_unconverged_total(usvmpc_handle *h, long long *total)
+{
+    if (!h || !total) return USVMPC_E_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    unsigned long long v = 0;
+    HIP_TRY(h, hipMemcpyAsync(&v, h->d_unconv_total, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *total = (long long)v;
+    return 0;
+}
+
 int usvmpc_handover_counts(usvmpc_handle *h, int n, int *counts)
 {
     if (!h || n < 1 || !counts) return USVMPC_E_ARG;
@@ -1695,6 +1817,24 @@ int usvmpc_handover_counts(usvmpc_handle *h, int n, int *counts)
     HIP_TRY(h, hipMemcpyAsync(ring, h->d_susp_count, sizeof(ring), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < n; i++) counts[i] = ring[(h->nsolves - n + i) % usvmpc_handle::RING];
+    return 0;
+}
+
+int usvmpc_handover_co_counts(usvmpc_handle *h, int n, int *finished, int *timeouts)
+{
+    if (!h || n < 1 || !finished) return USVMPC_E_ARG;
+    if (h->nsolves < n || n > usvmpc_handle::RING) { h->err = "fewer solves recorded than requested"; return USVMPC_E_ARG; }
+    for (int i = 0; i < n; i++) { finished[i] = 0; if (timeouts) timeouts[i] = 0; }
+    if (!h->d_co_ctl) return 0; // (no launch of this handle had a co-resident follow-up kernel)
+    HIP_TRY(h, hipSetDevice(h->device));
+    int ring[usvmpc_handle::RING * 8];
+    HIP_TRY(h, hipMemcpyAsync(ring, h->d_co_ctl, sizeof(ring), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; i++) {
+        const int r = (h->nsolves - n + i) % usvmpc_handle::RING;
+        finished[i] = ring[8 * r + 3];
+        if (timeouts) timeouts[i] = ring[8 * r + 4];
+    }
     return 0;
 }
 
@@ -1817,7 +1957,10 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
         h->handover_iter = value < 0.0 ? -1 : (int)value;   // (-1: the default - 24 when the follow-up launch works in LDS, else never)
         return 0;
     }
-    if (s == "handover_lds") { h->handover_lds = value != 0.0; reset_caps(h); return 0; } // the follow-up launch with the planes copied into LDS when the horizon fits (default), or always over the planes in HBM
+    if (s == "handover_lds") { h->handover_lds = value != 0.0; reset_caps(h); return 0; }
+    if (s == "handover_co") { h->handover_co = value < 0.0 ? -1 : (value != 0.0 ? 1 : 0); return 0; } // the follow-up kernel beside the draining launch (default) or only behind it
+    if (s == "handover_co_spin") { if (!(value >= 1.0 && value <= 2e9)) { h->err = "handover_co_spin out of range"; return USVMPC_E_ARG; } h->co_spin_limit = (int)value; return 0; }
+    if (s == "handover_co_wgs") { if (!(value >= 0.0 && value <= 1e6)) { h->err = "handover_co_wgs out of range"; return USVMPC_E_ARG; } h->co_wgs = (long)value; return 0; } // the follow-up launch with the planes copied into LDS when the horizon fits (default), or always over the planes in HBM
     if (s == "disturbance_mask") { // bit j: usvmpc_advance adds its noise to state j
         h->noise_mask = (unsigned)value;
         return 0;
@@ -2031,6 +2174,7 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream)
         const int rcs = spec_cancel(h);
         if (rcs) return rcs;
         h->pipeline = false; // (the caller's stream carries the caller's own ordering: nothing of this handle runs beside it)
+        h->handover_co = 0;
     }
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     h->stream = (hipStream_t)stream;

@@ -237,7 +237,7 @@ def make_batch(name, N, K, B, dt=None, seed=1234, moving=False, n_active=None, g
                 nx=nx, nu=nu, K=K, N=N, dt=dt, sim_steps=sim_steps, generator=generator)
 
 
-def make_bench_batch(name, N, K, B, seed=1234, moving=False, verbatim=False):
+def make_bench_batch(name, N, K, B, seed=1234, moving=False, verbatim=False, n_active=None):
     """The benchmark workload of SURVEY.md 8(d) for `name`: dt = 0.05 s, the "survey" generator.  SURVEY's obstacle field
     (range up to 6 m, course ray clear for 0.4 m + 1.2 s * u) is sized for the 2 s look-ahead of N = 40; other horizons scale
     both with it.  Shorter (BASELINE configs[1], Tf = 1 s): range up to 3 Tf metres, clear for 0.6 Tf - with the 2 s field a 1 s
@@ -250,6 +250,7 @@ def make_bench_batch(name, N, K, B, seed=1234, moving=False, verbatim=False):
     Tf = N * BENCH_DT
     long_h = Tf > 2.0 + 1e-9
     return make_batch(name, N, K, B, dt=BENCH_DT, seed=seed, moving=moving, generator="survey_verbatim" if verbatim else "survey",
+                      n_active=n_active,   # (fewer obstacles than slots: the rest parked at (1000, 1000), r = 0 - nmpc_guidance_ca1.cpp:365-376)
                       sim_steps=BENCH_SIM_STEPS[name], max_range=3.0 * Tf,
                       clip_time=1.1 * Tf if long_h else 0.6 * Tf)
 

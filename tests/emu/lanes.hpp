@@ -118,6 +118,9 @@ inline void drain_stores() {}
 inline void publish(int *flag, int v) { *flag = v; }
 inline int observe(const int *flag) { return *flag; }
 inline void set_bits(int *word, int bits) { *word |= bits; }
+inline void release_agent() {}
+inline void acquire_agent() {}
+inline bool claim(int *entry, int seen) { if (*entry != seen) return false; *entry = -2 - seen; return true; }
 
 // lane index inside the (emulated) wave: the group's quarter of its 4-group tile (a whole emulated wave: the fiber number)
 inline unsigned wave_lane() { return g_emu.rows > 1 ? (unsigned)(g_emu.cur & 63) : (unsigned)((g_emu.group & 3) * 16 + g_emu.cur); }

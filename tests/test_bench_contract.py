@@ -136,3 +136,30 @@ def test_round5_lines_carry_the_median_and_the_survey_verbatim_line_exists():
     one = json.load(open(os.path.join(ROOT, "profiles", "r05_g_bench_oracle_cpc_device_plain_plain.json")))["parity"]
     both = json.load(open(os.path.join(ROOT, "profiles", "r05_g_bench_cpc_both_sides_plain.json")))["parity"]
     assert one["count_above_1e-5"] > 20 and both["count_above_1e-5"] <= 3 and both["above_1e-5_without_kkt_certificate_or_beyond_5e-3"] == 0
+
+
+def test_rank_binding_falls_back_to_an_even_share_and_is_recorded():
+    """bench.py --bind-numa: every rank pins its host threads to its GPU's NUMA node (sysfs); without a GPU / NUMA information the usable CPUs
+    are split evenly among the ranks.  Single-rank runs are left alone by default."""
+    before = os.sched_getaffinity(0)
+    try:
+        assert bench.bind_to_gpu_numa(0, 1, "auto") == "not bound" and os.sched_getaffinity(0) == before
+        assert bench.bind_to_gpu_numa(0, 2, "off") == "not bound"
+        if len(before) >= 2:
+            msg = bench.bind_to_gpu_numa(1, 2, "on")
+            now = os.sched_getaffinity(0)
+            assert now and now <= before and ("even share" in msg or "NUMA node" in msg), msg
+            if "even share" in msg:
+                assert len(now) == len(before) // 2 and min(now) > min(before)
+    finally:
+        os.sched_setaffinity(0, before)
+
+
+def test_scale_run_script_names_every_sharded_config():
+    """tools/scale_run.sh: N = 1, 2, 4, 8 x (weak scaling, BASELINE configs[3] as ONE batch of 262 144, configs[4]'s OCP and batch), the
+    environment RCCL needs on this driver, the per-rank placement; the summary keeps ranks_seen / per-rank extremes / all-gather times."""
+    sh = open(os.path.join(ROOT, "tools", "scale_run.sh")).read()
+    for needle in ("for n in 1 2 4 8", "--global-batch 262144", "--global-batch 65536 --horizon 80 --obstacles 20 --moving", "HSA_ENABLE_IPC_MODE_LEGACY=0",
+                   "ranks_seen", "per_rank_ms_per_step_min_max", "allgather_ms", "efficiency_vs_n1", "--showtoponuma"):
+        assert needle in sh, needle
+    assert os.access(os.path.join(ROOT, "tools", "scale_run.sh"), os.X_OK)

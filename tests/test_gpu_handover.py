@@ -99,3 +99,59 @@ def test_default_hands_over_where_the_follow_up_works_in_lds():
         if want:
             assert handed < B and (it >= 24).any() and fu.max() < s.kernel_ms(3)[1].max()   # (the cold first ticks run longer than the last one)
         s.close()
+
+
+@pytest.mark.parametrize("name,N,K,B,hand,opts", [
+    ("usv_model_pf_ca", 40, 10, 20000, 12, ()),                        # the headline layout, most of the batch through the queue
+    ("usv_model_pf_ca", 40, 10, 20000, 24, ()),                        # ... at the default threshold
+    ("usv_model_pf_ca", 20, 3, 12000, 8, (("max_waves", 512),)),
+    ("usv_model_guidance_ca1", 20, 8, 12000, 6, ()),                   # soft rows
+    ("usv_model", 20, 0, 12000, 5, (("max_waves", 1024),)),
+    ("usv_model_pf_ca", 40, 10, 3000, 12, ()),                         # a mid-size batch: no queue, every instance resident from the start
+    ("usv_model_pf_ca", 40, 10, 20000, 12, (("handover_co_wgs", 16),)),   # few co-resident workgroups: most entries are left to the launch behind
+    ("usv_model_pf_ca", 40, 10, 20000, 12, (("handover_co_spin", 1),)),   # waits that give up at once: the launch behind does (nearly) everything
+])
+def test_co_resident_follow_up_does_not_change_a_bit(name, N, K, B, hand, opts):
+    """Option "handover_co" (usvmpc.hip usv_qp_resume_co): the follow-up kernel runs BESIDE the draining launch - entries published one by one
+    with an agent-scope release, claimed by compare-and-swap, finished on the latency mapping while the main launch still runs; what it does not
+    get to is done by the follow-up launch behind the main one.  Scheduling only - but this is the one hand-over whose producer and consumer run
+    at the same time on different XCDs: every output must equal the run without any hand-over, bit for bit, tick after tick."""
+    a = _make(name, N, K, B, 1234, (("wide", 0), ("lds_workspace", 0), ("handover_iter", 0)))
+    b = _make(name, N, K, B, 1234, (("wide", 0), ("lds_workspace", 0), ("handover_iter", hand), ("handover_co", 1)) + tuple(opts))
+    handed = co = 0
+    for t in range(5):
+        sa, sb = a.solve(), b.solve()
+        handed += int(b.handover_counts(1)[0])
+        fin, tmo = b.handover_co_counts(1)
+        co += int(fin[0])
+        assert fin[0] <= b.handover_counts(1)[0]
+        assert np.array_equal(sa, sb), (t, "statuses differ on %d instances; handed %d, beside %d, timeouts %d" % ((sa != sb).sum(), b.handover_counts(1)[0], fin[0], tmo[0]))
+        for f in ("qp_status", "qp_iter"):
+            assert np.array_equal(a.get_int(f), b.get_int(f)), (t, f)
+        fields = ("x", "u", "pi", "lam", "t", "res") + (("sl", "su") if name == "usv_model_guidance_ca1" else ())
+        for f in fields:
+            fa, fb = (a.get(f, 0), b.get(f, 0)) if f == "res" else (a.get_all(f), b.get_all(f))
+            assert np.array_equal(fa, fb, equal_nan=True), (t, f, float(np.nanmax(np.abs(fa - fb))))
+        a.advance(1e-3, seed=5 + t)
+        b.advance(1e-3, seed=5 + t)
+    assert handed > 0
+    print("handed over", name, N, K, B, handed, "of which beside the launch", co)
+    a.close()
+    b.close()
+
+
+def test_co_resident_follow_up_with_the_pipelined_lineariser():
+    name, N, K, B = "usv_model_pf_ca", 20, 3, 20000
+    a = _make(name, N, K, B, 7, (("handover_iter", 0),))
+    b = _make(name, N, K, B, 7, (("handover_iter", 10), ("handover_co", 1)))
+    for t in range(8):
+        a.solve_async(); a.advance(1e-3, seed=t)
+        b.solve_async(); b.advance(1e-3, seed=t)
+    a.sync(); b.sync()
+    assert b.pipeline_stats()[0] >= 3
+    assert int(b.handover_counts(4).sum()) > 0
+    for f in ("x", "u", "pi"):
+        assert np.array_equal(a.get_all(f), b.get_all(f), equal_nan=True), f
+    assert np.array_equal(a.get_int("qp_iter"), b.get_int("qp_iter")) and np.array_equal(a.get("x0", 0), b.get("x0", 0))
+    a.close()
+    b.close()

@@ -201,9 +201,9 @@ def test_full_size_batch_properties(oracle):
 # ------------------------------------------------------------------------------------------------------------------
 # The BASELINE configs on their SURVEY.md 8(d) workloads (dt = 0.05 s, obstacles inside the look-ahead: ACTIVE rows), closed loop
 # without disturbance, every tick compared from identical inputs (the iterate and x0 the device starts the tick from).
-def _run_survey(oracle, name, N, K, B, ticks, min_active, seed=1234, moving=False, min_ok=0.97, mapping=None):
+def _run_survey(oracle, name, N, K, B, ticks, min_active, seed=1234, moving=False, min_ok=0.97, mapping=None, verbatim=False, n_active=None):
     from mpc_collisionavoidance_amd import usv_models
-    wl = scenario.make_bench_batch(name, N, K, B, seed=seed, moving=moving)
+    wl = scenario.make_bench_batch(name, N, K, B, seed=seed, moving=moving, verbatim=verbatim, n_active=n_active)
     dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
     ocp = usv_models.make_ocp(name, N * dt, N, K)
     ocp.solver_options.sim_method_num_steps = steps
@@ -249,9 +249,11 @@ def _run_survey(oracle, name, N, K, B, ticks, min_active, seed=1234, moving=Fals
         s.sync()
         x0 = s.get("x0", 0)
     s.close()
-    print("survey parity", dict(model=name, N=N, K=K, B=B, ticks=ticks, compared=n_cmp, frac_above_1e5=n_above / max(1, n_cmp), above_1e5=n_above, kkt_certified_of_those=n_cert,
-                                active_row_frac=act))
+    out = dict(model=name, N=N, K=K, B=B, ticks=ticks, compared=n_cmp, frac_above_1e5=n_above / max(1, n_cmp), above_1e5=n_above, kkt_certified_of_those=n_cert,
+               active_row_frac=act, verbatim=verbatim, not_converged_frac_last_tick=float(1.0 - conv_g.mean()))
+    print("survey parity", out)
     assert act >= min_active, (name, act)
+    return out
 
 
 @pytest.mark.parametrize("name", ["usv_model_pf_ca", "usv_model_guidance_ca1"])
@@ -271,3 +273,17 @@ def test_config4_shape_on_its_survey_workload(oracle):
     """BASELINE configs[4] shape: N=80 (Tf = 4 s), 20 moving obstacles (per-stage p, two obstacle chunks)."""
     # (this workload's hard rows leave 2.5 % of the QPs without a feasible point - bench line, DESIGN.md section 6 - on both sides)
     _run_survey(oracle, "usv_model_pf_ca", 80, 20, 128, ticks=4, min_active=0.4, moving=True, min_ok=0.93)
+
+
+@pytest.mark.parametrize("name,n_active", [("usv_model_pf_ca", None), ("usv_model_guidance_ca1", None), ("usv_model_pf_ca", 6), ("usv_model_guidance_ca1", 6)])
+def test_config2_on_the_survey_generator_to_the_letter(oracle, name, n_active):
+    """SURVEY.md 8(d)'s generator WITHOUT the builder's departures (scenario.make_batch "survey_verbatim": no obstacle clip, acados' own
+    initial guess x_k = x0), N = 40 / K = 10 - what `bench.py --workload survey-verbatim` times.  For the hard-row model a share of the
+    QPs has no feasible point (an obstacle the vehicle can neither stop for nor turn away from): the device must call exactly those
+    unconverged / failed that the oracle does, and meet the parity rule on all the others.  n_active = 6: four of the ten slots unused -
+    parked at (1000, 1000) with radius 0 as the reference node's initializeObstacles does (src/nmpc_guidance_ca1.cpp:365-376)."""
+    hard = name == "usv_model_pf_ca"
+    r = _run_survey(oracle, name, 40, 10, 768, ticks=5, min_active=0.5 if n_active is None else 0.3, verbatim=True, n_active=n_active,
+                    min_ok=0.85 if hard else 0.97)
+    if hard and n_active is None:
+        assert r["not_converged_frac_last_tick"] >= 0.02   # (the clip the bench workload applies is what removes these)

@@ -247,6 +247,9 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  *       only: results are bit-identical to the un-pipelined sequence;
  *   "host_mirror" (default: on for handles whose caller-visible arrays total <= 1 MiB, i.e. the single-instance drop-in faces) -
  *       usvmpc_set writes a pinned host mirror and the next solve uploads the dirty fields in one asynchronous copy instead
+ *       (ordering: a set becomes visible on the device with the NEXT launch of the handle, not at the call - except once a device pointer
+ *       has been handed out (usvmpc_get_device_ptr): from then on stage-wise sets are enqueued on the handle's stream at the call, so that a
+ *       caller's own kernels on that stream see them in program order)
  *       of one synchronising copy per call (the reference issues 3N+4 setters per tick: scripts/usv_guidance_ca1/main.py:
  *       123-130, src/nmpc_guidance_ca1.cpp:567-574); x / u / status come back in one copy and usvmpc_get "x" / "u" is served
  *       from it.  0 switches it off for the handle (it cannot be switched on again);

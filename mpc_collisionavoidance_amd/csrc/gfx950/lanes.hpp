@@ -49,6 +49,14 @@ USV_DEV int bcast_i(int v)
     return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, true);
 }
 
+// USV_DPP_PAD (generated-model libraries only: genbuild.py defines it when the kernels of a user's model trip the hazard check): two
+// wait states in front of every group - the hazard cannot occur whatever the compiler schedules around the asm; same arithmetic, a
+// few per cent slower.  The stock library is never built with it: a hazard there is fixed at its site (lanes::settle).
+#ifdef USV_DPP_PAD
+#define USV_DPP_HEAD "s_nop 1\n\t"
+#else
+#define USV_DPP_HEAD ""
+#endif
 // c += bcast<K>(b_remote) * a_own
 template <int K>
 USV_DEV void fma_bc(double &c, double b_remote, double a_own)
@@ -59,7 +67,7 @@ USV_DEV void fma_bc(double &c, double b_remote, double a_own)
     // part: tools/micro/dpp_hazard.hip; accumulator and plain source are forwarded normally), so the BINARY is checked
     // instead: tools/check_dpp_hazard.py walks the disassembly and build() fails on a violation; lanes::settle() is the
     // cure at a site it flags.
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(c) : "v"(b_remote), "v"(a_own), "n"(K));
+    asm(USV_DPP_HEAD "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(c) : "v"(b_remote), "v"(a_own), "n"(K));
 }
 
 // The same for up to four terms into one accumulator, in the order given: c += bcast<K0>(b0) * a0; c += bcast<K1>(b1) * a1; ...
@@ -70,14 +78,14 @@ USV_DEV void fma_bc(double &c, double b_remote, double a_own)
 template <int K0, int K1>
 USV_DEV void fma_bc2(double &c, double b0, double a0, double b1, double a1)
 {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+    asm(USV_DPP_HEAD "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %0, %3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
         : "+&v"(c) : "v"(b0), "v"(a0), "v"(b1), "v"(a1), "n"(K0), "n"(K1));
 }
 template <int K0, int K1, int K2>
 USV_DEV void fma_bc3(double &c, double b0, double a0, double b1, double a1, double b2, double a2)
 {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+    asm(USV_DPP_HEAD "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %0, %3, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %0, %5, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
         : "+&v"(c) : "v"(b0), "v"(a0), "v"(b1), "v"(a1), "v"(b2), "v"(a2), "n"(K0), "n"(K1), "n"(K2));
@@ -85,7 +93,7 @@ USV_DEV void fma_bc3(double &c, double b0, double a0, double b1, double a1, doub
 template <int K0, int K1, int K2, int K3>
 USV_DEV void fma_bc4(double &c, double b0, double a0, double b1, double a1, double b2, double a2, double b3, double a3)
 {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+    asm(USV_DPP_HEAD "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %0, %3, %4 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %0, %5, %6 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %0, %7, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf"

@@ -687,9 +687,18 @@ int copy_field(usvmpc_handle *h, const char *field, int stage, double *host, siz
             // copy of everything in between - stale where a device-side writer (the guidance kernels, a caller holding a device pointer)
             // has written behind the mirror.  The stage is remembered; its rows go up with the next launch (mirror_flush), as one 2-D copy
             // per run of consecutive dirty stages - no HIP call here (the immediate copy made the NEXT set synchronise)
-            std::vector<char> &ds = h->dirty_stage[fi];
-            if (ds.size() != (size_t)f.stages) ds.assign((size_t)f.stages, 0);
-            ds[(size_t)(stage - f.stage_off)] = 1;
+            // A caller that holds device pointers (usvmpc_get_device_ptr: extern_access) orders its own kernels against this set by the
+            // stream: for it the rows go up NOW, as before (a deferred upload would land on top of what the caller's kernel
+            // wrote to the same stage after the set, and a caller kernel reading the field before the solve would see the old rows).
+            if (h->extern_access) {
+                HIP_TRY(h, hipSetDevice(h->device));
+                HIP_TRY(h, hipMemcpy2DAsync(h->arena + h->f_off[fi] + first, pitch, m + first, pitch, row, B, hipMemcpyHostToDevice, h->stream));
+                h->inflight = true;
+            } else {
+                std::vector<char> &ds = h->dirty_stage[fi];
+                if (ds.size() != (size_t)f.stages) ds.assign((size_t)f.stages, 0);
+                ds[(size_t)(stage - f.stage_off)] = 1;
+            }
         } else if (set) {
             const size_t lo = first, hi = whole ? B * pitch : first + row;
             if (h->dirty_lo[fi] >= h->dirty_hi[fi]) { h->dirty_lo[fi] = lo; h->dirty_hi[fi] = hi; }
@@ -1081,9 +1090,13 @@ int launch_pair(usvmpc_handle *h, int phase)
                     dev_alloc(h, &h->d_susp_rec, (size_t)h->B * 4, false))
                     return USVMPC_E_HIP;
             }
-            // default (-1): past 24 iterations when the follow-up launch works in LDS (measured over sizes and shapes: +1 % at 65 536 instances,
-            // +5 ... 15 % at 4 096 ... 12 288, never a loss), never when it would run over the planes in HBM (a loss: profiles/r05_handover.txt)
-            hand_it = h->handover_iter > 0 ? h->handover_iter : (h->resume_lds ? 24 : 0);
+            // default (-1): past 20 iterations when the follow-up works in LDS AND the batch is at most three times what the device holds at once
+            // (re-measured in round 6 under the default QP solver profile, whose solves are shorter - profiles/r06_handover_co.txt: with the
+            // follow-up kernel beside the launch -18 % per tick at 4 096 instances, -13 % at 8 192, -4 % at 16 384, 0 at 32 768, +1 % at
+            // 65 536; with it only behind the launch nothing is gained any more at any size), never when it would run over the planes in HBM (a
+            // loss: profiles/r05_handover.txt)
+            const bool small = h->qp_cap > 0 && (long)h->B <= 3 * h->qp_cap;
+            hand_it = h->handover_iter > 0 ? h->handover_iter : ((h->resume_lds && small) ? 20 : 0);
             hand = h->resume_cap > 0 && hand_it > 0;
         }
         h->ptrs.susp_count = hand ? h->d_susp_count + h->nsolves % usvmpc_handle::RING : nullptr;
@@ -1093,7 +1106,7 @@ int launch_pair(usvmpc_handle *h, int phase)
         const dim3 qg((unsigned)((ng * LANES + qp_block - 1) / qp_block)), qb(qp_block);
         // The follow-up kernel BESIDE the draining launch (usv_qp_resume_co): on a stream of its own, eligible together with the main launch;
         // what it does not get to is done by the follow-up launch behind the main one.  With the planes copied into LDS only (the form that pays).
-        const bool co = hand && h->handover_co > 0 && h->resume_lds && wide.resume_co != nullptr && h->own_stream;
+        const bool co = hand && h->handover_co != 0 && h->resume_lds && wide.resume_co != nullptr && h->own_stream;
         h->ptrs.co_ctl = nullptr;
         if (co) {
             if (!h->co_stream) {
@@ -1418,7 +1431,7 @@ int usvmpc_create(const usvmpc_desc *d, usvmpc_handle **out)
     h->lds_cap = 0;
     h->wide_mode = -1; h->wide_cap = 0; h->wide_hbm_cap = 0; h->last_wide = 0;
     h->wide_waves = -1; h->wide4_cap = 0; h->wide4_hbm_cap = 0;
-    h->handover_co = 0; h->co_spin_limit = 200000; h->co_wgs = 0; h->co_stream = nullptr; h->ev_co_pre = nullptr; h->ev_co_end = nullptr; h->d_co_ctl = nullptr;
+    h->handover_co = -1; h->co_spin_limit = 200000; h->co_wgs = 0; h->co_stream = nullptr; h->ev_co_pre = nullptr; h->ev_co_end = nullptr; h->d_co_ctl = nullptr;
     h->handover_iter = -1; for (bool &e : h->ev3_set) e = false; h->resume_lds = false; h->handover_lds = true; h->d_susp_count = nullptr; h->d_susp_list = nullptr; h->d_susp_rec = nullptr; h->resume_cap = 0;
     h->max_waves = 0;
     {

@@ -5,9 +5,9 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 tag=$1; out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python bench.py --cpu-sample 0 $BENCH_ARGS > $out/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python bench.py --cpu-sample 0 $BENCH_ARGS > $out/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python bench.py --cpu-sample 0 $BENCH_ARGS > $out/write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python bench.py --cpu-sample 0 --no-survey-verbatim $BENCH_ARGS > $out/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python bench.py --cpu-sample 0 --no-survey-verbatim $BENCH_ARGS > $out/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python bench.py --cpu-sample 0 --no-survey-verbatim $BENCH_ARGS > $out/write.log 2>&1
 python - <<PY
 import csv, glob, collections, json
 out = "$out"

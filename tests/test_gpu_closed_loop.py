@@ -87,14 +87,14 @@ def _closed_loop(oracle, name, N, K, B, ticks, sigma, tol_max, seed=1234, wide=N
         # its QP (tests/kkt.py) and stay within 5e-3 of the oracle's
         e = np.maximum(ex, eu)
         if tol_max < 1e-5:
-            # (soft-row model) instances that took the oracle's number of iterations: 99 % of a tick within tol_max (1e-7) and EVERY one
-            # within north_star's 1e-5 (measured worst over 256 x 25 solves: 1.7e-6, one instance; round 4's build - other rounding,
-            # same sources otherwise - had none above 1e-7).  An instance whose exit test is passed by a hair's breadth on one side only
-            # stops an iteration apart: at most `slack` of them (asserted below), each within SOFT_DIT_CAP = 1e-3 of the oracle AND
-            # carrying the KKT certificate when above 1e-5 (seen once in 256 x 25 solves: 1.4e-4, on every mapping alike, certified)
+            # (soft-row model) instances that took the oracle's number of iterations: EVERY one within tol_max (1e-7) - the bound of rounds
+            # 1 - 4 again (round 5 had widened it to 1e-5 for the maximum after one instance at 1.7e-6 under the R04 profile;
+            # under the default profile the worst over 512 x 25 + 256 x 25 solves is 1.5e-8).  An instance whose exit test is passed by a
+            # hair's breadth on one side only stops an iteration apart: at most `slack` of them (asserted below), each within
+            # SOFT_DIT_CAP = 1e-3 of the oracle AND carrying the KKT certificate when above 1e-5
             same = dit == 0
             if same.any():
-                assert np.percentile(e[same], 99) <= tol_max and e[same].max() <= parity_rule.NORTH_STAR, (name, t, np.percentile(e[same], 99), e[same].max())
+                assert e[same].max() <= tol_max, (name, t, np.percentile(e[same], 99), e[same].max())
             if (~same).any():
                 assert e[~same].max() <= parity_rule.SOFT_DIT_CAP, (name, t, e[~same].max())
                 okd = ok.copy()

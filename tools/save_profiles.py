@@ -26,18 +26,18 @@ fu = None   # the follow-up launch of a hand-over (usv_qp_resume): its bytes and
 for r in csv.reader(open(src + "/pmc_summary.csv")):
     if KERN in r[0]:
         kname, n, f, wv = r[0], int(r[1]), float(r[2]), float(r[3])
-    if KERN == "qp_rti" and "qp_resume" in r[0]:
-        fu = (int(r[1]), float(r[2]), float(r[3]))
+    if KERN == "qp_rti" and "qp_resume" in r[0]:   # (behind the launch, usv_qp_resume, and beside it, usv_qp_resume_co: the bytes of both belong to the solve)
+        fu = (int(r[1]), (fu[1] if fu else 0.0) + float(r[2]), (fu[2] if fu else 0.0) + float(r[3]))
 ms = None
 ms_fu = 0.0
 for r in csv.DictReader(open(src + "/trace/t_kernel_stats.csv")):
     if KERN in r["Name"]:
         ms = float(r["AverageNs"]) / 1e6
-    if KERN == "qp_rti" and "qp_resume" in r["Name"]:
+    if KERN == "qp_rti" and "qp_resume" in r["Name"] and "qp_resume_co" not in r["Name"]:   # (the kernel beside the launch overlaps it: its span is not added)
         ms_fu = float(r["AverageNs"]) / 1e6
 if fu is not None:
     f, wv, ms = f + fu[1], wv + fu[2], ms + ms_fu
-    kname += " + usv_qp_resume"
+    kname += " + usv_qp_resume (+ usv_qp_resume_co beside the launch)"
 tot = (2 * f + wv) * 1024
 pj = dst + "/pmc_traffic.json"
 J = json.load(open(pj))

@@ -163,3 +163,31 @@ def test_scale_run_script_names_every_sharded_config():
                    "ranks_seen", "per_rank_ms_per_step_min_max", "allgather_ms", "efficiency_vs_n1", "--showtoponuma"):
         assert needle in sh, needle
     assert os.access(os.path.join(ROOT, "tools", "scale_run.sh"), os.X_OK)
+
+
+def test_round6_lines_carry_the_profile_its_spread_and_the_survey_verbatim_region():
+    """the default line names the QP solver profile, compares against the oracle under that profile, prints what the
+    profile choice moves on the device (parity.profile_spread) and the survey's generator to the letter as a second timed region."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_b_bench_plain.json")))
+    assert d["config"]["hpipm_mode"].startswith("BALANCE") and d["roofline"]["kernel"] == "usv_qp_rti"   # (one launch: no hand-over at 65 536)
+    p = d["parity"]
+    assert p["oracle_options"] == {"hpipm_mode": "BALANCE"} and p["count_above_1e-5"] == 0 and p["rel_err_per_instance"]["max"] < 1e-5
+    assert p["above_1e-5_without_kkt_certificate_or_beyond_5e-3"] == 0 and p["kkt_certified_frac"] == 1.0
+    sp = p["profile_spread"]
+    assert sp["device_profile"] == "BALANCE" and sp["against_device_profile"] == "R04" and sp["compared"] > 2000 and 1e-3 < sp["max"] < 0.1
+    sv = d["survey_verbatim"]
+    assert 0.7 * d["value"] < sv["value"] < d["value"] and 0.03 < sv["qp_not_converged_frac"] < 0.12 and sv["steps"] == 10
+    assert sv["parity"]["rule_violations"] == 0 and sv["parity"]["status_agreement_frac"] > 0.99
+    ws = d["workload_stats"]
+    total = d["config"]["instances_total"] * d["steps"]
+    assert ws["unconverged_counted_over_steps"] == d["steps"]
+    assert abs(d["value"] - ws["solves_per_s_counting_unconverged_ones"] * (1.0 - ws["unconverged_solves_in_timed_region"] / total)) <= 1e-9 * d["value"]
+    assert len(d["config"]["per_rank_ms_per_step"]) == 1 and d["config"]["host_binding_rank0"] == "not bound"
+    # the profile of rounds 1 - 5 on the same kernels, and the oracle without its refinement: the outliers the default no longer has
+    r04 = json.load(open(os.path.join(ROOT, "profiles", "r06_b_bench_profile_r04_plain.json")))
+    assert r04["config"]["hpipm_mode"].startswith("R04") and r04["parity"]["count_above_1e-5"] >= 1 and r04["value"] < d["value"]
+    spd = json.load(open(os.path.join(ROOT, "profiles", "r06_b_bench_oracle_speed_plain.json")))["parity"]
+    assert spd["oracle_options"]["hpipm_mode"] == "SPEED" and spd["count_above_1e-5"] >= 1
+    # the mid-size batches run with the follow-up kernel beside the launch
+    b = json.load(open(os.path.join(ROOT, "profiles", "r06_b_bench_b8192_plain.json")))
+    assert "usv_qp_resume" in b["roofline"]["kernel_ms"] and b["value"] > 560e3

@@ -98,3 +98,29 @@ def test_device_reproduces_its_stored_outputs():
         assert (st == 0).all() and np.array_equal(s.get_int("qp_iter"), f["it_dev"])
         assert np.array_equal(s.get_all("x"), f["x_dev"]) and np.array_equal(s.get_all("u"), f["u_dev"]), wide
     s.close()
+
+
+def test_the_sensitive_instances_have_no_solution_to_compare_at_1e_5(oracle):
+    """What the one instance above 1e-5 and its neighbours are: QPs on which the oracle asked for 1e-11 does not converge at all (step length at
+    its floor at a degenerate vertex of the hard rows, control weight R = 0: status 4), and on which the oracle's OWN two Riccati forms - same
+    iteration counts - differ by up to 1e-2.  Device and oracle take the same number of iterations on every one of them; each returns a point
+    inside the tolerance ball HPIPM's exit test defines, 3e-6 ... 3e-5 apart."""
+    f = _load()
+    args = [np.ascontiguousarray(f[k]) for k in ("x0", "yref", "yref_e", "p", "lh")]
+    sens = f["kind"] != "ordinary"
+
+    def run(**o):
+        spec = oracle.spec(2, f["N"], f["N"] * f["dt"], f["K"], sim_steps=f["steps"], hpipm_mode=str(f["profile"]), **o)
+        x, u = f["x_in"].copy(), f["u_in"].copy()
+        st, it = oracle.rti_batch(spec, x, u, *args, threads=0)
+        return x, u, st, it
+
+    xt, ut, stt, itt = run(tol_stat=1e-11, tol_eq=1e-11, tol_ineq=1e-11, tol_comp=1e-11, qp_iter_max=200)
+    assert (stt[sens] == 4).all()
+    xs, us, sts, its = run()
+    xc, uc, stc, itc = run(riccati=oracle.RICCATI_CLASSIC)
+    assert (stc == 0).all() and np.array_equal(itc, its)
+    forms = _err(f, xc, uc, xs, us)
+    dev = _err(f, f["x_dev"], f["u_dev"], xs, us)
+    assert forms[sens].max() >= 1e-3 and forms[sens].max() >= 100 * dev[sens].max()   # the oracle's two forms differ far more than device and oracle do
+    assert forms[~sens].max() <= 1e-10

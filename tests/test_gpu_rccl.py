@@ -38,7 +38,7 @@ def test_bench_distributed_branch_under_the_launcher():
     env = _env()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--batch", "2048", "--cpu-sample", "0"]
+           "--batch", "2048", "--cpu-sample", "0", "--bind-numa", "on"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -47,3 +47,7 @@ def test_bench_distributed_branch_under_the_launcher():
     g = d["allgather"]
     assert g is not None and g["u0"]["shape"] == [2048, 2] and g["x1"]["shape"] == [2048, 14]
     assert g["trajectory"]["shape"] == [2048, 41 * 14 + 40 * 2]
+    # the multi-GPU line's placement record: the rank pinned itself to its GPU's NUMA node (or an even share of the CPUs), per-rank step times
+    c = d["config"]
+    assert ("NUMA node" in c["host_binding_rank0"] or "even share" in c["host_binding_rank0"]) and len(c["per_rank_ms_per_step"]) == 1
+    assert c["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"

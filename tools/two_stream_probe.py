@@ -20,6 +20,8 @@ for S in [int(a) for a in sys.argv[1:]] or [1, 2, 4]:
         scenario.load_into(s, sharding.split_workload(wl, S, r))
         s.set_option("static_obstacles", 1)
         s.set_option("disturbance_mask", scenario.NOISE_MASK[name])
+        if os.environ.get("MAXW"):   # resident waves per handle (e.g. 2048 / S: the handles share the device instead of queueing behind each other)
+            s.set_option("max_waves", float(os.environ["MAXW"]) if float(os.environ["MAXW"]) > 0 else 2048 // S)
         hs.append(s)
     for w in range(warm):
         for s in hs:

@@ -664,7 +664,7 @@ def main():
                 "algorithmic_bytes_per_solve": balg, "algorithmic_flops_per_solve": falg,
                 "kernel_ms": dict({"usv_linearize": float(lin_ms.mean()), ("usv_qp_cond" if cond_applied else "usv_qp_rti"): float((qp_ms - fu_ms).mean())},
                                   **({"usv_qp_resume": float(fu_ms.mean())} if float(fu_ms.mean()) > 0.0 else {})),
-                "kernel_ms_followup_note": ("the QP of a tick is two launches: usv_qp_rti, whose rows hand instances past 24 IPM iterations over once the launch's "
+                "kernel_ms_followup_note": ("the QP of a tick is two launches: usv_qp_rti, whose rows hand instances past 20 IPM iterations over once the launch's "
                                             "queue is empty, and usv_qp_resume, which finishes them on the latency mapping (option handover_iter); "
                                             "`achieved`, `traffic_GBs` and fp64_* are taken over the sum of the two, `traffic` is the sum of their bytes") if float(fu_ms.mean()) > 0.0 else None,
                 "kernel_ms_note": ("with pipeline_linearize (default for >= 16384 instances) the lineariser of tick t + 1 runs on a second stream "

@@ -266,8 +266,10 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  *       whose instance has passed this many IPM iterations leaves it to a follow-up launch on the latency mapping (kernel usv_qp_resume: one
  *       instance per wavefront, the suspended solve's planes copied into LDS first), which finishes it at half the time per iteration of a lone
  *       16-lane row - a launch ends with its 30 - 50 iteration instances on an otherwise idle device.  Scheduling only: the mappings return the
- *       same bits.  -1: past 24 iterations where the horizon's planes fit a CU's LDS (+1 % at 65 536 instances, +5 ... 15 % at 4 096 ... 12 288),
- *       never otherwise; 0: never; n > 0: past n.  Layouts: one obstacle chunk / no obstacle rows, packed box rows, no soft state bounds;
+ *       same bits.  -1: past 20 iterations where the horizon's planes fit a CU's LDS AND the batch is at most three times what the device holds at
+ *       once (re-measured under the default QP solver profile, whose solves are shorter: with "handover_co" -18 % per tick at 4 096 instances,
+ *       -13 % at 8 192, -4 % at 16 384, nothing from 32 768 up), never otherwise; 0: never; n > 0: past n, whatever the batch.  Layouts: one
+ *       obstacle chunk / no obstacle rows, packed box rows, no soft state bounds;
  *   "handover_lds" (default 1) - 0: the follow-up launch works over the planes in HBM whatever the horizon (measured: a loss);
  *   "handover_co" (default -1 = on where the follow-up works in LDS and the handle owns its stream; 0: off) - the follow-up kernel also runs
  *       BESIDE the draining launch (kernel usv_qp_resume_co on a stream of its own): its workgroups come onto the device as wavefronts of the

@@ -2143,8 +2143,9 @@ struct QpIpm {
     // A persistent launch ends with a drain: the instances in flight when its queue runs dry finish one by one while more and more of the
     // device idles (profiles/r03_tail.txt, r05_handover.txt).  The idea: a faster pass for ONE instance - the latency mapping - for the ones
     // that run longest.  (Built and measured in round 5: over COLD planes in HBM the one-instance-per-wave sweeps are slower per pass than the
-    // lone row they relieve; with the planes copied into LDS first - copy_in below - they are twice as fast and the hand-over pays at every batch
-    // size: on by default past 24 iterations, option "handover_iter".)  Once every instance of the launch has been handed out (the queue counter has passed the batch), a row whose
+    // lone row they relieve; with the planes copied into LDS first - copy_in below - they are twice as fast.  Round 6: under the default QP solver
+    // profile the hand-over pays for batches of a few thousand instances, with the follow-up kernel running beside the launch - usvmpc.hip
+    // launch_qp has the policy; option "handover_iter".)  Once every instance of the launch has been handed out (the queue counter has passed the batch), a row whose
     // instance has done handover_iter iterations leaves it where it stands: everything an iteration hands to the next is in the
     // workspace planes already (the pending step in P_DZ / P_DZA, multipliers and slacks in the row planes, the iterate in P_Z); what
     // lives in registers - step length and centring target of the pending step, the residual scale, the iteration count - goes into

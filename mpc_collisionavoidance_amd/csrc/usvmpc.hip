@@ -929,7 +929,11 @@ int launch_pair(usvmpc_handle *h, int phase)
             // Up to one instance per CU; with the queue and a horizon of 40 or more up to two (tools/latency_probe.py over 13 shapes x 7 batch sizes,
             // profiles/r05_f_policy_audit.txt: 512 instances 6 - 8 % under one wave each; at N = 20 the second round costs more than the row work saves)
             const long reach = (h->dynamic_rows && h->N >= 40) ? 2 * cap : cap;
-            if (cap > 0 && (h->wide_waves == 4 || ((SOFT || KCH == 2) && (long)h->B <= reach))) {
+            // (round 6, profiles/r06_b_policy_audit.txt: ONE chunk of hard rows also gains 2 - 4 % from four waves when the rows are many and the
+            // horizon long - usv_model_pf_ca N = 40 / K = 10: one instance 2.50 -> 2.40 ms, 64: 5.84 -> 5.63, 256: 4.03 -> 3.94; N = 100 / K = 8,
+            // 64: 9.62 -> 9.34; with K = 3 or 4 it loses - up to one instance per CU)
+            const bool hard_many = !SOFT && KCH == 1 && h->K >= 8 && h->N >= 40 && (long)h->B <= cap;
+            if (cap > 0 && (h->wide_waves == 4 || ((SOFT || KCH == 2) && (long)h->B <= reach) || hard_many)) {
                 long nw = (long)h->B;
                 int q0 = -1;
                 if (h->dynamic_rows && nw > cap) { nw = cap; q0 = (int)nw; }
@@ -1967,7 +1971,7 @@ int usvmpc_set_option(usvmpc_handle *h, const char *name, double value)
     }
     if (s == "handover_iter") { // IPM iterations after which a row of a drained launch hands its instance over to the follow-up launch; 0: never
         if (value > 1e6) { h->err = "handover_iter out of range"; return USVMPC_E_ARG; }
-        h->handover_iter = value < 0.0 ? -1 : (int)value;   // (-1: the default - 24 when the follow-up launch works in LDS, else never)
+        h->handover_iter = value < 0.0 ? -1 : (int)value;   // (-1: the default - launch_qp: past 20 for small batches when the follow-up works in LDS, else never)
         return 0;
     }
     if (s == "handover_lds") { h->handover_lds = value != 0.0; reset_caps(h); return 0; }

@@ -191,3 +191,19 @@ def test_round6_lines_carry_the_profile_its_spread_and_the_survey_verbatim_regio
     # the mid-size batches run with the follow-up kernel beside the launch
     b = json.load(open(os.path.join(ROOT, "profiles", "r06_c_bench_b8192_plain.json")))
     assert "usv_qp_resume" in b["roofline"]["kernel_ms"] and b["value"] > 560e3
+
+
+def test_scale_script_lines_have_the_plain_lines_keys():
+    """tools/scale_run.sh run on the one GPU a builder's box has (`tools/scale_run.sh out 1`; profiles/r06_scale_n1_*): its N = 1 lines are bench
+    lines like the plain one - same keys, same config keys -, the sharded configs name themselves, and the summary has one row per kind.  (The
+    N = 2, 4, 8 rows are the driver's / an 8-GPU node's to fill: no scaling curve has been measured.)"""
+    plain = json.load(open(os.path.join(ROOT, "profiles", "r06_c_bench_plain.json")))
+    weak = json.load(open(os.path.join(ROOT, "profiles", "r06_scale_n1_weak.json")))
+    assert set(weak) == set(plain) and set(weak["config"]) == set(plain["config"]) and set(weak["roofline"]) == set(plain["roofline"])
+    assert weak["n_gpus"] == 1 and weak["config"]["ranks_seen"] == 1 and "configs[2]" in weak["config"]["workload"]
+    c3 = json.load(open(os.path.join(ROOT, "profiles", "r06_scale_n1_cfg3.json")))
+    c4 = json.load(open(os.path.join(ROOT, "profiles", "r06_scale_n1_cfg4.json")))
+    assert c3["config"]["instances_total"] == 262144 and "ONE seed-1234 batch of 262144" in c3["config"]["workload"]
+    assert c4["config"]["instances_total"] == 65536 and c4["config"]["horizon"] == 80 and c4["config"]["obstacles"] == 20 and "moving" in c4["config"]["workload"]
+    summ = json.load(open(os.path.join(ROOT, "profiles", "r06_scale_n1_summary.json")))
+    assert set(summ) == {"weak", "cfg3", "cfg4"} and all(len(v) == 1 and v[0]["n_gpus"] == 1 and v[0]["efficiency_vs_n1"] == 1.0 for v in summ.values())

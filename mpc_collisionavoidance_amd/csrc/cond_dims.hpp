@@ -37,28 +37,30 @@ inline bool cond_dims(const DevSpec &S, int nx, int nu, int ipx, int ipy, int N2
     D.R = D.nbu + D.nbx + S.K; D.nrows = D.Mb * D.R;
     long o = 0;
     auto take = [&](long n) { const long at = o; o += (n + 15) / 16 * 16; return at; }; // 128-byte pieces
-    D.o_SR = take((long)D.Mb * D.nxr * D.nzh); D.o_cr = take((long)D.Mb * D.nxr);
+    const int nz = nx + nu;
+    // the matrix group: what every sweep brings into LDS for a block, in ONE piece - the kernel's LDS holds the same pieces in the same order
+    // at the same distances (CondIpm's constructor), so that the block comes in as one linear copy with all of a thread's loads in flight
+    D.o_SR = take(std::max<long>((long)D.Mb * D.nxr * D.nzh, 2L * nx * D.nzh + (long)nz * D.nzh)); // (the LDS piece doubles as (Sm, Sn, Tm) while condensing)
+    D.o_cr = take((long)D.Mb * D.nxr);
     D.o_BA = take((long)nx * D.nzh); D.o_bt = take(nx);
-    D.o_H0 = take((long)D.nzh * D.nzh); D.o_g0 = take(D.nzh);
+    D.o_g0 = take(D.nzh); D.o_H0 = take((long)D.nzh * D.nzh);
     D.o_row = take((soft ? 14L : 8L) * D.nrows); // ll, lu, tl, tu, dl, du, cx, cy (+ sl, su, lsl, lsu, tsl, tsu when the obstacle rows are soft)
-    D.o_Luu = take((long)D.nzh * D.nuh);     // [Luu; Lxu]: the first nuh columns of the eliminated stage matrix
+    D.o_Luu = take((long)D.nzh * D.nzh);     // the eliminated stage matrix as it stands in LDS ([Luu; Lxu] in its first nuh columns)
     D.o_P = take((long)nx * nx);             // P_{i+1}
     D.o_Pb = take(nx);
     D.o_w = take(D.nzh); D.o_pi = take(nx); D.o_rg = take(D.nzh); D.o_rb = take(nx);
     D.o_dwa = take(D.nzh); D.o_dw = take(D.nzh); D.o_dpi = take(nx); D.o_p = take(nx); D.o_lus = take(D.nuh); D.o_dg = take(D.nuh);
     D.blk = o;
     D.total = (long)(N2 + 1) * D.blk;
-    const int nz = nx + nu;
     long l = 0;
-    l += (long)(D.nzh + 1) * D.nzh;                                       // Gm
-    l += std::max<long>((long)D.Mb * D.nxr * D.nzh, 2L * nx * D.nzh + (long)nz * D.nzh); // SRm | (Sm, Sn, Tm) while condensing
-    l += 2L * nx * D.nzh;                                                 // BAm, PBm
-    l += (long)nx * nx + (long)nx * nz;                                   // Pn, BAk
+    l += (D.o_H0 - D.o_SR) + (long)(D.nzh + 1) * D.nzh + 16;              // the matrix group: SRm | vcr | BAm | vbt | vg0 | Gm
+    l += (long)nx * std::max(D.nzh, nz);                                  // PBm | BAk
+    l += (long)nx * nx;                                                   // Pn
     l += 4L * D.Mb * D.nxr + 3L * D.Mb * D.nxr + D.Mb + 3L * D.nuh;       // expansions, slots
-    l += 4L * nt + 64;                                                    // obstacle-row buffer of one pass, reductions
-    l += 2L * LANES + (D.nzh * (D.nzh + 1) / 2 + 1) / 2 + 1 + 3L * LANES + 7L * KMAX; // short tables (ints), triangle index table, spec copies
-    l += 8L * D.nzh + 12L * nx + 2L * D.nuh + 2L * nz + (long)D.Mb * nz + (long)D.Mb * D.nxr; // vectors
-    D.lds_doubles = l + 64;
+    l += 8;                                                               // reductions
+    l += 2L * LANES + (D.nzh * (D.nzh + 1) / 2 + 3) / 4 + 3L * LANES + (soft ? 7L : 1L) * KMAX; // short tables (ints), triangle index table (16 bits), spec copies
+    l += 7L * D.nzh + 10L * nx + 2L * D.nuh + 2L * nz + (long)D.Mb * nz; // vectors
+    D.lds_doubles = l + 8;   // (LDS is handed out in pieces of 1280 bytes, 128 to a CU: the 30-variable blocks of usv_model_pf_ca take 32 - four teams per CU)
     D.nt = nt;
     return true;
 }

@@ -34,14 +34,27 @@
 
 namespace usv {
 
+// Pointers into the team's LDS carry their address space in the type on the device: as plain `double *` members of the solver object the
+// compiler loses track of some of them and reads them through flat instructions (which wait on both memory counters), and each costs two
+// scalar registers instead of one.
+#if defined(__HIPCC__)
+#define USV_LDS __attribute__((address_space(3)))
+#else
+#define USV_LDS
+#endif
+using LD = USV_LDS double *;
+using LCD = const USV_LDS double *;
+
 // ---- the threads that work on one instance
 #if !defined(__HIPCC__) // compiled by a host compiler (the lane emulator's build, tests/emu): one thread plays the whole team
 struct CondTeam {
     static constexpr int NT = 1;
     static int tid() { return 0; }
     static void sync() {}
-    static double rmax(double v, double *) { return v; }
-    static double rsum(double v, double *) { return v; }
+    static double rmax(double v, LD) { return v; }
+    static double rsum(double v, LD) { return v; }
+    static double qsum(double v) { return v; }
+    static double lane_xor(double v, int) { return v; }
 };
 #define USV_CDEV inline
 #else
@@ -51,7 +64,7 @@ struct CondTeam {
     static_assert(NT % 64 == 0, "whole waves");
     __device__ static int tid() { return (int)threadIdx.x; }
     __device__ static void sync() { __syncthreads(); }
-    __device__ static double rmax(double v, double *red)
+    __device__ static double rmax(double v, LD red)
     {
         for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
         if constexpr (NT > 64) {
@@ -63,7 +76,7 @@ struct CondTeam {
         }
         return v;
     }
-    __device__ static double rsum(double v, double *red)
+    __device__ static double rsum(double v, LD red)
     {
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
         if constexpr (NT > 64) {
@@ -75,6 +88,14 @@ struct CondTeam {
         }
         return v;
     }
+    // sum over the four lanes of a quad (DPP quad_perm butterflies), the same bits in all four
+    __device__ static double qsum(double v)
+    {
+        v += lanes::dpp_mov<0xB1>(v); // quad_perm:[1,0,3,2]
+        v += lanes::dpp_mov<0x4E>(v); // quad_perm:[2,3,0,1]
+        return v;
+    }
+    __device__ static double lane_xor(double v, int o) { return __shfl_xor(v, o, 64); }
     // value of lane `src` (wave-uniform) of the calling wave
     __device__ static double lane_value(double v, int src)
     {
@@ -85,8 +106,43 @@ struct CondTeam {
 #define USV_CDEV __device__ __forceinline__
 #endif
 
-template <class M, int KCH, bool SOFT, class TM>
-struct CondIpm {
+#if defined(USV_COND_TIMING) && defined(__HIPCC__) // development build: cycles of thread 0 per phase (tools/cond_timing.py)
+__device__ unsigned long long usv_cond_ticks[32];
+#define USV_TICK(ph) tick(ph)
+#else
+#define USV_TICK(ph)
+#endif
+
+// The block's sizes (stages per block Mb, inputs nuh = Mb nu, variables nzh = nuh + nx): run-time values in general (MB = 0), compile-time
+// constants in the instantiations made for one block length (cond_kernels.hip: MB = 8, BASELINE configs[4]'s N = 80 -> N2 = 10) - every
+// matrix in LDS has nzh as its row stride, and with the stride known the dot products unroll with immediate offsets instead of an
+// address addition per operand (the kernel at four teams per CU is bound by instruction issue: profiles/r06_cond_sq_counters.txt).
+template <int MB, int NU_, int NX_>
+struct CondBlkSizes {
+    static constexpr int Mb = MB, nuh = MB * NU_, nzh = MB * NU_ + NX_;
+    USV_CDEV bool set_sizes(int mb, int, int) { return mb == MB; }
+};
+template <int NU_, int NX_>
+struct CondBlkSizes<0, NU_, NX_> {
+    int Mb, nuh, nzh;
+    USV_CDEV bool set_sizes(int mb, int nu_h, int nz_h) { Mb = mb; nuh = nu_h; nzh = nz_h; return true; }
+};
+
+template <class M, int KCH, bool SOFT, class TM, int MB = 0>
+struct CondIpm : CondBlkSizes<MB, M::NU, M::NX> {
+    using BS = CondBlkSizes<MB, M::NU, M::NX>;
+    using BS::Mb; using BS::nuh; using BS::nzh;
+#if defined(USV_COND_TIMING) && defined(__HIPCC__)
+    unsigned long long t_last = 0;
+    __device__ void tick(int ph)
+    {
+        if (tid == 0) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            if (ph >= 0) atomicAdd(&usv_cond_ticks[ph], t - t_last);
+            t_last = t;
+        }
+    }
+#endif
     static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU, NT = TM::NT;
     using MP = MatPack<M>;
     using WL = WsLayout<M, KCH, SOFT, false>;
@@ -110,13 +166,13 @@ struct CondIpm {
         int Mb, N2, N1, R1, nuh, nzh, nxr, R, nrows, nbu, nbx, ipx, ipy;
         int o_SR, o_cr, o_BA, o_bt, o_H0, o_g0, o_row, o_Luu, o_P, o_Pb, o_w, o_pi, o_rg, o_rb, o_dwa, o_dw, o_dpi, o_p, o_lus, o_dg;
         long blk;
-        const int *xr, *uvar, *xvar; // LDS
+        const USV_LDS int *xr, *uvar, *xvar;
     };
     struct SpecLocal {
         const double *Hc, *He;        // global (condensing / expansion only)
-        const double *HcD, *lb, *ub, *uh; // LDS: Hessian diagonal, box bounds per variable of [u;x], upper bounds of the obstacle rows
-        const double *zl, *zu, *Zl, *Zu, *bsl, *bsu; // LDS: slack penalties (scaled by dt) and lower bounds of the slacks, per obstacle row
-        const int *box_pos;           // LDS
+        LCD HcD, lb, ub, uh; // Hessian diagonal, box bounds per variable of [u;x], upper bounds of the obstacle rows
+        LCD zl, zu, Zl, Zu, bsl, bsu; // slack penalties (scaled by dt) and lower bounds of the slacks, per obstacle row
+        const USV_LDS int *box_pos;
         int N, K, B, Bp, npt, hdiag, p_static, iter_max, nbu, nbx, nc;
         double thr0, mu0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min;
         int cpc;            // option "cond_pred_corr" (qp_ipm.hpp, QpIpm::solve: the same rule on the dense stages)
@@ -125,13 +181,14 @@ struct CondIpm {
     const DevPtrs &P;
     SpecLocal S;
     DimsLocal D;
-    const int *tri; // LDS: element e of a lower triangle -> (row << 8) | column
+    const USV_LDS unsigned short *tri; // element e of a lower triangle -> (row << 8) | column
     double *cw; // the team's scratch area in HBM
-    int tid, N, Kn, Mb, N2, nuh, nzh, nxr, R, nrows;
+    int tid, N, Kn, N2, nxr, R, nrows;
+    int rs_log; // log2 of the thread group a stage's rows sit in (row_pass)
     long g, b;
     // LDS
-    double *Gm, *SRm, *Sm, *Sn, *Tm, *BAm, *PBm, *Pn, *BAk, *del, *delo, *dela, *delf, *yxr, *yxg, *wd, *wxy, *yur, *yug, *wu, *obuf, *red;
-    double *vw, *vdwa, *vdw, *vr, *vgt, *vrq, *vg0, *vt, *vpi, *vpin, *vxn, *vpv, *vPb, *vrb, *vbt, *vdx, *vdxn, *vtmp, *vlus, *vq, *vgk, *vzb, *vdz, *vcr, *vdg;
+    LD mat, Gm, SRm, Sm, Sn, Tm, BAm, PBm, Pn, BAk, del, delo, dela, delf, yxr, yxg, wd, wxy, yur, yug, wu, red;
+    LD vw, vdwa, vdw, vr, vgt, vrq, vg0, vt, vpi, vpin, vxn, vpv, vPb, vrb, vbt, vdx, vdxn, vtmp, vlus, vq, vgk, vzb, vdz, vcr, vdg;
     struct Norms { double rg, rb, rd, rm, musum; bool bad; };
     // second-order factor of the corrector targets of this pass / of the pending step: 0 where the corrected step was refused and the
     // centring-only one taken (the team holds one instance: a scalar)
@@ -153,47 +210,73 @@ struct CondIpm {
         D.o_row = (int)Dg.o_row; D.o_Luu = (int)Dg.o_Luu; D.o_P = (int)Dg.o_P; D.o_Pb = (int)Dg.o_Pb; D.o_w = (int)Dg.o_w; D.o_pi = (int)Dg.o_pi;
         D.o_rg = (int)Dg.o_rg; D.o_rb = (int)Dg.o_rb; D.o_dwa = (int)Dg.o_dwa; D.o_dw = (int)Dg.o_dw; D.o_dpi = (int)Dg.o_dpi; D.o_p = (int)Dg.o_p;
         D.o_lus = (int)Dg.o_lus; D.o_dg = (int)Dg.o_dg; D.blk = Dg.blk;
-        N = S.N; Kn = S.K; Mb = D.Mb; N2 = D.N2; nuh = D.nuh; nzh = D.nzh; nxr = D.nxr; R = D.R; nrows = D.nrows;
-        double *q = lds;
-        auto take = [&](long n) { double *at = q; q += n; return at; };
+        N = S.N; Kn = S.K; N2 = D.N2; nxr = D.nxr; R = D.R; nrows = D.nrows;
+        if (!this->set_sizes(D.Mb, D.nuh, D.nzh)) {
+#if defined(__HIPCC__)
+            __builtin_trap(); // (an instantiation for one block length launched with another: cond_kernels.hip picks by D.Mb)
+#endif
+        }
+        rs_log = 2;
+        while ((1 << rs_log) < R) rs_log++;
+        const LD lds0 = (LD)lds;
+        LD q = lds0;
+        auto take = [&](long n) { LD at = q; q += n; return at; };
         {   // the short tables
-            int *it = reinterpret_cast<int *>(take(2 * LANES + (nzh * (nzh + 1) / 2 + 1) / 2 + 1));
-            int *xr_ = it, *uvar_ = it + LANES, *xvar_ = it + 2 * LANES, *bpos_ = it + 3 * LANES, *tri_ = it + 4 * LANES;
-            double *sd = take(3 * LANES + 7 * KMAX);
+            USV_LDS int *it = (USV_LDS int *)take(2 * LANES + (nzh * (nzh + 1) / 2 + 3) / 4);
+            USV_LDS int *xr_ = it, *uvar_ = it + LANES, *xvar_ = it + 2 * LANES, *bpos_ = it + 3 * LANES;
+            USV_LDS unsigned short *tri_ = (USV_LDS unsigned short *)(it + 4 * LANES);
+            LD sd = take(3 * LANES + (SOFT ? 7 : 1) * KMAX);
             for (int e = tid; e < LANES; e += NT) {
                 xr_[e] = Dg.xr[e]; uvar_[e] = Dg.uvar[e]; xvar_[e] = Dg.xvar[e]; bpos_[e] = Sg.box_pos[e];
                 sd[e] = Sg.Hc[e * (LANES + 1)]; sd[LANES + e] = Sg.lb[e]; sd[2 * LANES + e] = Sg.ub[e];
             }
             for (int e = tid; e < KMAX; e += NT) {
-                double *so = sd + 3 * LANES;
-                so[e] = Sg.uh[e]; so[KMAX + e] = Sg.zl[e]; so[2 * KMAX + e] = Sg.zu[e]; so[3 * KMAX + e] = Sg.Zl[e]; so[4 * KMAX + e] = Sg.Zu[e];
-                so[5 * KMAX + e] = Sg.lsl[e]; so[6 * KMAX + e] = Sg.lsu[e];
+                LD so = sd + 3 * LANES;
+                so[e] = Sg.uh[e];
+                if constexpr (SOFT) {
+                    so[KMAX + e] = Sg.zl[e]; so[2 * KMAX + e] = Sg.zu[e]; so[3 * KMAX + e] = Sg.Zl[e]; so[4 * KMAX + e] = Sg.Zu[e];
+                    so[5 * KMAX + e] = Sg.lsl[e]; so[6 * KMAX + e] = Sg.lsu[e];
+                }
             }
             for (int a_ = tid; a_ < nzh; a_ += NT)
-                for (int c = 0; c <= a_; c++) tri_[a_ * (a_ + 1) / 2 + c] = (a_ << 8) | c;
+                for (int c = 0; c <= a_; c++) tri_[a_ * (a_ + 1) / 2 + c] = (unsigned short)((a_ << 8) | c);
             D.xr = xr_; D.uvar = uvar_; D.xvar = xvar_; S.box_pos = bpos_; tri = tri_;
             S.HcD = sd; S.lb = sd + LANES; S.ub = sd + 2 * LANES; S.uh = sd + 3 * LANES;
-            S.zl = S.uh + KMAX; S.zu = S.uh + 2 * KMAX; S.Zl = S.uh + 3 * KMAX; S.Zu = S.uh + 4 * KMAX; S.bsl = S.uh + 5 * KMAX; S.bsu = S.uh + 6 * KMAX;
+            constexpr int KS = SOFT ? KMAX : 0; // (hard obstacle rows have no slack data: the pointers are never followed)
+            S.zl = S.uh + KS; S.zu = S.uh + 2 * KS; S.Zl = S.uh + 3 * KS; S.Zu = S.uh + 4 * KS; S.bsl = S.uh + 5 * KS; S.bsu = S.uh + 6 * KS;
         }
-        Gm = take((long)(nzh + 1) * nzh);
-        const long nsr = (long)Mb * nxr * nzh, ncn = 2L * NX * nzh + (long)NZ * nzh;
-        SRm = take(nsr > ncn ? nsr : ncn);
+        // the matrix group, laid out as in the scratch block (cond_dims.hpp: o_SR .. o_H0): load_block brings it in as one linear copy
+        q += (16 - ((q - lds0) & 15)) & 15;
+        mat = q;
+        SRm = mat; vcr = mat + (D.o_cr - D.o_SR); BAm = mat + (D.o_BA - D.o_SR); vbt = mat + (D.o_bt - D.o_SR); vg0 = mat + (D.o_g0 - D.o_SR);
+        Gm = mat + (D.o_H0 - D.o_SR);
+        q = Gm + (long)(nzh + 1) * nzh;
         Sm = SRm; Sn = SRm + (long)NX * nzh; Tm = SRm + 2L * NX * nzh; // (condense phase only)
-        BAm = take((long)NX * nzh); PBm = take((long)NX * nzh);
-        Pn = take(NX * NX); BAk = take(NX * NZ);
+        PBm = take((long)NX * nzh);
+        Pn = take(NX * NX); BAk = PBm; // (a stage's [B A] while condensing / expanding; P+ [B A] in the sweeps)
         del = take(Mb * nxr); delo = take(Mb * nxr); dela = take(Mb * nxr); delf = take(Mb * nxr);
         yxr = take(Mb * nxr); yxg = take(Mb * nxr); wd = take(Mb * nxr); wxy = take(Mb);
         yur = take(nuh); yug = take(nuh); wu = take(nuh);
-        obuf = take(4 * NT); red = take(64);
-        vw = take(nzh); vdwa = take(nzh); vdw = take(nzh); vr = take(nzh); vgt = take(nzh); vrq = take(nzh); vg0 = take(nzh); vt = take(nzh);
-        vpi = take(NX); vpin = take(NX); vxn = take(NX); vpv = take(NX); vPb = take(NX); vrb = take(NX); vbt = take(NX); vdx = take(NX);
-        vdxn = take(NX); vtmp = take(NX); vq = take(NX); vlus = take(nuh); vgk = take(NZ); vzb = take(NZ); vdz = take(Mb * NZ); vcr = take(Mb * nxr);
-        take(NX); vdg = take(nuh);
+        red = take(8);
+        vw = take(nzh); vdwa = take(nzh); vdw = take(nzh); vr = take(nzh); vgt = take(nzh); vrq = take(nzh); vt = take(nzh);
+        vpi = take(NX); vpin = take(NX); vxn = take(NX); vpv = take(NX); vPb = take(NX); vrb = take(NX); vdx = take(NX);
+        vdxn = take(NX); vtmp = take(NX); vq = take(NX); vlus = take(nuh); vgk = take(NZ); vzb = take(NZ); vdz = take(Mb * NZ);
+        vdg = take(nuh);
 #if defined(__HIPCC__)
-        if (q - lds > Dg.lds_doubles) __builtin_trap(); // (cond_dims.hpp sizes the launch's LDS: the two counts must agree)
+        if (q - lds0 > Dg.lds_doubles) __builtin_trap(); // (cond_dims.hpp sizes the launch's LDS: the two counts must agree)
 #endif
     }
 
+    // Everything a thread derives from its index (element addresses, row / column splits) is invariant over the blocks and the iterations,
+    // and the compiler hoists all of it to the top of the kernel: hundreds of values that then live in scratch memory and come back through
+    // HBM-latency reloads inside the sweeps (386 registers wanted, 168 to be had).  Making the index opaque once per block keeps those values'
+    // lives one block long; recomputing them costs a few integer instructions.
+    USV_CDEV void forget_tid()
+    {
+#if defined(__HIPCC__)
+        asm volatile("" : "+v"(tid));
+#endif
+    }
     USV_CDEV double *blk(int i) const { return cw + (long)i * D.blk; }
     USV_CDEV const double *plane(int k, int e) const { return P.ws + (((long)k * S.Bp + g) * S.npt + e) * LANES; }
 
@@ -376,33 +459,105 @@ struct CondIpm {
         return TM::rmax(bad0, red) > 0.5;
     }
 
-    // ---- small dense pieces on LDS operands (team-parallel over output elements; call between syncs)
-    // out[j][r] = SRm[j][r][:] . v (+ cr)
-    USV_CDEV void expand_rows(double *out, const double *v, const double *cr) const
+    // a + sum over k = k0, k0 + st, ... < n of A(k) B(k), ascending k.  On the device the operands of eight terms are fetched before the first
+    // is used: a loop over a run-time count compiles to fetch - wait - multiply per term, one LDS round trip each, and the sweeps are made
+    // of such loops (tools/cond_timing.py).  Terms past the end multiply a valid operand by zero: the same bits as the plain loop.
+    template <class FA, class FB>
+    USV_CDEV static double dots(int k0, int st, int n, double a, FA A, FB B)
     {
-        for (int e = tid; e < Mb * nxr; e += NT) {
-            double a = cr ? cr[e] : 0.0;
-            const double *srow = SRm + (long)e * nzh;
-#pragma unroll 6
-            for (int c = 0; c < nzh; c++) a = fma(srow[c], v[c], a);
-            out[e] = a;
+        if constexpr (NT == 1) {
+            for (int k = k0; k < n; k += st) a = fma(A(k), B(k), a);
+        } else {
+            for (int kb = k0; kb < n; kb += 8 * st) {
+                double x[8], y[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int k = kb + u * st;
+                    const bool in = k < n;
+                    const int kk = in ? k : kb;
+                    x[u] = A(kk); y[u] = in ? B(kk) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) a = fma(x[u], y[u], a);
+            }
+        }
+        return a;
+    }
+    // ---- small dense pieces on LDS operands (team-parallel over output elements; call between syncs)
+    // out[j][r] = SRm[j][r][:] . v (+ cr): the values of the touched states at an iterate (cr: the offsets c_j) or along a step (cr = null) -
+    // up to three of them in one pass over the rows of S (o1 / o2 null: fewer)
+    USV_CDEV void expand_rows(LD o0, LCD v0, LCD cr, LD o1 = nullptr, LCD v1 = nullptr, LD o2 = nullptr, LCD v2 = nullptr) const
+    {
+        if (!v1) v1 = v0; // (a valid address; the sums of an absent output are dropped)
+        if (!v2) v2 = v0;
+        // on the device FOUR lanes (a quad) share a row's dot product - columns c = part, part + 4, ... - and add up by DPP: 4 x the threads
+        // at work, a quarter of the dependent LDS round trips (the one-thread team of the emulator sums in column order: rounding-level differences)
+        constexpr int Q = NT == 1 ? 1 : 4;
+        for (int t = tid; t < Q * Mb * nxr; t += NT) {
+            const int e = t / Q, part = t % Q;
+            double a0 = (cr && part == 0) ? cr[e] : 0.0, a1 = 0.0, a2 = 0.0;
+            const LCD srow = SRm + e * nzh;
+            if constexpr (NT == 1) {
+                for (int c = 0; c < nzh; c++) { const double sv = srow[c]; a0 = fma(sv, v0[c], a0); a1 = fma(sv, v1[c], a1); a2 = fma(sv, v2[c], a2); }
+            } else {
+                for (int cb = part; cb < nzh; cb += 8 * Q) { // (eight terms' operands in flight: see dots)
+                    double sv[8], x0[8], x1[8], x2[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int c = cb + u * Q;
+                        const bool in = c < nzh;
+                        const int cc = in ? c : cb;
+                        sv[u] = in ? srow[cc] : 0.0; x0[u] = v0[cc]; x1[u] = v1[cc]; x2[u] = v2[cc];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { a0 = fma(sv[u], x0[u], a0); a1 = fma(sv[u], x1[u], a1); a2 = fma(sv[u], x2[u], a2); }
+                }
+            }
+            a0 = TM::qsum(a0); a1 = TM::qsum(a1); a2 = TM::qsum(a2);
+            if (part == 0) {
+                o0[e] = a0;
+                if (o1) o1[e] = a1;
+                if (o2) o2[e] = a2;
+            }
         }
     }
     // out[c] += sum_{j,r} SRm[j][r][c] yx[j][r]  (+ yu at the u entries)
-    USV_CDEV void rows_transposed(double *out, const double *yx, const double *yu) const
+    USV_CDEV void rows_transposed(LD out, LCD yx, LCD yu) const
     {
-        for (int c = tid; c < nzh; c += NT) {
-            double a = out[c] + (c < nuh ? yu[c] : 0.0);
-#pragma unroll 8
-            for (int m = 0; m < Mb * nxr; m++) a = fma(SRm[(long)m * nzh + c], yx[m], a);
-            out[c] = a;
+        constexpr int Q = NT == 1 ? 1 : 4; // (a quad per output on the device, as in expand_rows)
+        for (int t = tid; t < Q * nzh; t += NT) {
+            const int c = t / Q, part = t % Q;
+            double a = part == 0 ? out[c] + (c < nuh ? yu[c] : 0.0) : 0.0;
+            a = dots(part, Q, Mb * nxr, a, [&](int m) { return SRm[m * nzh + c]; }, [&](int m) { return yx[m]; });
+            a = TM::qsum(a);
+            if (part == 0) out[c] = a;
         }
     }
-    // the block's rows at the current iterate: one pass of NT rows at a time; obstacle rows of a stage are summed in row order
-    // (deterministic) into the stage's position slots.  F(row index, j, q, Row &r, v, wa, wf) does the per-row work and returns
-    // (yr, yg, Gh): coefficients of c in the residual / in the reduced gradient, and of c c' in the Hessian.
+    // the block's rows at the current iterate.  F(row index, j, q, Row &r, rw, v, wa, wf, yr, yg, Gh) does the per-row work and returns
+    // (yr, yg, Gh): coefficients of c in the residual / in the reduced gradient, and of c c' in the Hessian; with `slots` they are left in
+    // the per-variable slots (yur, yug, wu / yxr, yxg, wd, wxy), the obstacle rows of a stage summed into the stage's position slots.
+    // On the device the rows of a stage sit in an aligned group of RS = 2^k >= R threads (NT / RS stages per pass) and those sums are lane
+    // butterflies inside the group - a fixed order, no staging buffer, no barrier; the emulator's one thread adds them in row order.
+    // the stored values of the thread's row in the first pass of row_pass, asked for BEFORE the block's matrix group (load_block) so that
+    // both come back in one round trip to HBM instead of two
+    struct RowRegs { double a[NRA]; bool got; };
+    USV_CDEV RowRegs row_issue(const double *W) const
+    {
+        RowRegs rr;
+        for (int k = 0; k < NRA; k++) rr.a[k] = 0.0;
+        rr.got = NT > 1;
+        if constexpr (NT > 1) {
+            const int j = tid >> rs_log, q = tid & ((1 << rs_log) - 1);
+            if (j < Mb && q < R) {
+                const double *rw = W + D.o_row + j * R + q;
+#pragma unroll
+                for (int k = 0; k < NRA; k++) rr.a[k] = rw[k * nrows];
+            }
+        }
+        return rr;
+    }
     template <class F>
-    USV_CDEV void row_pass(int i, double *W, bool slots, F f)
+    USV_CDEV void row_pass(int i, double *W, bool slots, const RowRegs &pre, F f)
     {
         if (slots) {
             for (int e = tid; e < Mb * nxr; e += NT) { yxr[e] = 0.0; yxg[e] = 0.0; wd[e] = 0.0; }
@@ -410,90 +565,135 @@ struct CondIpm {
             for (int e = tid; e < nuh; e += NT) { yur[e] = 0.0; yug[e] = 0.0; wu[e] = 0.0; }
         }
         TM::sync();
-        for (int base = 0; base < nrows; base += NT) {
-            const int e = base + tid;
-            const bool has = e < nrows;
-            const int j = has ? e / R : 0, q = has ? e - j * R : 0;
-            double yr = 0.0, yg = 0.0, Gh = 0.0, cx = 0.0, cy = 0.0;
-            bool obs = false;
-            if (has) {
-                double *rw = W + D.o_row + e;
-                Row r;
-                r.neutral(); // (sl = su = 0: the hard-row form still adds them)
-                r.ll = rw[0]; r.lu = rw[nrows]; r.tl = rw[2 * nrows]; r.tu = rw[3 * nrows];
-                r.dl = rw[4 * nrows]; r.du = rw[5 * nrows];
-                r.act = row_active(i, j, q);
-                double v, wa, wf;
-                if (q < D.nbu) {
-                    const int c = j * NU + D.uvar[q];
-                    v = vw[c]; wa = vdwa[c]; wf = vdw[c];
-                } else if (q < D.nbu + D.nbx) {
-                    const int m = j * nxr + D.xvar[q - D.nbu];
-                    v = del[m]; wa = dela[m]; wf = delf[m];
-                } else {
-                    obs = true;
-                    if constexpr (SOFT) {
-                        const int o = q - D.nbu - D.nbx;
-                        r.soft = r.act;
-                        r.sl = rw[8 * nrows]; r.su = rw[9 * nrows]; r.lsl = rw[10 * nrows]; r.lsu = rw[11 * nrows]; r.tsl = rw[12 * nrows]; r.tsu = rw[13 * nrows];
-                        r.zl = S.zl[o]; r.zu = S.zu[o]; r.Zl = S.Zl[o]; r.Zu = S.Zu[o]; r.bsl = S.bsl[o]; r.bsu = S.bsu[o];
-                    }
-                    cx = rw[6 * nrows]; cy = rw[7 * nrows];
-                    const int mx = j * nxr + D.ipx, my = j * nxr + D.ipy;
-                    v = cx * del[mx] + cy * del[my]; wa = cx * dela[mx] + cy * dela[my]; wf = cx * delf[mx] + cy * delf[my];
+        // one row: (j, q) of the block, e its index in the scratch area
+        auto one = [&](bool has, bool first, int e, int j, int q, double &yr, double &yg, double &Gh, double &cx, double &cy, bool &obs) {
+            yr = 0.0; yg = 0.0; Gh = 0.0; cx = 0.0; cy = 0.0; obs = false;
+            if (!has) return;
+            double *rw = W + D.o_row + e;
+            double a[NRA];
+            if (first && pre.got) {
+#pragma unroll
+                for (int k = 0; k < NRA; k++) a[k] = pre.a[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < NRA; k++) a[k] = rw[k * nrows];
+            }
+            Row r;
+            r.neutral(); // (sl = su = 0: the hard-row form still adds them)
+            r.ll = a[0]; r.lu = a[1]; r.tl = a[2]; r.tu = a[3];
+            r.dl = a[4]; r.du = a[5];
+            r.act = row_active(i, j, q);
+            double v, wa, wf;
+            if (q < D.nbu) {
+                const int c = j * NU + D.uvar[q];
+                v = vw[c]; wa = vdwa[c]; wf = vdw[c];
+            } else if (q < D.nbu + D.nbx) {
+                const int m = j * nxr + D.xvar[q - D.nbu];
+                v = del[m]; wa = dela[m]; wf = delf[m];
+            } else {
+                obs = true;
+                if constexpr (SOFT) {
+                    const int o = q - D.nbu - D.nbx;
+                    r.soft = r.act;
+                    r.sl = a[8 % NRA]; r.su = a[9 % NRA]; r.lsl = a[10 % NRA]; r.lsu = a[11 % NRA]; r.tsl = a[12 % NRA]; r.tsu = a[13 % NRA];
+                    r.zl = S.zl[o]; r.zu = S.zu[o]; r.Zl = S.Zl[o]; r.Zu = S.Zu[o]; r.bsl = S.bsl[o]; r.bsu = S.bsu[o];
                 }
-                f(e, j, q, r, rw, v, wa, wf, yr, yg, Gh);
-                if (!r.act) { yr = 0.0; yg = 0.0; Gh = 0.0; }
-                if (slots && !obs) {
-                    if (q < D.nbu) { const int c = j * NU + D.uvar[q]; yur[c] = yr; yug[c] = yg; wu[c] = Gh; }
-                    else { const int m = j * nxr + D.xvar[q - D.nbu]; yxr[m] = yr; yxg[m] = yg; wd[m] = Gh; }
+                cx = a[6]; cy = a[7];
+                const int mx = j * nxr + D.ipx, my = j * nxr + D.ipy;
+                v = cx * del[mx] + cy * del[my]; wa = cx * dela[mx] + cy * dela[my]; wf = cx * delf[mx] + cy * delf[my];
+            }
+            f(e, j, q, r, rw, v, wa, wf, yr, yg, Gh);
+            if (!r.act) { yr = 0.0; yg = 0.0; Gh = 0.0; }
+            if (slots && !obs) {
+                if (q < D.nbu) { const int c = j * NU + D.uvar[q]; yur[c] = yr; yug[c] = yg; wu[c] = Gh; }
+                else { const int m = j * nxr + D.xvar[q - D.nbu]; yxr[m] = yr; yxg[m] = yg; wd[m] = Gh; }
+            }
+        };
+        if constexpr (NT == 1) {
+            for (int e = 0; e < nrows; e++) {
+                const int j = e / R, q = e - j * R;
+                double yr, yg, Gh, cx, cy;
+                bool obs;
+                one(true, false, e, j, q, yr, yg, Gh, cx, cy, obs);
+                if (slots && obs) {
+                    yxr[j * nxr + D.ipx] += cx * yr; yxr[j * nxr + D.ipy] += cy * yr; yxg[j * nxr + D.ipx] += cx * yg; yxg[j * nxr + D.ipy] += cy * yg;
+                    wd[j * nxr + D.ipx] += cx * cx * Gh; wd[j * nxr + D.ipy] += cy * cy * Gh; wxy[j] += cx * cy * Gh;
                 }
             }
-            if (slots && Kn > 0) {
-                obuf[tid] = obs ? cx * yr : 0.0; obuf[NT + tid] = obs ? cy * yr : 0.0;
-                obuf[2 * NT + tid] = obs ? cx * yg : 0.0; obuf[3 * NT + tid] = obs ? cy * yg : 0.0;
-                TM::sync();
-                // stages this pass touches: j_lo .. j_hi; one thread per (stage, quantity)
-                const int j_lo = base / R, j_hi = (base + NT - 1 < nrows ? base + NT - 1 : nrows - 1) / R;
-                for (int t = tid; t < (j_hi - j_lo + 1) * 4; t += NT) {
-                    const int jj = j_lo + t / 4, w = t & 3;
-                    int e0 = jj * R + D.nbu + D.nbx, e1 = e0 + Kn;
-                    if (e0 < base) e0 = base;
-                    if (e1 > base + NT) e1 = base + NT;
-                    double a = 0.0;
-                    for (int ee = e0; ee < e1; ee++) a += obuf[w * NT + (ee - base)];
-                    double *dst = (w == 0) ? &yxr[jj * nxr + D.ipx] : (w == 1) ? &yxr[jj * nxr + D.ipy] : (w == 2) ? &yxg[jj * nxr + D.ipx] : &yxg[jj * nxr + D.ipy];
-                    *dst += a;
+        } else {
+            const int spp = NT >> rs_log;
+            for (int jb = 0; jb < Mb; jb += spp) {
+                const int j = jb + (tid >> rs_log), q = tid & ((1 << rs_log) - 1);
+                const bool has = j < Mb && q < R;
+                double yr, yg, Gh, cx, cy;
+                bool obs;
+                one(has, jb == 0, j * R + q, j, q, yr, yg, Gh, cx, cy, obs);
+                if (slots && Kn > 0) { // (every lane takes part in the butterflies; rows that are not obstacle rows add zeros)
+                    double s0 = cx * yr, s1 = cy * yr, s2 = cx * yg, s3 = cy * yg, s4 = cx * cx * Gh, s5 = cy * cy * Gh, s6 = cx * cy * Gh;
+                    for (int o = 1; o < (1 << rs_log); o <<= 1) {
+                        s0 += TM::lane_xor(s0, o); s1 += TM::lane_xor(s1, o); s2 += TM::lane_xor(s2, o); s3 += TM::lane_xor(s3, o);
+                        s4 += TM::lane_xor(s4, o); s5 += TM::lane_xor(s5, o); s6 += TM::lane_xor(s6, o);
+                    }
+                    if (q == 0 && j < Mb) { // (after the group's own bound rows on the position states, if any: LDS operations of a wave are in order)
+                        yxr[j * nxr + D.ipx] += s0; yxr[j * nxr + D.ipy] += s1; yxg[j * nxr + D.ipx] += s2; yxg[j * nxr + D.ipy] += s3;
+                        wd[j * nxr + D.ipx] += s4; wd[j * nxr + D.ipy] += s5; wxy[j] += s6;
+                    }
                 }
-                TM::sync();
-                obuf[tid] = obs ? cx * cx * Gh : 0.0; obuf[NT + tid] = obs ? cy * cy * Gh : 0.0; obuf[2 * NT + tid] = obs ? cx * cy * Gh : 0.0;
-                TM::sync();
-                for (int t = tid; t < (j_hi - j_lo + 1) * 3; t += NT) {
-                    const int jj = j_lo + t / 3, w = t % 3;
-                    int e0 = jj * R + D.nbu + D.nbx, e1 = e0 + Kn;
-                    if (e0 < base) e0 = base;
-                    if (e1 > base + NT) e1 = base + NT;
-                    double a = 0.0;
-                    for (int ee = e0; ee < e1; ee++) a += obuf[w * NT + (ee - base)];
-                    double *dst = (w == 0) ? &wd[jj * nxr + D.ipx] : (w == 1) ? &wd[jj * nxr + D.ipy] : &wxy[jj];
-                    *dst += a;
-                }
-                TM::sync();
             }
         }
         TM::sync();
     }
 
-    USV_CDEV void load_block(int i, double *W, bool hess)
+    // n doubles of the team's scratch area (HBM) into LDS - two pieces as one index range - with every load of a thread in flight before the
+    // first value is used.  (A loop of load -> LDS store pairs waits out one HBM round trip per element: the sweeps spent a fifth of their
+    // time there - tools/cond_timing.py.)
+    USV_CDEV void fetch2(LD dA, const double *sA, int nA, LD dB, const double *sB, int nB) const
     {
+        if constexpr (NT == 1) {
+            for (int e = 0; e < nA; e++) dA[e] = sA[e];
+            for (int e = 0; e < nB; e++) dB[e] = sB[e];
+        } else {
+            constexpr int U = 16;
+            const int n = nA + nB;
+            for (int base = tid; base < n; base += U * NT) {
+                double r[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int e = base + u * NT, ee = e < n ? e : n - 1;
+                    const double *p = ee < nA ? sA + ee : sB + (ee - nA);
+                    r[u] = *p;
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int e = base + u * NT;
+                    if (e < n) { const LD d = e < nA ? dA + e : dB + (e - nA); *d = r[u]; }
+                }
+            }
+        }
+    }
+    // the block's matrix group (S rows, c rows, [B A], b, g0 and - hess - H0, else the stored factor), its iterate / step vectors and up to
+    // three more vectors of at most nzh entries the sweep wants (LDS destination, offset in the block, length): ONE round trip to HBM
+    struct Ext { LD dst; int off, n; };
+    USV_CDEV void load_block(int i, double *W, bool hess, Ext x0 = Ext{nullptr, 0, 0}, Ext x1 = Ext{nullptr, 0, 0}, Ext x2 = Ext{nullptr, 0, 0})
+    {
+        forget_tid();
         TM::sync();
-        for (int e = tid; e < Mb * nxr * nzh; e += NT) SRm[e] = W[D.o_SR + e];
-        for (int e = tid; e < Mb * nxr; e += NT) vcr[e] = W[D.o_cr + e];
-        for (int e = tid; e < NX * nzh; e += NT) BAm[e] = W[D.o_BA + e];
-        for (int e = tid; e < nzh; e += NT) { vw[e] = W[D.o_w + e]; vdwa[e] = W[D.o_dwa + e]; vdw[e] = W[D.o_dw + e]; }
-        if (hess) {
-            for (int e = tid; e < nzh * nzh; e += NT) Gm[e] = W[D.o_H0 + e];
-            for (int e = tid; e < nzh; e += NT) vg0[e] = W[D.o_g0 + e];
+        const int ng = D.o_H0 - D.o_SR, nn = nzh * nzh;
+        if constexpr (NT == 1) {
+            for (int e = 0; e < nzh; e++) { vw[e] = W[D.o_w + e]; vdwa[e] = W[D.o_dwa + e]; vdw[e] = W[D.o_dw + e]; }
+            for (int e = 0; e < x0.n; e++) x0.dst[e] = W[x0.off + e];
+            for (int e = 0; e < x1.n; e++) x1.dst[e] = W[x1.off + e];
+            for (int e = 0; e < x2.n; e++) x2.dst[e] = W[x2.off + e];
+            fetch2(mat, W + D.o_SR, hess ? ng + nn : ng, Gm, W + D.o_Luu, hess ? 0 : nn);
+        } else {
+            auto at = [&](int off, int n) { return W[off + (tid < n ? tid : (n > 0 ? n - 1 : 0))]; }; // (n = 0: some valid address, value unused)
+            const double a0 = at(D.o_w, nzh), a1 = at(D.o_dwa, nzh), a2 = at(D.o_dw, nzh);
+            const double b0 = at(x0.off, x0.n), b1 = at(x1.off, x1.n), b2 = at(x2.off, x2.n);
+            fetch2(mat, W + D.o_SR, hess ? ng + nn : ng, Gm, W + D.o_Luu, hess ? 0 : nn);
+            if (tid < nzh) { vw[tid] = a0; vdwa[tid] = a1; vdw[tid] = a2; }
+            if (tid < x0.n) x0.dst[tid] = b0;
+            if (tid < x1.n) x1.dst[tid] = b1;
+            if (tid < x2.n) x2.dst[tid] = b2;
         }
         (void)i;
         TM::sync();
@@ -516,10 +716,18 @@ struct CondIpm {
                 const int r = tid < nzh ? tid : nzh - 1;
                 double y = vrq[r];
                 const double dg = vdg[r < nuh ? r : 0];
-                for (int c = 0; c < nuh; c++) {
-                    const double yc = TM::lane_value(y, c) * TM::lane_value(dg, c);
-                    const double l = Gm[r * nzh + c];
-                    y = (r == c) ? yc : (r > c ? fma(-l, yc, y) : y);
+                for (int cb = 0; cb < nuh; cb += 8) { // (the lane's eight entries of L fetched ahead of the eight dependent steps)
+                    double l[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) l[u] = Gm[r * nzh + (cb + u < nuh ? cb + u : cb)];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int c = cb + u;
+                        if (c < nuh) {
+                            const double yc = TM::lane_value(y, c) * TM::lane_value(dg, c);
+                            y = (r == c) ? yc : (r > c ? fma(-l[u], yc, y) : y);
+                        }
+                    }
                 }
                 if (tid < nzh) vrq[tid] = y;
             }
@@ -541,15 +749,61 @@ struct CondIpm {
                 const int r = tid < nuh ? tid : nuh - 1;
                 double y = vt[r];
                 const double dg = vdg[r];
-                for (int c = nuh - 1; c >= 0; c--) {
-                    const double yc = TM::lane_value(y, c) * TM::lane_value(dg, c);
-                    const double l = Gm[c * nzh + r];
-                    y = (r == c) ? yc : (r < c ? fma(-l, yc, y) : y);
+                for (int cb = nuh - 1; cb >= 0; cb -= 8) {
+                    double l[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) l[u] = Gm[(cb - u >= 0 ? cb - u : cb) * nzh + r];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int c = cb - u;
+                        if (c >= 0) {
+                            const double yc = TM::lane_value(y, c) * TM::lane_value(dg, c);
+                            y = (r == c) ? yc : (r < c ? fma(-l[u], yc, y) : y);
+                        }
+                    }
                 }
                 if (tid < nuh) vt[tid] = y;
             }
         }
         TM::sync();
+    }
+
+    // Cholesky of the nuh input columns of the stage matrix in Gm (lower triangle), left-looking: column c = (G[:, c] - sum_{k<c} L[:, k] L[c, k])
+    // / sqrt(pivot); [Luu; Lxu] stays in their place, vdg holds 1 / diagonal.  On the device ONE wave does it - lane r owns row r, the pivot
+    // travels by readlane - with no workgroup barrier inside (the right-looking form this replaces had one per column and waited on it).
+    // Returns 5 for a pivot that is not positive, else 0.  Call between syncs.
+    USV_CDEV double factor_panel()
+    {
+        double bad = 0.0;
+        if constexpr (NT == 1) {
+            for (int c = 0; c < nuh; c++) {
+                for (int r = c; r < nzh; r++) {
+                    double v = Gm[r * nzh + c];
+                    for (int k = 0; k < c; k++) v = fma(-Gm[r * nzh + k], Gm[c * nzh + k], v);
+                    Gm[r * nzh + c] = v;
+                }
+                const double piv = Gm[c * nzh + c];
+                if (!(piv > 0.0)) bad = 5.0;
+                const double dg = 1.0 / sqrt(piv);
+                vdg[c] = dg;
+                for (int r = c; r < nzh; r++) Gm[r * nzh + c] *= dg;
+            }
+        } else {
+            if (tid < 64) {
+                const int r = tid < nzh ? tid : nzh - 1;
+                const LD row = Gm + r * nzh;
+                for (int c = 0; c < nuh; c++) { // (rows above c compute on values nobody reads)
+                    double v = row[c];
+                    v = dots(0, 1, c, v, [&](int k) { return -row[k]; }, [&](int k) { return Gm[c * nzh + k]; });
+                    const double piv = TM::lane_value(v, c);
+                    if (!(piv > 0.0)) bad = 5.0;
+                    const double dg = 1.0 / sqrt(piv);
+                    if (tid >= c && tid < nzh) row[c] = v * dg;
+                    if (tid == 0) vdg[c] = dg;
+                }
+            }
+        }
+        return bad;
     }
 
     // ------------------------------------------------------------------ backward sweep with factorisation
@@ -579,13 +833,13 @@ struct CondIpm {
         }
         for (int i = N2 - 1; i >= 0; i--) {
             double *W = blk(i);
-            load_block(i, W, true);
-            for (int e = tid; e < NX; e += NT) { vpi[e] = W[D.o_pi + e]; vbt[e] = W[D.o_bt + e]; }
+            USV_TICK(1);
+            const RowRegs rr = row_issue(W);
+            load_block(i, W, true, Ext{vpi, D.o_pi, NX}, Ext{vtmp, D.o_dpi, pend ? NX : 0});
+            USV_TICK(2);
             if (pend) { // rows need the old iterate and both steps
-                expand_rows(delo, vw, vcr);
-                expand_rows(dela, vdwa, nullptr);
-                expand_rows(delf, vdw, nullptr);
-                for (int e = tid; e < NX; e += NT) { vpi[e] = fma(a_prev, W[D.o_dpi + e], vpi[e]); W[D.o_pi + e] = vpi[e]; }
+                expand_rows(delo, vw, vcr, dela, vdwa, delf, vdw);
+                for (int e = tid; e < NX; e += NT) { vpi[e] = fma(a_prev, vtmp[e], vpi[e]); W[D.o_pi + e] = vpi[e]; }
                 TM::sync();
                 // (the old values of the u rows are read from vw before it moves: keep a copy in vt)
                 for (int e = tid; e < nzh; e += NT) vt[e] = vw[e];
@@ -593,10 +847,12 @@ struct CondIpm {
                 for (int e = tid; e < nzh; e += NT) { vw[e] = fma(a_prev, vdw[e], vw[e]); W[D.o_w + e] = vw[e]; }
             }
             TM::sync();
+            USV_TICK(3);
             expand_rows(del, vw, vcr);
             TM::sync();
+            USV_TICK(4);
             double rd = 0.0, rm = 0.0, mus = 0.0, bd = 0.0, rgs = 0.0;
-            row_pass(i, W, true, [&](int e, int j, int q, Row &r, double *rw, double v, double wa, double wf, double &yr, double &yg, double &Gh) {
+            row_pass(i, W, true, rr, [&](int e, int j, int q, Row &r, double *rw, double v, double wa, double wf, double &yr, double &yg, double &Gh) {
                 (void)e;
                 if (pend && r.act) {
                     double vo; // the row's value at the iterate the step was computed at
@@ -629,19 +885,27 @@ struct CondIpm {
                     }
                 }
             });
+            USV_TICK(5);
             // r = g0 + H0 w + BA' pi_{i+1} - [0; pi_i];  rb = bt + BA w - x_{i+1}
-            for (int c = tid; c < nzh; c += NT) {
-                double a = vg0[c];
-#pragma unroll 6
-                for (int m = 0; m < nzh; m++) a = fma(Gm[c * nzh + m], vw[m], a);
-                for (int s = 0; s < NX; s++) a = fma(BAm[s * nzh + c], vpin[s], a);
-                if (i >= 1 && c >= nuh) a -= vpi[c - nuh];
-                vr[c] = a;
-            }
-            for (int s = tid; s < NX; s += NT) {
-                double a = vbt[s] - vxn[s];
-                for (int c = 0; c < nzh; c++) a = fma(BAm[s * nzh + c], vw[c], a);
-                vrb[s] = a;
+            {   // (a quad per entry: vr in the first 4 nzh threads, rb in the next 4 NX - expand_rows has the arrangement)
+                constexpr int Q = NT == 1 ? 1 : 4;
+                for (int t = tid; t < Q * (nzh + NX); t += NT) {
+                    const int c = t / Q, part = t % Q;
+                    if (c < nzh) {
+                        double a = part == 0 ? vg0[c] : 0.0;
+                        a = dots(part, Q, nzh, a, [&](int m) { return Gm[c * nzh + m]; }, [&](int m) { return vw[m]; });
+                        a = dots(part, Q, NX, a, [&](int s_) { return BAm[s_ * nzh + c]; }, [&](int s_) { return vpin[s_]; });
+                        a = TM::qsum(a);
+                        if (i >= 1 && c >= nuh) a -= vpi[c - nuh];
+                        if (part == 0) vr[c] = a;
+                    } else {
+                        const int s_ = c - nzh;
+                        double a = part == 0 ? vbt[s_] - vxn[s_] : 0.0;
+                        a = dots(part, Q, nzh, a, [&](int m) { return BAm[s_ * nzh + m]; }, [&](int m) { return vw[m]; });
+                        a = TM::qsum(a);
+                        if (part == 0) vrb[s_] = a;
+                    }
+                }
             }
             TM::sync();
             rows_transposed(vr, yxr, yur);
@@ -658,6 +922,7 @@ struct CondIpm {
             badf = fmax(badf, bd);
             TM::sync();
             rows_transposed(vgt, yxg, yug);
+            USV_TICK(6);
             // Ht = H0 + diag_u(wu) + sum_j SR_j' W_j SR_j   (lower triangle), then G = Ht + BA' P+ BA
             for (int e = tid; e < NX * nzh; e += NT) {
                 const int s = e / nzh, c = e - s * nzh;
@@ -675,18 +940,19 @@ struct CondIpm {
             for (int e = tid; e < NX * NX; e += NT) W[D.o_P + e] = Pn[e];
             for (int e = tid; e < NX; e += NT) W[D.o_p + e] = vpv[e];
             TM::sync();
+            USV_TICK(7);
             const int ntri = nzh * (nzh + 1) / 2;
             for (int e = tid; e < ntri; e += NT) {
                 const int a_ = tri[e] >> 8, c = tri[e] & 255;
                 double acc = Gm[a_ * nzh + c];
                 if (a_ == c && a_ < nuh) acc += wu[a_];
 #pragma unroll 8
-                for (int m = 0; m < Mb * nxr; m++) acc = fma(SRm[(long)m * nzh + a_] * wd[m], SRm[(long)m * nzh + c], acc);
+                for (int m = 0; m < Mb * nxr; m++) acc = fma(SRm[m * nzh + a_] * wd[m], SRm[m * nzh + c], acc);
                 if (Kn > 0)
-                    for (int j = 0; j < Mb; j++) {
-                        const double *sx = SRm + (long)(j * nxr + D.ipx) * nzh, *sy = SRm + (long)(j * nxr + D.ipy) * nzh;
-                        acc = fma(wxy[j], sx[a_] * sy[c] + sy[a_] * sx[c], acc);
-                    }
+                    acc = dots(0, 1, Mb, acc, [&](int j) { return wxy[j]; }, [&](int j) {
+                        const LCD sx = SRm + (j * nxr + D.ipx) * nzh, sy = SRm + (j * nxr + D.ipy) * nzh;
+                        return sx[a_] * sy[c] + sy[a_] * sx[c];
+                    });
 #pragma unroll
                 for (int s = 0; s < NX; s++) acc = fma(BAm[s * nzh + a_], PBm[s * nzh + c], acc);
                 Gm[a_ * nzh + c] = acc;
@@ -697,36 +963,26 @@ struct CondIpm {
                 for (int s = 0; s < NX; s++) a = fma(BAm[s * nzh + c], vPb[s] + vpv[s], a);
                 vrq[c] = a;
             }
-            // eliminate the nuh input columns: [Luu; Lxu] stays in their place, the Schur complement P_i in the x block.  One barrier
-            // per column: the trailing update uses the UNSCALED column (times 1 / pivot), which nothing writes during the step; the
-            // columns are scaled to Cholesky form in one pass afterwards.
-            for (int c = 0; c < nuh; c++) {
-                TM::sync();
-                const double piv = Gm[c * nzh + c];
-                if (!(piv > 0.0)) badf = fmax(badf, 5.0);
-                const double ipiv = 1.0 / piv;
-                if (tid == 0) vdg[c] = 1.0 / sqrt(piv);
-                const int nr = nzh - c - 1; // rows c+1 .. nzh-1, lower triangle of the trailing block
-                for (int e = tid; e < nr * (nr + 1) / 2; e += NT) {
-                    const int rr = c + 1 + (tri[e] >> 8), c2 = c + 1 + (tri[e] & 255);
-                    Gm[rr * nzh + c2] = fma(-Gm[rr * nzh + c] * ipiv, Gm[c2 * nzh + c], Gm[rr * nzh + c2]);
-                }
-            }
+            USV_TICK(8);
+            // eliminate the nuh input columns (factor_panel), then the Schur complement P_i = Gxx - Lxu Lxu' straight into Pn, both triangles
+            // from the lower one (rq and the stored P_{i+1} above no longer need Pn: a barrier lies between)
             TM::sync();
-            for (int e = tid; e < nzh * nuh; e += NT) {
-                const int r = e / nuh, c = e - r * nuh;
-                if (r >= c) Gm[r * nzh + c] *= vdg[c]; // (diagonal: piv / sqrt(piv))
+            badf = fmax(badf, factor_panel());
+            TM::sync();
+            USV_TICK(9);
+            for (int e = tid; e < NX * NX; e += NT) {
+                const int s_ = e / NX, m = e - s_ * NX;
+                const int rr = nuh + (s_ >= m ? s_ : m), c2 = nuh + (s_ >= m ? m : s_);
+                Pn[e] = dots(0, 1, nuh, Gm[rr * nzh + c2], [&](int k) { return -Gm[rr * nzh + k]; }, [&](int k) { return Gm[c2 * nzh + k]; });
             }
             solve_forward();
-            for (int e = tid; e < nzh * nuh; e += NT) { const int r = e / nuh, c = e - r * nuh; W[D.o_Luu + e] = Gm[r * nzh + c]; }
+            USV_TICK(10);
+            for (int e = tid; e < nzh * nzh; e += NT) W[D.o_Luu + e] = Gm[e];
             for (int c = tid; c < nuh; c += NT) { W[D.o_lus + c] = vrq[c]; W[D.o_dg + c] = vdg[c]; }
             // hand over to block i - 1
-            for (int e = tid; e < NX * NX; e += NT) {
-                const int s = e / NX, m = e - s * NX;
-                Pn[e] = (m <= s) ? Gm[(nuh + s) * nzh + nuh + m] : Gm[(nuh + m) * nzh + nuh + s];
-            }
             for (int s = tid; s < NX; s += NT) { vpv[s] = vrq[nuh + s]; vxn[s] = vw[nuh + s]; vpin[s] = vpi[s]; }
             TM::sync();
+            USV_TICK(11);
         }
         nm.rg = TM::rmax(nm.rg, red); nm.rb = TM::rmax(nm.rb, red); nm.rd = TM::rmax(nm.rd, red); nm.rm = TM::rmax(nm.rm, red);
         nm.musum = TM::rsum(nm.musum, red);
@@ -741,6 +997,7 @@ struct CondIpm {
             }
         }
         nm.rb = fmax(nm.rb, TM::rmax(e0m, red));
+        USV_TICK(12);
         nm.bad = TM::rmax(badf, red) > 0.5; // (badf: 1 terminal residual, 2 row, 3 stationarity, 4 dynamics, 5 pivot, 6 initial state)
         return nm;
     }
@@ -755,19 +1012,19 @@ struct CondIpm {
         }
         for (int i = N2 - 1; i >= 0; i--) {
             double *W = blk(i);
-            load_block(i, W, false);
-            for (int e = tid; e < nzh * nuh; e += NT) { const int r = e / nuh, c = e - r * nuh; Gm[r * nzh + c] = W[D.o_Luu + e]; }
-            for (int e = tid; e < NX; e += NT) { vPb[e] = W[D.o_Pb + e]; W[D.o_p + e] = vpv[e]; }
-            for (int c = tid; c < nuh; c += NT) vdg[c] = W[D.o_dg + c];
-            for (int c = tid; c < nzh; c += NT) vgt[c] = W[D.o_rg + c];
-            expand_rows(del, vw, vcr);
-            expand_rows(dela, vdwa, nullptr);
+            const RowRegs rr = row_issue(W);
+            load_block(i, W, false, Ext{vPb, D.o_Pb, NX}, Ext{vdg, D.o_dg, nuh}, Ext{vgt, D.o_rg, nzh});
+            for (int e = tid; e < NX; e += NT) W[D.o_p + e] = vpv[e];
+            USV_TICK(13);
+            expand_rows(del, vw, vcr, dela, vdwa);
             TM::sync();
-            row_pass(i, W, true, [&](int, int, int, Row &r, double *, double v, double wa, double, double &yr, double &yg, double &Gh) {
+            USV_TICK(14);
+            row_pass(i, W, true, rr, [&](int, int, int, Row &r, double *, double v, double wa, double, double &yr, double &yg, double &Gh) {
                 double g0_, g1_;
                 r.resid(v); r.targets_pred(); r.reduce(g0_, g1_); r.expand(wa); r.template targets_corr<true>(sigmu, so_cur); r.reduce(Gh, yg);
                 yr = 0.0;
             });
+            USV_TICK(15);
             rows_transposed(vgt, yxg, yug);
             TM::sync();
             for (int c = tid; c < nzh; c += NT) {
@@ -779,6 +1036,7 @@ struct CondIpm {
             for (int c = tid; c < nuh; c += NT) W[D.o_lus + c] = vrq[c];
             for (int s = tid; s < NX; s += NT) vpv[s] = vrq[nuh + s];
             TM::sync();
+            USV_TICK(16);
         }
     }
 
@@ -794,11 +1052,9 @@ struct CondIpm {
         }
         for (int i = 0; i < N2; i++) {
             double *W = blk(i);
-            load_block(i, W, false);
-            for (int e = tid; e < nzh * nuh; e += NT) { const int r = e / nuh, c = e - r * nuh; Gm[r * nzh + c] = W[D.o_Luu + e]; }
-            for (int c = tid; c < nuh; c += NT) { vlus[c] = W[D.o_lus + c]; vdg[c] = W[D.o_dg + c]; }
-            for (int s = tid; s < NX; s += NT) vrb[s] = W[D.o_rb + s];
-            TM::sync();
+            const RowRegs rr = row_issue(W);
+            load_block(i, W, false, Ext{vlus, D.o_lus, nuh}, Ext{vdg, D.o_dg, nuh}, Ext{vrb, D.o_rb, NX});
+            USV_TICK(17);
             // t = lus + Lxu' dx;  du = -Luu^-T t
             for (int c = tid; c < nuh; c += NT) {
                 double a = vlus[c];
@@ -806,22 +1062,27 @@ struct CondIpm {
                 vt[c] = a;
             }
             solve_backward();
-            double *dst = corr ? vdw : vdwa;
+            const LD dst = corr ? vdw : vdwa;
             for (int c = tid; c < nzh; c += NT) {
                 const double v = (c < nuh) ? -vt[c] : vdx[c - nuh];
                 dst[c] = v;
                 W[(corr ? D.o_dw : D.o_dwa) + c] = v;
             }
             TM::sync();
-            for (int s = tid; s < NX; s += NT) {
-                double a = vrb[s];
-                for (int c = 0; c < nzh; c++) a = fma(BAm[s * nzh + c], dst[c], a);
-                vdxn[s] = a;
+            {
+                constexpr int Q = NT == 1 ? 1 : 4;
+                for (int t = tid; t < Q * NX; t += NT) {
+                    const int s = t / Q, part = t % Q;
+                    double a = part == 0 ? vrb[s] : 0.0;
+                    a = dots(part, Q, nzh, a, [&](int c) { return BAm[s * nzh + c]; }, [&](int c) { return dst[c]; });
+                    a = TM::qsum(a);
+                    if (part == 0) vdxn[s] = a;
+                }
             }
-            expand_rows(del, vw, vcr);
-            expand_rows(dela, vdwa, nullptr);
-            if (corr) expand_rows(delf, vdw, nullptr);
+            USV_TICK(18);
+            expand_rows(del, vw, vcr, dela, vdwa, corr ? delf : nullptr, corr ? vdw : nullptr);
             TM::sync();
+            USV_TICK(19);
             if (corr) { // dpi_{i+1} = p_{i+1} + P_{i+1} dx_{i+1}
                 double *Wn = blk(i + 1);
                 for (int s = tid; s < NX; s += NT) {
@@ -830,7 +1091,7 @@ struct CondIpm {
                     Wn[D.o_dpi + s] = a;
                 }
             }
-            row_pass(i, W, false, [&](int, int, int, Row &r, double *, double v, double wa, double wf, double &, double &, double &) {
+            row_pass(i, W, false, rr, [&](int, int, int, Row &r, double *, double v, double wa, double wf, double &, double &, double &) {
                 double g0_, g1_;
                 r.resid(v); r.targets_pred(); r.reduce(g0_, g1_); r.expand(wa);
                 if (corr) { r.template targets_corr<true>(sigmu, so_cur); r.reduce(g0_, g1_); r.expand(wf); }
@@ -848,6 +1109,7 @@ struct CondIpm {
             });
             for (int s = tid; s < NX; s += NT) vdx[s] = vdxn[s];
             TM::sync();
+            USV_TICK(21);
         }
         {
             double *W = blk(N2);
@@ -856,6 +1118,7 @@ struct CondIpm {
         qmax = TM::rmax(qmax, red);
         alpha = 1.0 / qmax;
         S1 = TM::rsum(s1, red); S2 = TM::rsum(s2, red);
+        USV_TICK(22);
     }
 
     // ------------------------------------------------------------------ expansion + RTI step + outputs
@@ -990,7 +1253,9 @@ struct CondIpm {
     {
         g = group;
         b = P.perm ? (long)P.perm[g] : g;
+        USV_TICK(-1);
         const bool bad0 = condense();
+        USV_TICK(0);
         so_cur = 1.0; so_prv = 1.0;
         int status = bad0 ? 4 : 1, it = 0;
         Norms nm{0.0, 0.0, 0.0, 0.0, 0.0, false};
@@ -1029,7 +1294,9 @@ struct CondIpm {
             pend = true;
             it++;
         }
+        USV_TICK(-1);
         finish(status, it, nm);
+        USV_TICK(20);
     }
 };
 

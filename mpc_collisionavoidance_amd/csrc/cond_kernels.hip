@@ -17,18 +17,24 @@ namespace usv {
 // teams at 168 registers (three waves per SIMD) beat 64 / 128 threads at any budget (233 against 285 .. 425 ms at 8192 instances).  With
 // 13-variable blocks (usv_model_guidance_ca1, 5 stages per block) a team needs a few KB and twelve 64-thread teams fit: 188 ms against
 // 378 ms with 256-thread teams at 65536 instances.  Both are built; cond_prepare takes the one with more resident waves per CU.
-#ifndef USV_COND_MINWAVES // waves per SIMD the kernels are compiled for (register budget 512 / that)
-#define USV_COND_MINWAVES 3
+#ifndef USV_COND_MINWAVES // waves per SIMD the kernels with hard obstacle rows (or none) are compiled for (register budget 512 / that)
+#define USV_COND_MINWAVES 4
 #endif
+// Round 6 (docs/rounds/r06.md section 7): with the thread index made opaque once per block (CondIpm::forget_tid) the kernels want 155 - 173
+// registers instead of 386, LDS per team of the 30-variable blocks went from 53 to 40 KB, and FOUR 256-thread teams per CU at 128 registers
+// (11 spilled) beat three at 168: 126 against 171 ms at 8192 instances (205 ms before the round).  The soft-row kernels (usv_model_guidance_ca1:
+// twelve or more 64-thread teams per CU) spill 150 registers at 128 and stay at three waves per SIMD.
+template <bool SOFT> constexpr int cond_minwaves() { return SOFT ? 3 : USV_COND_MINWAVES; }
 
 // One instance per workgroup of NT threads, the condensed block's matrices in LDS, the instance's condensed QP in the
 // workgroup's scratch area in HBM; workgroups pull further instances from the queue as they finish.
-template <class M, int KCH, bool SOFT, int NT>
-__global__ void __launch_bounds__(NT, USV_COND_MINWAVES) usv_qp_cond(DevPtrs P, const CondDims *Dp, double *scratch, int nB, int queue0)
+// MB: stages per block the instantiation is made for (0: any - CondBlkSizes).
+template <class M, int KCH, bool SOFT, int NT, int MB>
+__global__ void __launch_bounds__(NT, cond_minwaves<SOFT>()) usv_qp_cond(DevPtrs P, const CondDims *Dp, double *scratch, int nB, int queue0)
 {
     extern __shared__ double cond_lds[];
     __shared__ int nxt;
-    CondIpm<M, KCH, SOFT, CondTeam<NT>> q(P, *Dp, scratch + (long)blockIdx.x * Dp->total, cond_lds);
+    CondIpm<M, KCH, SOFT, CondTeam<NT>, MB> q(P, *Dp, scratch + (long)blockIdx.x * Dp->total, cond_lds);
     long g = blockIdx.x;
     while (g < nB) {
         q.solve(g);
@@ -41,10 +47,16 @@ __global__ void __launch_bounds__(NT, USV_COND_MINWAVES) usv_qp_cond(DevPtrs P, 
 
 namespace {
 
+// block length a 256-thread instantiation with compile-time sizes exists for (0: none): usv_model_pf_ca with 8 stages per block
+template <class M, bool SOFT> struct CondFixed { static constexpr int MB = 0; };
+#if !defined(USV_GEN_ONLY)
+template <> struct CondFixed<ModelM2, false> { static constexpr int MB = 8; };
+#endif
+
 template <class M, int KCH, bool SOFT, int NT>
 int occupancy_of(const DevSpec &S, int N2, CondDims &D, size_t &lds, int &nb)
 {
-    auto kern = &usv_qp_cond<M, KCH, SOFT, NT>;
+    auto kern = &usv_qp_cond<M, KCH, SOFT, NT, 0>; // (the fixed-length instantiations use the same LDS and no more registers)
     nb = 0;
     if (!cond_dims(S, M::NX, M::NU, M::IPX, M::IPY, N2, NT, SOFT, D)) return USVMPC_E_ARG;
     lds = (size_t)D.lds_doubles * sizeof(double);
@@ -72,10 +84,15 @@ int prepare_for(const DevSpec &S, int N2, CondDims &D, size_t &lds, int &nb, std
 }
 
 template <class M, int KCH, bool SOFT>
-int run_for(int nt, hipStream_t st, long teams, size_t lds, const DevPtrs &P, const CondDims *dD, double *scratch, int B)
+int run_for(int nt, int mb, hipStream_t st, long teams, size_t lds, const DevPtrs &P, const CondDims *dD, double *scratch, int B)
 {
-    if (nt == 64) hipLaunchKernelGGL((usv_qp_cond<M, KCH, SOFT, 64>), dim3((unsigned)teams), dim3(64), lds, st, P, dD, scratch, B, (int)teams);
-    else hipLaunchKernelGGL((usv_qp_cond<M, KCH, SOFT, 256>), dim3((unsigned)teams), dim3(256), lds, st, P, dD, scratch, B, (int)teams);
+    if (nt == 64) hipLaunchKernelGGL((usv_qp_cond<M, KCH, SOFT, 64, 0>), dim3((unsigned)teams), dim3(64), lds, st, P, dD, scratch, B, (int)teams);
+    else if (CondFixed<M, SOFT>::MB > 0 && mb == CondFixed<M, SOFT>::MB) {
+        constexpr int MBF = CondFixed<M, SOFT>::MB;
+        auto kern = &usv_qp_cond<M, KCH, SOFT, 256, MBF>;
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        hipLaunchKernelGGL(kern, dim3((unsigned)teams), dim3(256), lds, st, P, dD, scratch, B, (int)teams);
+    } else hipLaunchKernelGGL((usv_qp_cond<M, KCH, SOFT, 256, 0>), dim3((unsigned)teams), dim3(256), lds, st, P, dD, scratch, B, (int)teams);
     return 0;
 }
 
@@ -113,12 +130,24 @@ int cond_prepare(int model, int kch, const DevSpec &S, int N2, CondDims &D, size
     return USVMPC_E_ARG;
 }
 
-int cond_run(int model, int kch, int nt, hipStream_t st, long teams, size_t lds_bytes, const DevPtrs &P, const CondDims *dD, double *scratch, int B)
+int cond_run(int model, int kch, int nt, int mb, hipStream_t st, long teams, size_t lds_bytes, const DevPtrs &P, const CondDims *dD, double *scratch, int B)
 {
-#define USV_COND_RUN(M, K, SF) run_for<M, K, SF>(nt, st, teams, lds_bytes, P, dD, scratch, B)
+#define USV_COND_RUN(M, K, SF) run_for<M, K, SF>(nt, mb, st, teams, lds_bytes, P, dD, scratch, B)
     USV_COND_DISPATCH(USV_COND_RUN)
 #undef USV_COND_RUN
     return -1;
 }
 
 } // namespace usv
+
+#if defined(USV_COND_TIMING) // development build only (tools/cond_timing.py): cycles of a team's first thread per phase of cond_ipm.hpp
+extern "C" int usvmpc_debug_cond_ticks(unsigned long long *out32, int reset)
+{
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(usv::usv_cond_ticks), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(usv::usv_cond_ticks), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -113,25 +113,27 @@ __device__ unsigned long long usv_cond_ticks[32];
 #define USV_TICK(ph)
 #endif
 
-// The block's sizes (stages per block Mb, inputs nuh = Mb nu, variables nzh = nuh + nx): run-time values in general (MB = 0), compile-time
-// constants in the instantiations made for one block length (cond_kernels.hip: MB = 8, BASELINE configs[4]'s N = 80 -> N2 = 10) - every
-// matrix in LDS has nzh as its row stride, and with the stride known the dot products unroll with immediate offsets instead of an
-// address addition per operand (the kernel at four teams per CU is bound by instruction issue: profiles/r06_cond_sq_counters.txt).
-template <int MB, int NU_, int NX_>
+// The block's sizes (stages per block Mb, inputs nuh = Mb nu, variables nzh = nuh + nx, touched states nxr): run-time values in general
+// (MB = 0), compile-time constants in the instantiations made for one shape (cond_kernels.hip: MB = 8, NXR = 7 - BASELINE configs[4]'s
+// N = 80 -> N2 = 10 with usv_model_pf_ca's bounds).  Every matrix in LDS has nzh as its row stride and every LDS array starts at a sum of
+// these sizes: with them known the dot products unroll with immediate offsets instead of an address addition per operand, and the
+// fifty array addresses stop being live scalar values (the kernel at four teams per CU is bound by instruction issue:
+// profiles/r06_cond_sq_counters.txt).
+template <int MB, int NXR, int NU_, int NX_>
 struct CondBlkSizes {
-    static constexpr int Mb = MB, nuh = MB * NU_, nzh = MB * NU_ + NX_;
-    USV_CDEV bool set_sizes(int mb, int, int) { return mb == MB; }
+    static constexpr int Mb = MB, nuh = MB * NU_, nzh = MB * NU_ + NX_, nxr = NXR;
+    USV_CDEV bool set_sizes(int mb, int, int, int nx_r) { return mb == MB && nx_r == NXR; }
 };
-template <int NU_, int NX_>
-struct CondBlkSizes<0, NU_, NX_> {
-    int Mb, nuh, nzh;
-    USV_CDEV bool set_sizes(int mb, int nu_h, int nz_h) { Mb = mb; nuh = nu_h; nzh = nz_h; return true; }
+template <int NXR, int NU_, int NX_>
+struct CondBlkSizes<0, NXR, NU_, NX_> {
+    int Mb, nuh, nzh, nxr;
+    USV_CDEV bool set_sizes(int mb, int nu_h, int nz_h, int nx_r) { Mb = mb; nuh = nu_h; nzh = nz_h; nxr = nx_r; return true; }
 };
 
-template <class M, int KCH, bool SOFT, class TM, int MB = 0>
-struct CondIpm : CondBlkSizes<MB, M::NU, M::NX> {
-    using BS = CondBlkSizes<MB, M::NU, M::NX>;
-    using BS::Mb; using BS::nuh; using BS::nzh;
+template <class M, int KCH, bool SOFT, class TM, int MB = 0, int NXR = 0>
+struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
+    using BS = CondBlkSizes<MB, NXR, M::NU, M::NX>;
+    using BS::Mb; using BS::nuh; using BS::nzh; using BS::nxr;
 #if defined(USV_COND_TIMING) && defined(__HIPCC__)
     unsigned long long t_last = 0;
     __device__ void tick(int ph)
@@ -183,7 +185,7 @@ struct CondIpm : CondBlkSizes<MB, M::NU, M::NX> {
     DimsLocal D;
     const USV_LDS unsigned short *tri; // element e of a lower triangle -> (row << 8) | column
     double *cw; // the team's scratch area in HBM
-    int tid, N, Kn, N2, nxr, R, nrows;
+    int tid, N, Kn, N2, R, nrows;
     int rs_log; // log2 of the thread group a stage's rows sit in (row_pass)
     long g, b;
     // LDS
@@ -206,14 +208,21 @@ struct CondIpm : CondBlkSizes<MB, M::NU, M::NX> {
         S.cpc = Sg.cpc; S.cpc_factor = Sg.cpc_factor;
         D.Mb = Dg.Mb; D.N2 = Dg.N2; D.N1 = Dg.N1; D.R1 = Dg.R1; D.nuh = Dg.nuh; D.nzh = Dg.nzh; D.nxr = Dg.nxr; D.R = Dg.R; D.nrows = Dg.nrows; D.nbu = Dg.nbu; D.nbx = Dg.nbx;
         D.ipx = Dg.ipx; D.ipy = Dg.ipy;
-        D.o_SR = (int)Dg.o_SR; D.o_cr = (int)Dg.o_cr; D.o_BA = (int)Dg.o_BA; D.o_bt = (int)Dg.o_bt; D.o_H0 = (int)Dg.o_H0; D.o_g0 = (int)Dg.o_g0;
-        D.o_row = (int)Dg.o_row; D.o_Luu = (int)Dg.o_Luu; D.o_P = (int)Dg.o_P; D.o_Pb = (int)Dg.o_Pb; D.o_w = (int)Dg.o_w; D.o_pi = (int)Dg.o_pi;
+        D.o_Luu = (int)Dg.o_Luu; D.o_P = (int)Dg.o_P; D.o_Pb = (int)Dg.o_Pb; D.o_w = (int)Dg.o_w; D.o_pi = (int)Dg.o_pi;
         D.o_rg = (int)Dg.o_rg; D.o_rb = (int)Dg.o_rb; D.o_dwa = (int)Dg.o_dwa; D.o_dw = (int)Dg.o_dw; D.o_dpi = (int)Dg.o_dpi; D.o_p = (int)Dg.o_p;
         D.o_lus = (int)Dg.o_lus; D.o_dg = (int)Dg.o_dg; D.blk = Dg.blk;
-        N = S.N; Kn = S.K; N2 = D.N2; nxr = D.nxr; R = D.R; nrows = D.nrows;
-        if (!this->set_sizes(D.Mb, D.nuh, D.nzh)) {
+        N = S.N; Kn = S.K; N2 = D.N2; R = D.R; nrows = D.nrows;
+        bool fits = this->set_sizes(D.Mb, D.nuh, D.nzh, D.nxr); // (an instantiation for one shape launched with another: cond_kernels.hip picks by D.Mb, D.nxr)
+        {   // the matrix group's offsets from the sizes (cond_dims.hpp's rule: compile-time values where the sizes are), checked against the host's
+            auto pad = [](int n) { return (n + 15) / 16 * 16; };
+            const int n_sr = Mb * nxr * nzh, n_cn = 2 * NX * nzh + NZ * nzh;
+            D.o_SR = 0; D.o_cr = pad(n_sr > n_cn ? n_sr : n_cn); D.o_BA = D.o_cr + pad(Mb * nxr); D.o_bt = D.o_BA + pad(NX * nzh);
+            D.o_g0 = D.o_bt + pad(NX); D.o_H0 = D.o_g0 + pad(nzh); D.o_row = D.o_H0 + pad(nzh * nzh);
+            fits = fits && Dg.o_SR == 0 && Dg.o_cr == D.o_cr && Dg.o_BA == D.o_BA && Dg.o_bt == D.o_bt && Dg.o_g0 == D.o_g0 && Dg.o_H0 == D.o_H0 && Dg.o_row == D.o_row;
+        }
+        if (!fits) {
 #if defined(__HIPCC__)
-            __builtin_trap(); // (an instantiation for one block length launched with another: cond_kernels.hip picks by D.Mb)
+            __builtin_trap();
 #endif
         }
         rs_log = 2;
@@ -284,25 +293,46 @@ struct CondIpm : CondBlkSizes<MB, M::NU, M::NX> {
     USV_CDEV void load_stage(int k)
     {
         static constexpr EntTab TAB = make_tab();
+        const double *Hm = (k < N) ? S.Hc : S.He;
+        // (device) what the stage needs from HBM - the iterate, the stored entries of [B A], b_k, the gradient plane - is asked for at once,
+        // one element of each per thread, before anything is waited for: one round trip instead of three
+        double zb0 = 0.0, gq0 = 0.0, ent0 = 0.0, q0 = 0.0;
+        if constexpr (NT > 1) {
+            if (tid < NZ) {
+                zb0 = tid < NU ? ((k < N) ? P.u[((long)b * N + k) * NU + tid] : 0.0) : P.x[((long)b * (N + 1) + k) * NX + (tid - NU)];
+                gq0 = plane(k, WL::P_GQ)[tid];
+            }
+            if (k < N) {
+                if (tid < MP::NE) ent0 = plane(k, WL::P_MAT + tid / 16)[tid % 16];
+                if (tid < NX) q0 = plane(k, WL::P_RB0)[NU + tid];
+            }
+        }
         TM::sync();
         for (int e = tid; e < NX * NZ; e += NT) {
             const int j = e / NZ, c = e - j * NZ;
             BAk[e] = (c == NU + j && ((M::DIAG_ONE >> j) & 1u)) ? 1.0 : 0.0;
         }
         for (int e = tid; e < NZ; e += NT) {
-            double zb = 0.0;
-            if (e < NU) zb = (k < N) ? P.u[((long)b * N + k) * NU + e] : 0.0;
-            else zb = P.x[((long)b * (N + 1) + k) * NX + (e - NU)];
+            double zb = zb0;
+            if constexpr (NT == 1) {
+                if (e < NU) zb = (k < N) ? P.u[((long)b * N + k) * NU + e] : 0.0;
+                else zb = P.x[((long)b * (N + 1) + k) * NX + (e - NU)];
+            }
             vzb[e] = zb;
         }
         TM::sync();
         if (k < N) {
-            for (int s = tid; s < MP::NE; s += NT) BAk[TAB.row[s] * NZ + TAB.col[s]] = plane(k, WL::P_MAT + s / 16)[s % 16];
-            for (int e = tid; e < NX; e += NT) vq[e] = plane(k, WL::P_RB0)[NU + e];
+            if constexpr (NT == 1) {
+                for (int s = 0; s < MP::NE; s++) BAk[TAB.row[s] * NZ + TAB.col[s]] = plane(k, WL::P_MAT + s / 16)[s % 16];
+                for (int e = 0; e < NX; e++) vq[e] = plane(k, WL::P_RB0)[NU + e];
+            } else {
+                if (tid < MP::NE) BAk[TAB.row[tid] * NZ + TAB.col[tid]] = ent0;
+                for (int s = tid + NT; s < MP::NE; s += NT) BAk[TAB.row[s] * NZ + TAB.col[s]] = plane(k, WL::P_MAT + s / 16)[s % 16];
+                if (tid < NX) vq[tid] = q0;
+            }
         }
-        const double *Hm = (k < N) ? S.Hc : S.He;
         for (int e = tid; e < NZ; e += NT) {
-            double a = plane(k, WL::P_GQ)[e];
+            double a = NT == 1 ? plane(k, WL::P_GQ)[e] : gq0;
             if (S.hdiag && k < N) a = fma(S.HcD[e], vzb[e], a);
             else for (int c = 0; c < NZ; c++) a = fma(Hm[e * LANES + c], vzb[c], a);
             vgk[e] = a;

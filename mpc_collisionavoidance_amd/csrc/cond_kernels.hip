@@ -28,13 +28,13 @@ template <bool SOFT> constexpr int cond_minwaves() { return SOFT ? 3 : USV_COND_
 
 // One instance per workgroup of NT threads, the condensed block's matrices in LDS, the instance's condensed QP in the
 // workgroup's scratch area in HBM; workgroups pull further instances from the queue as they finish.
-// MB: stages per block the instantiation is made for (0: any - CondBlkSizes).
-template <class M, int KCH, bool SOFT, int NT, int MB>
+// MB, NXR: stages per block and touched states the instantiation is made for (0, 0: any - CondBlkSizes).
+template <class M, int KCH, bool SOFT, int NT, int MB, int NXR>
 __global__ void __launch_bounds__(NT, cond_minwaves<SOFT>()) usv_qp_cond(DevPtrs P, const CondDims *Dp, double *scratch, int nB, int queue0)
 {
     extern __shared__ double cond_lds[];
     __shared__ int nxt;
-    CondIpm<M, KCH, SOFT, CondTeam<NT>, MB> q(P, *Dp, scratch + (long)blockIdx.x * Dp->total, cond_lds);
+    CondIpm<M, KCH, SOFT, CondTeam<NT>, MB, NXR> q(P, *Dp, scratch + (long)blockIdx.x * Dp->total, cond_lds);
     long g = blockIdx.x;
     while (g < nB) {
         q.solve(g);
@@ -47,16 +47,17 @@ __global__ void __launch_bounds__(NT, cond_minwaves<SOFT>()) usv_qp_cond(DevPtrs
 
 namespace {
 
-// block length a 256-thread instantiation with compile-time sizes exists for (0: none): usv_model_pf_ca with 8 stages per block
-template <class M, bool SOFT> struct CondFixed { static constexpr int MB = 0; };
+// the shape a 256-thread instantiation with compile-time sizes exists for (0: none): usv_model_pf_ca with 8 stages per block and its 7 touched
+// states (5 bounded + the position) - BASELINE configs[4] with qp_cond_N = 10
+template <class M, bool SOFT> struct CondFixed { static constexpr int MB = 0, NXR = 0; };
 #if !defined(USV_GEN_ONLY)
-template <> struct CondFixed<ModelM2, false> { static constexpr int MB = 8; };
+template <> struct CondFixed<ModelM2, false> { static constexpr int MB = 8, NXR = 7; };
 #endif
 
 template <class M, int KCH, bool SOFT, int NT>
 int occupancy_of(const DevSpec &S, int N2, CondDims &D, size_t &lds, int &nb)
 {
-    auto kern = &usv_qp_cond<M, KCH, SOFT, NT, 0>; // (the fixed-length instantiations use the same LDS and no more registers)
+    auto kern = &usv_qp_cond<M, KCH, SOFT, NT, 0, 0>; // (the fixed-shape instantiations use the same LDS and no more registers)
     nb = 0;
     if (!cond_dims(S, M::NX, M::NU, M::IPX, M::IPY, N2, NT, SOFT, D)) return USVMPC_E_ARG;
     lds = (size_t)D.lds_doubles * sizeof(double);
@@ -84,15 +85,15 @@ int prepare_for(const DevSpec &S, int N2, CondDims &D, size_t &lds, int &nb, std
 }
 
 template <class M, int KCH, bool SOFT>
-int run_for(int nt, int mb, hipStream_t st, long teams, size_t lds, const DevPtrs &P, const CondDims *dD, double *scratch, int B)
+int run_for(const CondDims &Dh, hipStream_t st, long teams, size_t lds, const DevPtrs &P, const CondDims *dD, double *scratch, int B)
 {
-    if (nt == 64) hipLaunchKernelGGL((usv_qp_cond<M, KCH, SOFT, 64, 0>), dim3((unsigned)teams), dim3(64), lds, st, P, dD, scratch, B, (int)teams);
-    else if (CondFixed<M, SOFT>::MB > 0 && mb == CondFixed<M, SOFT>::MB) {
-        constexpr int MBF = CondFixed<M, SOFT>::MB;
-        auto kern = &usv_qp_cond<M, KCH, SOFT, 256, MBF>;
+    const int nt = Dh.nt;
+    if (nt == 64) hipLaunchKernelGGL((usv_qp_cond<M, KCH, SOFT, 64, 0, 0>), dim3((unsigned)teams), dim3(64), lds, st, P, dD, scratch, B, (int)teams);
+    else if (CondFixed<M, SOFT>::MB > 0 && Dh.Mb == CondFixed<M, SOFT>::MB && Dh.nxr == CondFixed<M, SOFT>::NXR) {
+        auto kern = &usv_qp_cond<M, KCH, SOFT, 256, CondFixed<M, SOFT>::MB, CondFixed<M, SOFT>::NXR>;
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         hipLaunchKernelGGL(kern, dim3((unsigned)teams), dim3(256), lds, st, P, dD, scratch, B, (int)teams);
-    } else hipLaunchKernelGGL((usv_qp_cond<M, KCH, SOFT, 256, 0>), dim3((unsigned)teams), dim3(256), lds, st, P, dD, scratch, B, (int)teams);
+    } else hipLaunchKernelGGL((usv_qp_cond<M, KCH, SOFT, 256, 0, 0>), dim3((unsigned)teams), dim3(256), lds, st, P, dD, scratch, B, (int)teams);
     return 0;
 }
 
@@ -130,9 +131,9 @@ int cond_prepare(int model, int kch, const DevSpec &S, int N2, CondDims &D, size
     return USVMPC_E_ARG;
 }
 
-int cond_run(int model, int kch, int nt, int mb, hipStream_t st, long teams, size_t lds_bytes, const DevPtrs &P, const CondDims *dD, double *scratch, int B)
+int cond_run(int model, int kch, const CondDims &Dh, hipStream_t st, long teams, size_t lds_bytes, const DevPtrs &P, const CondDims *dD, double *scratch, int B)
 {
-#define USV_COND_RUN(M, K, SF) run_for<M, K, SF>(nt, mb, st, teams, lds_bytes, P, dD, scratch, B)
+#define USV_COND_RUN(M, K, SF) run_for<M, K, SF>(Dh, st, teams, lds_bytes, P, dD, scratch, B)
     USV_COND_DISPATCH(USV_COND_RUN)
 #undef USV_COND_RUN
     return -1;

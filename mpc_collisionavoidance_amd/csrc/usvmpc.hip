@@ -764,7 +764,7 @@ int launch_cond(usvmpc_handle *h)
         HIP_TRY(h, hipMemsetAsync(h->ptrs.t_out, 0, nbytes, h->stream));
         h->export_at = h->nsolves + 1;
     }
-    if (cond_run(h->desc.model, h->kch, h->cond_dims.nt, h->cond_dims.Mb, h->stream, h->cond_teams, h->cond_lds, h->ptrs, h->d_cond_dims, h->d_cond_scratch, h->B)) {
+    if (cond_run(h->desc.model, h->kch, h->cond_dims, h->stream, h->cond_teams, h->cond_lds, h->ptrs, h->d_cond_dims, h->d_cond_scratch, h->B)) {
         h->err = "partial condensing: no kernel for this model in this library";
         return USVMPC_E_ARG;
     }

@@ -55,6 +55,7 @@ struct CondTeam {
     static double rsum(double v, LD) { return v; }
     static double qsum(double v) { return v; }
     static double lane_xor(double v, int) { return v; }
+    static double rsqrt(double v) { return 1.0 / sqrt(v); }
 };
 #define USV_CDEV inline
 #else
@@ -64,9 +65,18 @@ struct CondTeam {
     static_assert(NT % 64 == 0, "whole waves");
     __device__ static int tid() { return (int)threadIdx.x; }
     __device__ static void sync() { __syncthreads(); }
+    // max / sum over the team.  Inside a wave: xor butterflies through the LDS permute unit.  (Round 6 tried DPP butterflies over the rows of 16
+    // lanes + four readlanes: 2 % faster at configs[4]'s shape, and a stand-alone check agreed with this form - but one soft-row instance of
+    // tests/test_condensing.py then ended with status 3; not understood, not kept.)
+    template <class OP>
+    __device__ static double wave_all(double v, OP op)
+    {
+        for (int o = 32; o >= 1; o >>= 1) v = op(v, __shfl_xor(v, o, 64));
+        return v;
+    }
     __device__ static double rmax(double v, LD red)
     {
-        for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+        v = wave_all(v, [](double a, double b) { return fmax(a, b); });
         if constexpr (NT > 64) {
             sync();
             if ((tid() & 63) == 0) red[tid() >> 6] = v;
@@ -78,7 +88,7 @@ struct CondTeam {
     }
     __device__ static double rsum(double v, LD red)
     {
-        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        v = wave_all(v, [](double a, double b) { return a + b; });
         if constexpr (NT > 64) {
             sync();
             if ((tid() & 63) == 0) red[tid() >> 6] = v;
@@ -96,6 +106,16 @@ struct CondTeam {
         return v;
     }
     __device__ static double lane_xor(double v, int o) { return __shfl_xor(v, o, 64); }
+    // 1 / sqrt(v): the hardware estimate and two Newton steps (a full-precision square root and a division are ~80 instructions, and the
+    // panel factorisation runs them on its critical path once per column); within an ulp or two of the quotient
+    __device__ static double rsqrt(double v)
+    {
+        double y = __builtin_amdgcn_rsq(v);
+        const double h = 0.5 * v;
+        y = y * fma(-h * y, y, 1.5);
+        y = y * fma(-h * y, y, 1.5);
+        return y;
+    }
     // value of lane `src` (wave-uniform) of the calling wave
     __device__ static double lane_value(double v, int src)
     {
@@ -276,6 +296,13 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
 #endif
     }
 
+    static constexpr int pad16(int n) { return (n + 15) / 16 * 16; }
+    // doubles of the matrix group in front of H0 (cond_dims.hpp: o_H0 - o_SR)
+    static constexpr int group_doubles(int mb, int nx_r, int nz_h)
+    {
+        const int n_sr = mb * nx_r * nz_h, n_cn = 2 * NX * nz_h + NZ * nz_h;
+        return pad16(n_sr > n_cn ? n_sr : n_cn) + pad16(mb * nx_r) + pad16(NX * nz_h) + pad16(NX) + pad16(nz_h);
+    }
     // Everything a thread derives from its index (element addresses, row / column splits) is invariant over the blocks and the iterations,
     // and the compiler hoists all of it to the top of the kernel: hundreds of values that then live in scratch memory and come back through
     // HBM-latency reloads inside the sweeps (386 registers wanted, 168 to be had).  Making the index opaque once per block keeps those values'
@@ -586,13 +613,15 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
         }
         return rr;
     }
-    template <class F>
-    USV_CDEV void row_pass(int i, double *W, bool slots, const RowRegs &pre, F f)
+    // SLOTS: 0 none, 1 all of them, 2 the reduced-gradient ones only (yug, yxg: all the corrector's right-hand side reads)
+    template <int SLOTS, class F>
+    USV_CDEV void row_pass(int i, double *W, const RowRegs &pre, F f)
     {
+        constexpr bool slots = SLOTS != 0, all = SLOTS == 1;
         if (slots) {
-            for (int e = tid; e < Mb * nxr; e += NT) { yxr[e] = 0.0; yxg[e] = 0.0; wd[e] = 0.0; }
-            for (int e = tid; e < Mb; e += NT) wxy[e] = 0.0;
-            for (int e = tid; e < nuh; e += NT) { yur[e] = 0.0; yug[e] = 0.0; wu[e] = 0.0; }
+            for (int e = tid; e < Mb * nxr; e += NT) { yxg[e] = 0.0; if (all) { yxr[e] = 0.0; wd[e] = 0.0; } }
+            if (all) for (int e = tid; e < Mb; e += NT) wxy[e] = 0.0;
+            for (int e = tid; e < nuh; e += NT) { yug[e] = 0.0; if (all) { yur[e] = 0.0; wu[e] = 0.0; } }
         }
         TM::sync();
         // one row: (j, q) of the block, e its index in the scratch area
@@ -635,8 +664,8 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
             f(e, j, q, r, rw, v, wa, wf, yr, yg, Gh);
             if (!r.act) { yr = 0.0; yg = 0.0; Gh = 0.0; }
             if (slots && !obs) {
-                if (q < D.nbu) { const int c = j * NU + D.uvar[q]; yur[c] = yr; yug[c] = yg; wu[c] = Gh; }
-                else { const int m = j * nxr + D.xvar[q - D.nbu]; yxr[m] = yr; yxg[m] = yg; wd[m] = Gh; }
+                if (q < D.nbu) { const int c = j * NU + D.uvar[q]; yug[c] = yg; if (all) { yur[c] = yr; wu[c] = Gh; } }
+                else { const int m = j * nxr + D.xvar[q - D.nbu]; yxg[m] = yg; if (all) { yxr[m] = yr; wd[m] = Gh; } }
             }
         };
         if constexpr (NT == 1) {
@@ -646,8 +675,11 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
                 bool obs;
                 one(true, false, e, j, q, yr, yg, Gh, cx, cy, obs);
                 if (slots && obs) {
-                    yxr[j * nxr + D.ipx] += cx * yr; yxr[j * nxr + D.ipy] += cy * yr; yxg[j * nxr + D.ipx] += cx * yg; yxg[j * nxr + D.ipy] += cy * yg;
-                    wd[j * nxr + D.ipx] += cx * cx * Gh; wd[j * nxr + D.ipy] += cy * cy * Gh; wxy[j] += cx * cy * Gh;
+                    yxg[j * nxr + D.ipx] += cx * yg; yxg[j * nxr + D.ipy] += cy * yg;
+                    if (all) {
+                        yxr[j * nxr + D.ipx] += cx * yr; yxr[j * nxr + D.ipy] += cy * yr;
+                        wd[j * nxr + D.ipx] += cx * cx * Gh; wd[j * nxr + D.ipy] += cy * cy * Gh; wxy[j] += cx * cy * Gh;
+                    }
                 }
             }
         } else {
@@ -661,12 +693,18 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
                 if (slots && Kn > 0) { // (every lane takes part in the butterflies; rows that are not obstacle rows add zeros)
                     double s0 = cx * yr, s1 = cy * yr, s2 = cx * yg, s3 = cy * yg, s4 = cx * cx * Gh, s5 = cy * cy * Gh, s6 = cx * cy * Gh;
                     for (int o = 1; o < (1 << rs_log); o <<= 1) {
-                        s0 += TM::lane_xor(s0, o); s1 += TM::lane_xor(s1, o); s2 += TM::lane_xor(s2, o); s3 += TM::lane_xor(s3, o);
-                        s4 += TM::lane_xor(s4, o); s5 += TM::lane_xor(s5, o); s6 += TM::lane_xor(s6, o);
+                        s2 += TM::lane_xor(s2, o); s3 += TM::lane_xor(s3, o);
+                        if (all) {
+                            s0 += TM::lane_xor(s0, o); s1 += TM::lane_xor(s1, o);
+                            s4 += TM::lane_xor(s4, o); s5 += TM::lane_xor(s5, o); s6 += TM::lane_xor(s6, o);
+                        }
                     }
                     if (q == 0 && j < Mb) { // (after the group's own bound rows on the position states, if any: LDS operations of a wave are in order)
-                        yxr[j * nxr + D.ipx] += s0; yxr[j * nxr + D.ipy] += s1; yxg[j * nxr + D.ipx] += s2; yxg[j * nxr + D.ipy] += s3;
-                        wd[j * nxr + D.ipx] += s4; wd[j * nxr + D.ipy] += s5; wxy[j] += s6;
+                        yxg[j * nxr + D.ipx] += s2; yxg[j * nxr + D.ipy] += s3;
+                        if (all) {
+                            yxr[j * nxr + D.ipx] += s0; yxr[j * nxr + D.ipy] += s1;
+                            wd[j * nxr + D.ipx] += s4; wd[j * nxr + D.ipy] += s5; wxy[j] += s6;
+                        }
                     }
                 }
             }
@@ -719,7 +757,23 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
             auto at = [&](int off, int n) { return W[off + (tid < n ? tid : (n > 0 ? n - 1 : 0))]; }; // (n = 0: some valid address, value unused)
             const double a0 = at(D.o_w, nzh), a1 = at(D.o_dwa, nzh), a2 = at(D.o_dw, nzh);
             const double b0 = at(x0.off, x0.n), b1 = at(x1.off, x1.n), b2 = at(x2.off, x2.n);
-            fetch2(mat, W + D.o_SR, hess ? ng + nn : ng, Gm, W + D.o_Luu, hess ? 0 : nn);
+            if constexpr (MB > 0) { // sizes known: 16-byte loads and LDS stores, a fixed number per thread, all loads first
+                using V2 = double __attribute__((ext_vector_type(2)));
+                constexpr int NG = group_doubles(MB, NXR, nzh), NN = nzh * nzh;
+                static_assert(NG % 2 == 0 && NN % 2 == 0, "pairs");
+                constexpr int UA = (NG / 2 + NT - 1) / NT, UB = (NN / 2 + NT - 1) / NT;
+                const double *sB = hess ? W + D.o_H0 : W + D.o_Luu;
+                V2 ra[UA], rb[UB];
+#pragma unroll
+                for (int u = 0; u < UA; u++) { const int e = 2 * (tid + u * NT); ra[u] = *(const V2 *)(W + (e < NG ? e : NG - 2)); }
+#pragma unroll
+                for (int u = 0; u < UB; u++) { const int e = 2 * (tid + u * NT); rb[u] = *(const V2 *)(sB + (e < NN ? e : NN - 2)); }
+#pragma unroll
+                for (int u = 0; u < UA; u++) { const int e = 2 * (tid + u * NT); if (e < NG) *(USV_LDS V2 *)(mat + e) = ra[u]; }
+#pragma unroll
+                for (int u = 0; u < UB; u++) { const int e = 2 * (tid + u * NT); if (e < NN) *(USV_LDS V2 *)(Gm + e) = rb[u]; }
+            } else
+                fetch2(mat, W + D.o_SR, hess ? ng + nn : ng, Gm, W + D.o_Luu, hess ? 0 : nn);
             if (tid < nzh) { vw[tid] = a0; vdwa[tid] = a1; vdw[tid] = a2; }
             if (tid < x0.n) x0.dst[tid] = b0;
             if (tid < x1.n) x1.dst[tid] = b1;
@@ -818,6 +872,28 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
                 vdg[c] = dg;
                 for (int r = c; r < nzh; r++) Gm[r * nzh + c] *= dg;
             }
+        } else if constexpr (MB > 0) { // sizes known: the lane's row of the panel in registers, row c's entries by readlane - no LDS inside
+            if (tid < 64) {
+                const int r = tid < nzh ? tid : nzh - 1;
+                const LD row = Gm + r * nzh;
+                double own[nuh];
+#pragma unroll
+                for (int c = 0; c < nuh; c++) own[c] = row[c];
+#pragma unroll
+                for (int c = 0; c < nuh; c++) { // (rows above c compute on values nobody reads)
+                    double v = own[c];
+#pragma unroll
+                    for (int k = 0; k < c; k++) v = fma(-own[k], TM::lane_value(own[k], c), v);
+                    const double piv = TM::lane_value(v, c);
+                    if (!(piv > 0.0)) bad = 5.0;
+                    const double dg = TM::rsqrt(piv);
+                    own[c] = v * dg;
+                    if (tid == 0) vdg[c] = dg;
+                }
+#pragma unroll
+                for (int c = 0; c < nuh; c++)
+                    if (tid >= c && tid < nzh) row[c] = own[c];
+            }
         } else {
             if (tid < 64) {
                 const int r = tid < nzh ? tid : nzh - 1;
@@ -827,7 +903,7 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
                     v = dots(0, 1, c, v, [&](int k) { return -row[k]; }, [&](int k) { return Gm[c * nzh + k]; });
                     const double piv = TM::lane_value(v, c);
                     if (!(piv > 0.0)) bad = 5.0;
-                    const double dg = 1.0 / sqrt(piv);
+                    const double dg = TM::rsqrt(piv);
                     if (tid >= c && tid < nzh) row[c] = v * dg;
                     if (tid == 0) vdg[c] = dg;
                 }
@@ -882,7 +958,7 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
             TM::sync();
             USV_TICK(4);
             double rd = 0.0, rm = 0.0, mus = 0.0, bd = 0.0, rgs = 0.0;
-            row_pass(i, W, true, rr, [&](int e, int j, int q, Row &r, double *rw, double v, double wa, double wf, double &yr, double &yg, double &Gh) {
+            row_pass<1>(i, W, rr, [&](int e, int j, int q, Row &r, double *rw, double v, double wa, double wf, double &yr, double &yg, double &Gh) {
                 (void)e;
                 if (pend && r.act) {
                     double vo; // the row's value at the iterate the step was computed at
@@ -1049,7 +1125,7 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
             expand_rows(del, vw, vcr, dela, vdwa);
             TM::sync();
             USV_TICK(14);
-            row_pass(i, W, true, rr, [&](int, int, int, Row &r, double *, double v, double wa, double, double &yr, double &yg, double &Gh) {
+            row_pass<2>(i, W, rr, [&](int, int, int, Row &r, double *, double v, double wa, double, double &yr, double &yg, double &Gh) {
                 double g0_, g1_;
                 r.resid(v); r.targets_pred(); r.reduce(g0_, g1_); r.expand(wa); r.template targets_corr<true>(sigmu, so_cur); r.reduce(Gh, yg);
                 yr = 0.0;
@@ -1121,7 +1197,7 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
                     Wn[D.o_dpi + s] = a;
                 }
             }
-            row_pass(i, W, false, rr, [&](int, int, int, Row &r, double *, double v, double wa, double wf, double &, double &, double &) {
+            row_pass<0>(i, W, rr, [&](int, int, int, Row &r, double *, double v, double wa, double wf, double &, double &, double &) {
                 double g0_, g1_;
                 r.resid(v); r.targets_pred(); r.reduce(g0_, g1_); r.expand(wa);
                 if (corr) { r.template targets_corr<true>(sigmu, so_cur); r.reduce(g0_, g1_); r.expand(wf); }

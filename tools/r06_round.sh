@@ -43,5 +43,6 @@ if [ $W = all ] || [ $W = prof ]; then
   BENCH_ARGS='--batch 1024 --horizon 20 --obstacles 3' tools/profile_round.sh ${R}_cfg1 > $out/prof_cfg1.log 2>&1
   BENCH_ARGS='--horizon 80 --obstacles 20 --moving' tools/profile_round.sh ${R}_cfg4 > $out/prof_cfg4.log 2>&1
   BENCH_ARGS='--batch 8192' tools/profile_round.sh ${R}_b8192 > $out/prof_b8192.log 2>&1
+  BENCH_ARGS='--horizon 80 --obstacles 20 --moving --batch 8192 --cond-N 10' tools/profile_round.sh ${R}_cond > $out/prof_cond.log 2>&1   # (usv_qp_cond)
   tail -3 $out/prof.log
 fi

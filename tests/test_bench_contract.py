@@ -168,7 +168,7 @@ def test_scale_run_script_names_every_sharded_config():
 def test_round6_lines_carry_the_profile_its_spread_and_the_survey_verbatim_region():
     """the default line names the QP solver profile, compares against the oracle under that profile, prints what the
     profile choice moves on the device (parity.profile_spread) and the survey's generator to the letter as a second timed region."""
-    d = json.load(open(os.path.join(ROOT, "profiles", "r06_c_bench_plain.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_d_bench_plain.json")))
     assert d["config"]["hpipm_mode"].startswith("BALANCE") and d["roofline"]["kernel"] == "usv_qp_rti"   # (one launch: no hand-over at 65 536)
     p = d["parity"]
     assert p["oracle_options"] == {"hpipm_mode": "BALANCE"} and p["count_above_1e-5"] == 0 and p["rel_err_per_instance"]["max"] < 1e-5
@@ -184,12 +184,12 @@ def test_round6_lines_carry_the_profile_its_spread_and_the_survey_verbatim_regio
     assert abs(d["value"] - ws["solves_per_s_counting_unconverged_ones"] * (1.0 - ws["unconverged_solves_in_timed_region"] / total)) <= 1e-9 * d["value"]
     assert len(d["config"]["per_rank_ms_per_step"]) == 1 and d["config"]["host_binding_rank0"] == "not bound"
     # the profile of rounds 1 - 5 on the same kernels, and the oracle without its refinement: the outliers the default no longer has
-    r04 = json.load(open(os.path.join(ROOT, "profiles", "r06_c_bench_profile_r04_plain.json")))
+    r04 = json.load(open(os.path.join(ROOT, "profiles", "r06_d_bench_profile_r04_plain.json")))
     assert r04["config"]["hpipm_mode"].startswith("R04") and r04["parity"]["count_above_1e-5"] >= 1 and r04["value"] < d["value"]
-    spd = json.load(open(os.path.join(ROOT, "profiles", "r06_c_bench_oracle_speed_plain.json")))["parity"]
+    spd = json.load(open(os.path.join(ROOT, "profiles", "r06_d_bench_oracle_speed_plain.json")))["parity"]
     assert spd["oracle_options"]["hpipm_mode"] == "SPEED" and spd["count_above_1e-5"] >= 1
     # the mid-size batches run with the follow-up kernel beside the launch
-    b = json.load(open(os.path.join(ROOT, "profiles", "r06_c_bench_b8192_plain.json")))
+    b = json.load(open(os.path.join(ROOT, "profiles", "r06_d_bench_b8192_plain.json")))
     assert "usv_qp_resume" in b["roofline"]["kernel_ms"] and b["value"] > 560e3
 
 
@@ -197,7 +197,7 @@ def test_scale_script_lines_have_the_plain_lines_keys():
     """tools/scale_run.sh run on the one GPU a builder's box has (`tools/scale_run.sh out 1`; profiles/r06_scale_n1_*): its N = 1 lines are bench
     lines like the plain one - same keys, same config keys -, the sharded configs name themselves, and the summary has one row per kind.  (The
     N = 2, 4, 8 rows are the driver's / an 8-GPU node's to fill: no scaling curve has been measured.)"""
-    plain = json.load(open(os.path.join(ROOT, "profiles", "r06_c_bench_plain.json")))
+    plain = json.load(open(os.path.join(ROOT, "profiles", "r06_d_bench_plain.json")))
     weak = json.load(open(os.path.join(ROOT, "profiles", "r06_scale_n1_weak.json")))
     assert set(weak) == set(plain) and set(weak["config"]) == set(plain["config"]) and set(weak["roofline"]) == set(plain["roofline"])
     assert weak["n_gpus"] == 1 and weak["config"]["ranks_seen"] == 1 and "configs[2]" in weak["config"]["workload"]

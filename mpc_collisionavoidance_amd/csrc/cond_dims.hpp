@@ -16,6 +16,7 @@ struct CondDims {
     int ipx, ipy;         // index in xr of the position states (-1 without obstacle rows)
     // per block
     long o_SR, o_cr, o_BA, o_bt, o_H0, o_g0, o_row, o_Luu, o_P, o_Pb, o_w, o_pi, o_rg, o_rb, o_dwa, o_dw, o_dpi, o_p, o_lus, o_dg, blk;
+    long o_cdel, o_cdela, o_cdelf; // the touched states' values at the iterate / along the affine and the final step, kept from the sweep that computes them
     long total;           // (N2 + 1) * blk
     long lds_doubles;     // LDS the kernel needs (doubles), for NT threads
     int nt;               // threads of a team (cond_prepare picks it: the instantiation with the most resident waves per CU)
@@ -50,6 +51,7 @@ inline bool cond_dims(const DevSpec &S, int nx, int nu, int ipx, int ipy, int N2
     D.o_Pb = take(nx);
     D.o_w = take(D.nzh); D.o_pi = take(nx); D.o_rg = take(D.nzh); D.o_rb = take(nx);
     D.o_dwa = take(D.nzh); D.o_dw = take(D.nzh); D.o_dpi = take(nx); D.o_p = take(nx); D.o_lus = take(D.nuh); D.o_dg = take(D.nuh);
+    D.o_cdel = take((long)D.Mb * D.nxr); D.o_cdela = take((long)D.Mb * D.nxr); D.o_cdelf = take((long)D.Mb * D.nxr);
     D.blk = o;
     D.total = (long)(N2 + 1) * D.blk;
     long l = 0;

@@ -186,7 +186,7 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
     // scalars are copied into members once (registers), the short tables into LDS.
     struct DimsLocal {
         int Mb, N2, N1, R1, nuh, nzh, nxr, R, nrows, nbu, nbx, ipx, ipy;
-        int o_SR, o_cr, o_BA, o_bt, o_H0, o_g0, o_row, o_Luu, o_P, o_Pb, o_w, o_pi, o_rg, o_rb, o_dwa, o_dw, o_dpi, o_p, o_lus, o_dg;
+        int o_SR, o_cr, o_BA, o_bt, o_H0, o_g0, o_row, o_Luu, o_P, o_Pb, o_w, o_pi, o_rg, o_rb, o_dwa, o_dw, o_dpi, o_p, o_lus, o_dg, o_cdel, o_cdela, o_cdelf;
         long blk;
         const USV_LDS int *xr, *uvar, *xvar;
     };
@@ -231,6 +231,7 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
         D.o_Luu = (int)Dg.o_Luu; D.o_P = (int)Dg.o_P; D.o_Pb = (int)Dg.o_Pb; D.o_w = (int)Dg.o_w; D.o_pi = (int)Dg.o_pi;
         D.o_rg = (int)Dg.o_rg; D.o_rb = (int)Dg.o_rb; D.o_dwa = (int)Dg.o_dwa; D.o_dw = (int)Dg.o_dw; D.o_dpi = (int)Dg.o_dpi; D.o_p = (int)Dg.o_p;
         D.o_lus = (int)Dg.o_lus; D.o_dg = (int)Dg.o_dg; D.blk = Dg.blk;
+        D.o_cdel = (int)Dg.o_cdel; D.o_cdela = (int)Dg.o_cdela; D.o_cdelf = (int)Dg.o_cdelf;
         N = S.N; Kn = S.K; N2 = D.N2; R = D.R; nrows = D.nrows;
         bool fits = this->set_sizes(D.Mb, D.nuh, D.nzh, D.nxr); // (an instantiation for one shape launched with another: cond_kernels.hip picks by D.Mb, D.nxr)
         {   // the matrix group's offsets from the sizes (cond_dims.hpp's rule: compile-time values where the sizes are), checked against the host's
@@ -740,9 +741,10 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
         }
     }
     // the block's matrix group (S rows, c rows, [B A], b, g0 and - hess - H0, else the stored factor), its iterate / step vectors and up to
-    // three more vectors of at most nzh entries the sweep wants (LDS destination, offset in the block, length): ONE round trip to HBM
+    // six more vectors the sweep wants (LDS destination, offset in the block, length; x0 - x2 at most a team long): ONE round trip to HBM
     struct Ext { LD dst; int off, n; };
-    USV_CDEV void load_block(int i, double *W, bool hess, Ext x0 = Ext{nullptr, 0, 0}, Ext x1 = Ext{nullptr, 0, 0}, Ext x2 = Ext{nullptr, 0, 0})
+    USV_CDEV void load_block(int i, double *W, bool hess, Ext x0 = Ext{nullptr, 0, 0}, Ext x1 = Ext{nullptr, 0, 0}, Ext x2 = Ext{nullptr, 0, 0},
+                             Ext x3 = Ext{nullptr, 0, 0}, Ext x4 = Ext{nullptr, 0, 0}, Ext x5 = Ext{nullptr, 0, 0})
     {
         forget_tid();
         TM::sync();
@@ -752,11 +754,14 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
             for (int e = 0; e < x0.n; e++) x0.dst[e] = W[x0.off + e];
             for (int e = 0; e < x1.n; e++) x1.dst[e] = W[x1.off + e];
             for (int e = 0; e < x2.n; e++) x2.dst[e] = W[x2.off + e];
+            for (int e = 0; e < x3.n; e++) x3.dst[e] = W[x3.off + e];
+            for (int e = 0; e < x4.n; e++) x4.dst[e] = W[x4.off + e];
+            for (int e = 0; e < x5.n; e++) x5.dst[e] = W[x5.off + e];
             fetch2(mat, W + D.o_SR, hess ? ng + nn : ng, Gm, W + D.o_Luu, hess ? 0 : nn);
         } else {
             auto at = [&](int off, int n) { return W[off + (tid < n ? tid : (n > 0 ? n - 1 : 0))]; }; // (n = 0: some valid address, value unused)
             const double a0 = at(D.o_w, nzh), a1 = at(D.o_dwa, nzh), a2 = at(D.o_dw, nzh);
-            const double b0 = at(x0.off, x0.n), b1 = at(x1.off, x1.n), b2 = at(x2.off, x2.n);
+            const double b0 = at(x0.off, x0.n), b1 = at(x1.off, x1.n), b2 = at(x2.off, x2.n), b3 = at(x3.off, x3.n), b4 = at(x4.off, x4.n), b5 = at(x5.off, x5.n);
             if constexpr (MB > 0) { // sizes known: 16-byte loads and LDS stores, a fixed number per thread, all loads first
                 using V2 = double __attribute__((ext_vector_type(2)));
                 constexpr int NG = group_doubles(MB, NXR, nzh), NN = nzh * nzh;
@@ -778,6 +783,12 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
             if (tid < x0.n) x0.dst[tid] = b0;
             if (tid < x1.n) x1.dst[tid] = b1;
             if (tid < x2.n) x2.dst[tid] = b2;
+            if (tid < x3.n) x3.dst[tid] = b3;
+            if (tid < x4.n) x4.dst[tid] = b4;
+            if (tid < x5.n) x5.dst[tid] = b5;
+            for (int e = tid + NT; e < x3.n; e += NT) x3.dst[e] = W[x3.off + e]; // (vectors over the touched states can be longer than a small team)
+            for (int e = tid + NT; e < x4.n; e += NT) x4.dst[e] = W[x4.off + e];
+            for (int e = tid + NT; e < x5.n; e += NT) x5.dst[e] = W[x5.off + e];
         }
         (void)i;
         TM::sync();
@@ -941,10 +952,10 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
             double *W = blk(i);
             USV_TICK(1);
             const RowRegs rr = row_issue(W);
-            load_block(i, W, true, Ext{vpi, D.o_pi, NX}, Ext{vtmp, D.o_dpi, pend ? NX : 0});
+            const int mx = Mb * nxr, mxp = pend ? mx : 0; // (pend: the values at the old iterate and along both steps are the ones the forward sweeps left)
+            load_block(i, W, true, Ext{vpi, D.o_pi, NX}, Ext{vtmp, D.o_dpi, pend ? NX : 0}, Ext{nullptr, 0, 0}, Ext{delo, D.o_cdel, mxp}, Ext{dela, D.o_cdela, mxp}, Ext{delf, D.o_cdelf, mxp});
             USV_TICK(2);
             if (pend) { // rows need the old iterate and both steps
-                expand_rows(delo, vw, vcr, dela, vdwa, delf, vdw);
                 for (int e = tid; e < NX; e += NT) { vpi[e] = fma(a_prev, vtmp[e], vpi[e]); W[D.o_pi + e] = vpi[e]; }
                 TM::sync();
                 // (the old values of the u rows are read from vw before it moves: keep a copy in vt)
@@ -956,6 +967,7 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
             USV_TICK(3);
             expand_rows(del, vw, vcr);
             TM::sync();
+            for (int e = tid; e < mx; e += NT) W[D.o_cdel + e] = del[e]; // (the other sweeps of this iteration, and the next backward sweep as the old values, read it back)
             USV_TICK(4);
             double rd = 0.0, rm = 0.0, mus = 0.0, bd = 0.0, rgs = 0.0;
             row_pass<1>(i, W, rr, [&](int e, int j, int q, Row &r, double *rw, double v, double wa, double wf, double &yr, double &yg, double &Gh) {
@@ -1119,11 +1131,9 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
         for (int i = N2 - 1; i >= 0; i--) {
             double *W = blk(i);
             const RowRegs rr = row_issue(W);
-            load_block(i, W, false, Ext{vPb, D.o_Pb, NX}, Ext{vdg, D.o_dg, nuh}, Ext{vgt, D.o_rg, nzh});
+            load_block(i, W, false, Ext{vPb, D.o_Pb, NX}, Ext{vdg, D.o_dg, nuh}, Ext{vgt, D.o_rg, nzh}, Ext{del, D.o_cdel, Mb * nxr}, Ext{dela, D.o_cdela, Mb * nxr});
             for (int e = tid; e < NX; e += NT) W[D.o_p + e] = vpv[e];
             USV_TICK(13);
-            expand_rows(del, vw, vcr, dela, vdwa);
-            TM::sync();
             USV_TICK(14);
             row_pass<2>(i, W, rr, [&](int, int, int, Row &r, double *, double v, double wa, double, double &yr, double &yg, double &Gh) {
                 double g0_, g1_;
@@ -1159,7 +1169,7 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
         for (int i = 0; i < N2; i++) {
             double *W = blk(i);
             const RowRegs rr = row_issue(W);
-            load_block(i, W, false, Ext{vlus, D.o_lus, nuh}, Ext{vdg, D.o_dg, nuh}, Ext{vrb, D.o_rb, NX});
+            load_block(i, W, false, Ext{vlus, D.o_lus, nuh}, Ext{vdg, D.o_dg, nuh}, Ext{vrb, D.o_rb, NX}, Ext{del, D.o_cdel, Mb * nxr}, Ext{dela, D.o_cdela, corr ? Mb * nxr : 0});
             USV_TICK(17);
             // t = lus + Lxu' dx;  du = -Luu^-T t
             for (int c = tid; c < nuh; c += NT) {
@@ -1186,8 +1196,9 @@ struct CondIpm : CondBlkSizes<MB, NXR, M::NU, M::NX> {
                 }
             }
             USV_TICK(18);
-            expand_rows(del, vw, vcr, dela, vdwa, corr ? delf : nullptr, corr ? vdw : nullptr);
+            expand_rows(corr ? delf : dela, dst, nullptr); // (the values at the iterate come from the backward sweep, along the affine step from the first forward sweep)
             TM::sync();
+            for (int e = tid; e < Mb * nxr; e += NT) W[(corr ? D.o_cdelf : D.o_cdela) + e] = (corr ? delf : dela)[e];
             USV_TICK(19);
             if (corr) { // dpi_{i+1} = p_{i+1} + P_{i+1} dx_{i+1}
                 double *Wn = blk(i + 1);

@@ -410,3 +410,25 @@ def test_config4_shape_hip_vs_condensing_oracle(oracle):
         worst_obj = max(worst_obj, abs(jh - jc) / max(1.0, abs(jc)))
         worst_viol, worst_eq = max(worst_viol, vh), max(worst_eq, eh)
     assert worst_obj <= 1e-6 and worst_viol <= 1e-6 and worst_eq <= 1e-8, (worst_obj, worst_viol, worst_eq)
+
+
+def test_condensing_kernels_in_the_library_have_the_resources_the_design_counts_on():
+    """docs/rounds/r06.md section 7 / DESIGN.md section 6: the hard-row condensing kernels are compiled for four waves per SIMD (128 registers;
+    with the thread index opaque per block they spill a few dozen at most, 172 before), the soft-row ones for three (168), and the instantiation with
+    the compile-time block shape of BASELINE configs[4] (8 stages per block, 7 touched states) exists next to the run-time-shape one."""
+    import os, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = _capi.lib_path()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "so_resources.py"), lib, "usv_qp_cond"], capture_output=True, text=True).stdout
+    rows = {}
+    for line in out.splitlines():
+        name = line[:line.index(" vgpr ")].strip()
+        f = line[line.index(" vgpr "):].split()
+        rows[name] = {f[i]: f[i + 1] for i in range(0, len(f) - 1, 2)}
+    fixed = [n for n in rows if n.endswith("256, 8, 7>")]
+    assert sorted(fixed) == ["usv_qp_cond<ModelM2, 1, false, 256, 8, 7>", "usv_qp_cond<ModelM2, 2, false, 256, 8, 7>"], sorted(rows)
+    for n, r in rows.items():
+        soft = ", true, " in n
+        assert int(r["vgpr"]) <= (168 if soft else 128), (n, r)
+        assert int(r["spill"]) <= 64, (n, r)          # (reloads of spilled registers were what set the pace of this kernel)
+    assert all(n.endswith(", 0, 0>") or n in fixed for n in rows), sorted(rows)

@@ -225,6 +225,56 @@ def survey_verbatim_leg(args, name, N, K, B, device, parity_sample):
     return out
 
 
+def configs4_condensed_leg(args, device):
+    """A third short region of the default line: BASELINE configs[4] ("+ partial condensing") at its per-GPU share - usv_model_pf_ca, N = 80, 20 MOVING
+    obstacles, 8192 instances - solved with qp_solver_cond_N = 10 (usv_qp_cond: condense on the device, IPM on the ten dense stages, expand) and, on the
+    same inputs, uncondensed (usv_qp_rti, the default formulation).  Tick 0 (both cold starts coincide) compares the two solutions; then 2 warm-up +
+    4 timed closed-loop ticks each.  Returns the `configs4_condensed` object of the line."""
+    from mpc_collisionavoidance_amd import BatchOcpSolver, scenario, usv_models
+    from tests import util
+    name, N, K, B, N2 = "usv_model_pf_ca", 80, 20, 8192, 10
+    dt, steps = scenario.BENCH_DT, scenario.BENCH_SIM_STEPS[name]
+    wl = scenario.make_bench_batch(name, N, K, B, seed=1234, moving=True)
+    out = {"workload": "BASELINE.json configs[4] at its per-GPU share: batch=%d, %s, N=%d, %d moving obstacles; qp_solver_cond_N=%d against the uncondensed default" % (B, name, N, K, N2)}
+    sol = {}
+    for key, cn in (("condensed", N2), ("uncondensed", 0)):
+        ocp = usv_models.make_ocp(name, N * dt, N, K)
+        ocp.solver_options.sim_method_num_steps = steps
+        ocp.solver_options.hpipm_mode = args.hpipm_mode
+        if cn:
+            ocp.solver_options.qp_solver_cond_N = cn
+        s = BatchOcpSolver(ocp, B, device=device)
+        scenario.load_into(s, wl)
+        s.set_option("disturbance_mask", scenario.NOISE_MASK[name])
+        st = s.solve()
+        sol[key] = (st.copy(), s.get_int("qp_status").copy(), s.get_int("qp_iter").copy(), s.get_all("x").copy(), s.get_all("u").copy())
+        for w in range(2):
+            s.advance(1e-3, seed=5000 + w)
+            s.solve_async()
+        s.advance(1e-3, seed=5002)
+        s.sync()
+        nst = 4
+        unconv0 = s.unconverged_total()
+        t0 = time.perf_counter()
+        for k in range(nst):
+            s.solve_async()
+            s.advance(1e-3, seed=6000 + k)
+        s.sync()
+        el = time.perf_counter() - t0
+        unconv = s.unconverged_total() - unconv0
+        out[key] = {"value": (B * nst - unconv) / el, "unit": "converged solves/s", "ms_per_step": el / nst * 1e3, "steps": nst,
+                    "kernel": "usv_qp_cond" if cn else "usv_qp_rti", "qp_not_converged_frac": float((s.get_int("qp_status") != 0).mean()),
+                    "qp_iter_mean": float(s.get_int("qp_iter").mean())}
+        s.close()
+    (sc, qc, ic, xc, uc), (su, qu, iu, xu, uu) = sol["condensed"], sol["uncondensed"]
+    both = (qc == 0) & (qu == 0)
+    e = np.maximum(util.rel_err_per_instance(xc[both], xu[both]), util.rel_err_per_instance(uc[both], uu[both])) if both.any() else np.zeros(1)
+    out["tick0_condensed_vs_uncondensed"] = {"status_agreement_frac": float((sc == su).mean()), "converged_on_both_sides_frac": float(both.mean()),
+                                             "same_iteration_count_frac": float((ic == iu)[both].mean()) if both.any() else 0.0,
+                                             "rel_err_per_instance": {"p50": float(np.percentile(e, 50)), "p99": float(np.percentile(e, 99)), "max": float(e.max())}}
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: become N ranks under torch.distributed.run."""
     import torch
@@ -271,7 +321,8 @@ def main():
     ap.add_argument("--spread-mode", default="R04", choices=["BALANCE", "SPEED", "ROBUST", "R04", "none"],
                     help="second profile for parity.profile_spread: the device under --hpipm-mode against the device under this profile on the parity sample")
     ap.add_argument("--no-survey-verbatim", action="store_true",
-                    help="skip the second timed region on SURVEY 8(d)'s generator to the letter (the `survey_verbatim` key of the default line)")
+                    help="skip the extra timed regions of the default line: SURVEY 8(d)'s generator to the letter (`survey_verbatim`) and BASELINE configs[4] with "
+                         "qp_solver_cond_N = 10 against its uncondensed default (`configs4_condensed`)")
     ap.add_argument("--bind-numa", default="auto", choices=["auto", "on", "off"],
                     help="pin each rank's host threads to its GPU's NUMA node (auto: under a multi-rank launch)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
@@ -597,6 +648,11 @@ def main():
         solver.sync()
         survey_verbatim = survey_verbatim_leg(args, name, N, K, B, local_rank, min(S1, 128) if check else 0)
 
+    # ---- BASELINE configs[4] with its partial condensing applied, beside the uncondensed default at the same shape (same conditions as the region above)
+    configs4_condensed = None
+    if survey_verbatim is not None:
+        configs4_condensed = configs4_condensed_leg(args, local_rank)
+
     departures = "none"
     if args.workload == "survey" and name == "usv_model_pf_ca":
         departures = ("(1) %d RK4 steps per interval (the model cannot take one 0.05 s step); (2) obstacle clip: an obstacle whose keep-out circle "
@@ -691,6 +747,7 @@ def main():
             },
             "parity": parity,
             "survey_verbatim": survey_verbatim,
+            "configs4_condensed": configs4_condensed,
             "allgather": gather,
         }
         print(json.dumps(out))

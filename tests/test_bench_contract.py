@@ -219,3 +219,20 @@ def test_condensed_line_of_round_6_meets_the_bar_set_for_it():
     assert len(stats) == 1 and float(stats[0].rsplit('"', 1)[1].split(",")[3]) <= 110e6      # (average duration, ns: the instantiation with the compile-time block shape)
     unc = json.load(open(os.path.join(ROOT, "profiles", "r06_e_bench_cfg4_b8192_per_gpu_plain.json")))
     assert unc["value"] > b["value"]     # (the uncondensed sweep is still the faster formulation at this shape: it stays the default)
+
+
+def test_default_line_carries_configs4_with_its_condensing_applied():
+    """The default line as the driver prints it at the end of round 6 (profiles/r06_f_bench_plain.json: the library of the r06_e set, bench.py with the
+    third region): BASELINE configs[4] at its per-GPU share solved with qp_solver_cond_N = 10 and uncondensed, the two solutions compared on tick 0."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_f_bench_plain.json")))
+    e = json.load(open(os.path.join(ROOT, "profiles", "r06_e_bench_plain.json")))
+    assert d["config"]["lib_sha256"] == e["config"]["lib_sha256"] and set(d) == set(e) | {"configs4_condensed"}
+    assert d["roofline"]["traffic"] is not None and abs(d["roofline"]["traffic"] - 353e9) < 5e9        # (the PMC table is keyed by that library)
+    c = d["configs4_condensed"]
+    assert c["condensed"]["kernel"] == "usv_qp_cond" and c["uncondensed"]["kernel"] == "usv_qp_rti"
+    assert c["condensed"]["ms_per_step"] <= 110.0 and c["condensed"]["value"] >= 70e3 and c["uncondensed"]["value"] > c["condensed"]["value"]
+    t = c["tick0_condensed_vs_uncondensed"]
+    assert t["status_agreement_frac"] >= 0.995 and t["same_iteration_count_frac"] >= 0.999 and t["converged_on_both_sides_frac"] >= 0.9
+    assert t["rel_err_per_instance"]["p50"] <= 1e-9 and t["rel_err_per_instance"]["p99"] <= 1e-5 and t["rel_err_per_instance"]["max"] <= 1e-3
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "def configs4_condensed_leg" in src and '"configs4_condensed": configs4_condensed' in src

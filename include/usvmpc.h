@@ -275,7 +275,7 @@ int usvmpc_set_stream(usvmpc_handle *h, void *stream);
  *       BESIDE the draining launch (kernel usv_qp_resume_co on a stream of its own): its workgroups come onto the device as wavefronts of the
  *       main launch leave, wait - a bounded wait, "handover_co_spin" polls - for list entries to appear and finish those instances while the
  *       main launch is still draining; what they do not get to is done by the launch behind it (every entry is taken by exactly one of the
- *       two).  Scheduling only.  "handover_co_wgs": workgroups of that kernel (0 = as many as the follow-up launch may hold);
+ *       two).  Scheduling only.  "handover_co_wgs": workgroups of that kernel (0 = one per CU: what finds room beside the main launch's workgroups at once);
  *   "disturbance_mask" (default all ones) - bit j set: usvmpc_advance adds its noise to state j (the reference's commented
  *       hooks disturb x0[3] and x0[5] only: catkin_ws/src/nmpc_ca/scripts/usv_pf_ca/main.py:181-183). */
 int usvmpc_set_option(usvmpc_handle *h, const char *name, double value);

@@ -408,7 +408,7 @@ struct usvmpc_handle {
     // the follow-up kernel beside the draining launch (usv_qp_resume_co; option "handover_co": -1 = when the follow-up works in LDS, 0 never, 1 the same)
     int handover_co;
     int co_spin_limit;        // polls of ~1 us a co-resident workgroup waits for its entry before it gives up (option "handover_co_spin")
-    long co_wgs;              // workgroups of the co-resident launch (option "handover_co_wgs"; 0: as many as the follow-up launch may hold)
+    long co_wgs;              // workgroups of the co-resident launch (option "handover_co_wgs"; 0: one per CU - launch_qp says why)
     hipStream_t co_stream;    // nullptr until first used
     hipEvent_t ev_co_pre, ev_co_end;
     int *d_co_ctl;            // [RING][8] DevPtrs::co_ctl of the last launches
@@ -1131,8 +1131,12 @@ int launch_pair(usvmpc_handle *h, int phase)
         if (co) {
             hipLaunchKernelGGL(usv_co_done, dim3(1), dim3(1), 0, h->stream, h->ptrs.co_ctl);
             HIP_TRY(h, hipStreamWaitEvent(h->co_stream, h->ev_co_pre, 0));
+            // One follow-up workgroup per CU unless the caller asks otherwise (option "handover_co_wgs"): what finds room BESIDE the main launch's
+            // workgroups at once (75 KB of LDS next to their eight times 10 KB).  With two per CU - what fits once the main launch has left - some
+            // of them wait to be placed while the main launch runs, and about one tick in 1 500 then stalled until their waits ran out: the main
+            // launch took 410 ms instead of 9 (tools/co_soak.py, docs/rounds/r06.md section 8: 0 stalls in 16 000 ticks with one per CU, same pace).
             long nco = std::min<long>(h->resume_cap, (long)h->B);
-            if (h->co_wgs > 0) nco = std::min<long>(nco, h->co_wgs);
+            nco = std::min<long>(nco, h->co_wgs > 0 ? (long)h->co_wgs : (long)std::max(h->ncu, 1));
             hipLaunchKernelGGL(wide.resume_co, dim3((unsigned)nco), dim3(qp_block), xbytes, h->co_stream, h->ptrs, (int)qg.x, (int)h->B, h->co_spin_limit);
             HIP_TRY(h, hipEventRecord(h->ev_co_end, h->co_stream));
         }

@@ -159,3 +159,33 @@ def test_co_resident_follow_up_with_the_pipelined_lineariser():
     assert np.array_equal(a.get_int("qp_iter"), b.get_int("qp_iter")) and np.array_equal(a.get("x0", 0), b.get("x0", 0))
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+def test_default_policy_does_not_stall_over_many_ticks():
+    """docs/rounds/r06.md section 8: with two follow-up workgroups per CU (the default until the end of round 6) about one tick in 1500 of this loop
+    took 410 ms instead of 9 - the main launch did not end while follow-up workgroups that had found no room waited out their bound.  With one per CU
+    (the default since): no tick anywhere near that, and no workgroup of the follow-up kernel runs into its bound."""
+    import time
+    name, N, K, B, ticks = "usv_model_pf_ca", 40, 10, 4096, 1500
+    wl = scenario.make_bench_batch(name, N, K, B, seed=1234)
+    ocp = usv_models.make_ocp(name, N * scenario.BENCH_DT, N, K)
+    ocp.solver_options.sim_method_num_steps = scenario.BENCH_SIM_STEPS[name]
+    s = BatchOcpSolver(ocp, B)
+    scenario.load_into(s, wl)
+    s.set_option("static_obstacles", 1)
+    s.set_option("disturbance_mask", scenario.NOISE_MASK[name])
+    for w in range(5):
+        s.solve_async(); s.advance(1e-3, seed=100 + w)
+    s.sync()
+    t, finished, timeouts = np.zeros(ticks), 0, 0
+    for k in range(ticks):
+        t0 = time.perf_counter()
+        s.solve_async(); s.advance(1e-3, seed=1000 + k)
+        s.sync()
+        t[k] = time.perf_counter() - t0
+        fin, to = s.handover_co_counts(1)
+        finished += int(fin[0]); timeouts += int(to[0])
+    s.close()
+    assert finished > 100 * ticks        # (the follow-up kernel beside the launch is at work in this loop: hundreds of instances per tick)
+    assert timeouts == 0 and t.max() < 0.1 and t.max() < 8 * np.median(t), (timeouts, float(np.median(t)), float(t.max()))

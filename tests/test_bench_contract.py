@@ -168,7 +168,7 @@ def test_scale_run_script_names_every_sharded_config():
 def test_round6_lines_carry_the_profile_its_spread_and_the_survey_verbatim_region():
     """the default line names the QP solver profile, compares against the oracle under that profile, prints what the
     profile choice moves on the device (parity.profile_spread) and the survey's generator to the letter as a second timed region."""
-    d = json.load(open(os.path.join(ROOT, "profiles", "r06_f_bench_plain.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_g_bench_plain.json")))
     assert d["config"]["hpipm_mode"].startswith("BALANCE") and d["roofline"]["kernel"] == "usv_qp_rti"   # (one launch: no hand-over at 65 536)
     p = d["parity"]
     assert p["oracle_options"] == {"hpipm_mode": "BALANCE"} and p["count_above_1e-5"] == 0 and p["rel_err_per_instance"]["max"] < 1e-5
@@ -184,12 +184,12 @@ def test_round6_lines_carry_the_profile_its_spread_and_the_survey_verbatim_regio
     assert abs(d["value"] - ws["solves_per_s_counting_unconverged_ones"] * (1.0 - ws["unconverged_solves_in_timed_region"] / total)) <= 1e-9 * d["value"]
     assert len(d["config"]["per_rank_ms_per_step"]) == 1 and d["config"]["host_binding_rank0"] == "not bound"
     # the profile of rounds 1 - 5 on the same kernels, and the oracle without its refinement: the outliers the default no longer has
-    r04 = json.load(open(os.path.join(ROOT, "profiles", "r06_f_bench_profile_r04_plain.json")))
+    r04 = json.load(open(os.path.join(ROOT, "profiles", "r06_g_bench_profile_r04_plain.json")))
     assert r04["config"]["hpipm_mode"].startswith("R04") and r04["parity"]["count_above_1e-5"] >= 1 and r04["value"] < d["value"]
-    spd = json.load(open(os.path.join(ROOT, "profiles", "r06_f_bench_oracle_speed_plain.json")))["parity"]
+    spd = json.load(open(os.path.join(ROOT, "profiles", "r06_g_bench_oracle_speed_plain.json")))["parity"]
     assert spd["oracle_options"]["hpipm_mode"] == "SPEED" and spd["count_above_1e-5"] >= 1
     # the mid-size batches run with the follow-up kernel beside the launch
-    b = json.load(open(os.path.join(ROOT, "profiles", "r06_f_bench_b8192_plain.json")))
+    b = json.load(open(os.path.join(ROOT, "profiles", "r06_g_bench_b8192_plain.json")))
     assert "usv_qp_resume" in b["roofline"]["kernel_ms"] and b["value"] > 560e3
 
 
@@ -197,7 +197,7 @@ def test_scale_script_lines_have_the_plain_lines_keys():
     """tools/scale_run.sh run on the one GPU a builder's box has (`tools/scale_run.sh out 1`; profiles/r06_scale_n1_*): its N = 1 lines are bench
     lines like the plain one - same keys, same config keys -, the sharded configs name themselves, and the summary has one row per kind.  (The
     N = 2, 4, 8 rows are the driver's / an 8-GPU node's to fill: no scaling curve has been measured.)"""
-    plain = json.load(open(os.path.join(ROOT, "profiles", "r06_f_bench_plain.json")))
+    plain = json.load(open(os.path.join(ROOT, "profiles", "r06_g_bench_plain.json")))
     weak = json.load(open(os.path.join(ROOT, "profiles", "r06_scale_n1_weak.json")))
     # (the script's lines were taken before bench.py grew its third region: the plain line has that one key more)
     assert set(weak) <= set(plain) and set(plain) - set(weak) <= {"configs4_condensed"}
@@ -214,20 +214,20 @@ def test_scale_script_lines_have_the_plain_lines_keys():
 def test_condensed_line_of_round_6_meets_the_bar_set_for_it():
     """usv_qp_cond at BASELINE configs[4]'s per-GPU share (8192 instances, N = 80 -> qp_cond_N = 10) at most 110 ms per launch
     (205 ms at the start of round 6): the committed line and the rocprofv3 statistics of the same command."""
-    b = json.load(open(os.path.join(ROOT, "profiles", "r06_f_bench_cfg4_b8192_condN10_plain.json")))
+    b = json.load(open(os.path.join(ROOT, "profiles", "r06_g_bench_cfg4_b8192_condN10_plain.json")))
     assert b["config"]["qp_solver_cond_N"] == 10 and b["config"]["horizon"] == 80 and b["config"]["obstacles"] == 20 and b["config"]["instances_total"] == 8192
     assert b["roofline"]["kernel"] == "usv_qp_cond" and b["roofline"]["kernel_ms"]["usv_qp_cond"] <= 110.0 and b["value"] >= 70e3
-    stats = [l for l in open(os.path.join(ROOT, "profiles", "r06_f_cond_kernel_stats.csv")) if "usv_qp_cond<usv::ModelM2, 2, false, 256, 8, 7>" in l]
+    stats = [l for l in open(os.path.join(ROOT, "profiles", "r06_g_cond_kernel_stats.csv")) if "usv_qp_cond<usv::ModelM2, 2, false, 256, 8, 7>" in l]
     assert len(stats) == 1 and float(stats[0].rsplit('"', 1)[1].split(",")[3]) <= 110e6      # (average duration, ns: the instantiation with the compile-time block shape)
-    unc = json.load(open(os.path.join(ROOT, "profiles", "r06_f_bench_cfg4_b8192_per_gpu_plain.json")))
+    unc = json.load(open(os.path.join(ROOT, "profiles", "r06_g_bench_cfg4_b8192_per_gpu_plain.json")))
     assert unc["value"] > b["value"]     # (the uncondensed sweep is still the faster formulation at this shape: it stays the default)
 
 
 def test_default_line_carries_configs4_with_its_condensing_applied():
-    """The default line of the final evidence set (profiles/r06_f_bench_plain.json) has the third region: BASELINE configs[4] at its per-GPU share solved
+    """The default line of the final evidence set (profiles/r06_g_bench_plain.json) has the third region: BASELINE configs[4] at its per-GPU share solved
     with qp_solver_cond_N = 10 and uncondensed, the two solutions compared on tick 0; and the PMC table has the traffic of that library."""
-    d = json.load(open(os.path.join(ROOT, "profiles", "r06_f_bench_plain.json")))
-    pmc = [e for e in json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))) if e["round"] == "r06_f"]
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_g_bench_plain.json")))
+    pmc = [e for e in json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))) if e["round"] == "r06_g"]
     assert len(pmc) == 1 and pmc[0]["lib_sha256"] == d["config"]["lib_sha256"] and abs(pmc[0]["hbm_bytes_per_launch"] - 353e9) < 5e9
     c = d["configs4_condensed"]
     assert c["condensed"]["kernel"] == "usv_qp_cond" and c["uncondensed"]["kernel"] == "usv_qp_rti"

@@ -1,6 +1,6 @@
 """Soak of the default hand-over policy at the batch sizes where the follow-up kernel runs beside the launch: per-tick wall times over many
 closed-loop ticks, the follow-up kernel's timeouts (a workgroup that waited its whole bound), ticks far above the median.  (development aid, GPU)
-  python tools/co_soak.py [B ...] [--ticks N] [--opt name=value ...]"""
+  python tools/co_soak.py [B ...] [--ticks N] [--model usv_model_guidance_ca1] [--opt name=value ...]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,6 +15,8 @@ opts = []
 while "--opt" in args:
     i = args.index("--opt"); opts.append(args[i + 1].split("=")); del args[i:i + 2]
 name, N, K = "usv_model_pf_ca", 40, 10
+if "--model" in args:
+    i = args.index("--model"); name = args[i + 1]; del args[i:i + 2]
 for B in [int(a) for a in args] or [4096]:
     wl = scenario.make_bench_batch(name, N, K, B, seed=1234)
     ocp = usv_models.make_ocp(name, N * scenario.BENCH_DT, N, K)
